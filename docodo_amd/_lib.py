@@ -1,0 +1,131 @@
+"""ctypes binding of libdocodo_hip.so (C ABI declared in include/docodo_hip.h).
+
+There is no CPU fallback: importing this module without the built library raises, and every
+compute entry point fails with DCD_E_HIP when no MI355X is visible.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdocodo_hip.so")
+
+DCD_OK = 0
+DCD_E_BADARG, DCD_E_OVERFLOW, DCD_E_IO, DCD_E_HIP, DCD_E_RCCL = -1, -2, -3, -4, -5
+DCD_E_UNSUPPORTED, DCD_E_NOTFOUND, DCD_E_NOMEM, DCD_E_STATE = -6, -7, -8, -9
+DCD_ENC_LATIN1, DCD_ENC_UTF16LE = 1, 2
+DCD_OP_TERM, DCD_OP_AND, DCD_OP_OR = 0, 1, 2
+
+
+class DocodoError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("libdocodo_hip error %d: %s" % (code, msg))
+        self.code = code
+
+
+class BuildOpts(C.Structure):
+    _fields_ = [("device", C.c_int32), ("min_word_length", C.c_int32), ("max_word_length", C.c_int32),
+                ("encoding", C.c_int32), ("coord_base", C.c_uint64), ("vocab_capacity_log2", C.c_uint32),
+                ("reserved", C.c_uint32)]
+
+
+class BuildStats(C.Structure):
+    _fields_ = [("n_chars", C.c_uint64), ("n_pages", C.c_uint64), ("n_docs", C.c_uint64), ("n_postings", C.c_uint64),
+                ("n_terms", C.c_uint64), ("n_units", C.c_uint64), ("max_coord", C.c_uint64), ("index_bytes", C.c_uint64),
+                ("list_bytes", C.c_uint64), ("ms_tokenize", C.c_float), ("ms_vocab", C.c_float), ("ms_sort", C.c_float),
+                ("ms_pack", C.c_float), ("ms_image", C.c_float), ("ms_total", C.c_float), ("sort_passes", C.c_uint32),
+                ("vocab_capacity_log2", C.c_uint32)]
+
+
+class QueryOpts(C.Structure):
+    _fields_ = [("max_found_pages", C.c_int32), ("max_found_docs", C.c_int32), ("doc_rank_multiply", C.c_float),
+                ("want_sequences", C.c_int32)]
+
+
+class ResultsView(C.Structure):
+    _fields_ = [("n_queries", C.c_uint64), ("status", C.POINTER(C.c_int32)), ("page_off", C.POINTER(C.c_uint64)),
+                ("page_index", C.POINTER(C.c_uint32)), ("page_rank", C.POINTER(C.c_float)),
+                ("pos_off", C.POINTER(C.c_uint64)), ("pos", C.POINTER(C.c_int32)), ("doc_off", C.POINTER(C.c_uint64)),
+                ("doc_index", C.POINTER(C.c_uint32)), ("doc_rank", C.POINTER(C.c_float)),
+                ("doc_n_pages", C.POINTER(C.c_uint32)), ("seq_off", C.POINTER(C.c_uint64)),
+                ("seq_units", C.POINTER(C.c_uint16)), ("seq_R", C.POINTER(C.c_int32)), ("ms_device", C.c_float)]
+
+
+# name -> (restype, argtypes); mirrors include/docodo_hip.h one to one
+_vp, _sz, _i32, _u64, _u32 = C.c_void_p, C.c_size_t, C.c_int32, C.c_uint64, C.c_uint32
+_pz, _pi32, _pu64, _pu32 = C.POINTER(C.c_size_t), C.POINTER(C.c_int32), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)
+SIGNATURES = {
+    "dcd_version": (_i32, []),
+    "dcd_last_error": (_i32, [C.c_char_p, _sz]),
+    "dcd_device_count": (_i32, [_pi32]),
+    "dcd_seq_encode": (_i32, [_vp, _sz, _vp, _sz, _pz]),
+    "dcd_seq_decode": (_i32, [_vp, _sz, _vp, _sz, _pz]),
+    "dcd_seq_count": (_i32, [_vp, _sz, _pz]),
+    "dcd_seq_shift": (_i32, [_vp, _sz, _u64, _vp, _sz, _pz]),
+    "dcd_seq_and": (_i32, [_vp, _sz, _i32, _vp, _sz, _i32, _vp, _sz, _pz, _pi32]),
+    "dcd_seq_or": (_i32, [_vp, _sz, _i32, _vp, _sz, _i32, _vp, _sz, _pz, _pi32]),
+    "dcd_build_default_opts": (None, [C.POINTER(BuildOpts)]),
+    "dcd_build_create": (_i32, [C.POINTER(BuildOpts), C.POINTER(_vp)]),
+    "dcd_build_free": (None, [_vp]),
+    "dcd_build_add_doc": (_i32, [_vp, _vp, _sz, _vp, _sz]),
+    "dcd_build_add_pages": (_i32, [_vp, _vp, _u64, _vp, _sz, _vp, _vp, _i32, _u64, _vp, _sz]),
+    "dcd_build_add_pages_dev": (_i32, [_vp, _vp, _u64, _vp, _sz, _i32, _u64, _vp, _sz]),
+    "dcd_build_add": (_i32, [_vp, _vp, _sz, _u64]),
+    "dcd_build_end_page": (_i32, [_vp, _vp, _sz]),
+    "dcd_build_finish": (_i32, [_vp]),
+    "dcd_build_get_stats": (_i32, [_vp, C.POINTER(BuildStats)]),
+    "dcd_build_index_image": (_i32, [_vp, _vp, _sz, _pz]),
+    "dcd_build_list_image": (_i32, [_vp, _vp, _sz, _pz]),
+    "dcd_build_save": (_i32, [_vp, C.c_char_p]),
+    "dcd_index_from_build": (_i32, [_vp, C.POINTER(_vp)]),
+    "dcd_index_open": (_i32, [C.c_char_p, _i32, C.POINTER(_vp)]),
+    "dcd_index_from_images": (_i32, [_vp, _sz, _vp, _sz, _i32, C.POINTER(_vp)]),
+    "dcd_index_free": (None, [_vp]),
+    "dcd_index_count": (_i32, [_vp, _pu64]),
+    "dcd_index_max_coord": (_i32, [_vp, _pu64]),
+    "dcd_index_n_pages": (_i32, [_vp, _pu64]),
+    "dcd_index_n_docs": (_i32, [_vp, _pu64]),
+    "dcd_index_find": (_i32, [_vp, _vp, _sz, _pu32]),
+    "dcd_index_key": (_i32, [_vp, _u32, _vp, _sz, _pz]),
+    "dcd_index_get": (_i32, [_vp, _u32, _vp, _sz, _pz]),
+    "dcd_index_term_count": (_i32, [_vp, _u32, _pu64]),
+    "dcd_index_page_info": (_i32, [_vp, _u64, _pu64, _pu32, _vp, _sz, _pz]),
+    "dcd_index_doc_name": (_i32, [_vp, _u32, _vp, _sz, _pz]),
+    "dcd_query_default_opts": (None, [C.POINTER(QueryOpts)]),
+    "dcd_query_batch": (_i32, [_vp, _vp, _vp, _sz, C.POINTER(QueryOpts), C.POINTER(_vp)]),
+    "dcd_results_get": (_i32, [_vp, C.POINTER(ResultsView)]),
+    "dcd_results_free": (None, [_vp]),
+    "dcd_synth_corpus_host": (_i32, [_vp, _u64, _u64, _u32, _u32, C.c_double, _u64]),
+    "dcd_synth_corpus_dev": (_i32, [_vp, _u64, _u64, _u32, _u32, C.c_double, _u64, _i32]),
+    "dcd_synth_term": (_i32, [_u32, _u32, C.c_char_p, _sz, _pz]),
+    "dcd_synth_query_ranks": (_i32, [_vp, _u64, _u32, _i32, _u32, _u32, C.c_double, _u64]),
+}
+
+_LIB = None
+
+
+def lib():
+    """Loads libdocodo_hip.so; raises loudly when it was not built (no fallback path exists)."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("libdocodo_hip.so is missing (%s): run `python -c 'import __graft_entry__ as g; g.build()'` "
+                               "or `make -C docodo_amd/csrc`. docodo_amd has no CPU fallback." % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            f = getattr(L, name)  # AttributeError here == header/library mismatch
+            f.restype = res
+            f.argtypes = args
+        _LIB = L
+    return _LIB
+
+
+def last_error():
+    buf = C.create_string_buffer(2048)
+    lib().dcd_last_error(buf, len(buf))
+    return buf.value.decode("utf-8", "replace")
+
+
+def check(code):
+    if code != DCD_OK:
+        raise DocodoError(code, last_error())
+    return code

@@ -1,0 +1,774 @@
+// dcd_build.hip -- the build path on the device: tokenise -> exact vocabulary -> stable radix
+// sort by term -> 15-bit var-ushort pack -> ".index" byte image, everything resident in HBM.
+//
+// Replaces IndexTask's page loop (Build.cs:477-541), Index.Builder.Add/Save (Build.cs:324-404)
+// and, for one coordinate space, the merge functions (Index.cs:537-752).
+#include <algorithm>
+
+#include "dcd_build_int.h"
+#include "dcd_codec.h"
+#include "dcd_scan.h"
+#include "dcd_sort.h"
+#include "dcd_tokenize.h"
+
+namespace dcd {
+
+constexpr u32 MAX_CODE_LEN = 63;  // explicit index codes (Builder.Add); text tokens are <= 32
+
+// ================================================================================================
+// kernels
+// ================================================================================================
+template <typename CharT>
+__global__ __launch_bounds__(TK_THREADS) void k_tok_count(const CharT* __restrict__ text, TokParams P, CharTables16 tab,
+                                                         u32* __restrict__ tile_count) {
+  __shared__ TokLds<CharT> L;
+  u32 total = tokenize_tile<CharT>(text, P, tab, blockIdx.x, L);
+  if (threadIdx.x == 0) tile_count[blockIdx.x] = total;
+}
+
+template <typename CharT>
+__global__ __launch_bounds__(TK_THREADS) void k_tok_emit(const CharT* __restrict__ text, TokParams P, CharTables16 tab,
+                                                        TextView<CharT> tv, VocabTable vt, const u64* __restrict__ tile_off,
+                                                        uint2* __restrict__ tuples) {
+  __shared__ TokLds<CharT> L;
+  u32 total = tokenize_tile<CharT>(text, P, tab, blockIdx.x, L);
+  const int64_t lo = (int64_t)((u64)blockIdx.x * TK_TILE) - TK_PRE;
+  u64 obase = tile_off[blockIdx.x];
+  for (u32 k = threadIdx.x; k < total; k += TK_THREADS) {
+    u32 t = L.tok[k];
+    u32 i = t & 0xFFFFu, len = t >> 16;
+    HashState hs;
+    hs.init(len);
+    for (u32 j = 0; j < len; j++) hs.add((u32)L.txt[i + j]);
+    u64 gpos = (u64)(lo + (int64_t)i);
+    const CharT* s = &L.txt[i];
+    u32 slot = vocab_lookup_insert<CharT>(vt, tv, hs.fin(), len, gpos, [s](u32 j) { return (u32)s[j]; });
+    tuples[obase + k] = make_uint2(slot, (u32)gpos);
+  }
+}
+
+// explicit postings (Builder.Add(code, coord), Build.cs:324): codes live in the pool, verbatim
+template <typename CharT>
+__global__ void k_explicit(const CharT* __restrict__ pool, const u32* __restrict__ xoff, const u32* __restrict__ xlen,
+                           const u32* __restrict__ xcoord, u64 n, TextView<CharT> tv, VocabTable vt, uint2* __restrict__ tuples) {
+  u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  u32 len = xlen[i];
+  const CharT* s = pool + xoff[i];
+  HashState hs;
+  hs.init(len);
+  for (u32 j = 0; j < len; j++) hs.add((u32)s[j]);
+  u32 slot = vocab_lookup_insert<CharT>(vt, tv, hs.fin(), len, tv.n_chars + xoff[i], [s](u32 j) { return (u32)s[j]; });
+  tuples[i] = make_uint2(slot, xcoord[i]);
+}
+
+struct SlotUsed {
+  const u64* slots;
+  __device__ __forceinline__ u32 operator()(u64 i) const { return slots[i] != 0 ? 1u : 0u; }
+};
+
+__global__ void k_vocab_compact(const u64* __restrict__ slots, u64 cap, const u32* __restrict__ excl, u64* __restrict__ term_word,
+                                u32* __restrict__ term_slot, u32* __restrict__ maxlen) {
+  u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= cap) return;
+  u64 w = slots[i];
+  if (w) {
+    u32 d = excl[i];
+    term_word[d] = w;
+    term_slot[d] = (u32)i;
+    atomicMax(maxlen, voc_len(w));
+  }
+}
+
+// sort key chunk: characters [c*K, c*K+K) of the term, big-endian packed (K = 4 for bytes, 2 for
+// UTF-16 units) so that integer order == String.CompareOrdinal order; missing characters are 0.
+template <typename CharT>
+__global__ void k_term_keys(uint2* __restrict__ perm, u64 n, const u64* __restrict__ term_word, TextView<CharT> tv, u32 chunk,
+                            bool init) {
+  u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  u32 t = init ? (u32)i : perm[i].y;
+  u64 w = term_word[t];
+  u32 len = voc_len(w);
+  u64 pos = voc_pos(w);
+  constexpr u32 K = sizeof(CharT) == 1 ? 4 : 2;
+  u32 key = 0;
+#pragma unroll
+  for (u32 j = 0; j < K; j++) {
+    u32 ci = chunk * K + j;
+    u32 ch = ci < len ? tv.canon_char(pos + ci) : 0u;
+    key = (key << (32 / K)) | ch;
+  }
+  perm[i] = make_uint2(key, t);
+}
+
+__global__ void k_assign_rank(const uint2* __restrict__ perm, u64 n, const u32* __restrict__ term_slot, const u64* __restrict__ term_word,
+                              u32* __restrict__ rank_of_slot, u64* __restrict__ rk_word) {
+  u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  u32 d = perm[r].y;
+  rank_of_slot[term_slot[d]] = (u32)r;
+  rk_word[r] = term_word[d];
+}
+
+struct TermLenF {
+  const u64* rk_word;
+  __device__ __forceinline__ u32 operator()(u64 r) const { return voc_len(rk_word[r]); }
+};
+
+template <typename CharT>
+__global__ void k_term_strings(const u64* __restrict__ rk_word, u64 n, const u32* __restrict__ str_off, TextView<CharT> tv,
+                               u16* __restrict__ out) {
+  u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  u64 w = rk_word[r];
+  u32 len = voc_len(w);
+  u64 pos = voc_pos(w);
+  u32 o = str_off[r];
+  for (u32 j = 0; j < len; j++) out[o + j] = (u16)tv.canon_char(pos + j);
+}
+
+__global__ void k_set_u64(u64* p, u64 v) { *p = v; }
+__global__ void k_swap_xy(uint2* p, u64 n) {
+  u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) { uint2 v = p[i]; p[i] = make_uint2(v.y, v.x); }
+}
+__global__ void k_max_y(const uint2* p, u64 n, u32* out) {
+  u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  u32 v = i < n ? p[i].y : 0u;
+  v = wave_max(v);
+  if (lane_id() == 0) atomicMax(out, v);
+}
+
+// ".index" record sizes: 7-bit-length-prefixed UTF-8 key + i32 unit count + units (Appendix A.3)
+__device__ __forceinline__ u32 utf8_len_units(const u16* s, u32 n) {
+  u32 b = 0;
+  for (u32 i = 0; i < n; i++) {
+    u32 c = s[i];
+    if (c < 0x80) b += 1;
+    else if (c < 0x800) b += 2;
+    else if (c >= 0xD800 && c <= 0xDBFF && i + 1 < n && s[i + 1] >= 0xDC00 && s[i + 1] <= 0xDFFF) { b += 4; i++; }
+    else b += 3;
+  }
+  return b;
+}
+struct RecSizeF {
+  const u16* chars;
+  const u32* str_off;
+  const u64* unit_start;
+  __device__ __forceinline__ u64 operator()(u64 r) const {
+    u32 kb = utf8_len_units(chars + str_off[r], str_off[r + 1] - str_off[r]);
+    return (u64)(kb < 128 ? 1 : 2) + kb + 4 + 2 * (unit_start[r + 1] - unit_start[r]);
+  }
+};
+
+__global__ void k_img_headers(const u16* __restrict__ chars, const u32* __restrict__ str_off, const u64* __restrict__ unit_start,
+                              const u64* __restrict__ rec_off, u64 n, u64 img_base, u8* __restrict__ img, u64* __restrict__ pay_off) {
+  u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  const u16* s = chars + str_off[r];
+  u32 len = str_off[r + 1] - str_off[r];
+  u32 kb = utf8_len_units(s, len);
+  u64 o = img_base + rec_off[r];
+  if (kb < 128) img[o++] = (u8)kb;
+  else { img[o++] = (u8)(kb | 0x80); img[o++] = (u8)(kb >> 7); }
+  for (u32 i = 0; i < len; i++) {
+    u32 c = s[i];
+    if (c >= 0xD800 && c <= 0xDBFF && i + 1 < len && s[i + 1] >= 0xDC00 && s[i + 1] <= 0xDFFF) {
+      c = 0x10000 + ((c - 0xD800) << 10) + (s[i + 1] - 0xDC00);
+      i++;
+    } else if (c >= 0xD800 && c <= 0xDFFF) c = 0xFFFD;
+    if (c < 0x80) img[o++] = (u8)c;
+    else if (c < 0x800) { img[o++] = (u8)(0xC0 | (c >> 6)); img[o++] = (u8)(0x80 | (c & 0x3F)); }
+    else if (c < 0x10000) { img[o++] = (u8)(0xE0 | (c >> 12)); img[o++] = (u8)(0x80 | ((c >> 6) & 0x3F)); img[o++] = (u8)(0x80 | (c & 0x3F)); }
+    else { img[o++] = (u8)(0xF0 | (c >> 18)); img[o++] = (u8)(0x80 | ((c >> 12) & 0x3F)); img[o++] = (u8)(0x80 | ((c >> 6) & 0x3F)); img[o++] = (u8)(0x80 | (c & 0x3F)); }
+  }
+  u32 nu = (u32)(unit_start[r + 1] - unit_start[r]);
+  img[o++] = (u8)nu; img[o++] = (u8)(nu >> 8); img[o++] = (u8)(nu >> 16); img[o++] = (u8)(nu >> 24);
+  pay_off[r] = o;
+}
+
+constexpr int IMG_UPT = 8;  // units per thread
+__global__ void k_img_units(const u16* __restrict__ units, u64 n_units, const u64* __restrict__ unit_start, u64 n_terms,
+                            const u64* __restrict__ pay_off, u8* __restrict__ img) {
+  u64 u0 = ((u64)blockIdx.x * blockDim.x + threadIdx.x) * IMG_UPT;
+  if (u0 >= n_units) return;
+  // term of unit u0: last t with unit_start[t] <= u0
+  u64 a = 0, b = n_terms;
+  while (a + 1 < b) { u64 m = (a + b) >> 1; if (unit_start[m] <= u0) a = m; else b = m; }
+  u64 t = a;
+  u64 next = unit_start[t + 1];
+  u64 dst = pay_off[t] + 2 * (u0 - unit_start[t]);
+  for (int k = 0; k < IMG_UPT; k++) {
+    u64 u = u0 + k;
+    if (u >= n_units) break;
+    while (u >= next) { t++; next = unit_start[t + 1]; dst = pay_off[t]; }
+    u16 v = units[u];
+    img[dst] = (u8)v;
+    img[dst + 1] = (u8)(v >> 8);
+    dst += 2;
+  }
+}
+
+__global__ void k_put_u64_bytes(u8* img, u64 v) {
+  for (int i = 0; i < 8; i++) img[i] = (u8)(v >> (8 * i));
+}
+
+}  // namespace dcd
+
+using namespace dcd;
+
+// ================================================================================================
+// handle
+// ================================================================================================
+struct ExplicitPosting { u32 off, len; u64 coord; };
+
+struct dcd_build {
+  dcd_build_opts opts;
+  int device = 0;
+  hipStream_t st = nullptr;
+  bool finished = false;
+  // text
+  DevBuf<u8> text_own;        // raw bytes of the staged text (char size 1 or 2)
+  const void* text_dev = nullptr;
+  bool text_borrowed = false;
+  u64 n_chars = 0, text_cap = 0;
+  std::vector<u64> page_off;  // [n_pages + 1]
+  PageTable pages;
+  // explicit postings
+  std::vector<u16> xpool;     // code characters (UTF-16 units; narrowed for Latin-1 builds)
+  std::vector<ExplicitPosting> xps;
+  bool last_is_explicit = false;
+  u64 last_explicit_coord = 0;
+  ustr pending_source;        // AddDoc bookkeeping
+  // results
+  DeviceIndex ix;
+  DevBuf<u8> image;
+  u64 image_bytes = 0;
+  std::vector<u8> list_image;
+  dcd_build_stats stats;
+  bool adopted = false;       // DeviceIndex moved into a dcd_index
+  int csize() const { return opts.encoding == DCD_ENC_UTF16LE ? 2 : 1; }
+};
+
+namespace dcd {
+// UTF-16 class/lower tables on the device (built lazily per device from dcd_unicode.cpp)
+int32_t get_char_tables16(int device, CharTables16* out);
+DeviceIndex* build_take_index(dcd_build* b) {
+  if (!b->finished || b->adopted) return nullptr;
+  b->adopted = true;
+  return &b->ix;
+}
+int build_device(dcd_build* b) { return b->device; }
+}  // namespace dcd
+
+static ustr mk16(const u16* p, size_t n) { return ustr((const char16_t*)p, n); }
+
+extern "C" {
+
+void dcd_build_default_opts(dcd_build_opts* o) {
+  if (!o) return;
+  memset(o, 0, sizeof *o);
+  o->device = 0;
+  o->min_word_length = 3;
+  o->max_word_length = 32;
+  o->encoding = DCD_ENC_LATIN1;
+  o->coord_base = 0;
+  o->vocab_capacity_log2 = 0;
+}
+
+int32_t dcd_build_create(const dcd_build_opts* opts, dcd_build** out) {
+  if (!out) DCD_FAIL(DCD_E_BADARG, "dcd_build_create: out is NULL");
+  dcd_build_opts o;
+  if (opts) o = *opts; else dcd_build_default_opts(&o);
+  if (o.encoding != DCD_ENC_LATIN1 && o.encoding != DCD_ENC_UTF16LE)
+    DCD_FAIL(DCD_E_UNSUPPORTED, "unsupported text encoding %d (supported: LATIN1, UTF16LE)", o.encoding);
+  if (o.min_word_length < 1 || o.max_word_length > 32 || o.min_word_length > o.max_word_length)
+    DCD_FAIL(DCD_E_BADARG, "word length limits must satisfy 1 <= min <= max <= 32");
+  DCD_TRY(ensure_device(o.device));
+  dcd_build* h = new dcd_build();
+  h->opts = o;
+  h->device = o.device;
+  memset(&h->stats, 0, sizeof h->stats);
+  hipError_t e = hipStreamCreateWithFlags(&h->st, hipStreamNonBlocking);
+  if (e != hipSuccess) { delete h; DCD_FAIL(DCD_E_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
+  h->page_off.push_back(0);
+  *out = h;
+  return DCD_OK;
+}
+
+void dcd_build_free(dcd_build* h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  if (h->st) { (void)hipStreamSynchronize(h->st); (void)hipStreamDestroy(h->st); }
+  delete h;
+}
+
+int32_t dcd_build_add_doc(dcd_build* h, const uint16_t* source, size_t source_len, const uint16_t* name, size_t name_len) {
+  if (!h || (!source && source_len) || (!name && name_len)) DCD_FAIL(DCD_E_BADARG, "dcd_build_add_doc: NULL argument");
+  if (h->finished) DCD_FAIL(DCD_E_STATE, "build already finished");
+  if (source_len == 0) DCD_FAIL(DCD_E_BADARG, "sourceid must not be empty (Build.cs:350)");
+  if (h->pages.doc_per_page) DCD_FAIL(DCD_E_STATE, "cannot mix explicit documents with docs_per_page pages");
+  DocMeta d;
+  d.name = mk16(source, source_len) + u":" + mk16(name, name_len);
+  d.first_page = h->pages.end.size();
+  h->pages.docs.push_back(d);
+  return DCD_OK;
+}
+
+static int32_t append_pages_meta(dcd_build* h, const uint64_t* page_off, size_t n_pages, u64 n_chars, const uint16_t* page_ids,
+                                 const uint64_t* ids_off, int32_t docs_per_page, uint64_t first_doc, const uint16_t* source,
+                                 size_t source_len) {
+  if (docs_per_page) {
+    if (!h->pages.docs.empty() || (!h->pages.end.empty() && !h->pages.doc_per_page))
+      DCD_FAIL(DCD_E_STATE, "cannot mix docs_per_page with explicit documents");
+    if (h->pages.end.empty()) {
+      h->pages.doc_per_page = true;
+      h->pages.first_doc = first_doc;
+      h->pages.source = source_len ? mk16(source, source_len) : ustr(u"syn");
+    } else if (first_doc != h->pages.first_doc + h->pages.end.size()) {
+      DCD_FAIL(DCD_E_BADARG, "docs_per_page batches must continue the document numbering");
+    }
+  } else if (h->pages.docs.empty()) {
+    DCD_FAIL(DCD_E_STATE, "dcd_build_add_doc must precede pages (Build.cs:345-347)");
+  }
+  if (page_off[0] != 0 || page_off[n_pages] != n_chars) DCD_FAIL(DCD_E_BADARG, "page_off must start at 0 and end at n_chars");
+  bool uniform = ids_off == nullptr;
+  if (uniform) {
+    if (!h->pages.ids.empty()) DCD_FAIL(DCD_E_STATE, "cannot mix uniform and explicit page ids");
+    h->pages.uniform_id = u"1";
+  } else if (h->pages.ids.empty() && !h->pages.end.empty()) {
+    DCD_FAIL(DCD_E_STATE, "cannot mix uniform and explicit page ids");
+  }
+  u64 base = h->n_chars;
+  for (size_t p = 0; p < n_pages; p++) {
+    if (page_off[p + 1] < page_off[p]) DCD_FAIL(DCD_E_BADARG, "page_off must be ascending");
+    u64 len = page_off[p + 1] - page_off[p];
+    if (len == 0) continue;  // empty pages are skipped entirely (Build.cs:483)
+    if (!uniform) {
+      ustr id = mk16(page_ids + ids_off[p], (size_t)(ids_off[p + 1] - ids_off[p]));
+      if (id == u"0") DCD_FAIL(DCD_E_UNSUPPORTED, "header pages (id \"0\", Build.cs:485-524) are not handled by this entry point yet");
+      h->pages.ids.push_back(id);
+    }
+    h->page_off.push_back(base + page_off[p + 1]);
+    h->pages.end.push_back(h->opts.coord_base + base + page_off[p + 1]);
+    if (!docs_per_page) h->pages.page_doc.push_back((u32)(h->pages.docs.size() - 1));
+  }
+  if (docs_per_page) {
+    // every page is its own document: empty pages would break the numbering
+    if (h->pages.end.size() != (h->page_off.size() - 1)) DCD_FAIL(DCD_E_BADARG, "internal page bookkeeping");
+    for (size_t p = 0; p < n_pages; p++)
+      if (page_off[p + 1] == page_off[p]) DCD_FAIL(DCD_E_BADARG, "docs_per_page requires non-empty pages");
+  }
+  h->last_is_explicit = false;
+  return DCD_OK;
+}
+
+int32_t dcd_build_add_pages(dcd_build* h, const void* text, uint64_t n_chars, const uint64_t* page_off, size_t n_pages,
+                            const uint16_t* page_ids, const uint64_t* ids_off, int32_t docs_per_page, uint64_t first_doc,
+                            const uint16_t* source, size_t source_len) {
+  if (!h || (!text && n_chars) || !page_off) DCD_FAIL(DCD_E_BADARG, "dcd_build_add_pages: NULL argument");
+  if (h->finished) DCD_FAIL(DCD_E_STATE, "build already finished");
+  if (h->text_borrowed) DCD_FAIL(DCD_E_STATE, "cannot append host text after dcd_build_add_pages_dev");
+  if (ids_off && !page_ids) DCD_FAIL(DCD_E_BADARG, "ids_off without page_ids");
+  if (h->n_chars + n_chars >= (1ull << 32)) DCD_FAIL(DCD_E_OVERFLOW, "one build segment holds < 2^32 characters; shard larger corpora");
+  DCD_TRY(append_pages_meta(h, page_off, n_pages, n_chars, page_ids, ids_off, docs_per_page, first_doc, source, source_len));
+  DCD_TRY(ensure_device(h->device));
+  const int cs = h->csize();
+  u64 need = (h->n_chars + n_chars) * cs + 64;
+  if (need > h->text_cap) {
+    u64 ncap = std::max<u64>(need, h->text_cap * 2);
+    DevBuf<u8> nb;
+    DCD_TRY(nb.alloc(h->device, ncap));
+    if (h->n_chars) DCD_HIP(hipMemcpyAsync(nb.p, h->text_own.p, h->n_chars * cs, hipMemcpyDeviceToDevice, h->st));
+    DCD_HIP(hipStreamSynchronize(h->st));
+    h->text_own = std::move(nb);
+    h->text_cap = ncap;
+  }
+  if (n_chars) DCD_HIP(hipMemcpyAsync(h->text_own.p + h->n_chars * cs, text, n_chars * cs, hipMemcpyHostToDevice, h->st));
+  DCD_HIP(hipStreamSynchronize(h->st));  // the caller may reuse `text` as soon as we return
+  h->n_chars += n_chars;
+  h->text_dev = h->text_own.p;
+  return DCD_OK;
+}
+
+int32_t dcd_build_add_pages_dev(dcd_build* h, const void* text_dev, uint64_t n_chars, const uint64_t* page_off_host, size_t n_pages,
+                                int32_t docs_per_page, uint64_t first_doc, const uint16_t* source, size_t source_len) {
+  if (!h || !text_dev || !page_off_host) DCD_FAIL(DCD_E_BADARG, "dcd_build_add_pages_dev: NULL argument");
+  if (h->finished) DCD_FAIL(DCD_E_STATE, "build already finished");
+  if (h->n_chars) DCD_FAIL(DCD_E_STATE, "dcd_build_add_pages_dev must be the only text batch of its build");
+  if (((uintptr_t)text_dev & 15) != 0) DCD_FAIL(DCD_E_BADARG, "device text must be 16-byte aligned");
+  if (n_chars >= (1ull << 32)) DCD_FAIL(DCD_E_OVERFLOW, "one build segment holds < 2^32 characters; shard larger corpora");
+  DCD_TRY(append_pages_meta(h, page_off_host, n_pages, n_chars, nullptr, nullptr, docs_per_page, first_doc, source, source_len));
+  h->text_dev = text_dev;
+  h->text_borrowed = true;
+  h->n_chars = n_chars;
+  return DCD_OK;
+}
+
+int32_t dcd_build_add(dcd_build* h, const uint16_t* code, size_t len, uint64_t coord) {
+  if (!h || (!code && len)) DCD_FAIL(DCD_E_BADARG, "dcd_build_add: NULL argument");
+  if (h->finished) DCD_FAIL(DCD_E_STATE, "build already finished");
+  if (len == 0 || len > MAX_CODE_LEN) DCD_FAIL(DCD_E_UNSUPPORTED, "index codes must be 1..%u UTF-16 units long", MAX_CODE_LEN);
+  if (coord < h->opts.coord_base || coord - h->opts.coord_base >= (1ull << 32))
+    DCD_FAIL(DCD_E_OVERFLOW, "explicit coordinate outside this segment's 2^32 window");
+  if (h->opts.encoding == DCD_ENC_LATIN1)
+    for (size_t i = 0; i < len; i++)
+      if (code[i] > 0xFF) DCD_FAIL(DCD_E_UNSUPPORTED, "code unit > 0xFF in a LATIN1 build; create the build with DCD_ENC_UTF16LE");
+  ExplicitPosting x;
+  x.off = (u32)h->xpool.size();
+  x.len = (u32)len;
+  x.coord = coord;
+  h->xpool.insert(h->xpool.end(), code, code + len);
+  h->xps.push_back(x);
+  h->last_is_explicit = true;
+  h->last_explicit_coord = coord;
+  return DCD_OK;
+}
+
+int32_t dcd_build_end_page(dcd_build* h, const uint16_t* id, size_t len) {
+  if (!h || (!id && len)) DCD_FAIL(DCD_E_BADARG, "dcd_build_end_page: NULL argument");
+  if (h->finished) DCD_FAIL(DCD_E_STATE, "build already finished");
+  if (h->pages.docs.empty()) DCD_FAIL(DCD_E_STATE, "dcd_build_add_doc must precede pages (Build.cs:345-347)");
+  if (h->n_chars) DCD_FAIL(DCD_E_UNSUPPORTED, "EndPage(id) after device-tokenised text is not supported; pages end where their text ends");
+  // EndPage(id) -> EndPage(id, maxCoord): the page ends at the last added coordinate (Build.cs:359-367)
+  if (!h->pages.uniform_id.empty() && h->pages.ids.empty() && !h->pages.end.empty()) DCD_FAIL(DCD_E_STATE, "cannot mix uniform and explicit page ids");
+  h->pages.ids.push_back(mk16(id, len));
+  h->pages.end.push_back(h->last_explicit_coord);
+  h->pages.page_doc.push_back((u32)(h->pages.docs.size() - 1));
+  return DCD_OK;
+}
+
+}  // extern "C"
+
+// ================================================================================================
+// finish: the device pipeline
+// ================================================================================================
+template <typename CharT>
+static int32_t finish_impl(dcd_build* h) {
+  const int dev = h->device;
+  hipStream_t st = h->st;
+  DCD_TRY(ensure_device(dev));
+  EvTimer t_all, t_tok, t_voc, t_sort, t_pack, t_img;
+  DCD_TRY(t_all.init(st)); DCD_TRY(t_tok.init(st)); DCD_TRY(t_voc.init(st));
+  DCD_TRY(t_sort.init(st)); DCD_TRY(t_pack.init(st)); DCD_TRY(t_img.init(st));
+
+  const u64 n_chars = h->n_chars;
+  const u64 n_pages_dev = h->page_off.size() - 1;
+  const u64 n_tiles = div_up(n_chars, TK_TILE);
+  const u64 n_x = h->xps.size();
+  const CharT* text = (const CharT*)h->text_dev;
+
+  CharTables16 tab{nullptr, nullptr};
+  if (sizeof(CharT) == 2) DCD_TRY(get_char_tables16(dev, &tab));
+
+  // ---- uploads (not part of the timed device pipeline: the text is already resident) ----------
+  DevBuf<u64> d_page_off;
+  DCD_TRY(d_page_off.alloc(dev, n_pages_dev + 1));
+  DCD_HIP(hipMemcpyAsync(d_page_off.p, h->page_off.data(), (n_pages_dev + 1) * 8, hipMemcpyHostToDevice, st));
+  DevBuf<CharT> d_pool;
+  DevBuf<u32> d_xoff, d_xlen, d_xcoord;
+  if (n_x) {
+    std::vector<CharT> pool(h->xpool.size());
+    for (size_t i = 0; i < pool.size(); i++) pool[i] = (CharT)h->xpool[i];
+    std::vector<u32> xo(n_x), xl(n_x), xc(n_x);
+    for (u64 i = 0; i < n_x; i++) { xo[i] = h->xps[i].off; xl[i] = h->xps[i].len; xc[i] = (u32)(h->xps[i].coord - h->opts.coord_base); }
+    DCD_TRY(d_pool.alloc(dev, pool.size()));
+    DCD_TRY(d_xoff.alloc(dev, n_x)); DCD_TRY(d_xlen.alloc(dev, n_x)); DCD_TRY(d_xcoord.alloc(dev, n_x));
+    DCD_HIP(hipMemcpyAsync(d_pool.p, pool.data(), pool.size() * sizeof(CharT), hipMemcpyHostToDevice, st));
+    DCD_HIP(hipMemcpyAsync(d_xoff.p, xo.data(), n_x * 4, hipMemcpyHostToDevice, st));
+    DCD_HIP(hipMemcpyAsync(d_xlen.p, xl.data(), n_x * 4, hipMemcpyHostToDevice, st));
+    DCD_HIP(hipMemcpyAsync(d_xcoord.p, xc.data(), n_x * 4, hipMemcpyHostToDevice, st));
+    DCD_HIP(hipStreamSynchronize(st));
+  }
+  DevBuf<u64> d_page_end;
+  if (!h->pages.end.empty()) {
+    DCD_TRY(d_page_end.alloc(dev, h->pages.end.size()));
+    DCD_HIP(hipMemcpyAsync(d_page_end.p, h->pages.end.data(), h->pages.end.size() * 8, hipMemcpyHostToDevice, st));
+  }
+  DCD_HIP(hipStreamSynchronize(st));
+
+  DCD_TRY(t_all.start());
+  // ---- 1. tokenise: count pass -------------------------------------------------------------------
+  DCD_TRY(t_tok.start());
+  TokParams P;
+  P.n_chars = n_chars;
+  P.page_off = d_page_off.p;
+  P.n_pages = n_pages_dev;
+  P.min_len = (u32)h->opts.min_word_length;
+  P.max_len = (u32)h->opts.max_word_length;
+  DevBuf<u32> tile_count;
+  DevBuf<u64> tile_off, scan_scr64;
+  u64 n_text_tok = 0;
+  if (n_tiles) {
+    DCD_TRY(tile_count.alloc(dev, n_tiles));
+    DCD_TRY(tile_off.alloc(dev, n_tiles));
+    DCD_TRY(scan_scr64.alloc(dev, scan_scratch_elems(n_tiles)));
+    hipLaunchKernelGGL((k_tok_count<CharT>), dim3((u32)n_tiles), dim3(TK_THREADS), 0, st, text, P, tab, tile_count.p);
+    scan_exclusive<u32, u64>(tile_count.p, tile_off.p, n_tiles, scan_scr64.p, st);
+    DCD_HIP(hipMemcpyAsync(&n_text_tok, scan_scr64.p + scan_nblocks(n_tiles), 8, hipMemcpyDeviceToHost, st));
+    DCD_HIP(hipStreamSynchronize(st));
+  }
+  const u64 N = n_text_tok + n_x;
+  if (N >= (1ull << 32)) DCD_FAIL(DCD_E_OVERFLOW, "more than 2^32 postings in one build segment");
+
+  // ---- 2. vocabulary table + emit ---------------------------------------------------------------
+  DevBuf<uint2> tupA, tupB;
+  DCD_TRY(tupA.alloc(dev, N ? N : 1));
+  DCD_TRY(tupB.alloc(dev, N ? N : 1));
+  u32 cap_log2 = h->opts.vocab_capacity_log2;
+  if (cap_log2 == 0) {
+    cap_log2 = log2_ceil((N ? N : 1) / 4 + 1);
+    if (cap_log2 < 12) cap_log2 = 12;
+    if (cap_log2 > 25) cap_log2 = 25;
+  }
+  DevBuf<u64> slots;
+  DevBuf<u32> d_flags;  // [0] overflow, [1] maxlen, [2] max coord (explicit)
+  DCD_TRY(d_flags.alloc(dev, 4));
+  TextView<CharT> tv;
+  tv.text = text; tv.n_chars = n_chars; tv.pool = d_pool.p; tv.tab = tab;
+  u64 V = 0;
+  DevBuf<u32> slot_excl;
+  DevBuf<u32> scan_scr32;
+  for (;;) {
+    if (cap_log2 > 30) DCD_FAIL(DCD_E_OVERFLOW, "vocabulary does not fit a 2^30-slot table");
+    const u64 cap = 1ull << cap_log2;
+    DCD_TRY(slots.alloc(dev, cap));
+    DCD_HIP(hipMemsetAsync(slots.p, 0, cap * 8, st));
+    DCD_HIP(hipMemsetAsync(d_flags.p, 0, 16, st));
+    VocabTable vt;
+    vt.slots = slots.p; vt.mask = (u32)(cap - 1); vt.overflow = d_flags.p;
+    if (n_tiles)
+      hipLaunchKernelGGL((k_tok_emit<CharT>), dim3((u32)n_tiles), dim3(TK_THREADS), 0, st, text, P, tab, tv, vt, tile_off.p, tupA.p);
+    if (n_x)
+      hipLaunchKernelGGL((k_explicit<CharT>), dim3((u32)div_up(n_x, 256)), dim3(256), 0, st, d_pool.p, d_xoff.p, d_xlen.p, d_xcoord.p,
+                         n_x, tv, vt, tupA.p + n_text_tok);
+    // compaction: dense ids for the used slots
+    DCD_TRY(slot_excl.alloc(dev, cap));
+    DCD_TRY(scan_scr32.alloc(dev, std::max<u64>(scan_scratch_elems(cap), scan_scratch_elems((u64)RS_MAX_BLOCKS << 10))));
+    scan_exclusive_f<SlotUsed, u32>(SlotUsed{slots.p}, slot_excl.p, cap, scan_scr32.p, st);
+    u32 flags[4] = {0, 0, 0, 0};
+    u32 v32 = 0;
+    DCD_HIP(hipMemcpyAsync(flags, d_flags.p, 16, hipMemcpyDeviceToHost, st));
+    DCD_HIP(hipMemcpyAsync(&v32, scan_scr32.p + scan_nblocks(cap), 4, hipMemcpyDeviceToHost, st));
+    DCD_HIP(hipStreamSynchronize(st));
+    V = v32;
+    if (flags[0] || V * 2 > cap) { cap_log2 += 2; continue; }  // overflow or load > 0.5: rebuild larger
+    break;
+  }
+  const u64 cap = 1ull << cap_log2;
+  DCD_TRY(t_tok.stop());
+  // maxCoord = coordinate of the last posting added (Build.cs:326)
+  u32 last_text_coord = 0;
+  if (n_text_tok) DCD_HIP(hipMemcpyAsync(&last_text_coord, &tupA.p[n_text_tok - 1].y, 4, hipMemcpyDeviceToHost, st));
+
+  // ---- 3. vocabulary: compact, sort the term strings ordinally -------------------------------
+  DCD_TRY(t_voc.start());
+  DevBuf<u64> term_word, rk_word;
+  DevBuf<u32> term_slot, rank_of_slot, d_hist;
+  DevBuf<uint2> permA, permB;
+  DCD_TRY(term_word.alloc(dev, V ? V : 1));
+  DCD_TRY(rk_word.alloc(dev, V ? V : 1));
+  DCD_TRY(term_slot.alloc(dev, V ? V : 1));
+  DCD_TRY(rank_of_slot.alloc(dev, cap));
+  DCD_TRY(d_hist.alloc(dev, (u64)RS_MAX_BLOCKS << 10));
+  DCD_TRY(permA.alloc(dev, V ? V : 1));
+  DCD_TRY(permB.alloc(dev, V ? V : 1));
+  u32 maxlen = 0;
+  if (V) {
+    hipLaunchKernelGGL(k_vocab_compact, dim3((u32)div_up(cap, 256)), dim3(256), 0, st, slots.p, cap, slot_excl.p, term_word.p,
+                       term_slot.p, d_flags.p + 1);
+    DCD_HIP(hipMemcpyAsync(&maxlen, d_flags.p + 1, 4, hipMemcpyDeviceToHost, st));
+    DCD_HIP(hipStreamSynchronize(st));
+    constexpr u32 K = sizeof(CharT) == 1 ? 4 : 2;
+    const u32 nchunks = (maxlen + K - 1) / K;
+    uint2* cur = permA.p;
+    uint2* other = permB.p;
+    for (int c = (int)nchunks - 1; c >= 0; c--) {
+      hipLaunchKernelGGL((k_term_keys<CharT>), dim3((u32)div_up(V, 256)), dim3(256), 0, st, cur, V, term_word.p, tv, (u32)c,
+                         c == (int)nchunks - 1);
+      uint2* res = rs_sort(cur, other, nullptr, V, 32, d_hist.p, scan_scr32.p, st);
+      if (res != cur) { other = cur; cur = res; }
+    }
+    hipLaunchKernelGGL(k_assign_rank, dim3((u32)div_up(V, 256)), dim3(256), 0, st, cur, V, term_slot.p, term_word.p, rank_of_slot.p,
+                       rk_word.p);
+  }
+  DCD_TRY(t_voc.stop());
+
+  // ---- 4. sort the tuples by term (stable; explicit postings first need coordinate order) ----
+  DCD_TRY(t_sort.start());
+  uint2* sorted = tupA.p;
+  int passes = 0;
+  if (N) {
+    uint2* a = tupA.p;
+    uint2* b = tupB.p;
+    if (n_x) {
+      // mixed input is not in coordinate order: LSD over the coordinate bits first
+      hipLaunchKernelGGL(k_max_y, dim3((u32)div_up(N, 256)), dim3(256), 0, st, a, N, d_flags.p + 2);
+      u32 maxc = 0;
+      DCD_HIP(hipMemcpyAsync(&maxc, d_flags.p + 2, 4, hipMemcpyDeviceToHost, st));
+      DCD_HIP(hipStreamSynchronize(st));
+      hipLaunchKernelGGL(k_swap_xy, dim3((u32)div_up(N, 256)), dim3(256), 0, st, a, N);
+      int p1 = 0;
+      uint2* r = rs_sort(a, b, nullptr, N, (int)log2_ceil((u64)maxc + 1), d_hist.p, scan_scr32.p, st, &p1);
+      passes += p1;
+      if (r != a) { b = a; a = r; }
+      hipLaunchKernelGGL(k_swap_xy, dim3((u32)div_up(N, 256)), dim3(256), 0, st, a, N);
+    }
+    int p2 = 0;
+    sorted = rs_sort(a, b, rank_of_slot.p, N, (int)log2_ceil(V ? V : 1), d_hist.p, scan_scr32.p, st, &p2);
+    passes += p2;
+  }
+  DCD_TRY(t_sort.stop());
+
+  // ---- 5. pack: deltas -> var-ushort units (IndexSequence.Builder.Add) -----------------------
+  DCD_TRY(t_pack.start());
+  DeviceIndex& ix = h->ix;
+  ix.device = dev;
+  DCD_TRY(ix.term_unit_start.alloc(dev, V + 1));
+  DCD_TRY(ix.term_item_start.alloc(dev, V + 1));
+  DevBuf<u64> enc_part;
+  u64 enb = encode_nblocks(N);
+  DCD_TRY(enc_part.alloc(dev, enb + 1));
+  u64 U = 0;
+  EncSrcPairs src;
+  src.p = sorted; src.base = h->opts.coord_base; src.term_unit_start = ix.term_unit_start.p; src.term_item_start = ix.term_item_start.p;
+  if (N) {
+    hipLaunchKernelGGL((k_enc_reduce<EncSrcPairs>), dim3((u32)enb), dim3(CODEC_THREADS), 0, st, src, N, enc_part.p);
+    hipLaunchKernelGGL((k_scan_partials<u64>), dim3(1), dim3(1024), 0, st, enc_part.p, enb);
+    DCD_HIP(hipMemcpyAsync(&U, enc_part.p + enb, 8, hipMemcpyDeviceToHost, st));
+    DCD_HIP(hipStreamSynchronize(st));
+  }
+  DCD_TRY(ix.units.alloc(dev, U ? U : 1));
+  if (N) hipLaunchKernelGGL((k_enc_write<EncSrcPairs>), dim3((u32)enb), dim3(CODEC_THREADS), 0, st, src, N, enc_part.p, ix.units.p);
+  hipLaunchKernelGGL(k_set_u64, dim3(1), dim3(1), 0, st, ix.term_unit_start.p + V, U);
+  hipLaunchKernelGGL(k_set_u64, dim3(1), dim3(1), 0, st, ix.term_item_start.p + V, N);
+  DCD_TRY(t_pack.stop());
+
+  // ---- 6. keys + ".index" image -----------------------------------------------------------------
+  DCD_TRY(t_img.start());
+  DCD_TRY(ix.term_str_off.alloc(dev, V + 1));
+  u32 total_chars = 0;
+  if (V) {
+    scan_exclusive_f<TermLenF, u32>(TermLenF{rk_word.p}, ix.term_str_off.p, V, scan_scr32.p, st);
+    DCD_HIP(hipMemcpyAsync(&total_chars, scan_scr32.p + scan_nblocks(V), 4, hipMemcpyDeviceToHost, st));
+    DCD_HIP(hipStreamSynchronize(st));
+  }
+  DCD_HIP(hipMemcpyAsync(ix.term_str_off.p + V, &total_chars, 4, hipMemcpyHostToDevice, st));
+  DCD_TRY(ix.term_chars.alloc(dev, total_chars ? total_chars : 1));
+  DevBuf<u64> rec_off, pay_off, scr64b;
+  DCD_TRY(rec_off.alloc(dev, V + 1));
+  DCD_TRY(pay_off.alloc(dev, V + 1));
+  DCD_TRY(scr64b.alloc(dev, scan_scratch_elems(V ? V : 1)));
+  u64 rec_total = 0;
+  if (V) {
+    hipLaunchKernelGGL((k_term_strings<CharT>), dim3((u32)div_up(V, 256)), dim3(256), 0, st, rk_word.p, V, ix.term_str_off.p, tv,
+                       ix.term_chars.p);
+    scan_exclusive_f<RecSizeF, u64>(RecSizeF{ix.term_chars.p, ix.term_str_off.p, ix.term_unit_start.p}, rec_off.p, V, scr64b.p, st);
+    DCD_HIP(hipMemcpyAsync(&rec_total, scr64b.p + scan_nblocks(V), 8, hipMemcpyDeviceToHost, st));
+  }
+  DCD_HIP(hipStreamSynchronize(st));
+  u64 max_coord = 0;
+  {
+    // coordinate of the last Add call: the later of (last explicit posting, last text token)
+    if (h->last_is_explicit && n_x) max_coord = h->last_explicit_coord;
+    else if (n_text_tok) max_coord = h->opts.coord_base + last_text_coord;
+    else if (n_x) max_coord = h->last_explicit_coord;
+  }
+  h->image_bytes = 8 + rec_total;
+  DCD_TRY(h->image.alloc(dev, h->image_bytes));
+  hipLaunchKernelGGL(k_put_u64_bytes, dim3(1), dim3(1), 0, st, h->image.p, max_coord);
+  if (V) {
+    hipLaunchKernelGGL(k_img_headers, dim3((u32)div_up(V, 256)), dim3(256), 0, st, ix.term_chars.p, ix.term_str_off.p,
+                       ix.term_unit_start.p, rec_off.p, V, (u64)8, h->image.p, pay_off.p);
+    if (U)
+      hipLaunchKernelGGL(k_img_units, dim3((u32)div_up(div_up(U, IMG_UPT), 256)), dim3(256), 0, st, ix.units.p, U, ix.term_unit_start.p, V,
+                         pay_off.p, h->image.p);
+  }
+  DCD_TRY(t_img.stop());
+  DCD_TRY(t_all.stop());
+  DCD_HIP(hipStreamSynchronize(st));
+  DCD_HIP(hipGetLastError());
+
+  // ---- host mirrors + stats ----------------------------------------------------------------------
+  ix.n_terms = V; ix.n_units = U; ix.n_postings = N; ix.max_coord = max_coord;
+  ix.page_end = std::move(d_page_end);
+  ix.h_term_chars.resize(total_chars);
+  ix.h_term_str_off.resize(V + 1);
+  ix.h_term_unit_start.resize(V + 1);
+  ix.h_term_item_start.resize(V + 1);
+  if (total_chars) DCD_HIP(hipMemcpy(ix.h_term_chars.data(), ix.term_chars.p, (size_t)total_chars * 2, hipMemcpyDeviceToHost));
+  DCD_HIP(hipMemcpy(ix.h_term_str_off.data(), ix.term_str_off.p, (V + 1) * 4, hipMemcpyDeviceToHost));
+  DCD_HIP(hipMemcpy(ix.h_term_unit_start.data(), ix.term_unit_start.p, (V + 1) * 8, hipMemcpyDeviceToHost));
+  DCD_HIP(hipMemcpy(ix.h_term_item_start.data(), ix.term_item_start.p, (V + 1) * 8, hipMemcpyDeviceToHost));
+  ix.pages = h->pages;
+  write_list_image(h->pages, h->list_image);
+
+  dcd_build_stats& s = h->stats;
+  s.n_chars = n_chars; s.n_pages = h->pages.n_pages(); s.n_docs = h->pages.n_docs();
+  s.n_postings = N; s.n_terms = V; s.n_units = U; s.max_coord = max_coord;
+  s.index_bytes = h->image_bytes; s.list_bytes = h->list_image.size();
+  s.ms_tokenize = t_tok.ms(); s.ms_vocab = t_voc.ms(); s.ms_sort = t_sort.ms(); s.ms_pack = t_pack.ms(); s.ms_image = t_img.ms();
+  s.ms_total = t_all.ms();
+  s.sort_passes = (u32)passes; s.vocab_capacity_log2 = cap_log2;
+  h->finished = true;
+  return DCD_OK;
+}
+
+extern "C" {
+
+int32_t dcd_build_finish(dcd_build* h) {
+  if (!h) DCD_FAIL(DCD_E_BADARG, "dcd_build_finish: NULL handle");
+  if (h->finished) DCD_FAIL(DCD_E_STATE, "build already finished");
+  if (h->opts.encoding == DCD_ENC_UTF16LE) return finish_impl<u16>(h);
+  return finish_impl<u8>(h);
+}
+
+int32_t dcd_build_get_stats(dcd_build* h, dcd_build_stats* out) {
+  if (!h || !out) DCD_FAIL(DCD_E_BADARG, "dcd_build_get_stats: NULL argument");
+  if (!h->finished) DCD_FAIL(DCD_E_STATE, "dcd_build_finish has not run");
+  *out = h->stats;
+  return DCD_OK;
+}
+
+int32_t dcd_build_index_image(dcd_build* h, uint8_t* out, size_t cap, size_t* n) {
+  if (!h || !n) DCD_FAIL(DCD_E_BADARG, "dcd_build_index_image: NULL argument");
+  if (!h->finished) DCD_FAIL(DCD_E_STATE, "dcd_build_finish has not run");
+  *n = (size_t)h->image_bytes;
+  if (!out || cap < h->image_bytes) return DCD_E_OVERFLOW;
+  DCD_TRY(ensure_device(h->device));
+  DCD_HIP(hipMemcpy(out, h->image.p, h->image_bytes, hipMemcpyDeviceToHost));
+  return DCD_OK;
+}
+
+int32_t dcd_build_list_image(dcd_build* h, uint8_t* out, size_t cap, size_t* n) {
+  if (!h || !n) DCD_FAIL(DCD_E_BADARG, "dcd_build_list_image: NULL argument");
+  if (!h->finished) DCD_FAIL(DCD_E_STATE, "dcd_build_finish has not run");
+  *n = h->list_image.size();
+  if (!out || cap < h->list_image.size()) return DCD_E_OVERFLOW;
+  memcpy(out, h->list_image.data(), h->list_image.size());
+  return DCD_OK;
+}
+
+int32_t dcd_build_save(dcd_build* h, const char* dir_utf8) {
+  if (!h || !dir_utf8) DCD_FAIL(DCD_E_BADARG, "dcd_build_save: NULL argument");
+  if (!h->finished) DCD_FAIL(DCD_E_STATE, "dcd_build_finish has not run");
+  std::vector<u8> img(h->image_bytes);
+  size_t n = 0;
+  DCD_TRY(dcd_build_index_image(h, img.data(), img.size(), &n));
+  std::string d(dir_utf8);
+  if (!d.empty() && d.back() != '/') d.push_back('/');
+  FILE* f = fopen((d + ".index").c_str(), "wb");
+  if (!f) DCD_FAIL(DCD_E_IO, "cannot create %s.index", d.c_str());
+  bool ok = fwrite(img.data(), 1, img.size(), f) == img.size();
+  ok = fclose(f) == 0 && ok;
+  if (!ok) DCD_FAIL(DCD_E_IO, "short write to %s.index", d.c_str());
+  f = fopen((d + ".index.list").c_str(), "wb");
+  if (!f) DCD_FAIL(DCD_E_IO, "cannot create %s.index.list", d.c_str());
+  ok = fwrite(h->list_image.data(), 1, h->list_image.size(), f) == h->list_image.size();
+  ok = fclose(f) == 0 && ok;
+  if (!ok) DCD_FAIL(DCD_E_IO, "short write to %s.index.list", d.c_str());
+  return DCD_OK;
+}
+
+}  // extern "C"

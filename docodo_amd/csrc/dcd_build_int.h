@@ -1,0 +1,59 @@
+// dcd_build_int.h -- internal layout of a finished build: the HBM-resident index that both the
+// ".index" image writer and the query path consume.
+#pragma once
+#include <string>
+#include <vector>
+
+#include "dcd_common.h"
+
+namespace dcd {
+
+typedef std::u16string ustr;
+
+// Documents / pages as Index.Builder.pages keeps them (Build.cs:343-367): a document entry opens a
+// doc, page entries carry the id and the END coordinate of the page.
+struct DocMeta {
+  ustr name;           // "source:name" (Build.cs:355)
+  u64 first_page;      // index of its first page in the page table
+};
+struct PageTable {
+  // Explicit pages (ids stored) ...
+  std::vector<ustr> ids;          // per page id; empty vector when `uniform_id` is used
+  ustr uniform_id;                // id shared by all pages (synthetic corpora: "1")
+  std::vector<u64> end;           // END coordinate per page (IndexPageList key, Build.cs:66)
+  std::vector<DocMeta> docs;      // explicit docs
+  // ... or one document per page named by its decimal index
+  bool doc_per_page = false;
+  ustr source;                    // source name for doc_per_page
+  u64 first_doc = 0;
+  std::vector<u32> page_doc;      // doc index per page (explicit docs only)
+  u64 n_pages() const { return end.size(); }
+  u64 n_docs() const { return doc_per_page ? end.size() : docs.size(); }
+  ustr doc_name(u64 d) const;
+  ustr page_id(u64 p) const { return ids.empty() ? uniform_id : ids[p]; }
+  u32 doc_of_page(u64 p) const { return doc_per_page ? (u32)p : page_doc[p]; }
+};
+
+// Device-resident index (term order = String.CompareOrdinal order of the keys, Index.cs:142-151)
+struct DeviceIndex {
+  int device = 0;
+  u64 n_terms = 0, n_units = 0, n_postings = 0, max_coord = 0;
+  DevBuf<u16> units;             // all posting lists back to back, term 0 first
+  DevBuf<u64> term_unit_start;   // [n_terms + 1]
+  DevBuf<u64> term_item_start;   // [n_terms + 1] posting (value) counts as differences
+  DevBuf<u16> term_chars;        // keys, UTF-16 code units, back to back
+  DevBuf<u32> term_str_off;      // [n_terms + 1]
+  DevBuf<u64> page_end;          // [n_pages] END coordinates (device copy of PageTable::end)
+  // host mirrors (small): keys for dcd_index_find, offsets
+  std::vector<u16> h_term_chars;
+  std::vector<u32> h_term_str_off;
+  std::vector<u64> h_term_unit_start;
+  std::vector<u64> h_term_item_start;
+  PageTable pages;
+};
+
+void write_list_image(const PageTable& pt, std::vector<u8>& out);  // ".index.list", Build.cs:99-118
+void utf16_to_utf8(const u16* s, size_t n, std::string& out);
+bool utf8_to_utf16(const u8* p, size_t n, ustr& out);
+
+}  // namespace dcd

@@ -1,0 +1,111 @@
+// dcd_codec.h -- device kernels of the 15-bit var-ushort delta code (IndexSequence.cs:63-84
+// encode, :114-136 decode), shared by the codec entry points, the build's pack stage and the
+// query path.  All work is HBM-streaming: reduce -> scan of per-block partials -> apply.
+#pragma once
+#include "dcd_common.h"
+#include "dcd_prims.h"
+#include "dcd_scan.h"
+
+namespace dcd {
+
+constexpr int CODEC_THREADS = 256;
+constexpr int CODEC_ITEMS = 8;
+constexpr int CODEC_TILE = CODEC_THREADS * CODEC_ITEMS;
+
+// ---- delta sources for the encoder -----------------------------------------------------------
+// Src::delta(i) -> u64 delta of item i; Src::on_item(i, unit_offset, delta) -> side outputs.
+struct EncSrcValues {  // plain ascending values, first delta from 0 (IndexSequence.Builder.Add)
+  const u64* v;
+  __device__ __forceinline__ u64 delta(u64 i) const { return v[i] - (i ? v[i - 1] : 0ull); }
+  __device__ __forceinline__ void on_item(u64, u64, u64) const {}
+};
+
+// Sorted (term, coord) pairs of the build: the first posting of a term is coded from 0 (absolute
+// coordinate = base + local), the others as differences (Build.cs:324-333 -> IndexSequence.cs:63).
+struct EncSrcPairs {
+  const uint2* p;      // x = term rank, y = segment-local coordinate
+  u64 base;            // global coordinate of local 0
+  u64* term_unit_start;  // [n_terms+1]
+  u64* term_item_start;  // [n_terms+1]
+  __device__ __forceinline__ bool head(u64 i) const { return i == 0 || p[i].x != p[i - 1].x; }
+  __device__ __forceinline__ u64 delta(u64 i) const {
+    uint2 c = p[i];
+    if (i == 0) return base + c.y;
+    uint2 q = p[i - 1];
+    return q.x != c.x ? base + c.y : (u64)c.y - (u64)q.y;
+  }
+  __device__ __forceinline__ void on_item(u64 i, u64 off, u64) const {
+    if (head(i)) { term_unit_start[p[i].x] = off; term_item_start[p[i].x] = i; }
+  }
+};
+
+template <typename Src>
+__global__ __launch_bounds__(CODEC_THREADS) void k_enc_reduce(Src src, u64 n, u64* __restrict__ partial) {
+  __shared__ u32 lds[4];
+  u64 base = (u64)blockIdx.x * CODEC_TILE;
+  u32 s = 0;
+#pragma unroll
+  for (int j = 0; j < CODEC_ITEMS; j++) {
+    u64 i = base + (u64)j * CODEC_THREADS + threadIdx.x;
+    if (i < n) s += seq_nunits(src.delta(i));
+  }
+  s = wave_sum(s);
+  if (lane_id() == 0) lds[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = (u64)lds[0] + lds[1] + lds[2] + lds[3];
+}
+
+template <typename Src>
+__global__ __launch_bounds__(CODEC_THREADS) void k_enc_write(Src src, u64 n, const u64* __restrict__ partial,
+                                                            u16* __restrict__ out) {
+  __shared__ u32 lds[5];
+  u64 base = (u64)blockIdx.x * CODEC_TILE + (u64)threadIdx.x * CODEC_ITEMS;
+  u64 d[CODEC_ITEMS];
+  u32 nu[CODEC_ITEMS];
+  u32 s = 0;
+#pragma unroll
+  for (int j = 0; j < CODEC_ITEMS; j++) {
+    u64 i = base + j;
+    d[j] = i < n ? src.delta(i) : 0;
+    nu[j] = i < n ? seq_nunits(d[j]) : 0;
+    s += nu[j];
+  }
+  u32 tot;
+  u64 off = partial[blockIdx.x] + block_scan_excl<u32, 4>(s, lds, &tot);
+#pragma unroll
+  for (int j = 0; j < CODEC_ITEMS; j++) {
+    u64 i = base + j;
+    if (i < n) {
+      src.on_item(i, off, d[j]);
+      for (u32 g = 0; g < nu[j]; g++) out[off + g] = seq_unit(d[j], g, nu[j]);
+      off += nu[j];
+    }
+  }
+}
+
+// Encodes n items.  partial: >= div_up(n, CODEC_TILE) + 1 u64 (grand total of units left in
+// partial[nblocks]).  out must hold the total (<= 5 n).
+template <typename Src>
+inline void encode_launch(const Src& src, u64 n, u64* partial, u16* out, hipStream_t st) {
+  u64 nb = div_up(n ? n : 1, CODEC_TILE);
+  hipLaunchKernelGGL((k_enc_reduce<Src>), dim3((u32)nb), dim3(CODEC_THREADS), 0, st, src, n, partial);
+  hipLaunchKernelGGL((k_scan_partials<u64>), dim3(1), dim3(1024), 0, st, partial, nb);
+  hipLaunchKernelGGL((k_enc_write<Src>), dim3((u32)nb), dim3(CODEC_THREADS), 0, st, src, n, partial, out);
+}
+inline u64 encode_nblocks(u64 n) { return div_up(n ? n : 1, CODEC_TILE); }
+
+// ---- decoder ----------------------------------------------------------------------------------
+// A value ends at every unit whose bit 15 is clear.  Step 1 counts terminators per block, step 2
+// lets each terminator thread gather its group (walking back over continuation units) into a
+// delta, step 3 prefix-sums the deltas (u64, wrapping like the C# ulong).
+__global__ void k_dec_count(const u16* __restrict__ u, u64 n, u64* __restrict__ partial);
+__global__ void k_dec_deltas(const u16* __restrict__ u, u64 n, const u64* __restrict__ partial, u64* __restrict__ deltas);
+__global__ void k_add_inplace(u64* __restrict__ excl, const u64* __restrict__ deltas, u64 n);
+
+// units[0..n) -> values.  scratch_a: >= div_up(n,CODEC_TILE)+1 u64; deltas: >= n_values u64
+// (n is always enough); scan_scratch: >= scan_scratch_elems(n) u64.  *n_values_dev = partial[nb].
+void decode_count_launch(const u16* units, u64 n, u64* partial, hipStream_t st);   // partial[nb] = #values
+void decode_values_launch(const u16* units, u64 n, const u64* partial_scanned, u64 n_values, u64* deltas,
+                          u64* values, u64* scan_scratch, hipStream_t st);
+
+}  // namespace dcd

@@ -1,0 +1,197 @@
+// dcd_codec.hip -- IndexSequence codec entry points (dcd_seq_encode / decode / count / shift).
+// Reference: IndexSequence.cs:63-90 (Builder.Add/AddRange), :114-136 (SeqEnumerator.MoveNext),
+// :191-202 (Shift).
+#include "dcd_codec.h"
+
+namespace dcd {
+
+__global__ __launch_bounds__(CODEC_THREADS) void k_dec_count(const u16* __restrict__ u, u64 n, u64* __restrict__ partial) {
+  __shared__ u32 lds[4];
+  u64 base = (u64)blockIdx.x * CODEC_TILE;
+  u32 s = 0;
+#pragma unroll
+  for (int j = 0; j < CODEC_ITEMS; j++) {
+    u64 i = base + (u64)j * CODEC_THREADS + threadIdx.x;
+    if (i < n) s += (u[i] & 0x8000u) ? 0u : 1u;
+  }
+  s = wave_sum(s);
+  if (lane_id() == 0) lds[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = (u64)lds[0] + lds[1] + lds[2] + lds[3];
+}
+
+__global__ __launch_bounds__(CODEC_THREADS) void k_dec_deltas(const u16* __restrict__ u, u64 n, const u64* __restrict__ partial,
+                                                             u64* __restrict__ deltas) {
+  __shared__ u32 lds[5];
+  u64 base = (u64)blockIdx.x * CODEC_TILE + (u64)threadIdx.x * CODEC_ITEMS;
+  u16 v[CODEC_ITEMS];
+  u32 cnt = 0;
+#pragma unroll
+  for (int j = 0; j < CODEC_ITEMS; j++) {
+    u64 i = base + j;
+    v[j] = i < n ? u[i] : (u16)0x8000;
+    cnt += (v[j] & 0x8000u) ? 0u : 1u;
+  }
+  u32 tot;
+  u64 vi = partial[blockIdx.x] + block_scan_excl<u32, 4>(cnt, lds, &tot);
+#pragma unroll
+  for (int j = 0; j < CODEC_ITEMS; j++) {
+    u64 i = base + j;
+    if (i < n && !(v[j] & 0x8000u)) {
+      // group = maximal run of continuation units ending at i; low group first.  C# shifts a
+      // ulong by (15 k) & 63 (IndexSequence.cs:126), reproduced for non-canonical input.
+      u64 s = i;
+      while (s > 0 && (u[s - 1] & 0x8000u)) s--;
+      u64 d = 0;
+      u32 sh = 0;
+      for (u64 k = s; k <= i; k++) { d += ((u64)(u[k] & 0x7FFFu)) << (sh & 63u); sh += 15; }
+      deltas[vi++] = d;
+    }
+  }
+}
+
+__global__ void k_add_inplace(u64* __restrict__ excl, const u64* __restrict__ deltas, u64 n) {
+  u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) excl[i] += deltas[i];
+}
+
+void decode_count_launch(const u16* units, u64 n, u64* partial, hipStream_t st) {
+  u64 nb = div_up(n ? n : 1, CODEC_TILE);
+  hipLaunchKernelGGL(k_dec_count, dim3((u32)nb), dim3(CODEC_THREADS), 0, st, units, n, partial);
+  hipLaunchKernelGGL((k_scan_partials<u64>), dim3(1), dim3(1024), 0, st, partial, nb);
+}
+
+void decode_values_launch(const u16* units, u64 n, const u64* partial_scanned, u64 n_values, u64* deltas, u64* values,
+                          u64* scan_scratch, hipStream_t st) {
+  u64 nb = div_up(n ? n : 1, CODEC_TILE);
+  hipLaunchKernelGGL(k_dec_deltas, dim3((u32)nb), dim3(CODEC_THREADS), 0, st, units, n, partial_scanned, deltas);
+  if (n_values) {
+    scan_exclusive<u64, u64>(deltas, values, n_values, scan_scratch, st);
+    hipLaunchKernelGGL(k_add_inplace, dim3((u32)div_up(n_values, 256)), dim3(256), 0, st, values, deltas, n_values);
+  }
+}
+
+// per-thread stream + device for the stateless seq_* entry points
+struct SeqCtx {
+  int device = 0;
+  hipStream_t st = nullptr;
+};
+static int32_t seq_ctx(SeqCtx** out) {
+  static thread_local SeqCtx ctx;
+  DCD_TRY(ensure_device(ctx.device));
+  if (!ctx.st) DCD_HIP(hipStreamCreateWithFlags(&ctx.st, hipStreamNonBlocking));
+  *out = &ctx;
+  return DCD_OK;
+}
+
+}  // namespace dcd
+
+using namespace dcd;
+
+extern "C" {
+
+int32_t dcd_seq_encode(const uint64_t* values, size_t n, uint16_t* out, size_t cap, size_t* n_units) {
+  if ((!values && n) || !n_units) DCD_FAIL(DCD_E_BADARG, "dcd_seq_encode: NULL argument");
+  if (n == 0) { *n_units = 0; return DCD_OK; }
+  SeqCtx* c;
+  DCD_TRY(seq_ctx(&c));
+  DevBuf<u64> dv, part;
+  DevBuf<u16> du;
+  u64 nb = encode_nblocks(n);
+  DCD_TRY(dv.alloc(c->device, n));
+  DCD_TRY(part.alloc(c->device, nb + 1));
+  DCD_TRY(du.alloc(c->device, 5 * n));
+  DCD_HIP(hipMemcpyAsync(dv.p, values, n * 8, hipMemcpyHostToDevice, c->st));
+  EncSrcValues src{dv.p};
+  encode_launch(src, n, part.p, du.p, c->st);
+  u64 total = 0;
+  DCD_HIP(hipMemcpyAsync(&total, part.p + nb, 8, hipMemcpyDeviceToHost, c->st));
+  DCD_HIP(hipStreamSynchronize(c->st));
+  *n_units = (size_t)total;
+  if (total > cap || !out) {
+    if (out || cap) DCD_FAIL(DCD_E_OVERFLOW, "dcd_seq_encode: need %llu units, cap %zu", (unsigned long long)total, cap);
+    return DCD_E_OVERFLOW;
+  }
+  DCD_HIP(hipMemcpy(out, du.p, total * 2, hipMemcpyDeviceToHost));
+  return DCD_OK;
+}
+
+static int32_t seq_decode_impl(const uint16_t* units, size_t n_units, uint64_t* out, size_t cap, size_t* n, bool want) {
+  if ((!units && n_units) || !n) DCD_FAIL(DCD_E_BADARG, "dcd_seq_decode: NULL argument");
+  if (n_units == 0) { *n = 0; return DCD_OK; }
+  SeqCtx* c;
+  DCD_TRY(seq_ctx(&c));
+  DevBuf<u16> du;
+  DevBuf<u64> part;
+  u64 nb = div_up(n_units, CODEC_TILE);
+  DCD_TRY(du.alloc(c->device, n_units));
+  DCD_TRY(part.alloc(c->device, nb + 1));
+  DCD_HIP(hipMemcpyAsync(du.p, units, n_units * 2, hipMemcpyHostToDevice, c->st));
+  decode_count_launch(du.p, n_units, part.p, c->st);
+  u64 nv = 0;
+  DCD_HIP(hipMemcpyAsync(&nv, part.p + nb, 8, hipMemcpyDeviceToHost, c->st));
+  DCD_HIP(hipStreamSynchronize(c->st));
+  *n = (size_t)nv;
+  if (!want) return DCD_OK;
+  if (nv > cap || (!out && nv)) {
+    if (out || cap) DCD_FAIL(DCD_E_OVERFLOW, "dcd_seq_decode: need %llu values, cap %zu", (unsigned long long)nv, cap);
+    return DCD_E_OVERFLOW;
+  }
+  if (nv == 0) return DCD_OK;
+  DevBuf<u64> deltas, vals, sscr;
+  DCD_TRY(deltas.alloc(c->device, nv));
+  DCD_TRY(vals.alloc(c->device, nv));
+  DCD_TRY(sscr.alloc(c->device, scan_scratch_elems(nv)));
+  decode_values_launch(du.p, n_units, part.p, nv, deltas.p, vals.p, sscr.p, c->st);
+  DCD_HIP(hipMemcpyAsync(out, vals.p, nv * 8, hipMemcpyDeviceToHost, c->st));
+  DCD_HIP(hipStreamSynchronize(c->st));
+  return DCD_OK;
+}
+
+int32_t dcd_seq_decode(const uint16_t* units, size_t n_units, uint64_t* out, size_t cap, size_t* n) {
+  return seq_decode_impl(units, n_units, out, cap, n, true);
+}
+
+int32_t dcd_seq_count(const uint16_t* units, size_t n_units, size_t* n_values) {
+  return seq_decode_impl(units, n_units, nullptr, 0, n_values, false);
+}
+
+// IndexSequence.Shift (IndexSequence.cs:191-202) rewrites only the first value's <= 5 units and
+// keeps the tail verbatim: O(1) arithmetic + a memcpy, so it is done in place on the host buffer
+// (there is nothing data-parallel to launch).
+int32_t dcd_seq_shift(const uint16_t* units, size_t n_units, uint64_t shift, uint16_t* out, size_t cap, size_t* n_out) {
+  if ((!units && n_units) || !n_out) DCD_FAIL(DCD_E_BADARG, "dcd_seq_shift: NULL argument");
+  if (n_units == 0 || shift == 0) {
+    *n_out = n_units;
+    if (n_units > cap) return DCD_E_OVERFLOW;
+    if (out && n_units) memmove(out, units, n_units * 2);
+    return DCD_OK;
+  }
+  // first value (MoveNext once)
+  u64 first = 0;
+  size_t q = 0;
+  u32 sh = 0;
+  bool more = true;
+  while (more && q < n_units) {
+    u16 v = units[q++];
+    more = (v & 0x8000u) != 0;
+    first += ((u64)(v & 0x7FFFu)) << (sh & 63u);
+    sh += 15;
+  }
+  if (more) DCD_FAIL(DCD_E_BADARG, "dcd_seq_shift: sequence holds no complete value");
+  u64 d = shift + first;
+  u16 head[5];
+  size_t nh = 0;
+  do {
+    if (d > 0x7FFF) { head[nh++] = (u16)(0x8000u | (d & 0x7FFFu)); d >>= 15; }
+    else { head[nh++] = (u16)d; break; }
+  } while (d > 0);
+  size_t total = nh + (n_units - q);
+  *n_out = total;
+  if (total > cap || !out) return DCD_E_OVERFLOW;
+  memmove(out + nh, units + q, (n_units - q) * 2);
+  memcpy(out, head, nh * 2);
+  return DCD_OK;
+}
+
+}  // extern "C"

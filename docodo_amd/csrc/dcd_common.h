@@ -1,0 +1,120 @@
+// dcd_common.h -- shared host-side plumbing of libdocodo_hip: status/error handling, a caching
+// device allocator (no hipMalloc inside timed regions), per-handle streams, HIP-event timers.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/docodo_hip.h"
+
+typedef uint8_t u8;
+typedef uint16_t u16;
+typedef uint32_t u32;
+typedef uint64_t u64;
+
+namespace dcd {
+
+// ---- thread-local last error --------------------------------------------------------------
+void set_error(const char* fmt, ...);
+const std::string& last_error();
+
+struct Status {
+  int32_t code;
+};
+
+#define DCD_FAIL(code_, ...)          \
+  do {                                \
+    ::dcd::set_error(__VA_ARGS__);    \
+    return (code_);                   \
+  } while (0)
+
+#define DCD_HIP(expr)                                                                        \
+  do {                                                                                       \
+    hipError_t e_ = (expr);                                                                  \
+    if (e_ != hipSuccess) {                                                                  \
+      ::dcd::set_error("HIP error %d (%s) at %s:%d: %s", (int)e_, hipGetErrorString(e_),     \
+                       __FILE__, __LINE__, #expr);                                           \
+      return DCD_E_HIP;                                                                      \
+    }                                                                                        \
+  } while (0)
+
+#define DCD_TRY(expr)            \
+  do {                           \
+    int32_t s_ = (expr);         \
+    if (s_ != DCD_OK) return s_; \
+  } while (0)
+
+// ---- caching device allocator ---------------------------------------------------------------
+// Blocks are rounded up to 2 MiB (>= 1 MiB requests) or 64 KiB and kept in a per-device free list
+// when released, so that repeated builds / query batches of the same shape do not call hipMalloc.
+int32_t dev_alloc(int device, size_t bytes, void** out);
+void dev_release(int device, void* p);   // back to the pool
+void dev_pool_trim(int device);          // hipFree everything cached
+
+// RAII device buffer bound to the pool
+template <typename T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t n = 0;  // elements
+  int device = 0;
+  DevBuf() {}
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+  DevBuf(DevBuf&& o) noexcept : p(o.p), n(o.n), device(o.device) { o.p = nullptr; o.n = 0; }
+  DevBuf& operator=(DevBuf&& o) noexcept {
+    if (this != &o) { reset(); p = o.p; n = o.n; device = o.device; o.p = nullptr; o.n = 0; }
+    return *this;
+  }
+  ~DevBuf() { reset(); }
+  void reset() {
+    if (p) dev_release(device, p);
+    p = nullptr;
+    n = 0;
+  }
+  int32_t alloc(int dev, size_t count) {
+    reset();
+    device = dev;
+    void* q = nullptr;
+    int32_t s = dev_alloc(dev, (count ? count : 1) * sizeof(T), &q);
+    if (s != DCD_OK) return s;
+    p = (T*)q;
+    n = count;
+    return DCD_OK;
+  }
+  size_t bytes() const { return n * sizeof(T); }
+};
+
+// ---- HIP event timer ------------------------------------------------------------------------
+struct EvTimer {
+  hipEvent_t a = nullptr, b = nullptr;
+  hipStream_t s = nullptr;
+  int32_t init(hipStream_t st) {
+    s = st;
+    if (!a) DCD_HIP(hipEventCreate(&a));
+    if (!b) DCD_HIP(hipEventCreate(&b));
+    return DCD_OK;
+  }
+  int32_t start() { DCD_HIP(hipEventRecord(a, s)); return DCD_OK; }
+  int32_t stop() { DCD_HIP(hipEventRecord(b, s)); return DCD_OK; }
+  float ms() {  // call after the stream was synchronised
+    float t = 0;
+    if (hipEventElapsedTime(&t, a, b) != hipSuccess) return -1.f;
+    return t;
+  }
+  ~EvTimer() {
+    if (a) (void)hipEventDestroy(a);
+    if (b) (void)hipEventDestroy(b);
+  }
+};
+
+inline u64 div_up(u64 a, u64 b) { return (a + b - 1) / b; }
+inline u32 log2_ceil(u64 v) { u32 r = 0; while ((1ull << r) < v) r++; return r; }
+
+int32_t ensure_device(int device);  // DCD_E_HIP when no usable device
+
+}  // namespace dcd

@@ -1,0 +1,280 @@
+// dcd_index.hip -- the loaded index: Index.Load (Index.cs:312-380), dictionary lookups
+// (SortedList keys, Index.cs:151, 235), this[key] (Index.cs:255-263), page table accessors
+// (IndexPageList, Build.cs:41-149).  Query evaluation lives in dcd_query.hip.
+#include <algorithm>
+
+#include "dcd_index_int.h"
+
+namespace dcd {
+DeviceIndex* build_take_index(dcd_build* b);
+int build_device(dcd_build* b);
+}  // namespace dcd
+
+using namespace dcd;
+
+// Parses a ".index" image into the DeviceIndex layout (units back to back + directory).
+static int32_t parse_index_image(const u8* p, size_t n, DeviceIndex& ix, std::vector<u16>& units) {
+  if (n < 8) DCD_FAIL(DCD_E_IO, ".index image shorter than its MaxCoord header");
+  u64 mc = 0;
+  for (int i = 0; i < 8; i++) mc |= (u64)p[i] << (8 * i);
+  ix.max_coord = mc;
+  size_t i = 8;
+  ix.h_term_chars.clear();
+  ix.h_term_str_off.assign(1, 0);
+  ix.h_term_unit_start.assign(1, 0);
+  ustr prev;
+  bool first = true;
+  while (i < n) {
+    u32 len = 0;
+    int sh = 0;
+    for (;;) {
+      if (i >= n) DCD_FAIL(DCD_E_IO, "truncated key length in .index");
+      u8 c = p[i++];
+      len |= (u32)(c & 0x7F) << sh;
+      sh += 7;
+      if (!(c & 0x80)) break;
+    }
+    if (i + len + 4 > n) DCD_FAIL(DCD_E_IO, "truncated record in .index");
+    ustr key;
+    utf8_to_utf16(p + i, len, key);
+    i += len;
+    u32 nu = 0;
+    for (int k = 0; k < 4; k++) nu |= (u32)p[i + k] << (8 * k);
+    i += 4;
+    if ((int32_t)nu < 0 || i + 2ull * nu > n) DCD_FAIL(DCD_E_IO, "truncated posting list in .index");
+    if (!first && !(prev < key)) DCD_FAIL(DCD_E_IO, "keys of .index are not strictly ascending (String.CompareOrdinal)");
+    first = false;
+    prev = key;
+    ix.h_term_chars.insert(ix.h_term_chars.end(), (const u16*)key.data(), (const u16*)key.data() + key.size());
+    ix.h_term_str_off.push_back((u32)ix.h_term_chars.size());
+    size_t u0 = units.size();
+    units.resize(u0 + nu);
+    memcpy(units.data() + u0, p + i, 2ull * nu);
+    i += 2ull * nu;
+    ix.h_term_unit_start.push_back((u64)units.size());
+  }
+  ix.n_terms = ix.h_term_str_off.size() - 1;
+  ix.n_units = units.size();
+  return DCD_OK;
+}
+
+// IndexPageList.Load, Build.cs:119-148
+static int32_t parse_list_image(const u8* p, size_t n, PageTable& pt) {
+  size_t i = 0;
+  pt = PageTable();
+  while (i + 8 <= n) {
+    u64 v = 0;
+    for (int k = 0; k < 8; k++) v |= (u64)p[i + k] << (8 * k);
+    i += 8;
+    u32 len = 0;
+    int sh = 0;
+    bool ok = true;
+    for (;;) {
+      if (i >= n) { ok = false; break; }
+      u8 c = p[i++];
+      len |= (u32)(c & 0x7F) << sh;
+      sh += 7;
+      if (!(c & 0x80)) break;
+    }
+    if (!ok || i + len > n) break;  // EndOfStream: the reference stops silently
+    ustr s;
+    utf8_to_utf16(p + i, len, s);
+    i += len;
+    if (s.empty() || s[0] != u':') {
+      DocMeta d;
+      d.name = s;
+      d.first_page = pt.end.size();
+      pt.docs.push_back(d);
+    } else {
+      if (pt.docs.empty()) { DocMeta d; d.first_page = 0; pt.docs.push_back(d); }
+      pt.ids.push_back(s.substr(1));
+      pt.end.push_back(v);
+      pt.page_doc.push_back((u32)(pt.docs.size() - 1));
+    }
+  }
+  return DCD_OK;
+}
+
+__global__ void k_count_term_values(const u16* __restrict__ units, const u64* __restrict__ unit_start, u64 n_terms,
+                                    u64* __restrict__ counts) {
+  // one wave per term: number of terminator units
+  u64 t = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (t >= n_terms) return;
+  u64 a = unit_start[t], b = unit_start[t + 1];
+  u32 c = 0;
+  for (u64 i = a + lane_id(); i < b; i += 64) c += (units[i] & 0x8000u) ? 0u : 1u;
+  c = wave_sum(c);
+  if (lane_id() == 0) counts[t] = c;
+}
+
+static int32_t index_from_host(DeviceIndex& ix, const std::vector<u16>& units, int device) {
+  DCD_TRY(ensure_device(device));
+  ix.device = device;
+  u64 V = ix.n_terms, U = ix.n_units;
+  DCD_TRY(ix.units.alloc(device, U ? U : 1));
+  DCD_TRY(ix.term_unit_start.alloc(device, V + 1));
+  DCD_TRY(ix.term_item_start.alloc(device, V + 1));
+  DCD_TRY(ix.term_chars.alloc(device, ix.h_term_chars.size() ? ix.h_term_chars.size() : 1));
+  DCD_TRY(ix.term_str_off.alloc(device, V + 1));
+  if (U) DCD_HIP(hipMemcpy(ix.units.p, units.data(), U * 2, hipMemcpyHostToDevice));
+  DCD_HIP(hipMemcpy(ix.term_unit_start.p, ix.h_term_unit_start.data(), (V + 1) * 8, hipMemcpyHostToDevice));
+  if (!ix.h_term_chars.empty())
+    DCD_HIP(hipMemcpy(ix.term_chars.p, ix.h_term_chars.data(), ix.h_term_chars.size() * 2, hipMemcpyHostToDevice));
+  DCD_HIP(hipMemcpy(ix.term_str_off.p, ix.h_term_str_off.data(), (V + 1) * 4, hipMemcpyHostToDevice));
+  // posting counts per term (Count()): terminator units, counted on the device
+  DevBuf<u64> counts;
+  DCD_TRY(counts.alloc(device, V + 1));
+  std::vector<u64> hc(V + 1, 0);
+  if (V) {
+    hipLaunchKernelGGL(k_count_term_values, dim3((u32)div_up(V * 64, 256)), dim3(256), 0, 0, ix.units.p, ix.term_unit_start.p, V, counts.p);
+    DCD_HIP(hipGetLastError());
+    DCD_HIP(hipMemcpy(hc.data(), counts.p, V * 8, hipMemcpyDeviceToHost));
+  }
+  ix.h_term_item_start.assign(V + 1, 0);
+  for (u64 t = 0; t < V; t++) ix.h_term_item_start[t + 1] = ix.h_term_item_start[t] + hc[t];
+  ix.n_postings = ix.h_term_item_start[V];
+  DCD_HIP(hipMemcpy(ix.term_item_start.p, ix.h_term_item_start.data(), (V + 1) * 8, hipMemcpyHostToDevice));
+  if (!ix.pages.end.empty()) {
+    DCD_TRY(ix.page_end.alloc(device, ix.pages.end.size()));
+    DCD_HIP(hipMemcpy(ix.page_end.p, ix.pages.end.data(), ix.pages.end.size() * 8, hipMemcpyHostToDevice));
+  }
+  return DCD_OK;
+}
+
+static int32_t read_file(const std::string& path, std::vector<u8>& out) {
+  FILE* f = fopen(path.c_str(), "rb");
+  if (!f) DCD_FAIL(DCD_E_IO, "cannot open %s", path.c_str());
+  fseek(f, 0, SEEK_END);
+  long n = ftell(f);
+  fseek(f, 0, SEEK_SET);
+  out.resize((size_t)n);
+  bool ok = n == 0 || fread(out.data(), 1, (size_t)n, f) == (size_t)n;
+  fclose(f);
+  if (!ok) DCD_FAIL(DCD_E_IO, "short read from %s", path.c_str());
+  return DCD_OK;
+}
+
+extern "C" {
+
+int32_t dcd_index_from_build(dcd_build* b, dcd_index** out) {
+  if (!b || !out) DCD_FAIL(DCD_E_BADARG, "dcd_index_from_build: NULL argument");
+  DeviceIndex* src = build_take_index(b);
+  if (!src) DCD_FAIL(DCD_E_STATE, "build is not finished or its index was already adopted");
+  dcd_index* h = new dcd_index();
+  h->ix = std::move(*src);
+  hipError_t e = hipStreamCreateWithFlags(&h->st, hipStreamNonBlocking);
+  if (e != hipSuccess) { delete h; DCD_FAIL(DCD_E_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
+  *out = h;
+  return DCD_OK;
+}
+
+int32_t dcd_index_from_images(const uint8_t* index_img, size_t n_index, const uint8_t* list_img, size_t n_list, int32_t device,
+                              dcd_index** out) {
+  if (!index_img || !out || (!list_img && n_list)) DCD_FAIL(DCD_E_BADARG, "dcd_index_from_images: NULL argument");
+  DCD_TRY(ensure_device(device));
+  std::unique_ptr<dcd_index> h(new dcd_index());
+  std::vector<u16> units;
+  DCD_TRY(parse_index_image(index_img, n_index, h->ix, units));
+  DCD_TRY(parse_list_image(list_img, n_list, h->ix.pages));
+  DCD_TRY(index_from_host(h->ix, units, device));
+  DCD_HIP(hipStreamCreateWithFlags(&h->st, hipStreamNonBlocking));
+  *out = h.release();
+  return DCD_OK;
+}
+
+int32_t dcd_index_open(const char* dir_utf8, int32_t device, dcd_index** out) {
+  if (!dir_utf8 || !out) DCD_FAIL(DCD_E_BADARG, "dcd_index_open: NULL argument");
+  std::string d(dir_utf8);
+  if (!d.empty() && d.back() != '/') d.push_back('/');
+  std::vector<u8> a, b;
+  DCD_TRY(read_file(d + ".index", a));
+  DCD_TRY(read_file(d + ".index.list", b));
+  return dcd_index_from_images(a.data(), a.size(), b.data(), b.size(), device, out);
+}
+
+void dcd_index_free(dcd_index* h) {
+  if (!h) return;
+  (void)hipSetDevice(h->ix.device);
+  if (h->st) { (void)hipStreamSynchronize(h->st); (void)hipStreamDestroy(h->st); }
+  delete h;
+}
+
+int32_t dcd_index_count(dcd_index* h, uint64_t* n) { if (!h || !n) DCD_FAIL(DCD_E_BADARG, "NULL argument"); *n = h->ix.n_terms; return DCD_OK; }
+int32_t dcd_index_max_coord(dcd_index* h, uint64_t* v) { if (!h || !v) DCD_FAIL(DCD_E_BADARG, "NULL argument"); *v = h->ix.max_coord; return DCD_OK; }
+int32_t dcd_index_n_pages(dcd_index* h, uint64_t* n) { if (!h || !n) DCD_FAIL(DCD_E_BADARG, "NULL argument"); *n = h->ix.pages.n_pages(); return DCD_OK; }
+int32_t dcd_index_n_docs(dcd_index* h, uint64_t* n) { if (!h || !n) DCD_FAIL(DCD_E_BADARG, "NULL argument"); *n = h->ix.pages.n_docs(); return DCD_OK; }
+
+int32_t dcd_index_find(dcd_index* h, const uint16_t* key, size_t len, uint32_t* term) {
+  if (!h || (!key && len) || !term) DCD_FAIL(DCD_E_BADARG, "dcd_index_find: NULL argument");
+  const DeviceIndex& ix = h->ix;
+  // binary search over the ordinally sorted keys (String.CompareOrdinal = UTF-16 code-unit order)
+  u64 a = 0, b = ix.n_terms;
+  while (a < b) {
+    u64 m = (a + b) >> 1;
+    const u16* s = ix.h_term_chars.data() + ix.h_term_str_off[m];
+    size_t sl = ix.h_term_str_off[m + 1] - ix.h_term_str_off[m];
+    size_t k = 0;
+    int cmp = 0;
+    while (k < sl && k < len) { if (s[k] != key[k]) { cmp = s[k] < key[k] ? -1 : 1; break; } k++; }
+    if (cmp == 0) cmp = sl < len ? -1 : (sl > len ? 1 : 0);
+    if (cmp == 0) { *term = (u32)m; return DCD_OK; }
+    if (cmp < 0) a = m + 1; else b = m;
+  }
+  return DCD_E_NOTFOUND;  // missing term: empty sequence in the reference (Search.cs:235,256); no message
+}
+
+int32_t dcd_index_key(dcd_index* h, uint32_t term, uint16_t* out, size_t cap, size_t* len) {
+  if (!h || !len) DCD_FAIL(DCD_E_BADARG, "dcd_index_key: NULL argument");
+  if (term >= h->ix.n_terms) DCD_FAIL(DCD_E_BADARG, "term %u out of range", term);
+  size_t n = h->ix.h_term_str_off[term + 1] - h->ix.h_term_str_off[term];
+  *len = n;
+  if (!out || cap < n) return DCD_E_OVERFLOW;
+  memcpy(out, h->ix.h_term_chars.data() + h->ix.h_term_str_off[term], n * 2);
+  return DCD_OK;
+}
+
+int32_t dcd_index_get(dcd_index* h, uint32_t term, uint16_t* out, size_t cap, size_t* n_units) {
+  if (!h || !n_units) DCD_FAIL(DCD_E_BADARG, "dcd_index_get: NULL argument");
+  if (term >= h->ix.n_terms) DCD_FAIL(DCD_E_BADARG, "term %u out of range", term);
+  u64 a = h->ix.h_term_unit_start[term], b = h->ix.h_term_unit_start[term + 1];
+  *n_units = (size_t)(b - a);
+  if (!out || cap < b - a) return DCD_E_OVERFLOW;
+  DCD_TRY(ensure_device(h->ix.device));
+  if (b > a) DCD_HIP(hipMemcpy(out, h->ix.units.p + a, (b - a) * 2, hipMemcpyDeviceToHost));
+  return DCD_OK;
+}
+
+int32_t dcd_index_term_count(dcd_index* h, uint32_t term, uint64_t* n_values) {
+  if (!h || !n_values) DCD_FAIL(DCD_E_BADARG, "dcd_index_term_count: NULL argument");
+  if (term >= h->ix.n_terms) DCD_FAIL(DCD_E_BADARG, "term %u out of range", term);
+  *n_values = h->ix.h_term_item_start[term + 1] - h->ix.h_term_item_start[term];
+  return DCD_OK;
+}
+
+int32_t dcd_index_page_info(dcd_index* h, uint64_t page, uint64_t* end_coord, uint32_t* doc, uint16_t* id_out, size_t id_cap,
+                            size_t* id_len) {
+  if (!h) DCD_FAIL(DCD_E_BADARG, "dcd_index_page_info: NULL handle");
+  const PageTable& pt = h->ix.pages;
+  if (page >= pt.n_pages()) DCD_FAIL(DCD_E_BADARG, "page out of range");
+  if (end_coord) *end_coord = pt.end[page];
+  if (doc) *doc = pt.doc_of_page(page);
+  ustr id = pt.page_id(page);
+  if (id_len) *id_len = id.size();
+  if (id_out) {
+    if (id_cap < id.size()) return DCD_E_OVERFLOW;
+    memcpy(id_out, id.data(), id.size() * 2);
+  }
+  return DCD_OK;
+}
+
+int32_t dcd_index_doc_name(dcd_index* h, uint32_t doc, uint16_t* out, size_t cap, size_t* len) {
+  if (!h || !len) DCD_FAIL(DCD_E_BADARG, "dcd_index_doc_name: NULL argument");
+  if (doc >= h->ix.pages.n_docs()) DCD_FAIL(DCD_E_BADARG, "doc out of range");
+  ustr s = h->ix.pages.doc_name(doc);
+  *len = s.size();
+  if (!out || cap < s.size()) return DCD_E_OVERFLOW;
+  memcpy(out, s.data(), s.size() * 2);
+  return DCD_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,96 @@
+// dcd_prims.h -- device primitives for gfx950: 64-lane wave scans / ballots, block scans through
+// LDS, and the 15-bit var-ushort unit arithmetic shared by codec, pack and query kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+typedef uint8_t u8;
+typedef uint16_t u16;
+typedef uint32_t u32;
+typedef uint64_t u64;
+
+#define DCD_WAVE 64
+
+namespace dcd {
+
+__device__ __forceinline__ u32 lane_id() { return __lane_id(); }
+
+// lanes strictly below this lane
+__device__ __forceinline__ u64 lanemask_lt() { return (1ull << lane_id()) - 1ull; }
+
+__device__ __forceinline__ u32 popc64(u64 m) { return (u32)__popcll(m); }
+
+// number of set bits of m at lanes below the caller (v_mbcnt_lo/hi)
+__device__ __forceinline__ u32 mbcnt(u64 m) {
+  return __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u));
+}
+
+__device__ __forceinline__ u64 ballot64(bool p) { return __ballot(p); }
+
+// inclusive wave scan (sum)
+__device__ __forceinline__ u32 wave_scan_incl(u32 v) {
+#pragma unroll
+  for (int d = 1; d < DCD_WAVE; d <<= 1) {
+    u32 t = __shfl_up(v, d, DCD_WAVE);
+    if ((int)lane_id() >= d) v += t;
+  }
+  return v;
+}
+__device__ __forceinline__ u64 wave_scan_incl(u64 v) {
+#pragma unroll
+  for (int d = 1; d < DCD_WAVE; d <<= 1) {
+    u64 t = __shfl_up(v, d, DCD_WAVE);
+    if ((int)lane_id() >= d) v += t;
+  }
+  return v;
+}
+__device__ __forceinline__ u32 wave_sum(u32 v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, DCD_WAVE);
+  return v;
+}
+__device__ __forceinline__ u64 wave_sum(u64 v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, DCD_WAVE);
+  return v;
+}
+__device__ __forceinline__ u32 wave_max(u32 v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) { u32 t = __shfl_xor(v, d, DCD_WAVE); v = t > v ? t : v; }
+  return v;
+}
+
+// Block-wide exclusive scan of one value per thread.  NW = waves per block.  `lds` needs NW+1
+// entries of T.  Returns the exclusive prefix; *total receives the block sum (all threads).
+template <typename T, int NW>
+__device__ __forceinline__ T block_scan_excl(T v, T* lds, T* total) {
+  const u32 lane = lane_id(), w = threadIdx.x >> 6;
+  T incl = wave_scan_incl(v);
+  if (lane == DCD_WAVE - 1) lds[w] = incl;
+  __syncthreads();
+  if (w == 0) {
+    T s = lane < (u32)NW ? lds[lane] : (T)0;
+    T si = wave_scan_incl(s);
+    if (lane < (u32)NW) lds[lane] = si - s;  // exclusive per-wave base
+    if (lane == NW - 1) lds[NW] = si;
+  }
+  __syncthreads();
+  T base = lds[w];
+  *total = lds[NW];
+  __syncthreads();
+  return base + incl - v;
+}
+
+// ---- 15-bit var-ushort code (IndexSequence.cs:13-15, 63-84) --------------------------------
+// number of ushort units the delta d occupies: 1 + [d >= 2^15] + [d >= 2^30] + [d >= 2^45] + [d >= 2^60]
+__device__ __forceinline__ u32 seq_nunits(u64 d) {
+  return 1u + (d >= (1ull << 15)) + (d >= (1ull << 30)) + (d >= (1ull << 45)) + (d >= (1ull << 60));
+}
+// unit #g (0-based, g < n) of delta d occupying n units: low group first, bit 15 = "more follow"
+__device__ __forceinline__ u16 seq_unit(u64 d, u32 g, u32 n) {
+  u32 grp = (u32)(d >> (15u * g)) & 0x7FFFu;
+  return (u16)(grp | (g + 1 < n ? 0x8000u : 0u));
+}
+
+}  // namespace dcd

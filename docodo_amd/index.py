@@ -1,0 +1,292 @@
+"""Index / Index.Builder mirror over the C ABI (reference: Docodo.NET/Index.cs, Build.cs, Search.cs).
+
+This is the host-side stand-in for the C# shim described in INTEGRATION.md: same method names and
+argument meaning as the reference where the hot path is concerned; everything numeric happens in
+libdocodo_hip.so on the GPU.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import BuildOpts, BuildStats, QueryOpts, ResultsView, check, lib
+from .sequence import IndexSequence
+
+
+def _u16(s):
+    a = np.frombuffer(s.encode("utf-16-le", "surrogatepass"), dtype=np.uint16).copy()
+    return a, (a.ctypes.data if a.size else None), a.size
+
+
+class SearchOptions:  # Search.cs:262-276
+    def __init__(self, dist=0):
+        self.dist = dist
+
+
+class Builder:
+    """Index.Builder (Build.cs:258-437) fused with the IndexTask page loop (Build.cs:445-564)."""
+
+    def __init__(self, encoding=_lib.DCD_ENC_LATIN1, coord_base=0, device=0, min_word_length=3, max_word_length=32,
+                 vocab_capacity_log2=0):
+        o = BuildOpts()
+        lib().dcd_build_default_opts(C.byref(o))
+        o.device, o.encoding, o.coord_base = device, encoding, coord_base
+        o.min_word_length, o.max_word_length = min_word_length, max_word_length
+        o.vocab_capacity_log2 = vocab_capacity_log2
+        self.encoding = encoding
+        self.h = C.c_void_p()
+        check(lib().dcd_build_create(C.byref(o), C.byref(self.h)))
+        self._keep = []
+
+    def close(self):
+        if self.h:
+            lib().dcd_build_free(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def AddDoc(self, sourceid, name):  # Build.cs:348
+        a, p, n = _u16(sourceid)
+        b, q, m = _u16(name)
+        check(lib().dcd_build_add_doc(self.h, p, n, q, m))
+
+    def _text_array(self, text):
+        if isinstance(text, str):
+            if self.encoding == _lib.DCD_ENC_UTF16LE:
+                return np.frombuffer(text.encode("utf-16-le", "surrogatepass"), dtype=np.uint16).copy()
+            return np.frombuffer(text.encode("latin-1"), dtype=np.uint8).copy()
+        dt = np.uint16 if self.encoding == _lib.DCD_ENC_UTF16LE else np.uint8
+        return np.ascontiguousarray(text, dtype=dt)
+
+    def AddPages(self, text, page_off=None, page_ids=None, docs_per_page=False, first_doc=0, source="syn"):
+        """Body pages back to back (the per-page loop of IndexTask, Build.cs:477-541)."""
+        t = self._text_array(text)
+        off = np.ascontiguousarray(page_off if page_off is not None else [0, t.size], dtype=np.uint64)
+        ids_p = idoff_p = None
+        if page_ids is not None:
+            joined = "".join(page_ids)
+            ids_a, ids_p, _ = _u16(joined)
+            idoff = np.zeros(len(page_ids) + 1, np.uint64)
+            idoff[1:] = np.cumsum([len(x.encode("utf-16-le")) // 2 for x in page_ids])
+            idoff_p = idoff.ctypes.data
+            self._keep += [ids_a, idoff]
+        s, sp, sn = _u16(source)
+        check(lib().dcd_build_add_pages(self.h, t.ctypes.data if t.size else None, t.size, off.ctypes.data, off.size - 1,
+                                        ids_p, idoff_p, 1 if docs_per_page else 0, first_doc, sp, sn))
+
+    def AddPagesDev(self, text_dev_ptr, n_chars, page_off, docs_per_page=True, first_doc=0, source="syn"):
+        off = np.ascontiguousarray(page_off, dtype=np.uint64)
+        s, sp, sn = _u16(source)
+        check(lib().dcd_build_add_pages_dev(self.h, text_dev_ptr, n_chars, off.ctypes.data, off.size - 1,
+                                            1 if docs_per_page else 0, first_doc, sp, sn))
+
+    def Add(self, code, coord):  # Build.cs:324
+        a, p, n = _u16(code)
+        check(lib().dcd_build_add(self.h, p, n, int(coord)))
+
+    def AddWord(self, word, coord):
+        """Build.cs:302-316 with GetWordCodes == identity (Stemmers.Clear(), no vocab, no stop words:
+        the parity configuration of SURVEY.md §8d); a host that stems passes its codes to Add()."""
+        self.Add(word, coord)
+
+    def EndPage(self, id):  # Build.cs:359
+        a, p, n = _u16(id)
+        check(lib().dcd_build_end_page(self.h, p, n))
+
+    def Finish(self):
+        check(lib().dcd_build_finish(self.h))
+        return self.stats
+
+    @property
+    def stats(self):
+        s = BuildStats()
+        check(lib().dcd_build_get_stats(self.h, C.byref(s)))
+        return s
+
+    def _image(self, fn):
+        n = C.c_size_t(0)
+        fn(self.h, None, 0, C.byref(n))
+        out = np.empty(max(1, n.value), np.uint8)
+        check(fn(self.h, out.ctypes.data, out.size, C.byref(n)))
+        return out[:n.value].tobytes()
+
+    def index_image(self):
+        return self._image(lib().dcd_build_index_image)
+
+    def list_image(self):
+        return self._image(lib().dcd_build_list_image)
+
+    def Save(self, dirpath):
+        check(lib().dcd_build_save(self.h, dirpath.encode("utf-8")))
+
+    def Build(self):  # Build.cs:407-434 -> searchable Index
+        return Index.from_build(self)
+
+
+class QueryBatchResult:
+    """Numpy copy of a dcd_results batch (CSR layout of include/docodo_hip.h)."""
+
+    def __init__(self, view):
+        nq = view.n_queries
+
+        def arr(ptr, n, dt):
+            if n == 0 or not ptr:
+                return np.empty(0, dt)
+            return np.ctypeslib.as_array(ptr, shape=(n,)).astype(dt, copy=True)
+
+        self.n_queries = nq
+        self.status = arr(view.status, nq, np.int32)
+        self.page_off = arr(view.page_off, nq + 1, np.uint64)
+        npages = int(self.page_off[-1]) if nq else 0
+        self.page_index = arr(view.page_index, npages, np.uint32)
+        self.page_rank = arr(view.page_rank, npages, np.float32)
+        self.pos_off = arr(view.pos_off, npages + 1, np.uint64)
+        npos = int(self.pos_off[-1]) if npages else 0
+        self.pos = arr(view.pos, npos, np.int32)
+        self.doc_off = arr(view.doc_off, nq + 1, np.uint64)
+        ndocs = int(self.doc_off[-1]) if nq else 0
+        self.doc_index = arr(view.doc_index, ndocs, np.uint32)
+        self.doc_rank = arr(view.doc_rank, ndocs, np.float32)
+        self.doc_n_pages = arr(view.doc_n_pages, ndocs, np.uint32)
+        self.seq_off = arr(view.seq_off, nq + 1, np.uint64) if view.seq_off else None
+        if self.seq_off is not None:
+            self.seq_units = arr(view.seq_units, int(self.seq_off[-1]), np.uint16)
+            self.seq_R = arr(view.seq_R, nq, np.int32)
+        self.ms_device = view.ms_device
+
+    def pages(self, q):
+        a, b = int(self.page_off[q]), int(self.page_off[q + 1])
+        return [(int(self.page_index[i]), self.pos[int(self.pos_off[i]):int(self.pos_off[i + 1])], float(self.page_rank[i]))
+                for i in range(a, b)]
+
+    def docs(self, q):
+        a, b = int(self.doc_off[q]), int(self.doc_off[q + 1])
+        return [(int(self.doc_index[i]), float(self.doc_rank[i]), int(self.doc_n_pages[i])) for i in range(a, b)]
+
+
+class Index:
+    """Docodo.Index as far as the hot path goes: Load, Count, MaxCoord, this[key], batched Search."""
+
+    def __init__(self, handle):
+        self.h = handle
+
+    @classmethod
+    def from_build(cls, builder):
+        h = C.c_void_p()
+        check(lib().dcd_index_from_build(builder.h, C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def Load(cls, dirpath, device=0):  # Index.cs:312
+        h = C.c_void_p()
+        check(lib().dcd_index_open(dirpath.encode("utf-8"), device, C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def from_images(cls, index_bytes, list_bytes, device=0):
+        ib = np.frombuffer(index_bytes, np.uint8)
+        lb = np.frombuffer(list_bytes, np.uint8)
+        h = C.c_void_p()
+        check(lib().dcd_index_from_images(ib.ctypes.data, ib.size, lb.ctypes.data if lb.size else None, lb.size, device, C.byref(h)))
+        return cls(h)
+
+    def close(self):
+        if self.h:
+            lib().dcd_index_free(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _u64(self, fn):
+        v = C.c_uint64(0)
+        check(fn(self.h, C.byref(v)))
+        return v.value
+
+    @property
+    def Count(self):
+        return self._u64(lib().dcd_index_count)
+
+    @property
+    def MaxCoord(self):
+        return self._u64(lib().dcd_index_max_coord)
+
+    @property
+    def n_pages(self):
+        return self._u64(lib().dcd_index_n_pages)
+
+    @property
+    def n_docs(self):
+        return self._u64(lib().dcd_index_n_docs)
+
+    def find(self, key):
+        a, p, n = _u16(key)
+        t = C.c_uint32(0)
+        code = lib().dcd_index_find(self.h, p, n, C.byref(t))
+        if code == _lib.DCD_E_NOTFOUND:
+            return None
+        check(code)
+        return t.value
+
+    def key(self, term):
+        out = np.empty(64, np.uint16)
+        n = C.c_size_t(0)
+        check(lib().dcd_index_key(self.h, term, out.ctypes.data, out.size, C.byref(n)))
+        return out[:n.value].tobytes().decode("utf-16-le", "surrogatepass")
+
+    def get(self, term):
+        n = C.c_size_t(0)
+        lib().dcd_index_get(self.h, term, None, 0, C.byref(n))
+        out = np.empty(max(1, n.value), np.uint16)
+        check(lib().dcd_index_get(self.h, term, out.ctypes.data, out.size, C.byref(n)))
+        return IndexSequence(out[:n.value].copy())
+
+    def __getitem__(self, key):  # Index.cs:255
+        t = self.find(key)
+        if t is None:
+            raise KeyError(key)
+        return self.get(t)
+
+    def term_count(self, term):
+        v = C.c_uint64(0)
+        check(lib().dcd_index_term_count(self.h, term, C.byref(v)))
+        return v.value
+
+    def page_info(self, page):
+        end, doc, n = C.c_uint64(0), C.c_uint32(0), C.c_size_t(0)
+        out = np.empty(256, np.uint16)
+        check(lib().dcd_index_page_info(self.h, page, C.byref(end), C.byref(doc), out.ctypes.data, out.size, C.byref(n)))
+        return end.value, doc.value, out[:n.value].tobytes().decode("utf-16-le", "surrogatepass")
+
+    def doc_name(self, doc):
+        out = np.empty(1024, np.uint16)
+        n = C.c_size_t(0)
+        check(lib().dcd_index_doc_name(self.h, doc, out.ctypes.data, out.size, C.byref(n)))
+        return out[:n.value].tobytes().decode("utf-16-le", "surrogatepass")
+
+    def query_batch(self, prog, prog_off, max_found_pages=30000, max_found_docs=500, doc_rank_multiply=10.0,
+                    want_sequences=False, keep_handle=False):
+        prog = np.ascontiguousarray(prog, np.int32)
+        off = np.ascontiguousarray(prog_off, np.uint64)
+        o = QueryOpts()
+        lib().dcd_query_default_opts(C.byref(o))
+        o.max_found_pages, o.max_found_docs = max_found_pages, max_found_docs
+        o.doc_rank_multiply, o.want_sequences = doc_rank_multiply, 1 if want_sequences else 0
+        r = C.c_void_p()
+        check(lib().dcd_query_batch(self.h, prog.ctypes.data if prog.size else None, off.ctypes.data, off.size - 1,
+                                    C.byref(o), C.byref(r)))
+        try:
+            v = ResultsView()
+            check(lib().dcd_results_get(r, C.byref(v)))
+            if keep_handle:
+                return v.ms_device
+            return QueryBatchResult(v)
+        finally:
+            lib().dcd_results_free(r)

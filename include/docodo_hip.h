@@ -1,0 +1,226 @@
+/*
+ * docodo_hip.h -- C ABI of libdocodo_hip.so: the MI355X (gfx950) inverted-index build and
+ * query-evaluation path that drops in behind Docodo's Index / IndexSequence / Search surface.
+ *
+ * The reference (alexarchen/Docodo, 100 % C#) has no FFI boundary; this header IS the boundary a
+ * maintainer would P/Invoke (INTEGRATION.md shows the [DllImport] stubs).  Each entry point cites
+ * the reference code it replaces (paths relative to Docodo.NET/ in the reference tree).
+ *
+ * Conventions
+ *   - every function returns int32 status: DCD_OK or a negative DCD_E_* class; no C++ exception
+ *     or HIP error crosses the ABI; dcd_last_error() returns the calling thread's last message;
+ *   - inputs are caller-owned, only read during the call (C# pins string / ushort[] with `fixed`);
+ *   - outputs go to caller-provided buffers (cap in elements; the needed size is always written,
+ *     DCD_E_OVERFLOW if cap is too small -> call again) or to library-owned objects released by
+ *     the matching *_free; handles are opaque, independent, and usable from any thread
+ *     (one call at a time per handle);
+ *   - strings are UTF-16LE code units + length (what a C# `string` pins to) unless named *_utf8;
+ *   - "dev" pointers are HIP device pointers on the handle's device (hipMalloc / torch .data_ptr()).
+ *   - there is NO CPU fallback: without a usable HIP device every compute entry point fails with
+ *     DCD_E_HIP.
+ */
+#ifndef DOCODO_HIP_H
+#define DOCODO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DCD_OK 0
+#define DCD_E_BADARG (-1)
+#define DCD_E_OVERFLOW (-2)     /* output buffer too small / value does not fit */
+#define DCD_E_IO (-3)
+#define DCD_E_HIP (-4)          /* HIP runtime error or no device */
+#define DCD_E_RCCL (-5)
+#define DCD_E_UNSUPPORTED (-6)  /* e.g. unsupported text encoding */
+#define DCD_E_NOTFOUND (-7)
+#define DCD_E_NOMEM (-8)
+#define DCD_E_STATE (-9)        /* call order violated (e.g. query before finish) */
+
+#define DCD_ENC_LATIN1 1        /* 1 byte = 1 UTF-16 code unit (ASCII / ISO-8859-1) */
+#define DCD_ENC_UTF16LE 2       /* raw C# string memory */
+
+typedef struct dcd_build dcd_build;
+typedef struct dcd_index dcd_index;
+typedef struct dcd_results dcd_results;
+
+int32_t dcd_version(void);
+/* copies the calling thread's last error message (UTF-8, NUL-terminated); returns its length */
+int32_t dcd_last_error(char* buf, size_t cap);
+int32_t dcd_device_count(int32_t* n);
+
+/* ------------------------------------------------------------------------------------------
+ * IndexSequence codec and algebra on host buffers (IndexSequence.cs).  These are the per-object
+ * entry points a C# IndexSequence shim calls; batched work should use the build / query handles.
+ * ------------------------------------------------------------------------------------------ */
+/* IndexSequence.Builder.Add / AddRange, IndexSequence.cs:63-90: ascending u64 -> 15-bit var-ushort deltas */
+int32_t dcd_seq_encode(const uint64_t* values, size_t n, uint16_t* out, size_t cap, size_t* n_units);
+/* SeqEnumerator.MoveNext over the whole sequence, IndexSequence.cs:114-136 */
+int32_t dcd_seq_decode(const uint16_t* units, size_t n_units, uint64_t* out, size_t cap, size_t* n);
+/* LINQ Count() of the enumerator (Search.cs:307): number of VALUES, not units */
+int32_t dcd_seq_count(const uint16_t* units, size_t n_units, size_t* n_values);
+/* IndexSequence.Shift, IndexSequence.cs:191-202 */
+int32_t dcd_seq_shift(const uint16_t* units, size_t n_units, uint64_t shift, uint16_t* out, size_t cap, size_t* n_out);
+/* operator * / operator &, IndexSequence.cs:205-284 (proximity / ordered AND) */
+int32_t dcd_seq_and(const uint16_t* a, size_t na, int32_t Ra, const uint16_t* b, size_t nb, int32_t Rb,
+                    uint16_t* out, size_t cap, size_t* n_out, int32_t* R_out);
+/* operator +, IndexSequence.cs:286-322 (OR) */
+int32_t dcd_seq_or(const uint16_t* a, size_t na, int32_t Ra, const uint16_t* b, size_t nb, int32_t Rb,
+                   uint16_t* out, size_t cap, size_t* n_out, int32_t* R_out);
+
+/* ------------------------------------------------------------------------------------------
+ * Build: replaces the IndexTask page loop (Build.cs:465-553), Index.Builder (Build.cs:258-437)
+ * and the merge functions (Index.cs:537-752): everything between "pages arrive" and
+ * ".index / .index.list exist".
+ * ------------------------------------------------------------------------------------------ */
+typedef struct dcd_build_opts {
+  int32_t device;           /* HIP device ordinal */
+  int32_t min_word_length;  /* Index.MIN_WORD_LENGTH, Index.cs:113 (default 3) */
+  int32_t max_word_length;  /* Index.MAX_WORD_LENGTH, Index.cs:97  (default 32, max 32) */
+  int32_t encoding;         /* DCD_ENC_* of every text buffer handed to this handle */
+  uint64_t coord_base;      /* global coordinate of the first character (doc-range shards: text
+                               length of all previous shards; 0 for a single builder) */
+  uint32_t vocab_capacity_log2; /* 0 = auto; hash-table slots = 2^n (grown automatically on overflow) */
+  uint32_t reserved;
+} dcd_build_opts;
+
+void dcd_build_default_opts(dcd_build_opts* o);
+int32_t dcd_build_create(const dcd_build_opts* opts, dcd_build** out);
+void dcd_build_free(dcd_build* h);
+
+/* Builder.AddDoc(sourceid, name), Build.cs:348-356: opens a document; following pages belong to it */
+int32_t dcd_build_add_doc(dcd_build* h, const uint16_t* source, size_t source_len, const uint16_t* name, size_t name_len);
+/* The per-page body of IndexTask, Build.cs:477-541, for n_pages BODY pages at once: text holds the
+ * pages back to back (page p = [page_off[p], page_off[p+1]) in characters, page_off[0] = 0), the
+ * page ids are given as one UTF-16 string with ids_off[n_pages+1] offsets (ids_off == NULL: every
+ * page has id "1").  If docs_per_page != 0 each page opens its own document named by its decimal
+ * index first_doc + p under `source` (the synthetic corpora of SURVEY.md Appendix F) and no prior
+ * dcd_build_add_doc is needed.  Pages with id "0" (header pages, Build.cs:485-524) are tokenised
+ * on the host and enter the device pipeline as explicit postings.  Text is copied to the device
+ * by this call (asynchronously staged); the kernels run in dcd_build_finish. */
+int32_t dcd_build_add_pages(dcd_build* h, const void* text, uint64_t n_chars, const uint64_t* page_off,
+                            size_t n_pages, const uint16_t* page_ids, const uint64_t* ids_off,
+                            int32_t docs_per_page, uint64_t first_doc, const uint16_t* source, size_t source_len);
+/* Same, for text that already lives in device memory (bench / pipelines that tokenise where the
+ * text was produced).  The buffer must stay valid until dcd_build_finish returns. */
+int32_t dcd_build_add_pages_dev(dcd_build* h, const void* text_dev, uint64_t n_chars, const uint64_t* page_off_host,
+                                size_t n_pages, int32_t docs_per_page, uint64_t first_doc,
+                                const uint16_t* source, size_t source_len);
+/* Builder.Add(code, coord), Build.cs:324-341: explicit posting for an index code */
+int32_t dcd_build_add(dcd_build* h, const uint16_t* code, size_t len, uint64_t coord);
+/* Builder.EndPage(id) / EndPage(id, maxcoord), Build.cs:359-367 (explicit-posting API only) */
+int32_t dcd_build_end_page(dcd_build* h, const uint16_t* id, size_t len);
+/* Runs the device pipeline: tokenise -> vocabulary -> stable radix sort by term -> var-ushort pack
+ * -> ".index" byte image, all resident in HBM.  Equivalent of Builder.Save + MergeAll/MergeIndexes
+ * for one coordinate space (Build.cs:370-404, Index.cs:537-752). */
+int32_t dcd_build_finish(dcd_build* h);
+
+typedef struct dcd_build_stats {
+  uint64_t n_chars, n_pages, n_docs;
+  uint64_t n_postings;      /* Builder.TotalCount */
+  uint64_t n_terms;         /* distinct index codes */
+  uint64_t n_units;         /* total ushort units in all posting lists */
+  uint64_t max_coord;       /* Builder.maxCoord = coordinate of the last posting added, Build.cs:326 */
+  uint64_t index_bytes;     /* size of the .index image */
+  uint64_t list_bytes;      /* size of the .index.list image */
+  float ms_tokenize, ms_vocab, ms_sort, ms_pack, ms_image, ms_total; /* device time per stage (HIP events) */
+  uint32_t sort_passes, vocab_capacity_log2;
+} dcd_build_stats;
+int32_t dcd_build_get_stats(dcd_build* h, dcd_build_stats* out);
+
+/* Exact bytes of ".index" (Build.cs:375-386 / Appendix A.3) and ".index.list" (Build.cs:99-118) */
+int32_t dcd_build_index_image(dcd_build* h, uint8_t* out, size_t cap, size_t* n);
+int32_t dcd_build_list_image(dcd_build* h, uint8_t* out, size_t cap, size_t* n);
+/* Writes <dir>/.index and <dir>/.index.list (what Builder.Build() leaves behind, Build.cs:407-434) */
+int32_t dcd_build_save(dcd_build* h, const char* dir_utf8);
+
+/* ------------------------------------------------------------------------------------------
+ * Index + query: replaces Index.Load (Index.cs:312-380), this[key] / LoadSequence
+ * (Index.cs:198-216, 255-263), the IndexSequence operators as used by Search, Count()
+ * (Search.cs:307), PrepareSearchResult (Search.cs:365-420) and the ranks (Search.cs:99-111,
+ * 552-557, 599).
+ * ------------------------------------------------------------------------------------------ */
+int32_t dcd_index_from_build(dcd_build* b, dcd_index** out);          /* adopt the HBM-resident index */
+int32_t dcd_index_open(const char* dir_utf8, int32_t device, dcd_index** out);   /* Index.Load */
+int32_t dcd_index_from_images(const uint8_t* index_img, size_t n_index, const uint8_t* list_img, size_t n_list,
+                              int32_t device, dcd_index** out);
+void dcd_index_free(dcd_index* h);
+int32_t dcd_index_count(dcd_index* h, uint64_t* n_terms);              /* Index.Count */
+int32_t dcd_index_max_coord(dcd_index* h, uint64_t* v);                /* Index.MaxCoord */
+int32_t dcd_index_n_pages(dcd_index* h, uint64_t* n);
+int32_t dcd_index_n_docs(dcd_index* h, uint64_t* n);
+/* ordinal position of a key in the sorted dictionary (SortedList keys, Index.cs:151); DCD_E_NOTFOUND */
+int32_t dcd_index_find(dcd_index* h, const uint16_t* key, size_t len, uint32_t* term);
+int32_t dcd_index_key(dcd_index* h, uint32_t term, uint16_t* out, size_t cap, size_t* len);
+/* this[key]: the posting list's units (Index.cs:255-263) */
+int32_t dcd_index_get(dcd_index* h, uint32_t term, uint16_t* out, size_t cap, size_t* n_units);
+int32_t dcd_index_term_count(dcd_index* h, uint32_t term, uint64_t* n_values);   /* Count() */
+int32_t dcd_index_page_info(dcd_index* h, uint64_t page, uint64_t* end_coord, uint32_t* doc,
+                            uint16_t* id_out, size_t id_cap, size_t* id_len);
+int32_t dcd_index_doc_name(dcd_index* h, uint32_t doc, uint16_t* out, size_t cap, size_t* len);
+
+/* A query is a postfix program of int32 words over ordinal term ids:
+ *   DCD_OP_TERM, term, R   push this[term] with IndexSequence.R = R (Search.cs:302-312 computes R)
+ *   DCD_OP_AND             pop b, pop a, push a * b   (IndexSequence.cs:218-284)
+ *   DCD_OP_OR              pop b, pop a, push a + b   (IndexSequence.cs:286-322)
+ * prog_off[q] .. prog_off[q+1] delimit query q.  The batch is evaluated on the device; per query
+ * the final sequence goes through PrepareSearchResult + ranks with doc filter "accept all". */
+#define DCD_OP_TERM 0
+#define DCD_OP_AND 1
+#define DCD_OP_OR 2
+typedef struct dcd_query_opts {
+  int32_t max_found_pages;   /* Index.MAX_FOUND_PAGES, Index.cs:101 (30000) */
+  int32_t max_found_docs;    /* Index.MAX_FOUND_DOCS, Index.cs:102 (500) */
+  float doc_rank_multiply;   /* Index.DOC_RANK_MULTIPLY, Index.cs:115 (10) */
+  int32_t want_sequences;    /* also return the final IndexSequence units per query */
+} dcd_query_opts;
+void dcd_query_default_opts(dcd_query_opts* o);
+int32_t dcd_query_batch(dcd_index* h, const int32_t* prog, const uint64_t* prog_off, size_t n_queries,
+                        const dcd_query_opts* opts, dcd_results** out);
+
+/* Flat (CSR) view of a result batch; pointers stay valid until dcd_results_free. */
+typedef struct dcd_results_view {
+  uint64_t n_queries;
+  const int32_t* status;        /* per query: DCD_OK, or DCD_E_NOTFOUND if a coordinate lies beyond the
+                                   last page (the reference returns ErrorSearchResult, Search.cs:609) */
+  const uint64_t* page_off;     /* [n_queries+1] into the page arrays (foundPages, corpus order) */
+  const uint32_t* page_index;   /* index of the page in the page table */
+  const float* page_rank;       /* ResultDocPage.rank, Search.cs:99-111 */
+  const uint64_t* pos_off;      /* [total pages + 1] into pos */
+  const int32_t* pos;           /* page-relative positions, Search.cs:381,407 */
+  const uint64_t* doc_off;      /* [n_queries+1] into the doc arrays (foundDocs, ascending rank) */
+  const uint32_t* doc_index;
+  const float* doc_rank;        /* Search.cs:552-557 */
+  const uint32_t* doc_n_pages;  /* doc.pages.Count */
+  const uint64_t* seq_off;      /* [n_queries+1] into seq_units (only if want_sequences) */
+  const uint16_t* seq_units;
+  const int32_t* seq_R;
+  float ms_device;              /* device time of the batch (HIP events) */
+} dcd_results_view;
+int32_t dcd_results_get(dcd_results* r, dcd_results_view* out);
+void dcd_results_free(dcd_results* r);
+
+/* ------------------------------------------------------------------------------------------
+ * Measurement support (bench.py / tests): the synthetic corpus of SURVEY.md Appendix F.
+ * ------------------------------------------------------------------------------------------ */
+/* n_docs documents of exactly doc_bytes ASCII bytes each, Zipf(s) over vocab terms, per-doc
+ * splitmix64 stream whose state starts at mix(seed + doc * 0xD1B54A32D192ED03) (the
+ * survey's seed + doc * GOLDEN would make consecutive documents shifted copies).  Host and device
+ * variants produce identical bytes. */
+int32_t dcd_synth_corpus_host(uint8_t* out, uint64_t first_doc, uint64_t n_docs, uint32_t doc_bytes,
+                              uint32_t vocab, double zipf_s, uint64_t seed);
+int32_t dcd_synth_corpus_dev(void* out_dev, uint64_t first_doc, uint64_t n_docs, uint32_t doc_bytes,
+                             uint32_t vocab, double zipf_s, uint64_t seed, int32_t device);
+/* term string of Zipf rank k (1-based) -> ASCII bytes, returns length via *len */
+int32_t dcd_synth_term(uint32_t rank, uint32_t vocab, char* out, size_t cap, size_t* len);
+/* Zipf ranks restricted to [lo_rank, vocab]; query i draws from its own splitmix64 stream */
+int32_t dcd_synth_query_ranks(uint32_t* out, uint64_t n_queries, uint32_t terms_per_query, int32_t distinct,
+                              uint32_t lo_rank, uint32_t vocab, double zipf_s, uint64_t seed);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DOCODO_HIP_H */

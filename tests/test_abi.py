@@ -1,0 +1,83 @@
+"""CPU-side checks of the drop-in boundary: the library loads and exports every symbol that
+include/docodo_hip.h declares; host-only entry points behave; compute entry points fail loudly
+(DCD_E_HIP) instead of falling back when no GPU is present."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "docodo_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(dcd_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    import docodo_amd
+    from docodo_amd import _lib
+    L = docodo_amd.lib()
+    names = _declared()
+    assert len(names) >= 40
+    for n in names:
+        assert hasattr(L, n), "libdocodo_hip.so does not export %s" % n
+    assert sorted(_lib.SIGNATURES) == names, "python binding and header disagree"
+    assert L.dcd_version() >= 1
+
+
+def test_no_oracle_or_cpu_fallback_in_product():
+    """The product path must never import the oracle."""
+    for dp, _, fs in os.walk(os.path.join(ROOT, "docodo_amd")):
+        for f in fs:
+            if f.endswith((".py", ".cpp", ".hip", ".h")):
+                s = open(os.path.join(dp, f), errors="replace").read()
+                assert "import oracle" not in s and "from oracle" not in s and "liboracle" not in s, f
+
+
+def test_compute_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import docodo_amd
+    from docodo_amd import _lib
+    with pytest.raises(docodo_amd.DocodoError) as e:
+        docodo_amd.IndexSequence.from_values([1, 2, 3])
+    assert e.value.code == _lib.DCD_E_HIP
+    with pytest.raises(docodo_amd.DocodoError) as e:
+        docodo_amd.Builder()
+    assert e.value.code == _lib.DCD_E_HIP
+
+
+def test_synth_generator_host():
+    from docodo_amd import synth
+    t = synth.corpus_host(64)
+    assert t.size == 64 * 1024
+    docs = bytes(t).decode("ascii")
+    assert set(docs) <= set("abcdefghijklmnopqrstuvwxyz ")
+    # every document: whole words + single spaces, space padded to exactly 1024 bytes
+    for d in range(64):
+        doc = docs[d * 1024:(d + 1) * 1024]
+        body = doc.rstrip(" ")
+        assert "  " not in body and all(3 <= len(w) <= 10 for w in body.split(" "))
+    assert docs[:1024] != docs[1024:2048]
+    assert synth.term(1) == "aaaaaaa" and len({synth.term(k) for k in range(1, 5001)}) == 5000
+    r = synth.query_ranks(100, 3)
+    assert r.min() >= 101 and r.max() <= 100000 and all(len(set(x)) == 3 for x in r.tolist())
+    assert np.array_equal(synth.corpus_host(8, first_doc=8), t[8 * 1024:16 * 1024])
+
+
+def test_shift_is_host_side_and_matches_oracle(oracle_mod):
+    """dcd_seq_shift re-codes the first value only (IndexSequence.cs:191-202); runs without a GPU."""
+    import docodo_amd
+    o = oracle_mod
+    rng = np.random.default_rng(7)
+    vals = np.cumsum(rng.integers(0, 0x10000, 100, dtype=np.uint64))
+    u = o.seq_encode(np.concatenate([[0], vals]).astype(np.uint64))
+    for s in (0, 100, 0xFFFFF, 0xFFFFFFFF, (1 << 61) + 5):
+        q = docodo_amd.IndexSequence(u.copy())
+        q.Shift(s)
+        assert np.array_equal(q.units, o.seq_shift(u, s))

@@ -1,0 +1,183 @@
+"""GPU parity of the build path: the .index / .index.list byte images produced by the HIP pipeline
+must equal the CPU oracle's (bit-exact), on the synthetic Appendix-F corpora and on adversarial
+Latin-1 / UTF-16 texts (page boundaries inside words, tile-boundary tokens, over-long words, case)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_images(o, pages_text, ids=None, docs=None, latin1=True):
+    """pages_text: list of str (one per page).  docs: list of (source, name, n_pages) or None = doc per page."""
+    ix = o.Index(stemmers=[])
+    b = o.Builder(ix)
+    p = 0
+    if docs is None:
+        for i, t in enumerate(pages_text):
+            b.add_doc("syn", str(i))
+            b.index_page(ids[i] if ids else "1", t)
+    else:
+        for src, name, n in docs:
+            b.add_doc(src, name)
+            for _ in range(n):
+                b.index_page(ids[p] if ids else "1", pages_text[p])
+                p += 1
+    return b.save(), b
+
+
+def _gpu_images(pages_text, ids=None, docs=None, encoding=None, **kw):
+    import docodo_amd
+    enc = encoding or docodo_amd.DCD_ENC_LATIN1
+    b = docodo_amd.Builder(encoding=enc, **kw)
+    text = "".join(pages_text)
+    off = np.zeros(len(pages_text) + 1, np.uint64)
+    off[1:] = np.cumsum([len(t.encode("utf-16-le")) // 2 for t in pages_text])
+    if docs is None:
+        b.AddPages(text, off, page_ids=ids, docs_per_page=True)
+    else:
+        p = 0
+        for src, name, n in docs:
+            b.AddDoc(src, name)
+            sub = pages_text[p:p + n]
+            so = np.zeros(n + 1, np.uint64)
+            so[1:] = np.cumsum([len(t.encode("utf-16-le")) // 2 for t in sub])
+            b.AddPages("".join(sub), so, page_ids=ids[p:p + n] if ids else None)
+            p += n
+    st = b.Finish()
+    return (b.index_image(), b.list_image()), b, st
+
+
+@pytest.mark.parametrize("n_docs", [1, 7, 2000, 20000])
+def test_synthetic_corpus_images(oracle_mod, n_docs):
+    import docodo_amd
+    from docodo_amd import synth
+    text = synth.corpus_host(n_docs)
+    off = np.arange(n_docs + 1, dtype=np.uint64) * synth.DOC_BYTES
+    b = docodo_amd.Builder()
+    b.AddPages(text, off, docs_per_page=True)
+    st = b.Finish()
+    oix = oracle_mod.Index(stemmers=[])
+    ob = oracle_mod.Builder(oix)
+    ob.index_docs_latin1(text, off)
+    oi, ol = ob.save()
+    assert st.n_postings == ob.total_count and st.n_terms == ob.n_terms and st.max_coord == ob.max_coord
+    assert b.list_image() == ol
+    assert b.index_image() == oi
+
+
+def test_synthetic_device_generator_matches_host():
+    import torch
+    from docodo_amd import synth
+    n = 3000
+    d = torch.empty(n * synth.DOC_BYTES, dtype=torch.uint8, device="cuda")
+    synth.corpus_dev(d.data_ptr(), n, first_doc=17)
+    assert np.array_equal(d.cpu().numpy(), synth.corpus_host(n, first_doc=17))
+
+
+def test_device_resident_text_and_coord_base(oracle_mod):
+    """dcd_build_add_pages_dev + coord_base (doc-range shard with global coordinates)."""
+    import torch
+    import docodo_amd
+    from docodo_amd import synth
+    n, first = 1500, 4000
+    text = synth.corpus_host(n, first_doc=first)
+    off = np.arange(n + 1, dtype=np.uint64) * synth.DOC_BYTES
+    base = first * synth.DOC_BYTES
+    d = torch.from_numpy(text).cuda()
+    b = docodo_amd.Builder(coord_base=base)
+    b.AddPagesDev(d.data_ptr(), text.size, off, docs_per_page=True, first_doc=first)
+    b.Finish()
+    # oracle: index the first `first` docs as blanks is wasteful; instead shift-check per term
+    oix = oracle_mod.Index(stemmers=[])
+    ob = oracle_mod.Builder(oix)
+    ob.index_docs_latin1(text, off, first_doc=first)
+    oi, ol = ob.save()
+    oix.load(oi, ol)
+    ix = b.Build()
+    assert ix.Count == oix.count
+    keys = oix.keys()
+    for k in keys[:50] + keys[-50:]:
+        want = oracle_mod.seq_shift(oix.get(k), base)
+        assert np.array_equal(ix[k].units, want), k
+    assert ix.MaxCoord == oix.max_coord + base
+
+
+def _adversarial_pages():
+    rng = np.random.default_rng(99)
+    words = ["Pickwick", "ÀÉÎõü", "x", "ab", "abc", "A1b2C3", "12345", "mañana", "Straße", "ÞORN", "µ", "ª", "¼½", "²",
+             "a" * 32, "b" * 33, "c" * 40, "Z" * 31 + "9", "don't", "e-mail", "naïve", "ÿ", "×", "÷", "OLD", "old", "Old"]
+    seps = [" ", ", ", ".", "\n", "; ", "--", "\t", "×", " ÷ "]
+    pages = []
+    for p in range(300):
+        n = int(rng.integers(0, 120))
+        s = "".join(words[int(rng.integers(len(words)))] + seps[int(rng.integers(len(seps)))] for _ in range(n))
+        # cut pages at arbitrary points so that words straddle page boundaries
+        cut = int(rng.integers(0, len(s) + 1)) if s else 0
+        pages.append(s[:cut])
+        pages.append(s[cut:])
+    # long pages spanning several 4096-character tiles with words across tile borders
+    pages.append(("tileborder " * 2000))
+    pages.append("q" * 4090 + " word straddle" + "w" * 20 + " " + "v" * 5000 + " end")
+    return [p for p in pages]
+
+
+def test_adversarial_latin1(oracle_mod):
+    pages = _adversarial_pages()
+    docs = [("src", "doc%d" % i, 7) for i in range(len(pages) // 7)] + [("src", "tail", len(pages) % 7)]
+    docs = [d for d in docs if d[2]]
+    ids = [str(1 + (i % 7)) for i in range(len(pages))]
+    (oi, ol), ob = _oracle_images(oracle_mod, pages, ids=ids, docs=docs)
+    (gi, gl), gb, st = _gpu_images(pages, ids=ids, docs=docs)
+    assert st.n_postings == ob.total_count
+    assert gl == ol
+    assert gi == oi
+
+
+def test_utf16_testtext1_body_pages(oracle_mod, testtext1):
+    """TestText1 (IndexTest.cs:19-37, contains U+FFFD) through the UTF-16 tokeniser: 50 identical body
+    pages in 2 docs; per-word postings equal the oracle's (CoordTest's assertion, IndexTest.cs:140-157)."""
+    import docodo_amd
+    greek = "Ελληνικά ΚΕΦΑΛΑΊΑ кириллица ЗАГЛАВНЫЕ 数字１２３ ǅ ǆ İi ﬁ"
+    pages = [testtext1, greek + " " + testtext1[:100]] * 25
+    docs = [("Test", "Sample", 25), ("Test", "Dump", 25)]
+    ids = [str(i + 1) for i in range(25)] * 2
+    (oi, ol), ob = _oracle_images(oracle_mod, pages, ids=ids, docs=docs)
+    (gi, gl), gb, st = _gpu_images(pages, ids=ids, docs=docs, encoding=docodo_amd.DCD_ENC_UTF16LE)
+    assert st.n_postings == ob.total_count and st.n_terms == ob.n_terms
+    assert gl == ol
+    assert gi == oi
+
+
+def test_word_length_limits_and_empty(oracle_mod):
+    import docodo_amd
+    pages = ["", "a bb ccc dddd " * 50, "", "    ", "zzz"]
+    (gi, gl), gb, st = _gpu_images(pages, docs=[("s", "d", 5)], ids=["1", "2", "3", "4", "5"])
+    (oi, ol), ob = _oracle_images(oracle_mod, pages, docs=[("s", "d", 5)], ids=["1", "2", "3", "4", "5"])
+    assert gi == oi and gl == ol
+    # empty build: only the MaxCoord header
+    b = docodo_amd.Builder()
+    b.AddDoc("s", "d")
+    b.Finish()
+    assert b.index_image() == bytes(8)
+
+
+def test_explicit_postings_builder_api(oracle_mod, known):
+    """Index.Builder standalone path (BuilderTest, IndexTest.cs:272-313): AddWord(token, offset) for the
+    \\b\\w+\\b tokens of TestText1, EndPage("1"); identity codes (no stemmer / vocab)."""
+    import docodo_amd
+    ka = known["D13_builder"]
+    oix = oracle_mod.Index(stemmers=[])
+    ob = oracle_mod.Builder(oix)
+    ob.add_doc("A", "")
+    for off, tok in ka["tokens"]:
+        ob.add_word(tok, off)
+    ob.end_page("1")
+    oi, ol = ob.save()
+    b = docodo_amd.Builder(encoding=docodo_amd.DCD_ENC_UTF16LE)
+    b.AddDoc("A", "")
+    for off, tok in ka["tokens"]:
+        b.AddWord(tok, off)
+    b.EndPage("1")
+    b.Finish()
+    assert b.list_image() == ol
+    assert b.index_image() == oi
