@@ -110,6 +110,16 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise RuntimeError("libdocodo_hip.so is missing (%s): run `python -c 'import __graft_entry__ as g; g.build()'` "
                                "or `make -C docodo_amd/csrc`. docodo_amd has no CPU fallback." % LIB_PATH)
+        # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so.7 / libhsa-runtime64.
+        # If torch is going to be used in this process (bench.py, tests: device buffers, RCCL), it must
+        # be loaded first so that our NEEDED libamdhip64.so.7 binds to the same copy; two runtimes in
+        # one process leave the second without a GPU.  A host without torch (the C# shim) simply uses
+        # the system ROCm the library was linked against.
+        if os.environ.get("DOCODO_NO_TORCH") != "1":
+            try:
+                import torch  # noqa: F401
+            except Exception:
+                pass
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             f = getattr(L, name)  # AttributeError here == header/library mismatch
