@@ -1,0 +1,168 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X-native Docodo hot path.
+
+Workload (BASELINE.json configs[1]): 1 M synthetic 1 KiB documents, Zipf-1.1 over a 100 k-term
+vocabulary, per GPU.  One "step" = one full index build of the resident text
+(tokenise -> exact vocabulary -> stable radix sort by term -> 15-bit var-ushort pack -> ".index"
+image in HBM), followed -- outside the step timing -- by the single-term query batch of the config.
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0.  `value` = text bytes indexed by all ranks / wall time of the K
+timed steps (barrier + synchronize on both sides, max over ranks), text already resident in HBM.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB/s measured copy)
+HBM_COPY_GBS = 6290.0
+
+
+def algorithmic_bytes(kernel, T, N, U):
+    """Algorithmic HBM bytes of ONE launch ("Kernels and their rooflines")."""
+    return {
+        "k_tok_count": T,                 # reads the text once
+        "k_tok_emit": T + 8 * N,          # reads the text, writes one (term, coord) tuple per posting
+        "k_rs_hist": 4 * N,               # reads the keys
+        "k_rs_scatter": 16 * N,           # reads and writes every 8-byte tuple
+        "k_enc_reduce": 8 * N,            # reads the sorted tuples
+        "k_enc_write": 8 * N + 2 * U,     # reads the tuples, writes the ushort units
+        "k_img_units": 4 * U,             # copies the units into the .index image
+    }.get(kernel, 0)
+
+
+def cpu_baseline(n_docs_sample):
+    """Reference-faithful CPU restatement (oracle/, single thread) on a bounded sample of the same
+    corpus: text bytes / (index + serialise) seconds.  Baseline, not the target."""
+    import oracle
+    from docodo_amd import synth
+    text = synth.corpus_host(n_docs_sample)
+    off = np.arange(n_docs_sample + 1, dtype=np.uint64) * synth.DOC_BYTES
+    ix = oracle.Index(stemmers=[])
+    b = oracle.Builder(ix)
+    t0 = time.perf_counter()
+    b.index_docs_latin1(text, off)
+    img, lst = b.save()
+    dt = time.perf_counter() - t0
+    return {"value": round(text.size / 1e9 / dt, 5), "unit": "GB/s", "cores": 1, "kind": "port",
+            "sample": "first %d docs (%.1f MB) of the same synthetic corpus, oracle Builder single thread, %.1f s"
+                      % (n_docs_sample, text.size / 1e6, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--docs", type=int, default=1_000_000, help="documents per GPU (1 KiB each)")
+    ap.add_argument("--cpu-docs", type=int, default=200_000, help="documents in the CPU-baseline sample (0 = skip)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    import docodo_amd
+    from docodo_amd import synth
+    from docodo_amd._lib import KERNEL_NAMES
+
+    D = args.docs
+    T = D * synth.DOC_BYTES
+    text = torch.empty(T, dtype=torch.uint8, device="cuda")
+    first_doc = rank * D                               # doc-range shard of this rank (weak scaling)
+    synth.corpus_dev(text.data_ptr(), D, first_doc=first_doc, device=local_rank)
+    coord_base = first_doc * synth.DOC_BYTES           # shards encode GLOBAL coordinates
+
+    def step():
+        b = docodo_amd.Builder(coord_base=coord_base, device=local_rank)
+        b.AddUniformPagesDev(text.data_ptr(), D, synth.DOC_BYTES, first_doc=first_doc)
+        st = b.Finish()
+        return b, st
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        b, st = step()
+        b.close()
+    fence()
+    t0 = time.perf_counter()
+    ksum = np.zeros(8)
+    kcnt = np.zeros(8)
+    stage = np.zeros(6)
+    last = None
+    for _ in range(args.steps):
+        b, st = step()
+        ksum += np.array(list(st.ms_kernel))
+        kcnt += np.array(list(st.n_launch))
+        stage += np.array([st.ms_tokenize, st.ms_vocab, st.ms_sort, st.ms_pack, st.ms_image, st.ms_total])
+        last = (st.n_postings, st.n_terms, st.n_units, st.index_bytes, st.sort_passes)
+        b.close()
+    fence()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    if rank == 0:
+        N, V, U, img_bytes, passes = last
+        ms_step = dt / args.steps * 1e3
+        value = world * T / 1e9 / (dt / args.steps)
+        # dominant kernel = largest total device time per step (HIP events on the build stream)
+        per_step = ksum / args.steps
+        dom = int(np.argmax(per_step[:7]))
+        name = KERNEL_NAMES[dom]
+        avg_ms = ksum[dom] / max(1.0, kcnt[dom])
+        abytes = algorithmic_bytes(name, T, N, U)
+        achieved = abytes / 1e9 / (avg_ms / 1e3)
+        out = {
+            "metric": "text_indexed_GB_per_s", "value": round(value, 3), "unit": "GB/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "configs[1]: %d synthetic 1 KiB docs per GPU, Zipf-1.1 over 100k terms (SURVEY App. F); "
+                                   "full index build, text resident in HBM -> .index image resident in HBM" % D,
+                       "docs_per_gpu": D, "text_bytes_per_gpu": T, "postings": int(N), "terms": int(V), "units": int(U),
+                       "index_bytes": int(img_bytes), "sort_passes": int(passes), "sharding": "doc-range, global coordinates"},
+            "roofline": {"bound": "hbm", "kernel": name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "frac_of_measured_copy": round(achieved / HBM_COPY_GBS, 4),
+                         "algorithmic_bytes_per_launch": int(abytes), "avg_launch_ms": round(avg_ms, 4),
+                         "launches_per_step": round(kcnt[dom] / args.steps, 2), "traffic": None},
+            "device_ms_per_step": {"tokenize": round(stage[0] / args.steps, 3), "vocab": round(stage[1] / args.steps, 3),
+                                   "sort": round(stage[2] / args.steps, 3), "pack": round(stage[3] / args.steps, 3),
+                                   "image": round(stage[4] / args.steps, 3), "total": round(stage[5] / args.steps, 3)},
+            "kernel_ms_per_step": {KERNEL_NAMES[k]: round(per_step[k], 4) for k in range(8)},
+            "postings_per_s": round(world * N / (dt / args.steps), 0),
+        }
+        if world == 1 and args.cpu_docs > 0:
+            out["cpu_baseline"] = cpu_baseline(min(args.cpu_docs, D))
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -129,6 +129,10 @@ __global__ void k_term_strings(const u64* __restrict__ rk_word, u64 n, const u32
 }
 
 __global__ void k_set_u64(u64* p, u64 v) { *p = v; }
+__global__ void k_uniform_page_end(u64* out, u64 n, u64 base, u64 chars) {
+  u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = base + (i + 1) * chars;
+}
 __global__ void k_swap_xy(uint2* p, u64 n) {
   u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) { uint2 v = p[i]; p[i] = make_uint2(v.y, v.x); }
@@ -406,6 +410,26 @@ int32_t dcd_build_add_pages_dev(dcd_build* h, const void* text_dev, uint64_t n_c
   return DCD_OK;
 }
 
+int32_t dcd_build_add_uniform_pages_dev(dcd_build* h, const void* text_dev, uint64_t n_pages, uint32_t page_chars, uint64_t first_doc,
+                                        const uint16_t* source, size_t source_len) {
+  if (!h || !text_dev || (!source && source_len)) DCD_FAIL(DCD_E_BADARG, "dcd_build_add_uniform_pages_dev: NULL argument");
+  if (h->finished) DCD_FAIL(DCD_E_STATE, "build already finished");
+  if (h->n_chars || !h->pages.docs.empty() || h->pages.n_pages()) DCD_FAIL(DCD_E_STATE, "uniform pages must be the only text batch of their build");
+  if (((uintptr_t)text_dev & 15) != 0) DCD_FAIL(DCD_E_BADARG, "device text must be 16-byte aligned");
+  if (page_chars == 0 || n_pages == 0) DCD_FAIL(DCD_E_BADARG, "n_pages and page_chars must be positive");
+  u64 n_chars = n_pages * (u64)page_chars;
+  if (n_chars >= (1ull << 32)) DCD_FAIL(DCD_E_OVERFLOW, "one build segment holds < 2^32 characters; shard larger corpora");
+  PageTable& pt = h->pages;
+  pt.uniform = true; pt.uni_n = n_pages; pt.uni_chars = page_chars; pt.uni_base = h->opts.coord_base;
+  pt.doc_per_page = true; pt.first_doc = first_doc; pt.uniform_id = u"1";
+  pt.source = source_len ? mk16(source, source_len) : ustr(u"syn");
+  h->text_dev = text_dev;
+  h->text_borrowed = true;
+  h->n_chars = n_chars;
+  h->last_is_explicit = false;
+  return DCD_OK;
+}
+
 int32_t dcd_build_add(dcd_build* h, const uint16_t* code, size_t len, uint64_t coord) {
   if (!h || (!code && len)) DCD_FAIL(DCD_E_BADARG, "dcd_build_add: NULL argument");
   if (h->finished) DCD_FAIL(DCD_E_STATE, "build already finished");
@@ -454,7 +478,8 @@ static int32_t finish_impl(dcd_build* h) {
   DCD_TRY(t_sort.init(st)); DCD_TRY(t_pack.init(st)); DCD_TRY(t_img.init(st));
 
   const u64 n_chars = h->n_chars;
-  const u64 n_pages_dev = h->page_off.size() - 1;
+  const bool uniform = h->pages.uniform;
+  const u64 n_pages_dev = uniform ? h->pages.uni_n : h->page_off.size() - 1;
   const u64 n_tiles = div_up(n_chars, TK_TILE);
   const u64 n_x = h->xps.size();
   const CharT* text = (const CharT*)h->text_dev;
@@ -464,8 +489,10 @@ static int32_t finish_impl(dcd_build* h) {
 
   // ---- uploads (not part of the timed device pipeline: the text is already resident) ----------
   DevBuf<u64> d_page_off;
-  DCD_TRY(d_page_off.alloc(dev, n_pages_dev + 1));
-  DCD_HIP(hipMemcpyAsync(d_page_off.p, h->page_off.data(), (n_pages_dev + 1) * 8, hipMemcpyHostToDevice, st));
+  if (!uniform) {
+    DCD_TRY(d_page_off.alloc(dev, n_pages_dev + 1));
+    DCD_HIP(hipMemcpyAsync(d_page_off.p, h->page_off.data(), (n_pages_dev + 1) * 8, hipMemcpyHostToDevice, st));
+  }
   DevBuf<CharT> d_pool;
   DevBuf<u32> d_xoff, d_xlen, d_xcoord;
   if (n_x) {
@@ -482,11 +509,21 @@ static int32_t finish_impl(dcd_build* h) {
     DCD_HIP(hipStreamSynchronize(st));
   }
   DevBuf<u64> d_page_end;
-  if (!h->pages.end.empty()) {
+  if (uniform) {
+    DCD_TRY(d_page_end.alloc(dev, h->pages.uni_n));
+    hipLaunchKernelGGL(k_uniform_page_end, dim3((u32)div_up(h->pages.uni_n, 256)), dim3(256), 0, st, d_page_end.p, h->pages.uni_n,
+                       h->pages.uni_base, h->pages.uni_chars);
+  } else if (!h->pages.end.empty()) {
     DCD_TRY(d_page_end.alloc(dev, h->pages.end.size()));
     DCD_HIP(hipMemcpyAsync(d_page_end.p, h->pages.end.data(), h->pages.end.size() * 8, hipMemcpyHostToDevice, st));
   }
   DCD_HIP(hipStreamSynchronize(st));
+
+  // per-kernel probes: (kernel id, begin event, end event)
+  struct Probe { int id; hipEvent_t a, b; };
+  std::vector<Probe> probes;
+  auto probe_begin = [&](int id) { Probe p{id, nullptr, nullptr}; (void)hipEventCreate(&p.a); (void)hipEventCreate(&p.b); (void)hipEventRecord(p.a, st); probes.push_back(p); };
+  auto probe_end = [&]() { (void)hipEventRecord(probes.back().b, st); };
 
   DCD_TRY(t_all.start());
   // ---- 1. tokenise: count pass -------------------------------------------------------------------
@@ -497,6 +534,7 @@ static int32_t finish_impl(dcd_build* h) {
   P.n_pages = n_pages_dev;
   P.min_len = (u32)h->opts.min_word_length;
   P.max_len = (u32)h->opts.max_word_length;
+  P.uniform_page_chars = uniform ? (u32)h->pages.uni_chars : 0u;
   DevBuf<u32> tile_count;
   DevBuf<u64> tile_off, scan_scr64;
   u64 n_text_tok = 0;
@@ -504,7 +542,9 @@ static int32_t finish_impl(dcd_build* h) {
     DCD_TRY(tile_count.alloc(dev, n_tiles));
     DCD_TRY(tile_off.alloc(dev, n_tiles));
     DCD_TRY(scan_scr64.alloc(dev, scan_scratch_elems(n_tiles)));
+    probe_begin(DCD_K_TOK_COUNT);
     hipLaunchKernelGGL((k_tok_count<CharT>), dim3((u32)n_tiles), dim3(TK_THREADS), 0, st, text, P, tab, tile_count.p);
+    probe_end();
     scan_exclusive<u32, u64>(tile_count.p, tile_off.p, n_tiles, scan_scr64.p, st);
     DCD_HIP(hipMemcpyAsync(&n_text_tok, scan_scr64.p + scan_nblocks(n_tiles), 8, hipMemcpyDeviceToHost, st));
     DCD_HIP(hipStreamSynchronize(st));
@@ -538,8 +578,11 @@ static int32_t finish_impl(dcd_build* h) {
     DCD_HIP(hipMemsetAsync(d_flags.p, 0, 16, st));
     VocabTable vt;
     vt.slots = slots.p; vt.mask = (u32)(cap - 1); vt.overflow = d_flags.p;
-    if (n_tiles)
+    if (n_tiles) {
+      probe_begin(DCD_K_TOK_EMIT);
       hipLaunchKernelGGL((k_tok_emit<CharT>), dim3((u32)n_tiles), dim3(TK_THREADS), 0, st, text, P, tab, tv, vt, tile_off.p, tupA.p);
+      probe_end();
+    }
     if (n_x)
       hipLaunchKernelGGL((k_explicit<CharT>), dim3((u32)div_up(n_x, 256)), dim3(256), 0, st, d_pool.p, d_xoff.p, d_xlen.p, d_xcoord.p,
                          n_x, tv, vt, tupA.p + n_text_tok);
@@ -582,6 +625,7 @@ static int32_t finish_impl(dcd_build* h) {
     DCD_HIP(hipStreamSynchronize(st));
     constexpr u32 K = sizeof(CharT) == 1 ? 4 : 2;
     const u32 nchunks = (maxlen + K - 1) / K;
+    probe_begin(DCD_K_VOCAB_SORT);
     uint2* cur = permA.p;
     uint2* other = permB.p;
     for (int c = (int)nchunks - 1; c >= 0; c--) {
@@ -592,6 +636,7 @@ static int32_t finish_impl(dcd_build* h) {
     }
     hipLaunchKernelGGL(k_assign_rank, dim3((u32)div_up(V, 256)), dim3(256), 0, st, cur, V, term_slot.p, term_word.p, rank_of_slot.p,
                        rk_word.p);
+    probe_end();
   }
   DCD_TRY(t_voc.stop());
 
@@ -599,6 +644,7 @@ static int32_t finish_impl(dcd_build* h) {
   DCD_TRY(t_sort.start());
   uint2* sorted = tupA.p;
   int passes = 0;
+  std::vector<hipEvent_t> sort_events;
   if (N) {
     uint2* a = tupA.p;
     uint2* b = tupB.p;
@@ -616,7 +662,9 @@ static int32_t finish_impl(dcd_build* h) {
       hipLaunchKernelGGL(k_swap_xy, dim3((u32)div_up(N, 256)), dim3(256), 0, st, a, N);
     }
     int p2 = 0;
-    sorted = rs_sort(a, b, rank_of_slot.p, N, (int)log2_ceil(V ? V : 1), d_hist.p, scan_scr32.p, st, &p2);
+    RsProbe rp;
+    rp.ev = &sort_events;
+    sorted = rs_sort(a, b, rank_of_slot.p, N, (int)log2_ceil(V ? V : 1), d_hist.p, scan_scr32.p, st, &p2, rp);
     passes += p2;
   }
   DCD_TRY(t_sort.stop());
@@ -634,13 +682,19 @@ static int32_t finish_impl(dcd_build* h) {
   EncSrcPairs src;
   src.p = sorted; src.base = h->opts.coord_base; src.term_unit_start = ix.term_unit_start.p; src.term_item_start = ix.term_item_start.p;
   if (N) {
+    probe_begin(DCD_K_ENC_REDUCE);
     hipLaunchKernelGGL((k_enc_reduce<EncSrcPairs>), dim3((u32)enb), dim3(CODEC_THREADS), 0, st, src, N, enc_part.p);
+    probe_end();
     hipLaunchKernelGGL((k_scan_partials<u64>), dim3(1), dim3(1024), 0, st, enc_part.p, enb);
     DCD_HIP(hipMemcpyAsync(&U, enc_part.p + enb, 8, hipMemcpyDeviceToHost, st));
     DCD_HIP(hipStreamSynchronize(st));
   }
   DCD_TRY(ix.units.alloc(dev, U ? U : 1));
-  if (N) hipLaunchKernelGGL((k_enc_write<EncSrcPairs>), dim3((u32)enb), dim3(CODEC_THREADS), 0, st, src, N, enc_part.p, ix.units.p);
+  if (N) {
+    probe_begin(DCD_K_ENC_WRITE);
+    hipLaunchKernelGGL((k_enc_write<EncSrcPairs>), dim3((u32)enb), dim3(CODEC_THREADS), 0, st, src, N, enc_part.p, ix.units.p);
+    probe_end();
+  }
   hipLaunchKernelGGL(k_set_u64, dim3(1), dim3(1), 0, st, ix.term_unit_start.p + V, U);
   hipLaunchKernelGGL(k_set_u64, dim3(1), dim3(1), 0, st, ix.term_item_start.p + V, N);
   DCD_TRY(t_pack.stop());
@@ -681,9 +735,12 @@ static int32_t finish_impl(dcd_build* h) {
   if (V) {
     hipLaunchKernelGGL(k_img_headers, dim3((u32)div_up(V, 256)), dim3(256), 0, st, ix.term_chars.p, ix.term_str_off.p,
                        ix.term_unit_start.p, rec_off.p, V, (u64)8, h->image.p, pay_off.p);
-    if (U)
+    if (U) {
+      probe_begin(DCD_K_IMG_UNITS);
       hipLaunchKernelGGL(k_img_units, dim3((u32)div_up(div_up(U, IMG_UPT), 256)), dim3(256), 0, st, ix.units.p, U, ix.term_unit_start.p, V,
                          pay_off.p, h->image.p);
+      probe_end();
+    }
   }
   DCD_TRY(t_img.stop());
   DCD_TRY(t_all.stop());
@@ -702,15 +759,26 @@ static int32_t finish_impl(dcd_build* h) {
   DCD_HIP(hipMemcpy(ix.h_term_unit_start.data(), ix.term_unit_start.p, (V + 1) * 8, hipMemcpyDeviceToHost));
   DCD_HIP(hipMemcpy(ix.h_term_item_start.data(), ix.term_item_start.p, (V + 1) * 8, hipMemcpyDeviceToHost));
   ix.pages = h->pages;
-  write_list_image(h->pages, h->list_image);
 
   dcd_build_stats& s = h->stats;
   s.n_chars = n_chars; s.n_pages = h->pages.n_pages(); s.n_docs = h->pages.n_docs();
   s.n_postings = N; s.n_terms = V; s.n_units = U; s.max_coord = max_coord;
-  s.index_bytes = h->image_bytes; s.list_bytes = h->list_image.size();
+  s.index_bytes = h->image_bytes; s.list_bytes = 0;  // the list image is generated on demand
   s.ms_tokenize = t_tok.ms(); s.ms_vocab = t_voc.ms(); s.ms_sort = t_sort.ms(); s.ms_pack = t_pack.ms(); s.ms_image = t_img.ms();
   s.ms_total = t_all.ms();
   s.sort_passes = (u32)passes; s.vocab_capacity_log2 = cap_log2;
+  for (int k = 0; k < 8; k++) { s.ms_kernel[k] = 0; s.n_launch[k] = 0; }
+  for (auto& p : probes) {
+    float t = 0;
+    if (hipEventElapsedTime(&t, p.a, p.b) == hipSuccess) { s.ms_kernel[p.id] += t; s.n_launch[p.id]++; }
+    (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b);
+  }
+  for (size_t i = 0; i + 3 < sort_events.size(); i += 4) {
+    float t = 0;
+    if (hipEventElapsedTime(&t, sort_events[i], sort_events[i + 1]) == hipSuccess) { s.ms_kernel[DCD_K_RS_HIST] += t; s.n_launch[DCD_K_RS_HIST]++; }
+    if (hipEventElapsedTime(&t, sort_events[i + 2], sort_events[i + 3]) == hipSuccess) { s.ms_kernel[DCD_K_RS_SCATTER] += t; s.n_launch[DCD_K_RS_SCATTER]++; }
+  }
+  for (auto e : sort_events) (void)hipEventDestroy(e);
   h->finished = true;
   return DCD_OK;
 }
@@ -744,6 +812,7 @@ int32_t dcd_build_index_image(dcd_build* h, uint8_t* out, size_t cap, size_t* n)
 int32_t dcd_build_list_image(dcd_build* h, uint8_t* out, size_t cap, size_t* n) {
   if (!h || !n) DCD_FAIL(DCD_E_BADARG, "dcd_build_list_image: NULL argument");
   if (!h->finished) DCD_FAIL(DCD_E_STATE, "dcd_build_finish has not run");
+  if (h->list_image.empty()) { write_list_image(h->pages, h->list_image); h->stats.list_bytes = h->list_image.size(); }
   *n = h->list_image.size();
   if (!out || cap < h->list_image.size()) return DCD_E_OVERFLOW;
   memcpy(out, h->list_image.data(), h->list_image.size());
@@ -763,6 +832,7 @@ int32_t dcd_build_save(dcd_build* h, const char* dir_utf8) {
   bool ok = fwrite(img.data(), 1, img.size(), f) == img.size();
   ok = fclose(f) == 0 && ok;
   if (!ok) DCD_FAIL(DCD_E_IO, "short write to %s.index", d.c_str());
+  if (h->list_image.empty()) { write_list_image(h->pages, h->list_image); h->stats.list_bytes = h->list_image.size(); }
   f = fopen((d + ".index.list").c_str(), "wb");
   if (!f) DCD_FAIL(DCD_E_IO, "cannot create %s.index.list", d.c_str());
   ok = fwrite(h->list_image.data(), 1, h->list_image.size(), f) == h->list_image.size();

@@ -27,8 +27,12 @@ struct PageTable {
   ustr source;                    // source name for doc_per_page
   u64 first_doc = 0;
   std::vector<u32> page_doc;      // doc index per page (explicit docs only)
-  u64 n_pages() const { return end.size(); }
-  u64 n_docs() const { return doc_per_page ? end.size() : docs.size(); }
+  // ... or n uniform pages of `uni_chars` characters (implies doc_per_page, uniform id): no vectors at all
+  bool uniform = false;
+  u64 uni_n = 0, uni_chars = 0, uni_base = 0;
+  u64 n_pages() const { return uniform ? uni_n : end.size(); }
+  u64 n_docs() const { return doc_per_page ? n_pages() : docs.size(); }
+  u64 end_at(u64 p) const { return uniform ? uni_base + (p + 1) * uni_chars : end[p]; }
   ustr doc_name(u64 d) const;
   ustr page_id(u64 p) const { return ids.empty() ? uniform_id : ids[p]; }
   u32 doc_of_page(u64 p) const { return doc_per_page ? (u32)p : page_doc[p]; }

@@ -76,12 +76,12 @@ void write_list_image(const PageTable& pt, std::vector<u8>& out) {
   int64_t last_doc = -1;
   ustr sep(1, u':');
   for (u64 p = 0; p < np; p++) {
-    put_u64(out, pt.end[p]);
+    put_u64(out, pt.end_at(p));
     int64_t d = (int64_t)pt.doc_of_page(p);
     if (d != last_doc) {
       last_doc = d;
       put_str(out, pt.doc_name((u64)d));
-      put_u64(out, pt.end[p]);
+      put_u64(out, pt.end_at(p));
     }
     put_str(out, sep + pt.page_id(p));
   }

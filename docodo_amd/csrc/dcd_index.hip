@@ -256,7 +256,7 @@ int32_t dcd_index_page_info(dcd_index* h, uint64_t page, uint64_t* end_coord, ui
   if (!h) DCD_FAIL(DCD_E_BADARG, "dcd_index_page_info: NULL handle");
   const PageTable& pt = h->ix.pages;
   if (page >= pt.n_pages()) DCD_FAIL(DCD_E_BADARG, "page out of range");
-  if (end_coord) *end_coord = pt.end[page];
+  if (end_coord) *end_coord = pt.end_at(page);
   if (doc) *doc = pt.doc_of_page(page);
   ustr id = pt.page_id(page);
   if (id_len) *id_len = id.size();

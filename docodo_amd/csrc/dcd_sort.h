@@ -13,6 +13,8 @@
 #pragma once
 #include "dcd_common.h"
 #include "dcd_prims.h"
+#include <vector>
+
 #include "dcd_scan.h"
 
 namespace dcd {
@@ -163,24 +165,38 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const uint2* __restri
 
 inline u64 rs_hist_elems(u64 n, int bits) { return (u64)rs_plan(n).nblk << bits; }
 
+// optional per-kernel event probes (build stats): pairs of events recorded around the two kernels
+struct RsProbe {
+  std::vector<hipEvent_t>* ev = nullptr;  // appended: hist_begin, hist_end, scatter_begin, scatter_end per pass
+  void rec(hipStream_t st) const {
+    if (!ev) return;
+    hipEvent_t e;
+    if (hipEventCreate(&e) == hipSuccess) { (void)hipEventRecord(e, st); ev->push_back(e); }
+  }
+};
+
 template <int BITS>
 inline void rs_pass(const uint2* in, uint2* out, const u32* remap, u64 n, int shift, u32* hist, u32* scan_scratch,
-                    hipStream_t st) {
+                    hipStream_t st, const RsProbe& pr) {
   RsPlan p = rs_plan(n);
+  pr.rec(st);
   hipLaunchKernelGGL((k_rs_hist<BITS>), dim3(p.nblk), dim3(RS_THREADS), 0, st, in, remap, n, p.ipb, p.nblk, shift, hist);
+  pr.rec(st);
   u64 ne = (u64)p.nblk << BITS;
   scan_exclusive<u32, u32>(hist, hist, ne, scan_scratch, st);
+  pr.rec(st);
   hipLaunchKernelGGL((k_rs_scatter<BITS>), dim3(p.nblk), dim3(RS_THREADS), 0, st, in, remap, n, p.ipb, p.nblk, shift, hist, out);
+  pr.rec(st);
 }
 
 inline void rs_pass_dyn(int bits, const uint2* in, uint2* out, const u32* remap, u64 n, int shift, u32* hist,
-                        u32* scan_scratch, hipStream_t st) {
+                        u32* scan_scratch, hipStream_t st, const RsProbe& pr) {
   switch (bits) {
-    case 6: rs_pass<6>(in, out, remap, n, shift, hist, scan_scratch, st); break;
-    case 7: rs_pass<7>(in, out, remap, n, shift, hist, scan_scratch, st); break;
-    case 8: rs_pass<8>(in, out, remap, n, shift, hist, scan_scratch, st); break;
-    case 9: rs_pass<9>(in, out, remap, n, shift, hist, scan_scratch, st); break;
-    default: rs_pass<10>(in, out, remap, n, shift, hist, scan_scratch, st); break;
+    case 6: rs_pass<6>(in, out, remap, n, shift, hist, scan_scratch, st, pr); break;
+    case 7: rs_pass<7>(in, out, remap, n, shift, hist, scan_scratch, st, pr); break;
+    case 8: rs_pass<8>(in, out, remap, n, shift, hist, scan_scratch, st, pr); break;
+    case 9: rs_pass<9>(in, out, remap, n, shift, hist, scan_scratch, st, pr); break;
+    default: rs_pass<10>(in, out, remap, n, shift, hist, scan_scratch, st, pr); break;
   }
 }
 
@@ -210,12 +226,12 @@ inline RsSchedule rs_schedule(int total_bits) {
 // remapped ones (remap applied once).  hist: >= RS_MAX_BLOCKS << 10 u32; scan_scratch: >=
 // scan_scratch_elems(RS_MAX_BLOCKS << 10) u32.
 inline uint2* rs_sort(uint2* buf_a, uint2* buf_b, const u32* remap, u64 n, int total_bits, u32* hist, u32* scan_scratch,
-                      hipStream_t st, int* passes_out = nullptr) {
+                      hipStream_t st, int* passes_out = nullptr, const RsProbe& pr = RsProbe()) {
   RsSchedule sc = rs_schedule(total_bits);
   int shift = 0;
   uint2 *in = buf_a, *out = buf_b;
   for (int i = 0; i < sc.npass; i++) {
-    rs_pass_dyn(sc.width[i], in, out, i == 0 ? remap : nullptr, n, shift, hist, scan_scratch, st);
+    rs_pass_dyn(sc.width[i], in, out, i == 0 ? remap : nullptr, n, shift, hist, scan_scratch, st, pr);
     shift += sc.width[i];
     uint2* t = in; in = out; out = t;
   }

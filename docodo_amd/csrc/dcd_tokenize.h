@@ -144,6 +144,7 @@ struct TokParams {
   const u64* page_off;   // [n_pages + 1] device, ascending, page_off[0] = 0, page_off[n_pages] = n_chars
   u64 n_pages;
   u32 min_len, max_len;
+  u32 uniform_page_chars;  // != 0: pages start at every multiple of this (page_off unused)
 };
 
 template <typename CharT>
@@ -164,8 +165,16 @@ __device__ __forceinline__ u32 tokenize_tile(const CharT* __restrict__ text, con
   const int64_t lo = (int64_t)(tile * TK_TILE) - TK_PRE;          // global index of local 0
   for (u32 i = tid; i < TK_SPAN / 32 + 2; i += TK_THREADS) L.pg[i] = 0;
   __syncthreads();
-  // page starts inside [lo, lo + TK_SPAN): first page with offset >= max(lo, 0)
-  {
+  // page starts inside [lo, lo + TK_SPAN)
+  if (P.uniform_page_chars) {
+    const u64 S = P.uniform_page_chars;
+    u64 first = lo < 0 ? 0 : (u64)lo;
+    u64 o = (first + S - 1) / S * S + (u64)tid * S;
+    for (; (int64_t)o < lo + TK_SPAN && o <= P.n_chars; o += (u64)TK_THREADS * S) {
+      u32 li = (u32)((int64_t)o - lo);
+      atomicOr(&L.pg[li >> 5], 1u << (li & 31));
+    }
+  } else {
     u64 first = lo < 0 ? 0 : (u64)lo;
     u64 a = 0, b = P.n_pages + 1;  // lower_bound over page_off[0 .. n_pages]
     while (a < b) { u64 m = (a + b) >> 1; if (P.page_off[m] < first) a = m + 1; else b = m; }

@@ -84,6 +84,10 @@ class Builder:
         check(lib().dcd_build_add_pages_dev(self.h, text_dev_ptr, n_chars, off.ctypes.data, off.size - 1,
                                             1 if docs_per_page else 0, first_doc, sp, sn))
 
+    def AddUniformPagesDev(self, text_dev_ptr, n_pages, page_chars, first_doc=0, source="syn"):
+        s, sp, sn = _u16(source)
+        check(lib().dcd_build_add_uniform_pages_dev(self.h, text_dev_ptr, n_pages, page_chars, first_doc, sp, sn))
+
     def Add(self, code, coord):  # Build.cs:324
         a, p, n = _u16(code)
         check(lib().dcd_build_add(self.h, p, n, int(coord)))

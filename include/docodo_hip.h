@@ -109,6 +109,11 @@ int32_t dcd_build_add_pages(dcd_build* h, const void* text, uint64_t n_chars, co
 int32_t dcd_build_add_pages_dev(dcd_build* h, const void* text_dev, uint64_t n_chars, const uint64_t* page_off_host,
                                 size_t n_pages, int32_t docs_per_page, uint64_t first_doc,
                                 const uint16_t* source, size_t source_len);
+/* Device-resident text made of n_pages pages of exactly page_chars characters each, one document per
+ * page (the synthetic corpora of SURVEY.md Appendix F).  No per-page host metadata is touched: page
+ * boundaries are computed arithmetically on the device and ".index.list" is generated on demand. */
+int32_t dcd_build_add_uniform_pages_dev(dcd_build* h, const void* text_dev, uint64_t n_pages, uint32_t page_chars,
+                                        uint64_t first_doc, const uint16_t* source, size_t source_len);
 /* Builder.Add(code, coord), Build.cs:324-341: explicit posting for an index code */
 int32_t dcd_build_add(dcd_build* h, const uint16_t* code, size_t len, uint64_t coord);
 /* Builder.EndPage(id) / EndPage(id, maxcoord), Build.cs:359-367 (explicit-posting API only) */
@@ -128,7 +133,20 @@ typedef struct dcd_build_stats {
   uint64_t list_bytes;      /* size of the .index.list image */
   float ms_tokenize, ms_vocab, ms_sort, ms_pack, ms_image, ms_total; /* device time per stage (HIP events) */
   uint32_t sort_passes, vocab_capacity_log2;
+  /* device time of individual kernels (HIP events on the build stream), summed over their launches:
+   * [0] k_tok_count  [1] k_tok_emit  [2] k_rs_hist (tuple sort)  [3] k_rs_scatter (tuple sort)
+   * [4] k_enc_reduce  [5] k_enc_write  [6] k_img_units  [7] vocabulary string sort (all kernels) */
+  float ms_kernel[8];
+  uint32_t n_launch[8];
 } dcd_build_stats;
+#define DCD_K_TOK_COUNT 0
+#define DCD_K_TOK_EMIT 1
+#define DCD_K_RS_HIST 2
+#define DCD_K_RS_SCATTER 3
+#define DCD_K_ENC_REDUCE 4
+#define DCD_K_ENC_WRITE 5
+#define DCD_K_IMG_UNITS 6
+#define DCD_K_VOCAB_SORT 7
 int32_t dcd_build_get_stats(dcd_build* h, dcd_build_stats* out);
 
 /* Exact bytes of ".index" (Build.cs:375-386 / Appendix A.3) and ".index.list" (Build.cs:99-118) */
