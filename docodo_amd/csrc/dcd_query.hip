@@ -1,27 +1,786 @@
-// dcd_query.hip -- query evaluation (placeholder entry points; kernels follow).
+// dcd_query.hip -- batched query evaluation on the device.
+//
+// Replaces, per query: this[key] + Count() (Index.cs:255-263, Search.cs:307), the IndexSequence
+// operators * / + (IndexSequence.cs:218-322), PrepareSearchResult (Search.cs:365-420) and the page /
+// document ranks (Search.cs:99-111, 552-557, 599).
+//
+// Shape of the computation
+//   * the posting lists are decoded once per index into absolute coordinates (HBM-resident u64,
+//     built lazily on the first query: an auxiliary structure, the .index image stays canonical);
+//   * a query is a postfix program; programs advance in rounds, one binary operator per query and
+//     round, all operators of a round in ONE launch (k_pair_ops: one workgroup per operand pair);
+//   * k_pair_ops streams both operands through LDS in 1024-element tiles: merge path -> union with
+//     source tags -> gap chains -> "contains both operands" (and the ordered-mode prefix rule) ->
+//     compaction.  A chain that is still open at a tile border is written optimistically and rolled
+//     back if it closes without the other operand (exact restatement of the group logic of
+//     IndexSequence.cs:218-284);
+//   * k_result_count / k_result_fill walk the final sequence of each query (one workgroup per
+//     query): coordinate -> page by binary search over the page END table (IndexPageList.GetPage,
+//     Build.cs:74-97), page-relative positions, the 30000-page / 500-document caps, ranks.
+//
+// Operand streams must be strictly ascending (true for every posting list and every operator
+// result); equal values in both operands are merged as the reference does.
+#include <algorithm>
+#include <cmath>
+#include <memory>
+
+#include "dcd_codec.h"
 #include "dcd_index_int.h"
+#include "dcd_scan.h"
+
+namespace dcd {
+
+constexpr u32 NONE32 = 0xFFFFFFFFu;
+
+struct Seg {       // a sequence of absolute coordinates somewhere on the device
+  u64 off;         // element offset into index values (kind 0) or the work pool (kind 1)
+  u64 cnt_imm;     // count when cnt_ref == NONE32
+  u32 kind;
+  u32 cnt_ref;     // index into the device `counts` array (results of earlier operators)
+};
+struct PairOp {
+  Seg a, b;
+  int32_t Ra, Rb;
+  u32 op;          // DCD_OP_AND / DCD_OP_OR
+  u32 out_cnt_ref;
+  u64 out_off;     // into the work pool; capacity = cap(a) + cap(b)
+};
+struct FinalSeq {
+  Seg s;
+};
+
+__device__ __forceinline__ const u64* seg_ptr(const Seg& s, const u64* idx_values, const u64* pool) {
+  return (s.kind == 0 ? idx_values : pool) + s.off;
+}
+__device__ __forceinline__ u64 seg_cnt(const Seg& s, const u64* counts) { return s.cnt_ref == NONE32 ? s.cnt_imm : counts[s.cnt_ref]; }
+
+// ------------------------------------------------------------------------------------------------
+// whole-index decode: values[i] = absolute coordinate of posting i (term-relative prefix sum)
+// ------------------------------------------------------------------------------------------------
+__global__ void k_term_relative(const u64* __restrict__ excl, const u64* __restrict__ deltas, u64 n, const u64* __restrict__ item_start,
+                                u64 n_terms, u64* __restrict__ values) {
+  u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  u64 a = 0, b = n_terms;  // last t with item_start[t] <= i
+  while (a + 1 < b) { u64 m = (a + b) >> 1; if (item_start[m] <= i) a = m; else b = m; }
+  values[i] = excl[i] + deltas[i] - excl[item_start[a]];
+}
+
+// ------------------------------------------------------------------------------------------------
+// operator * / + on operand pairs
+// ------------------------------------------------------------------------------------------------
+constexpr int PO_THREADS = 256;
+constexpr int PO_ITEMS = 4;
+constexpr int PO_TILE = PO_THREADS * PO_ITEMS;
+
+struct PoState {
+  u64 ia, ib, cursor, out_start, prev_val;
+  u32 have_prev, prev_src, open, committed, seenA, seenEB;
+  u32 ca, cb, last_first_excl;
+};
+
+__global__ __launch_bounds__(PO_THREADS) void k_pair_ops(const PairOp* __restrict__ ops, u32 n_ops, const u64* __restrict__ idx_values,
+                                                        u64* __restrict__ pool, u64* __restrict__ counts) {
+  __shared__ u64 sA[PO_TILE], sB[PO_TILE];
+  __shared__ u32 s_firstA[PO_TILE + 2], s_hasEB[PO_TILE + 2];
+  __shared__ u32 s_scan[PO_THREADS / 64 + 1];
+  __shared__ PoState S;
+  const u32 tid = threadIdx.x;
+
+  for (u32 oi = blockIdx.x; oi < n_ops; oi += gridDim.x) {
+    const PairOp op = ops[oi];
+    const u64* A = seg_ptr(op.a, idx_values, pool);
+    const u64* B = seg_ptr(op.b, idx_values, pool);
+    const u64 na = seg_cnt(op.a, counts), nb = seg_cnt(op.b, counts);
+    u64* out = pool + op.out_off;
+    const u32 absR = (u32)max(abs(op.Ra), abs(op.Rb));
+    const bool ordered = op.Ra < 0 && op.Rb < 0 && absR != 0;   // R = -absR < 0  (IndexSequence.cs:221-222)
+    const bool is_or = op.op == DCD_OP_OR;
+    if (tid == 0) {
+      S.ia = S.ib = S.cursor = S.out_start = S.prev_val = 0;
+      S.have_prev = S.prev_src = S.open = S.committed = S.seenA = S.seenEB = 0;
+    }
+    __syncthreads();
+
+    while (S.ia < na || S.ib < nb) {
+      const u64 ia = S.ia, ib = S.ib;
+      const u32 ra = (u32)min((u64)PO_TILE, na - ia), rb = (u32)min((u64)PO_TILE, nb - ib);
+      for (u32 i = tid; i < ra; i += PO_THREADS) sA[i] = A[ia + i];
+      for (u32 i = tid; i < rb; i += PO_THREADS) sB[i] = B[ib + i];
+      for (u32 i = tid; i < PO_TILE + 2; i += PO_THREADS) { s_firstA[i] = NONE32; s_hasEB[i] = 0; }
+      __syncthreads();
+      const u32 cnt = min((u32)PO_TILE, ra + rb);
+      // merge path: split of diagonal d -> (i from A, d - i from B); ties take A first
+      auto split = [&](u32 d) -> u32 {
+        u32 lo = d > rb ? d - rb : 0u, hi = min(d, ra);
+        while (lo < hi) {
+          u32 mid = (lo + hi) >> 1;
+          if (sA[mid] <= sB[d - 1 - mid]) lo = mid + 1; else hi = mid;
+        }
+        return lo;
+      };
+      const u32 d0 = min(tid * PO_ITEMS, cnt), d1 = min(d0 + PO_ITEMS, cnt);
+      u32 i = split(d0), j = d0 - i;
+      if (tid == 0) { u32 ci = split(cnt); S.ca = ci; S.cb = cnt - ci; }
+      // element before d0
+      u64 pv = S.prev_val;
+      u32 psrc = S.prev_src, hp = S.have_prev;
+      if (d0 > 0) {
+        hp = 1;
+        bool ua = i > 0, ub = j > 0;
+        if (ua && ub) { if (sB[j - 1] >= sA[i - 1]) { pv = sB[j - 1]; psrc = 1; } else { pv = sA[i - 1]; psrc = 0; } }
+        else if (ua) { pv = sA[i - 1]; psrc = 0; }
+        else { pv = sB[j - 1]; psrc = 1; }
+      }
+      u64 val[PO_ITEMS];
+      u32 src[PO_ITEMS], dup[PO_ITEMS], brk[PO_ITEMS];
+      u32 nbrk = 0;
+#pragma unroll
+      for (int k = 0; k < PO_ITEMS; k++) {
+        val[k] = 0; src[k] = 0; dup[k] = 0; brk[k] = 0;
+        if (d0 + k < d1) {
+          bool takeA = i < ra && (j >= rb || sA[i] <= sB[j]);
+          u64 v = takeA ? sA[i] : sB[j];
+          if (takeA) i++; else j++;
+          val[k] = v;
+          src[k] = takeA ? 0u : 1u;
+          dup[k] = (!takeA && hp && psrc == 0 && pv == v) ? 1u : 0u;
+          brk[k] = !hp ? 1u : ((absR != 0 && v - pv > (u64)absR) ? 1u : 0u);
+          nbrk += brk[k];
+          pv = v; psrc = src[k]; hp = 1;
+        }
+      }
+      u32 total_brk;
+      u32 cbase = block_scan_excl<u32, PO_THREADS / 64>(nbrk, s_scan, &total_brk);
+      u32 cid[PO_ITEMS];
+      {
+        u32 c = cbase;
+#pragma unroll
+        for (int k = 0; k < PO_ITEMS; k++) { c += brk[k]; cid[k] = c; }
+      }
+      // first A element (tile position) per chain
+#pragma unroll
+      for (int k = 0; k < PO_ITEMS; k++) {
+        if (d0 + k < d1 && src[k] == 0) {
+          bool first_in_thread = true;
+          for (int q = 0; q < k; q++) if (src[q] == 0 && cid[q] == cid[k]) first_in_thread = false;
+          if (first_in_thread) atomicMin(&s_firstA[cid[k]], d0 + k);
+        }
+      }
+      __syncthreads();
+      u32 elig[PO_ITEMS];
+#pragma unroll
+      for (int k = 0; k < PO_ITEMS; k++) {
+        elig[k] = 0;
+        if (d0 + k < d1) {
+          bool seenA = s_firstA[cid[k]] <= d0 + k || (cid[k] == 0 && S.seenA);
+          elig[k] = (!ordered || seenA) ? 1u : 0u;
+          if (src[k] == 1 && elig[k]) {
+            bool first_in_thread = true;
+            for (int q = 0; q < k; q++) if (src[q] == 1 && elig[q] && cid[q] == cid[k]) first_in_thread = false;
+            if (first_in_thread) atomicOr(&s_hasEB[cid[k]], 1u);
+          }
+        }
+      }
+      __syncthreads();
+      const u32 last_cid = total_brk;
+      const bool final_tile = (ia + S.ca == na) && (ib + S.cb == nb);
+      auto commit_of = [&](u32 c) -> bool {
+        bool hasA = s_firstA[c] != NONE32 || (c == 0 && S.seenA);
+        bool hasEB = s_hasEB[c] != 0 || (c == 0 && S.seenEB);
+        return (hasA && hasEB) || (c == 0 && S.committed);
+      };
+      u32 emit[PO_ITEMS], nemit = 0;
+#pragma unroll
+      for (int k = 0; k < PO_ITEMS; k++) {
+        emit[k] = 0;
+        if (d0 + k < d1 && !dup[k]) {
+          if (is_or) emit[k] = 1;
+          else if (elig[k]) {
+            bool closed = cid[k] < last_cid || final_tile;
+            emit[k] = closed ? (commit_of(cid[k]) ? 1u : 0u) : 1u;
+          }
+        }
+        nemit += emit[k];
+      }
+      // roll back an open chain that closed in this tile without committing
+      u64 cursor = S.cursor;
+      if (!is_or && S.open && !S.committed && (last_cid > 0 || final_tile) && !commit_of(0)) cursor = S.out_start;
+      u32 total_emit;
+      u32 ebase = block_scan_excl<u32, PO_THREADS / 64>(nemit, s_scan, &total_emit);
+      {
+        u32 e = ebase;
+#pragma unroll
+        for (int k = 0; k < PO_ITEMS; k++) {
+          if (d0 + k < d1) {
+            if (brk[k] && cid[k] == last_cid) S.last_first_excl = e;  // first element of the tile's last chain
+            if (emit[k]) out[cursor + e] = val[k];
+            e += emit[k];
+          }
+        }
+      }
+      __syncthreads();
+      if (tid == 0) {
+        bool hasA = s_firstA[last_cid] != NONE32 || (last_cid == 0 && S.seenA);
+        bool hasEB = s_hasEB[last_cid] != 0 || (last_cid == 0 && S.seenEB);
+        bool com = (hasA && hasEB) || (last_cid == 0 && S.committed);
+        if (last_cid != 0 || !S.open) S.out_start = cursor + S.last_first_excl;
+        S.open = 1; S.seenA = hasA; S.seenEB = hasEB; S.committed = com;
+        S.cursor = cursor + total_emit;
+        S.ia = ia + S.ca; S.ib = ib + S.cb;
+      }
+      if (d1 == cnt && d0 < d1) { S.prev_val = val[d1 - d0 - 1]; S.prev_src = src[d1 - d0 - 1]; S.have_prev = 1; }
+      __syncthreads();
+    }
+    if (tid == 0) counts[op.out_cnt_ref] = S.cursor;
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// PrepareSearchResult + ranks
+// ------------------------------------------------------------------------------------------------
+struct ResParams {
+  const u64* page_end;   // [n_pages]
+  const u32* page_doc;   // [n_pages] or null (doc == page)
+  const u8* page_hdr;    // [n_pages] 1 = page id "0", or null
+  u64 n_pages;
+  u32 max_pages, max_docs;
+  float doc_mult;
+};
+struct QCounts { u64 n_pages, n_pos, n_docs; int32_t status; u32 pad; };
+
+constexpr int RS_T = 256;
+
+__device__ __forceinline__ u64 page_of(const ResParams& P, u64 c) {  // first page with end > c
+  u64 a = 0, b = P.n_pages;
+  while (a < b) { u64 m = (a + b) >> 1; if (P.page_end[m] > c) b = m; else a = m + 1; }
+  return a;
+}
+
+// One workgroup per query.  FILL = false: counts only.  FILL = true: writes the CSR arrays.
+template <bool FILL>
+__global__ __launch_bounds__(RS_T) void k_result(const FinalSeq* __restrict__ fin, u32 nq, const u64* __restrict__ idx_values,
+                                                const u64* __restrict__ pool, const u64* __restrict__ counts, ResParams P,
+                                                QCounts* __restrict__ qc, const u64* __restrict__ page_base, const u64* __restrict__ pos_base,
+                                                const u64* __restrict__ doc_base, u32* __restrict__ o_page_index, u64* __restrict__ o_pos_off,
+                                                int32_t* __restrict__ o_pos, u32* __restrict__ o_doc_index, u32* __restrict__ o_doc_first_page) {
+  __shared__ u32 s_scan[RS_T / 64 + 1];
+  __shared__ u64 s_page[RS_T];
+  __shared__ u64 c_prev_page;
+  __shared__ u32 c_pages, c_docs, c_err, c_done;
+  __shared__ u64 c_pos;
+  const u32 q = blockIdx.x, tid = threadIdx.x;
+  if (q >= nq) return;
+  const Seg sg = fin[q].s;
+  const u64* V = seg_ptr(sg, idx_values, pool);
+  const u64 n = seg_cnt(sg, counts);
+  if (tid == 0) { c_prev_page = ~0ull; c_pages = 0; c_docs = 0; c_err = 0; c_done = 0; c_pos = 0; }
+  __syncthreads();
+  const u64 pb = FILL ? page_base[q] : 0, sb = FILL ? pos_base[q] : 0, db = FILL ? doc_base[q] : 0;
+  for (u64 t0 = 0; t0 < n && !c_done; t0 += RS_T) {
+    u64 i = t0 + tid;
+    bool in = i < n;
+    u64 c = in ? V[i] : 0;
+    u64 p = in ? page_of(P, c) : 0;
+    s_page[tid] = p;
+    __syncthreads();
+    u64 pprev = tid == 0 ? c_prev_page : s_page[tid - 1];
+    bool err = in && p >= P.n_pages;
+    bool newp = in && (pprev == ~0ull || p != pprev);
+    u32 tot_np;
+    u32 ord = c_pages + block_scan_excl<u32, RS_T / 64>(newp ? 1u : 0u, s_scan, &tot_np) + (newp ? 1u : 0u) - 1u;  // page ordinal of element
+    // the loop breaks after the coordinate that makes foundPages.Count > MAX (Search.cs:409)
+    bool valid = in && (ord < P.max_pages || (ord == P.max_pages && newp));
+    // a coordinate beyond the last page is an error only if it is reached (before truncation)
+    u32 docp = 0, docprev = 0;
+    bool newd = false;
+    if (valid && newp && !err) {
+      docp = P.page_doc ? P.page_doc[p] : (u32)p;
+      if (pprev != ~0ull && pprev < P.n_pages) docprev = P.page_doc ? P.page_doc[pprev] : (u32)pprev;
+      newd = pprev == ~0ull || docp != docprev;
+    }
+    u32 tot_nd;
+    u32 dord = c_docs + block_scan_excl<u32, RS_T / 64>(newd ? 1u : 0u, s_scan, &tot_nd);
+    u32 tot_valid;
+    (void)block_scan_excl<u32, RS_T / 64>(valid ? 1u : 0u, s_scan, &tot_valid);
+    if (valid && err) atomicOr(&c_err, 1u);
+    if (FILL && valid && !err) {
+      u64 base = p == 0 ? 0ull : P.page_end[p - 1];
+      o_pos[sb + i] = (int32_t)(c - base);
+      if (newp) { o_page_index[pb + ord] = (u32)p; o_pos_off[pb + ord] = sb + i; }
+      if (newd && dord <= P.max_docs) {          // one extra entry marks the end of the last found doc
+        if (dord < P.max_docs) o_doc_index[db + dord] = docp;
+        o_doc_first_page[db + q + dord] = ord;   // (max_docs + 1 slots per query, see host side)
+      }
+    }
+    __syncthreads();
+    // totals among valid elements only (a page that starts beyond the cap must not count)
+    u32 tot_vnp, tot_vnd;
+    (void)block_scan_excl<u32, RS_T / 64>((valid && newp) ? 1u : 0u, s_scan, &tot_vnp);
+    (void)block_scan_excl<u32, RS_T / 64>((valid && newd) ? 1u : 0u, s_scan, &tot_vnd);
+    if (tid == 0) {
+      c_pages += tot_vnp;
+      c_docs += tot_vnd;
+      c_pos += tot_valid;
+      if (tot_valid < min((u64)RS_T, n - t0) || c_pages > P.max_pages) c_done = 1;
+      c_prev_page = s_page[min((u64)RS_T, n - t0) - 1];
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    if (!FILL) {
+      QCounts r;
+      r.status = c_err ? DCD_E_NOTFOUND : DCD_OK;
+      r.n_pages = c_err ? 0 : c_pages;
+      r.n_pos = c_err ? 0 : c_pos;
+      r.n_docs = c_err ? 0 : min(c_docs, P.max_docs);
+      r.pad = 0;
+      qc[q] = r;
+    } else if (!c_err) {
+      // sentinel: page ordinal where the doc run after the last found doc starts
+      u32 nd = min(c_docs, P.max_docs);
+      if (c_docs <= P.max_docs) o_doc_first_page[db + q + nd] = c_pages;
+    }
+  }
+}
+
+// page ranks (Search.cs:99-111): one thread per page
+__global__ void k_page_rank(const u64* __restrict__ pos_off, const int32_t* __restrict__ pos, u64 n_pages_total, float* __restrict__ rank) {
+  u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n_pages_total) return;
+  u64 a = pos_off[j], b = pos_off[j + 1];
+  float bonus = 0;
+  for (u64 k = a + 1; k < b; k++) {
+    int d = pos[k] - pos[k - 1];
+    bonus += (float)(30 / (d > 5 ? d : 5));
+  }
+  rank[j] = 1 + bonus + (float)log((double)(b - a));
+}
+
+// doc ranks (Search.cs:552-557) + ascending stable order (Search.cs:599): one workgroup per query
+__global__ __launch_bounds__(256) void k_doc_rank(u32 nq, const QCounts* __restrict__ qc, const u64* __restrict__ page_base,
+                                                 const u64* __restrict__ doc_base, const u32* __restrict__ doc_first_page,
+                                                 const u32* __restrict__ page_index, const float* __restrict__ page_rank, const u8* __restrict__ page_hdr,
+                                                 float mult, const u32* __restrict__ doc_index_in, u32* __restrict__ o_doc_index,
+                                                 float* __restrict__ o_doc_rank, u32* __restrict__ o_doc_npages) {
+  __shared__ float s_rank[512];
+  __shared__ u32 s_np[512];
+  const u32 q = blockIdx.x;
+  if (q >= nq) return;
+  const u32 nd = (u32)qc[q].n_docs;
+  const u64 pb = page_base[q], db = doc_base[q];
+  const u32* fp = doc_first_page + db + q;
+  {   // max_found_docs <= 512 is enforced on the host
+    for (u32 d = threadIdx.x; d < nd; d += blockDim.x) {
+      u32 a = fp[d], b = fp[d + 1];
+      double sum = 0;
+      for (u32 j = a; j < b; j++) sum += (double)page_rank[pb + j];
+      float r = (float)sum;
+      r = 1 + (float)log((double)r);
+      if (page_hdr && b > a && page_hdr[page_index[pb + a]]) r *= mult;
+      s_rank[d] = r;
+      s_np[d] = b - a;
+    }
+    __syncthreads();
+    for (u32 d = threadIdx.x; d < nd; d += blockDim.x) {
+      float r = s_rank[d];
+      u32 pos = 0;
+      for (u32 e = 0; e < nd; e++) pos += (s_rank[e] < r || (s_rank[e] == r && e < d)) ? 1u : 0u;
+      o_doc_index[db + pos] = doc_index_in[db + d];
+      o_doc_rank[db + pos] = r;
+      o_doc_npages[db + pos] = s_np[d];
+    }
+    __syncthreads();
+  }
+}
+
+struct QcPagesF { const QCounts* q; __device__ u64 operator()(u64 i) const { return q[i].n_pages; } };
+struct QcPosF { const QCounts* q; __device__ u64 operator()(u64 i) const { return q[i].n_pos; } };
+struct QcDocsF { const QCounts* q; __device__ u64 operator()(u64 i) const { return q[i].n_docs; } };
+
+}  // namespace dcd
 
 using namespace dcd;
+
+// ================================================================================================
+// host side
+// ================================================================================================
+struct dcd_results {
+  std::vector<int32_t> status;
+  std::vector<u64> page_off, pos_off, doc_off, seq_off;
+  std::vector<u32> page_index, doc_index, doc_n_pages;
+  std::vector<float> page_rank, doc_rank;
+  std::vector<int32_t> pos, seq_R;
+  std::vector<u16> seq_units;
+  float ms_device = 0;
+  bool have_seq = false;
+};
+
+static int32_t ensure_values(dcd_index* h) {
+  if (h->values_ready) return DCD_OK;
+  DeviceIndex& ix = h->ix;
+  const int dev = ix.device;
+  hipStream_t st = h->st;
+  const u64 U = ix.n_units, N = ix.n_postings, V = ix.n_terms;
+  DCD_TRY(h->values.alloc(dev, N ? N : 1));
+  if (N) {
+    DevBuf<u64> part, deltas, excl, sscr;
+    u64 nb = div_up(U, CODEC_TILE);
+    DCD_TRY(part.alloc(dev, nb + 1));
+    DCD_TRY(deltas.alloc(dev, N));
+    DCD_TRY(excl.alloc(dev, N));
+    DCD_TRY(sscr.alloc(dev, scan_scratch_elems(N)));
+    decode_count_launch(ix.units.p, U, part.p, st);
+    hipLaunchKernelGGL(k_dec_deltas, dim3((u32)nb), dim3(CODEC_THREADS), 0, st, ix.units.p, U, part.p, deltas.p);
+    scan_exclusive<u64, u64>(deltas.p, excl.p, N, sscr.p, st);
+    hipLaunchKernelGGL(k_term_relative, dim3((u32)div_up(N, 256)), dim3(256), 0, st, excl.p, deltas.p, N, ix.term_item_start.p, V, h->values.p);
+    DCD_HIP(hipStreamSynchronize(st));
+    DCD_HIP(hipGetLastError());
+  }
+  h->values_ready = true;
+  return DCD_OK;
+}
+
+// page metadata on the device (doc of page, header flag), built on demand
+struct PageDev {
+  DevBuf<u32> page_doc;
+  DevBuf<u8> page_hdr;
+  DevBuf<u64> page_end;  // only when the index did not bring one (loaded from images)
+};
+
+static int32_t make_res_params(dcd_index* h, const dcd_query_opts& o, PageDev& pd, ResParams* P) {
+  DeviceIndex& ix = h->ix;
+  const PageTable& pt = ix.pages;
+  const u64 np = pt.n_pages();
+  P->n_pages = np;
+  P->max_pages = (u32)o.max_found_pages;
+  P->max_docs = (u32)o.max_found_docs;
+  P->doc_mult = o.doc_rank_multiply;
+  P->page_doc = nullptr;
+  P->page_hdr = nullptr;
+  if (np && !ix.page_end.p) {
+    std::vector<u64> e(np);
+    for (u64 p = 0; p < np; p++) e[p] = pt.end_at(p);
+    DCD_TRY(ix.page_end.alloc(ix.device, np));
+    DCD_HIP(hipMemcpy(ix.page_end.p, e.data(), np * 8, hipMemcpyHostToDevice));
+  }
+  P->page_end = ix.page_end.p;
+  if (!pt.doc_per_page && np) {
+    DCD_TRY(pd.page_doc.alloc(ix.device, np));
+    DCD_HIP(hipMemcpy(pd.page_doc.p, pt.page_doc.data(), np * 4, hipMemcpyHostToDevice));
+    P->page_doc = pd.page_doc.p;
+  }
+  if (!pt.ids.empty()) {
+    std::vector<u8> hdr(np, 0);
+    bool any = false;
+    for (u64 p = 0; p < np; p++) if (pt.ids[p] == u"0") { hdr[p] = 1; any = true; }
+    if (any) {
+      DCD_TRY(pd.page_hdr.alloc(ix.device, np));
+      DCD_HIP(hipMemcpy(pd.page_hdr.p, hdr.data(), np, hipMemcpyHostToDevice));
+      P->page_hdr = pd.page_hdr.p;
+    }
+  }
+  return DCD_OK;
+}
+
+// Symbolic evaluation of one query's program: emits PairOps (grouped into rounds) and the final Seg.
+struct SymVal { Seg s; int32_t R; u64 cap; int round; };
+
+static int32_t run_batch(dcd_index* h, const int32_t* prog, const u64* prog_off, size_t nq, const dcd_query_opts& o, dcd_results* R,
+                         const u64* ext_values, const std::vector<SymVal>* ext_leaves) {
+  DeviceIndex& ix = h->ix;
+  const int dev = ix.device;
+  hipStream_t st = h->st;
+  DCD_TRY(ensure_device(dev));
+  if (!ext_values) DCD_TRY(ensure_values(h));
+  const u64* idx_values = ext_values ? ext_values : h->values.p;
+
+  // ---- plan --------------------------------------------------------------------------------------
+  std::vector<std::vector<PairOp>> rounds;
+  std::vector<FinalSeq> finals(nq);
+  std::vector<int32_t> finalR(nq, 0);
+  std::vector<u64> final_cap(nq, 0);
+  u64 pool_elems = 0;
+  u32 n_counts = 0;
+  for (size_t q = 0; q < nq; q++) {
+    std::vector<SymVal> stk;
+    for (u64 i = prog_off[q]; i < prog_off[q + 1];) {
+      int32_t opc = prog[i];
+      if (opc == DCD_OP_TERM) {
+        if (i + 3 > prog_off[q + 1]) DCD_FAIL(DCD_E_BADARG, "query %zu: truncated TERM", q);
+        int64_t t = prog[i + 1];
+        SymVal v;
+        if (ext_leaves) {
+          if (t < 0 || (size_t)t >= ext_leaves->size()) DCD_FAIL(DCD_E_BADARG, "query %zu: leaf %lld out of range", q, (long long)t);
+          v = (*ext_leaves)[(size_t)t];
+        } else {
+          if (t < 0 || (u64)t >= ix.n_terms) DCD_FAIL(DCD_E_BADARG, "query %zu: term %lld out of range", q, (long long)t);
+          v.s.kind = 0; v.s.off = ix.h_term_item_start[t]; v.s.cnt_ref = NONE32;
+          v.s.cnt_imm = ix.h_term_item_start[t + 1] - ix.h_term_item_start[t];
+          v.cap = v.s.cnt_imm; v.round = 0;
+        }
+        v.R = prog[i + 2];
+        stk.push_back(v);
+        i += 3;
+      } else if (opc == DCD_OP_AND || opc == DCD_OP_OR) {
+        if (stk.size() < 2) DCD_FAIL(DCD_E_BADARG, "query %zu: operator without two operands", q);
+        SymVal b = stk.back(); stk.pop_back();
+        SymVal a = stk.back(); stk.pop_back();
+        PairOp p;
+        p.a = a.s; p.b = b.s; p.Ra = a.R; p.Rb = b.R; p.op = (u32)opc;
+        p.out_off = pool_elems; p.out_cnt_ref = n_counts++;
+        SymVal r;
+        r.cap = a.cap + b.cap;
+        pool_elems += r.cap;
+        r.s.kind = 1; r.s.off = p.out_off; r.s.cnt_ref = p.out_cnt_ref; r.s.cnt_imm = 0;
+        int absR = std::max(std::abs(a.R), std::abs(b.R));
+        r.R = (a.R < 0 && b.R < 0) ? -absR : absR;                       // IndexSequence.cs:221-222, 288-289
+        r.round = std::max(a.round, b.round) + 1;
+        if ((int)rounds.size() < r.round) rounds.resize(r.round);
+        rounds[r.round - 1].push_back(p);
+        stk.push_back(r);
+        i += 1;
+      } else {
+        DCD_FAIL(DCD_E_BADARG, "query %zu: unknown opcode %d", q, opc);
+      }
+    }
+    if (stk.size() != 1) DCD_FAIL(DCD_E_BADARG, "query %zu: program leaves %zu values on the stack", q, stk.size());
+    finals[q].s = stk[0].s;
+    finalR[q] = stk[0].R;
+    final_cap[q] = stk[0].cap;
+  }
+  if (o.max_found_docs > 512 || o.max_found_docs < 0 || o.max_found_pages < 0) DCD_FAIL(DCD_E_BADARG, "max_found_docs must be in [0, 512]");
+
+  // ---- device buffers -------------------------------------------------------------------------------
+  DevBuf<u64> pool, counts;
+  DCD_TRY(pool.alloc(dev, pool_elems ? pool_elems : 1));
+  DCD_TRY(counts.alloc(dev, n_counts ? n_counts : 1));
+  std::vector<DevBuf<PairOp>> d_rounds(rounds.size());
+  for (size_t r = 0; r < rounds.size(); r++) {
+    DCD_TRY(d_rounds[r].alloc(dev, rounds[r].size()));
+    DCD_HIP(hipMemcpyAsync(d_rounds[r].p, rounds[r].data(), rounds[r].size() * sizeof(PairOp), hipMemcpyHostToDevice, st));
+  }
+  DevBuf<FinalSeq> d_fin;
+  DCD_TRY(d_fin.alloc(dev, nq ? nq : 1));
+  if (nq) DCD_HIP(hipMemcpyAsync(d_fin.p, finals.data(), nq * sizeof(FinalSeq), hipMemcpyHostToDevice, st));
+  PageDev pd;
+  ResParams P;
+  DCD_TRY(make_res_params(h, o, pd, &P));
+  DevBuf<QCounts> d_qc;
+  DevBuf<u64> d_pbase, d_sbase, d_dbase, sscr;
+  DCD_TRY(d_qc.alloc(dev, nq ? nq : 1));
+  DCD_TRY(d_pbase.alloc(dev, nq + 1)); DCD_TRY(d_sbase.alloc(dev, nq + 1)); DCD_TRY(d_dbase.alloc(dev, nq + 1));
+  DCD_TRY(sscr.alloc(dev, scan_scratch_elems(nq ? nq : 1)));
+  DCD_HIP(hipStreamSynchronize(st));
+
+  EvTimer tm;
+  DCD_TRY(tm.init(st));
+  DCD_TRY(tm.start());
+  for (size_t r = 0; r < rounds.size(); r++) {
+    u32 n = (u32)rounds[r].size();
+    u32 grid = n < 8192u ? n : 8192u;
+    hipLaunchKernelGGL(k_pair_ops, dim3(grid), dim3(PO_THREADS), 0, st, d_rounds[r].p, n, idx_values, pool.p, counts.p);
+  }
+  u64 tot_pages = 0, tot_pos = 0, tot_docs = 0;
+  if (nq) {
+    hipLaunchKernelGGL((k_result<false>), dim3((u32)nq), dim3(RS_T), 0, st, d_fin.p, (u32)nq, idx_values, pool.p, counts.p, P, d_qc.p,
+                       nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+    scan_exclusive_f<QcPagesF, u64>(QcPagesF{d_qc.p}, d_pbase.p, nq, sscr.p, st);
+    DCD_HIP(hipMemcpyAsync(&tot_pages, sscr.p + scan_nblocks(nq), 8, hipMemcpyDeviceToHost, st));
+    DCD_HIP(hipStreamSynchronize(st));
+    scan_exclusive_f<QcPosF, u64>(QcPosF{d_qc.p}, d_sbase.p, nq, sscr.p, st);
+    DCD_HIP(hipMemcpyAsync(&tot_pos, sscr.p + scan_nblocks(nq), 8, hipMemcpyDeviceToHost, st));
+    DCD_HIP(hipStreamSynchronize(st));
+    scan_exclusive_f<QcDocsF, u64>(QcDocsF{d_qc.p}, d_dbase.p, nq, sscr.p, st);
+    DCD_HIP(hipMemcpyAsync(&tot_docs, sscr.p + scan_nblocks(nq), 8, hipMemcpyDeviceToHost, st));
+    DCD_HIP(hipStreamSynchronize(st));
+  }
+  DCD_HIP(hipMemcpyAsync(d_pbase.p + nq, &tot_pages, 8, hipMemcpyHostToDevice, st));
+  DCD_HIP(hipMemcpyAsync(d_sbase.p + nq, &tot_pos, 8, hipMemcpyHostToDevice, st));
+  DCD_HIP(hipMemcpyAsync(d_dbase.p + nq, &tot_docs, 8, hipMemcpyHostToDevice, st));
+  DevBuf<u32> o_page_index, o_doc_index_tmp, o_doc_first, o_doc_index, o_doc_np;
+  DevBuf<u64> o_pos_off;
+  DevBuf<int32_t> o_pos;
+  DevBuf<float> o_page_rank, o_doc_rank;
+  DCD_TRY(o_page_index.alloc(dev, tot_pages + 1)); DCD_TRY(o_pos_off.alloc(dev, tot_pages + 1));
+  DCD_TRY(o_pos.alloc(dev, tot_pos + 1)); DCD_TRY(o_page_rank.alloc(dev, tot_pages + 1));
+  DCD_TRY(o_doc_index_tmp.alloc(dev, tot_docs + 1)); DCD_TRY(o_doc_index.alloc(dev, tot_docs + 1));
+  DCD_TRY(o_doc_first.alloc(dev, tot_docs + nq + 1));  // n_docs + 1 entries per query
+  DCD_TRY(o_doc_rank.alloc(dev, tot_docs + 1)); DCD_TRY(o_doc_np.alloc(dev, tot_docs + 1));
+  if (nq) {
+    hipLaunchKernelGGL((k_result<true>), dim3((u32)nq), dim3(RS_T), 0, st, d_fin.p, (u32)nq, idx_values, pool.p, counts.p, P, d_qc.p,
+                       d_pbase.p, d_sbase.p, d_dbase.p, o_page_index.p, o_pos_off.p, o_pos.p, o_doc_index_tmp.p, o_doc_first.p);
+    DCD_HIP(hipMemcpyAsync(o_pos_off.p + tot_pages, &tot_pos, 8, hipMemcpyHostToDevice, st));
+    if (tot_pages) hipLaunchKernelGGL(k_page_rank, dim3((u32)div_up(tot_pages, 256)), dim3(256), 0, st, o_pos_off.p, o_pos.p, tot_pages, o_page_rank.p);
+    hipLaunchKernelGGL(k_doc_rank, dim3((u32)nq), dim3(256), 0, st, (u32)nq, d_qc.p, d_pbase.p, d_dbase.p, o_doc_first.p, o_page_index.p,
+                       o_page_rank.p, P.page_hdr, P.doc_mult, o_doc_index_tmp.p, o_doc_index.p, o_doc_rank.p, o_doc_np.p);
+  }
+  DCD_TRY(tm.stop());
+  DCD_HIP(hipStreamSynchronize(st));
+  DCD_HIP(hipGetLastError());
+  R->ms_device = tm.ms();
+
+  // ---- download ------------------------------------------------------------------------------------
+  std::vector<QCounts> qc(nq);
+  if (nq) DCD_HIP(hipMemcpy(qc.data(), d_qc.p, nq * sizeof(QCounts), hipMemcpyDeviceToHost));
+  R->status.resize(nq);
+  for (size_t q = 0; q < nq; q++) R->status[q] = qc[q].status;
+  R->page_off.resize(nq + 1); R->doc_off.resize(nq + 1);
+  DCD_HIP(hipMemcpy(R->page_off.data(), d_pbase.p, (nq + 1) * 8, hipMemcpyDeviceToHost));
+  DCD_HIP(hipMemcpy(R->doc_off.data(), d_dbase.p, (nq + 1) * 8, hipMemcpyDeviceToHost));
+  R->page_index.resize(tot_pages); R->page_rank.resize(tot_pages); R->pos_off.resize(tot_pages + 1); R->pos.resize(tot_pos);
+  R->doc_index.resize(tot_docs); R->doc_rank.resize(tot_docs); R->doc_n_pages.resize(tot_docs);
+  if (tot_pages) {
+    DCD_HIP(hipMemcpy(R->page_index.data(), o_page_index.p, tot_pages * 4, hipMemcpyDeviceToHost));
+    DCD_HIP(hipMemcpy(R->page_rank.data(), o_page_rank.p, tot_pages * 4, hipMemcpyDeviceToHost));
+  }
+  DCD_HIP(hipMemcpy(R->pos_off.data(), o_pos_off.p, (tot_pages + 1) * 8, hipMemcpyDeviceToHost));
+  if (tot_pos) DCD_HIP(hipMemcpy(R->pos.data(), o_pos.p, tot_pos * 4, hipMemcpyDeviceToHost));
+  if (tot_docs) {
+    DCD_HIP(hipMemcpy(R->doc_index.data(), o_doc_index.p, tot_docs * 4, hipMemcpyDeviceToHost));
+    DCD_HIP(hipMemcpy(R->doc_rank.data(), o_doc_rank.p, tot_docs * 4, hipMemcpyDeviceToHost));
+    DCD_HIP(hipMemcpy(R->doc_n_pages.data(), o_doc_np.p, tot_docs * 4, hipMemcpyDeviceToHost));
+  }
+  if (o.want_sequences) {
+    // final IndexSequence units per query: re-encode the final coordinates from 0 (Builder.AddRange)
+    R->have_seq = true;
+    R->seq_off.assign(nq + 1, 0);
+    R->seq_R = finalR;
+    std::vector<u64> cnt(n_counts ? n_counts : 1);
+    if (n_counts) DCD_HIP(hipMemcpy(cnt.data(), counts.p, (size_t)n_counts * 8, hipMemcpyDeviceToHost));
+    for (size_t q = 0; q < nq; q++) {
+      const Seg& s = finals[q].s;
+      u64 n = s.cnt_ref == NONE32 ? s.cnt_imm : cnt[s.cnt_ref];
+      const u64* src = (s.kind == 0 ? idx_values : pool.p) + s.off;
+      size_t base = R->seq_units.size();
+      if (n) {
+        DevBuf<u64> part;
+        DevBuf<u16> du;
+        u64 nb = encode_nblocks(n);
+        DCD_TRY(part.alloc(dev, nb + 1));
+        DCD_TRY(du.alloc(dev, 5 * n));
+        EncSrcValues es{src};
+        encode_launch(es, n, part.p, du.p, st);
+        u64 total = 0;
+        DCD_HIP(hipMemcpyAsync(&total, part.p + nb, 8, hipMemcpyDeviceToHost, st));
+        DCD_HIP(hipStreamSynchronize(st));
+        R->seq_units.resize(base + total);
+        DCD_HIP(hipMemcpy(R->seq_units.data() + base, du.p, total * 2, hipMemcpyDeviceToHost));
+      }
+      R->seq_off[q + 1] = R->seq_units.size();
+    }
+  }
+  return DCD_OK;
+}
 
 extern "C" {
 
 void dcd_query_default_opts(dcd_query_opts* o) {
   if (!o) return;
-  o->max_found_pages = 30000;  // Index.cs:101
-  o->max_found_docs = 500;     // Index.cs:102
-  o->doc_rank_multiply = 10.f; // Index.cs:115
+  o->max_found_pages = 30000;   // Index.cs:101
+  o->max_found_docs = 500;      // Index.cs:102
+  o->doc_rank_multiply = 10.f;  // Index.cs:115
   o->want_sequences = 0;
 }
 
-int32_t dcd_query_batch(dcd_index*, const int32_t*, const uint64_t*, size_t, const dcd_query_opts*, dcd_results**) {
-  DCD_FAIL(DCD_E_UNSUPPORTED, "dcd_query_batch: not built yet");
+int32_t dcd_query_batch(dcd_index* h, const int32_t* prog, const uint64_t* prog_off, size_t n_queries, const dcd_query_opts* opts,
+                        dcd_results** out) {
+  if (!h || !prog_off || !out || (!prog && n_queries && prog_off[n_queries] != 0)) DCD_FAIL(DCD_E_BADARG, "dcd_query_batch: NULL argument");
+  dcd_query_opts o;
+  if (opts) o = *opts; else dcd_query_default_opts(&o);
+  std::unique_ptr<dcd_results> R(new dcd_results());
+  DCD_TRY(run_batch(h, prog, prog_off, n_queries, o, R.get(), nullptr, nullptr));
+  *out = R.release();
+  return DCD_OK;
 }
-int32_t dcd_results_get(dcd_results*, dcd_results_view*) { DCD_FAIL(DCD_E_UNSUPPORTED, "dcd_results_get: not built yet"); }
-void dcd_results_free(dcd_results*) {}
-int32_t dcd_seq_and(const uint16_t*, size_t, int32_t, const uint16_t*, size_t, int32_t, uint16_t*, size_t, size_t*, int32_t*) {
-  DCD_FAIL(DCD_E_UNSUPPORTED, "dcd_seq_and: not built yet");
+
+int32_t dcd_results_get(dcd_results* r, dcd_results_view* v) {
+  if (!r || !v) DCD_FAIL(DCD_E_BADARG, "dcd_results_get: NULL argument");
+  memset(v, 0, sizeof *v);
+  v->n_queries = r->status.size();
+  v->status = r->status.data();
+  v->page_off = r->page_off.data();
+  v->page_index = r->page_index.data();
+  v->page_rank = r->page_rank.data();
+  v->pos_off = r->pos_off.data();
+  v->pos = r->pos.data();
+  v->doc_off = r->doc_off.data();
+  v->doc_index = r->doc_index.data();
+  v->doc_rank = r->doc_rank.data();
+  v->doc_n_pages = r->doc_n_pages.data();
+  if (r->have_seq) { v->seq_off = r->seq_off.data(); v->seq_units = r->seq_units.data(); v->seq_R = r->seq_R.data(); }
+  v->ms_device = r->ms_device;
+  return DCD_OK;
 }
-int32_t dcd_seq_or(const uint16_t*, size_t, int32_t, const uint16_t*, size_t, int32_t, uint16_t*, size_t, size_t*, int32_t*) {
-  DCD_FAIL(DCD_E_UNSUPPORTED, "dcd_seq_or: not built yet");
+
+void dcd_results_free(dcd_results* r) { delete r; }
+
+}  // extern "C"
+
+// ---- operator * / + on host buffers (IndexSequence shim) ----------------------------------------
+static int32_t seq_binop(int opc, const u16* a, size_t na, int32_t Ra, const u16* b, size_t nb, int32_t Rb, u16* out, size_t cap,
+                         size_t* n_out, int32_t* R_out) {
+  if ((!a && na) || (!b && nb) || !n_out) DCD_FAIL(DCD_E_BADARG, "dcd_seq_and/or: NULL argument");
+  // a throw-away index handle on device 0 carrying only a stream; operands are decoded into a
+  // private value buffer that plays the role of the index values
+  dcd_index tmp;
+  tmp.ix.device = 0;
+  DCD_TRY(ensure_device(0));
+  DCD_HIP(hipStreamCreateWithFlags(&tmp.st, hipStreamNonBlocking));
+  struct Guard { hipStream_t s; ~Guard() { (void)hipStreamDestroy(s); } } g{tmp.st};
+  hipStream_t st = tmp.st;
+  const u16* src[2] = {a, b};
+  const size_t nu[2] = {na, nb};
+  u64 nv[2] = {0, 0};
+  DevBuf<u16> du[2];
+  DevBuf<u64> part[2];
+  for (int k = 0; k < 2; k++) {
+    if (!nu[k]) continue;
+    u64 nbk = div_up(nu[k], CODEC_TILE);
+    DCD_TRY(du[k].alloc(0, nu[k]));
+    DCD_TRY(part[k].alloc(0, nbk + 1));
+    DCD_HIP(hipMemcpyAsync(du[k].p, src[k], nu[k] * 2, hipMemcpyHostToDevice, st));
+    decode_count_launch(du[k].p, nu[k], part[k].p, st);
+    DCD_HIP(hipMemcpyAsync(&nv[k], part[k].p + nbk, 8, hipMemcpyDeviceToHost, st));
+  }
+  DCD_HIP(hipStreamSynchronize(st));
+  DevBuf<u64> vals, deltas, sscr;
+  DCD_TRY(vals.alloc(0, nv[0] + nv[1] + 1));
+  DCD_TRY(deltas.alloc(0, std::max(nv[0], nv[1]) + 1));
+  DCD_TRY(sscr.alloc(0, scan_scratch_elems(std::max(nv[0], nv[1]) + 1)));
+  u64 off = 0;
+  std::vector<SymVal> leaves(2);
+  for (int k = 0; k < 2; k++) {
+    if (nv[k]) decode_values_launch(du[k].p, nu[k], part[k].p, nv[k], deltas.p, vals.p + off, sscr.p, st);
+    DCD_HIP(hipStreamSynchronize(st));
+    leaves[k].s.kind = 0; leaves[k].s.off = off; leaves[k].s.cnt_ref = NONE32; leaves[k].s.cnt_imm = nv[k];
+    leaves[k].cap = nv[k]; leaves[k].round = 0; leaves[k].R = 0;
+    off += nv[k];
+  }
+  int32_t prog[7] = {DCD_OP_TERM, 0, Ra, DCD_OP_TERM, 1, Rb, opc};
+  u64 poff[2] = {0, 7};
+  dcd_query_opts o;
+  dcd_query_default_opts(&o);
+  o.want_sequences = 1;
+  o.max_found_pages = 0;  // no page table here: results are not wanted
+  dcd_results R;
+  tmp.ix.pages = PageTable();
+  DCD_TRY(run_batch(&tmp, prog, poff, 1, o, &R, vals.p, &leaves));
+  *n_out = R.seq_units.size();
+  if (R_out) *R_out = R.seq_R[0];
+  if (R.seq_units.size() > cap || (!out && !R.seq_units.empty())) return DCD_E_OVERFLOW;
+  if (!R.seq_units.empty()) memcpy(out, R.seq_units.data(), R.seq_units.size() * 2);
+  return DCD_OK;
+}
+
+extern "C" {
+int32_t dcd_seq_and(const uint16_t* a, size_t na, int32_t Ra, const uint16_t* b, size_t nb, int32_t Rb, uint16_t* out, size_t cap,
+                    size_t* n_out, int32_t* R_out) {
+  return seq_binop(DCD_OP_AND, a, na, Ra, b, nb, Rb, out, cap, n_out, R_out);
+}
+int32_t dcd_seq_or(const uint16_t* a, size_t na, int32_t Ra, const uint16_t* b, size_t nb, int32_t Rb, uint16_t* out, size_t cap,
+                   size_t* n_out, int32_t* R_out) {
+  return seq_binop(DCD_OP_OR, a, na, Ra, b, nb, Rb, out, cap, n_out, R_out);
 }
 }

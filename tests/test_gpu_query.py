@@ -1,0 +1,190 @@
+"""GPU parity of the query path against the CPU oracle: operators * / + (bit-exact units and R),
+PrepareSearchResult (pages, page-relative positions, caps), page / doc ranks (1e-5)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand_seq(rng, n, max_gap, start=0):
+    if n == 0:
+        return np.array([], np.uint64)
+    return (np.cumsum(rng.integers(1, max_gap, n, dtype=np.uint64)) + np.uint64(start)).astype(np.uint64)
+
+
+def _ops_cases():
+    rng = np.random.default_rng(321)
+    cases = []
+    for na, nb, ga, gb in [(0, 0, 10, 10), (0, 5, 10, 10), (7, 0, 10, 10), (1, 1, 5, 5), (50, 60, 40, 30), (1000, 1200, 300, 250),
+                           (5000, 300, 50, 4000), (3000, 3000, 3, 3), (20000, 17000, 700, 900), (4096, 4096, 2, 2),
+                           (100000, 2500, 60, 2400)]:
+        a, b = _rand_seq(rng, na, ga), _rand_seq(rng, nb, gb)
+        # force shared values (double-tagged elements)
+        if na and nb:
+            k = min(na, nb) // 3
+            b = np.unique(np.concatenate([b, a[rng.integers(0, na, k)]])).astype(np.uint64)
+        cases.append((a, b))
+    return cases
+
+
+@pytest.mark.parametrize("Ra,Rb", [(258, 259), (0, 0), (-7, -9), (-7, 258), (258, -9), (40, 3), (-1, -1), (0, -5), (100000, 1)])
+def test_operators_parity(oracle_mod, Ra, Rb):
+    import docodo_amd
+    o = oracle_mod
+    for a, b in _ops_cases():
+        ua, ub = o.seq_encode(a), o.seq_encode(b)
+        sa, sb = docodo_amd.IndexSequence(ua, Ra), docodo_amd.IndexSequence(ub, Rb)
+        want, wR = o.seq_and(ua, Ra, ub, Rb)
+        got = sa * sb
+        assert got.R == wR
+        assert np.array_equal(got.units, want), ("and", a.size, b.size, Ra, Rb)
+        want, wR = o.seq_or(ua, Ra, ub, Rb)
+        got = sa + sb
+        assert got.R == wR
+        assert np.array_equal(got.units, want), ("or", a.size, b.size)
+
+
+def test_long_chain_across_tiles(oracle_mod):
+    """One gap chain spanning many 1024-element tiles that gains its second operand only at the very
+    end (optimistic write kept) or never (rolled back); ordered mode with a late first-A."""
+    import docodo_amd
+    o = oracle_mod
+    a = np.arange(10, 10 + 5 * 6000, 5, dtype=np.uint64)          # dense: every gap 5
+    for b in (np.array([a[-1] + 3], np.uint64), np.array([a[-1] + 300], np.uint64), np.array([a[0] - 3], np.uint64),
+              np.array([a[3000] + 1], np.uint64)):
+        for Ra, Rb in ((10, 10), (-10, -10)):
+            for x, y in ((a, b), (b, a)):
+                ux, uy = o.seq_encode(x), o.seq_encode(y)
+                want, wR = o.seq_and(ux, Ra, uy, Rb)
+                got = docodo_amd.IndexSequence(ux, Ra) * docodo_amd.IndexSequence(uy, Rb)
+                assert got.R == wR and np.array_equal(got.units, want), (b, Ra, x.size)
+
+
+@pytest.fixture(scope="module")
+def synth_index(oracle_mod):
+    import docodo_amd
+    from docodo_amd import synth
+    n = 40000
+    text = synth.corpus_host(n)
+    off = np.arange(n + 1, dtype=np.uint64) * synth.DOC_BYTES
+    b = docodo_amd.Builder()
+    b.AddPages(text, off, docs_per_page=True)
+    b.Finish()
+    img, lst = b.index_image(), b.list_image()
+    ix = b.Build()
+    oix = oracle_mod.Index(stemmers=[])
+    assert oix.load(img, lst)
+    return ix, oix, img, lst
+
+
+def _check_result(res, q, ores, tol=1e-5):
+    assert res.status[q] == 0 and ores.Success
+    pages = res.pages(q)
+    assert len(pages) == len(ores.foundPages)
+    for (pi, pos, rank), op in zip(pages, ores.foundPages):
+        assert pi == op.page_index
+        assert np.array_equal(pos, op.pos)
+        assert abs(rank - op.rank) <= tol * max(1.0, abs(op.rank))
+    docs = res.docs(q)
+    assert len(docs) == len(ores.foundDocs)
+    for (di, rank, npg), od in zip(docs, ores.foundDocs):
+        assert abs(rank - od.rank) <= tol * max(1.0, abs(od.rank))
+        assert npg == od.n_pages
+    # same doc set; order may differ only among equal ranks
+    assert sorted(d[0] for d in docs) == sorted(d.doc_index for d in ores.foundDocs)
+
+
+def test_single_term_queries(synth_index):
+    import docodo_amd
+    from docodo_amd import synth
+    ix, oix, _, _ = synth_index
+    ranks = list(synth.query_ranks(40, 1, lo_rank=101)[:, 0]) + [1, 2, 3, 50]   # incl. terms past the 30000-page cap
+    words = [synth.term(int(k)) for k in ranks]
+    prog, off, kept = [], [0], []
+    for w in words:
+        t = ix.find(w)
+        if t is None:
+            assert oix.get(w) is None
+            continue
+        prog += [docodo_amd.DCD_OP_TERM, t, 255 + len(w)]
+        off.append(len(prog))
+        kept.append(w)
+    res = ix.query_batch(prog, off)
+    assert res.n_queries == len(kept)
+    for q, w in enumerate(kept):
+        _check_result(res, q, oix.search(w))
+
+
+def test_three_term_and_queries(synth_index, oracle_mod):
+    import docodo_amd
+    from docodo_amd import synth
+    ix, oix, _, _ = synth_index
+    ranks = synth.query_ranks(60, 3, lo_rank=20)
+    prog, off, reqs = [], [0], []
+    for row in ranks:
+        ws = [synth.term(int(k)) for k in row]
+        ts = [ix.find(w) for w in ws]
+        if any(t is None for t in ts):
+            continue
+        for k, (w, t) in enumerate(zip(ws, ts)):
+            prog += [docodo_amd.DCD_OP_TERM, t, 255 + len(w)]       # opt == null -> Dist = 255 (Search.cs:472)
+            if k:
+                prog.append(docodo_amd.DCD_OP_AND)
+        off.append(len(prog))
+        reqs.append(" ".join(ws))
+    res = ix.query_batch(prog, off, want_sequences=True)
+    for q, req in enumerate(reqs):
+        _check_result(res, q, oix.search(req))
+    # exact phrases: "w1 w2" -> R = -(len + 4) on both (Search.cs:308)
+    prog, off, reqs = [], [0], []
+    for row in ranks[:30]:
+        ws = [synth.term(int(k)) for k in row[:2]]
+        ts = [ix.find(w) for w in ws]
+        if any(t is None for t in ts):
+            continue
+        for k, (w, t) in enumerate(zip(ws, ts)):
+            prog += [docodo_amd.DCD_OP_TERM, t, -(len(w) + 4)]
+            if k:
+                prog.append(docodo_amd.DCD_OP_AND)
+        off.append(len(prog))
+        reqs.append('"' + " ".join(ws) + '"')
+    res = ix.query_batch(prog, off)
+    for q, req in enumerate(reqs):
+        _check_result(res, q, oix.search(req, oracle_mod.SearchOptions(dist=0)))
+
+
+def test_or_and_mixed_plan(synth_index):
+    import docodo_amd
+    from docodo_amd import synth
+    ix, oix, _, _ = synth_index
+    ws = [synth.term(k) for k in (120, 340, 777, 45)]
+    ts = [ix.find(w) for w in ws]
+    assert all(t is not None for t in ts)
+    T, A, O = docodo_amd.DCD_OP_TERM, docodo_amd.DCD_OP_AND, docodo_amd.DCD_OP_OR
+    R = [255 + len(w) for w in ws]
+    # a (b | c) d  ->  a.d()*(b.d()+c.d())*d.d()
+    prog = [T, ts[0], R[0], T, ts[1], R[1], T, ts[2], R[2], O, A, T, ts[3], R[3], A]
+    res = ix.query_batch(prog, [0, len(prog)])
+    _check_result(res, 0, oix.search("%s (%s | %s) %s" % tuple(ws)))
+
+
+def test_index_roundtrip_through_images(synth_index, oracle_mod):
+    """Index.Load (Index.cs:312-380): an index re-opened from the .index/.index.list bytes answers the same."""
+    import docodo_amd
+    from docodo_amd import synth
+    ix, oix, img, lst = synth_index
+    ix2 = docodo_amd.Index.from_images(img, lst)
+    assert ix2.Count == ix.Count == oix.count and ix2.MaxCoord == ix.MaxCoord == oix.max_coord
+    assert ix2.n_pages == oix.n_pages() and ix2.n_docs == oix.n_docs()
+    for k in (1, 150, 5000):
+        w = synth.term(k)
+        t = ix2.find(w)
+        if t is None:
+            continue
+        assert ix2.key(t) == w
+        assert np.array_equal(ix2.get(t).units, oix.get(w))
+        assert ix2.term_count(t) == oracle_mod.seq_decode(oix.get(w)).size
+        res = ix2.query_batch([docodo_amd.DCD_OP_TERM, t, 255 + len(w)], [0, 3])
+        _check_result(res, 0, oix.search(w))
+    assert ix2.page_info(3) == (oix.page_end(3), oix.page_doc(3), oix.page_id(3))
+    assert ix2.doc_name(5) == oix.doc_name(5)
