@@ -21,44 +21,67 @@ constexpr u32 MAX_CODE_LEN = 63;  // explicit index codes (Builder.Add); text to
 template <typename CharT>
 __global__ __launch_bounds__(TK_THREADS) void k_tok_count(const CharT* __restrict__ text, TokParams P, CharTables16 tab,
                                                          u32* __restrict__ tile_count) {
-  __shared__ TokLds<CharT> L;
-  u32 total = tokenize_tile<CharT>(text, P, tab, blockIdx.x, L);
-  if (threadIdx.x == 0) tile_count[blockIdx.x] = total;
+  __shared__ TokLds<CharT, false> S;
+  u32 keep;
+  u64 bnd;
+  tokenize_chunk<CharT, false>(text, P, tab, blockIdx.x, S, &keep, &bnd);
+  u32 c = wave_sum((u32)__builtin_popcount(keep));
+  if (lane_id() == 0) S.scan[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) tile_count[blockIdx.x] = S.scan[0] + S.scan[1] + S.scan[2] + S.scan[3];
 }
 
 template <typename CharT>
 __global__ __launch_bounds__(TK_THREADS) void k_tok_emit(const CharT* __restrict__ text, TokParams P, CharTables16 tab,
                                                         TextView<CharT> tv, VocabTable vt, const u64* __restrict__ tile_off,
                                                         uint2* __restrict__ tuples) {
-  __shared__ TokLds<CharT> L;
-  u32 total = tokenize_tile<CharT>(text, P, tab, blockIdx.x, L);
-  const int64_t lo = (int64_t)((u64)blockIdx.x * TK_TILE) - TK_PRE;
-  u64 obase = tile_off[blockIdx.x];
+  __shared__ TokLds<CharT, true> S;
+  u32 keep;
+  u64 bnd;
+  tokenize_chunk<CharT, true>(text, P, tab, blockIdx.x, S, &keep, &bnd);
+  u32 total;
+  u32 ex = block_scan_excl<u32, TK_THREADS / 64>((u32)__builtin_popcount(keep), S.scan, &total);
+  for (u32 m = keep; m;) {
+    u32 j = (u32)__builtin_ctz(m);
+    m &= m - 1;
+    u32 len = (u32)__builtin_ctzll(bnd >> (j + 1)) + 1u;
+    S.tok[ex++] = (threadIdx.x * TK_CPT + j) | (len << 16);
+  }
+  __syncthreads();
+  const u64 tile_start = (u64)blockIdx.x * TK_TILE;
+  const u64 obase = tile_off[blockIdx.x];
+  constexpr u32 CS = sizeof(CharT);
+  constexpr u64 LDS_TXT_BYTES = (u64)(TK_TILE + TK_HALO * TK_CPT) * CS + 16;
   for (u32 k = threadIdx.x; k < total; k += TK_THREADS) {
-    u32 t = L.tok[k];
-    u32 i = t & 0xFFFFu, len = t >> 16;
+    const u32 t = S.tok[k];
+    const u32 i = t & 0xFFFFu, len = t >> 16;
+    const u32 nbytes = len * CS, nw = (nbytes + 3u) >> 2;
+    const u32* txt = S.txt;
+    auto word = [txt, i, nbytes](u32 q) -> u32 { return str_word(txt, (u64)i * CS, q, LDS_TXT_BYTES) & tail_mask(nbytes, q); };
     HashState hs;
     hs.init(len);
-    for (u32 j = 0; j < len; j++) hs.add((u32)L.txt[i + j]);
-    u64 gpos = (u64)(lo + (int64_t)i);
-    const CharT* s = &L.txt[i];
-    u32 slot = vocab_lookup_insert<CharT>(vt, tv, hs.fin(), len, gpos, [s](u32 j) { return (u32)s[j]; });
+    for (u32 q = 0; q < nw; q++) hs.add(word(q));
+    const u64 gpos = tile_start + i;
+    u32 slot = vocab_lookup_insert<CharT>(vt, tv, hs.fin(), len, gpos, word);
     tuples[obase + k] = make_uint2(slot, (u32)gpos);
   }
 }
 
 // explicit postings (Builder.Add(code, coord), Build.cs:324): codes live in the pool, verbatim
 template <typename CharT>
-__global__ void k_explicit(const CharT* __restrict__ pool, const u32* __restrict__ xoff, const u32* __restrict__ xlen,
-                           const u32* __restrict__ xcoord, u64 n, TextView<CharT> tv, VocabTable vt, uint2* __restrict__ tuples) {
+__global__ void k_explicit(const u32* __restrict__ xoff, const u32* __restrict__ xlen, const u32* __restrict__ xcoord, u64 n,
+                           TextView<CharT> tv, VocabTable vt, uint2* __restrict__ tuples) {
   u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  u32 len = xlen[i];
-  const CharT* s = pool + xoff[i];
+  constexpr u32 CS = sizeof(CharT);
+  const u32 len = xlen[i], nbytes = len * CS, nw = (nbytes + 3u) >> 2;
+  const u32* pool32 = reinterpret_cast<const u32*>(tv.pool);
+  const u64 boff = (u64)xoff[i] * CS, pbytes = tv.n_pool * CS;
+  auto word = [pool32, boff, pbytes, nbytes](u32 q) -> u32 { return str_word(pool32, boff, q, pbytes) & tail_mask(nbytes, q); };
   HashState hs;
   hs.init(len);
-  for (u32 j = 0; j < len; j++) hs.add((u32)s[j]);
-  u32 slot = vocab_lookup_insert<CharT>(vt, tv, hs.fin(), len, tv.n_chars + xoff[i], [s](u32 j) { return (u32)s[j]; });
+  for (u32 q = 0; q < nw; q++) hs.add(word(q));
+  u32 slot = vocab_lookup_insert<CharT>(vt, tv, hs.fin(), len, tv.n_chars + xoff[i], word);
   tuples[i] = make_uint2(slot, xcoord[i]);
 }
 
@@ -70,14 +93,16 @@ struct SlotUsed {
 __global__ void k_vocab_compact(const u64* __restrict__ slots, u64 cap, const u32* __restrict__ excl, u64* __restrict__ term_word,
                                 u32* __restrict__ term_slot, u32* __restrict__ maxlen) {
   u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= cap) return;
-  u64 w = slots[i];
+  u64 w = i < cap ? slots[i] : 0;
+  u32 l = 0;
   if (w) {
     u32 d = excl[i];
     term_word[d] = w;
     term_slot[d] = (u32)i;
-    atomicMax(maxlen, voc_len(w));
+    l = voc_len(w);
   }
+  l = wave_max(l);                      // one atomic per wave, not per term
+  if (l && lane_id() == 0) atomicMax(maxlen, l);
 }
 
 // sort key chunk: characters [c*K, c*K+K) of the term, big-endian packed (K = 4 for bytes, 2 for
@@ -496,8 +521,8 @@ static int32_t finish_impl(dcd_build* h) {
   DevBuf<CharT> d_pool;
   DevBuf<u32> d_xoff, d_xlen, d_xcoord;
   if (n_x) {
-    std::vector<CharT> pool(h->xpool.size());
-    for (size_t i = 0; i < pool.size(); i++) pool[i] = (CharT)h->xpool[i];
+    std::vector<CharT> pool((h->xpool.size() + 8) / 4 * 4, (CharT)0);   // zero padded: read as aligned 32-bit words
+    for (size_t i = 0; i < h->xpool.size(); i++) pool[i] = (CharT)h->xpool[i];
     std::vector<u32> xo(n_x), xl(n_x), xc(n_x);
     for (u64 i = 0; i < n_x; i++) { xo[i] = h->xps[i].off; xl[i] = h->xps[i].len; xc[i] = (u32)(h->xps[i].coord - h->opts.coord_base); }
     DCD_TRY(d_pool.alloc(dev, pool.size()));
@@ -558,15 +583,16 @@ static int32_t finish_impl(dcd_build* h) {
   DCD_TRY(tupB.alloc(dev, N ? N : 1));
   u32 cap_log2 = h->opts.vocab_capacity_log2;
   if (cap_log2 == 0) {
-    cap_log2 = log2_ceil((N ? N : 1) / 4 + 1);
+    // first guess: one slot per 16 postings (grown x4 and the emit re-run if the load exceeds 1/2)
+    cap_log2 = log2_ceil((N ? N : 1) / 16 + 1);
     if (cap_log2 < 12) cap_log2 = 12;
-    if (cap_log2 > 25) cap_log2 = 25;
+    if (cap_log2 > 24) cap_log2 = 24;
   }
   DevBuf<u64> slots;
   DevBuf<u32> d_flags;  // [0] overflow, [1] maxlen, [2] max coord (explicit)
   DCD_TRY(d_flags.alloc(dev, 4));
   TextView<CharT> tv;
-  tv.text = text; tv.n_chars = n_chars; tv.pool = d_pool.p; tv.tab = tab;
+  tv.text = text; tv.n_chars = n_chars; tv.pool = d_pool.p; tv.n_pool = d_pool.n; tv.tab = tab;
   u64 V = 0;
   DevBuf<u32> slot_excl;
   DevBuf<u32> scan_scr32;
@@ -584,7 +610,7 @@ static int32_t finish_impl(dcd_build* h) {
       probe_end();
     }
     if (n_x)
-      hipLaunchKernelGGL((k_explicit<CharT>), dim3((u32)div_up(n_x, 256)), dim3(256), 0, st, d_pool.p, d_xoff.p, d_xlen.p, d_xcoord.p,
+      hipLaunchKernelGGL((k_explicit<CharT>), dim3((u32)div_up(n_x, 256)), dim3(256), 0, st, d_xoff.p, d_xlen.p, d_xcoord.p,
                          n_x, tv, vt, tupA.p + n_text_tok);
     // compaction: dense ids for the used slots
     DCD_TRY(slot_excl.alloc(dev, cap));

@@ -1,18 +1,22 @@
-// dcd_tokenize.h -- tokenise + vocabulary kernels of the build path.
+// dcd_tokenize.h -- tokenise + vocabulary device code of the build path (gfx950).
 //
 // Replaces the hot loop of IndexTask (Build.cs:477-532): c = page.text.ToLower();
 // foreach Match in Regex.Matches(c, @"\p{L}+|\p{N}+") with MIN_WORD_LENGTH <= len <= MAX_WORD_LENGTH
 // -> index.AddWord(m.Value, coord + m.Index); and the dictionary lookup of Index.Builder.Add
 // (Build.cs:324-333).  Coordinates are UTF-16 code-unit indices.
 //
-// Data flow per 4096-character tile (one 256-thread workgroup):
-//   HBM text --16 B/lane--> lower-case + classify --> LDS (chars, boundary bitmask)
-//   token starts = class != 0 at a class change or page start; length = distance to the next
-//   boundary bit (one 64-bit window read + ctz);  kept tokens are compacted through a block scan;
-//   each kept token is hashed from LDS, looked up / inserted in the global open-addressing table
-//   (one 64-bit CAS word per term = {tag, length, position of the canonical occurrence}; equality
-//   is verified against the canonical occurrence's characters, so the vocabulary is EXACT, not
-//   probabilistic) and emitted as (slot, local coordinate) in text order.
+// Data flow per 4096-character tile (one 256-thread workgroup, one 16-character chunk per lane):
+//   HBM --16 B/lane--> registers: SWAR lower-casing + classification of 4 bytes per ALU op
+//   (Latin-1 path; UTF-16 goes through 64 Ki-entry tables) -> two 16-bit masks per chunk
+//   (letter / number) -> LDS (520 B) -> ONE barrier -> every lane rebuilds a 64-bit boundary window
+//   (its own chunk + 48 characters of look-ahead) from the neighbours' masks: token starts =
+//   class != 0 at a class change or page start, token length = ctz of the shifted window.
+//   The count kernel stops here (popcount -> tile total).  The emit kernel also stages the
+//   lower-cased text in LDS, compacts the kept tokens through a block scan, and for each token
+//   hashes its 32-bit words from LDS, looks it up / inserts it in the global open-addressing table
+//   (one 64-bit CAS word per term = {tag, length, position of the canonical occurrence}; equality is
+//   verified word-wise against the canonical occurrence, so the vocabulary is EXACT, not
+//   probabilistic) and writes (slot, local coordinate) in text order.
 #pragma once
 #include "dcd_common.h"
 #include "dcd_prims.h"
@@ -20,52 +24,135 @@
 namespace dcd {
 
 constexpr int TK_THREADS = 256;
-constexpr int TK_CPT = 16;                           // characters per thread
-constexpr int TK_TILE = TK_THREADS * TK_CPT;         // 4096
-constexpr int TK_PRE = 16;                           // staged before the tile (previous character)
-constexpr int TK_POST = 48;                          // staged after the tile (token end look-ahead >= 33)
-constexpr int TK_SPAN = TK_PRE + TK_TILE + TK_POST;  // 4160
-constexpr int TK_CHUNKS = TK_SPAN / TK_CPT;          // 260
-constexpr int TK_MAXTOK = TK_TILE / 2 + 1;           // tokens of length 1 separated by one character
+constexpr int TK_CPT = 16;                       // characters per lane
+constexpr int TK_TILE = TK_THREADS * TK_CPT;     // 4096
+constexpr int TK_HALO = 4;                       // look-ahead chunks after the tile (>= 33 characters)
+constexpr int TK_MASKS = TK_THREADS + TK_HALO + 1 + 11;  // slot 0 = chunk before the tile; padded
+constexpr int TK_MAXTOK = TK_TILE / 2 + 1;       // tokens of length 1 separated by one character
 
-// vocabulary slot word: [63:48] tag  [47:42] length (1..32 -> stored as-is, 6 bits incl. 32)  [41:0] position
+// vocabulary slot word: [63:48] tag  [47:42] length (1..63)  [41:0] position of the canonical occurrence
 constexpr u64 VOC_POS_MASK = (1ull << 42) - 1;
 __host__ __device__ inline u64 voc_word(u32 tag, u32 len, u64 pos) { return ((u64)(tag & 0xFFFFu) << 48) | ((u64)(len & 63u) << 42) | pos; }
 __host__ __device__ inline u32 voc_len(u64 w) { return (u32)(w >> 42) & 63u; }
 __host__ __device__ inline u64 voc_pos(u64 w) { return w & VOC_POS_MASK; }
 
-// ---- character classes -----------------------------------------------------------------------
-// class: 0 = other, 1 = \p{L}, 2 = \p{N}.  Latin-1 (byte == code unit) is computed arithmetically;
-// UTF-16 goes through 64 Ki-entry tables (L2 resident).
 struct CharTables16 {
-  const u8* cls;     // [65536]
-  const u16* lower;  // [65536]
+  const u8* cls;     // [65536] bit0 = \p{L}, bit1 = \p{N}
+  const u16* lower;  // [65536] String.ToLower per code unit
 };
+
+// ---- SWAR Latin-1 (byte == UTF-16 code unit) --------------------------------------------------
+// flags live in bit 7 of each byte; additions never carry across bytes (operands <= 0x7F + 0x7F)
+__device__ __forceinline__ u32 swar_eq7(u32 x7, u32 k) {   // bit7 set where the 7-bit byte equals k
+  u32 y = x7 ^ k;
+  return ~((y + 0x7F7F7F7Fu) | y) & 0x80808080u;
+}
+__device__ __forceinline__ u32 swar_lower4(u32 w) {
+  const u32 hi = w & 0x80808080u, x = w & 0x7F7F7F7Fu;
+  u32 up = ((x + 0x3F3F3F3Fu) & ~(x + 0x25252525u)) & 0x80808080u & ~hi;        // 'A'..'Z'
+  if (hi) {
+    u32 lat = ((x + 0x40404040u) & ~(x + 0x21212121u)) & hi;                    // 0xC0..0xDE
+    u32 y = x ^ 0x57575757u;                                                    // except 0xD7
+    up |= lat & (((y + 0x7F7F7F7Fu) | y) & 0x80808080u);
+  }
+  return w + (up >> 2);  // + 0x20 where upper case
+}
+// class flags of already lower-cased bytes: *Lf letters, *Df numbers (bit 7 per byte)
+__device__ __forceinline__ void swar_class4(u32 lw, u32* Lf, u32* Df) {
+  const u32 hi = lw & 0x80808080u, x = lw & 0x7F7F7F7Fu;
+  u32 L = ((x + 0x1F1F1F1Fu) & ~(x + 0x05050505u)) & 0x80808080u & ~hi;         // 'a'..'z'
+  u32 D = ((x + 0x50505050u) & ~(x + 0x46464646u)) & 0x80808080u & ~hi;         // '0'..'9'
+  if (hi) {
+    u32 y = x ^ 0x77777777u;                                                    // >= 0xDF except 0xF7
+    L |= (x + 0x21212121u) & hi & (((y + 0x7F7F7F7Fu) | y) & 0x80808080u);
+    L |= (swar_eq7(x, 0x2A2A2A2Au) | swar_eq7(x, 0x35353535u) | swar_eq7(x, 0x3A3A3A3Au)) & hi;   // ª µ º
+    D |= (swar_eq7(x, 0x32323232u) | swar_eq7(x, 0x33333333u) | swar_eq7(x, 0x39393939u) |       // ² ³ ¹
+          swar_eq7(x, 0x3C3C3C3Cu) | swar_eq7(x, 0x3D3D3D3Du) | swar_eq7(x, 0x3E3E3E3Eu)) & hi;   // ¼ ½ ¾
+  }
+  *Lf = L;
+  *Df = D;
+}
+__device__ __forceinline__ u32 swar_nibble(u32 f) { return ((((f >> 7) & 0x01010101u) * 0x01020408u) >> 24) & 0xFu; }
 
 __device__ __forceinline__ u32 lower_latin1(u32 c) {
   bool up = (c - 0x41u) < 26u || (c >= 0xC0u && c <= 0xDEu && c != 0xD7u);
   return c + (up ? 32u : 0u);
 }
-__device__ __forceinline__ u32 class_latin1_lower(u32 lc) {  // lc already lower-cased
-  bool L = (lc - 0x61u) < 26u || (lc >= 0xDFu && lc != 0xF7u) || lc == 0xAAu || lc == 0xB5u || lc == 0xBAu;
-  bool N = (lc - 0x30u) < 10u || lc == 0xB2u || lc == 0xB3u || lc == 0xB9u || (lc >= 0xBCu && lc <= 0xBEu);
-  return L ? 1u : (N ? 2u : 0u);
-}
 
+// ---- chunk loading + classification ------------------------------------------------------------
+// Loads 16 characters starting at global index g0 (may lie partly outside [0, n_chars): zeros),
+// returns the lower-cased characters as packed 32-bit words and the letter / number masks.
 template <typename CharT>
-struct CharOps;
+struct Chunk;
+
 template <>
-struct CharOps<u8> {
-  __device__ static __forceinline__ u32 lower(u32 c, const CharTables16&) { return lower_latin1(c); }
-  __device__ static __forceinline__ u32 cls(u32 lc, const CharTables16&) { return class_latin1_lower(lc); }
-};
-template <>
-struct CharOps<u16> {
-  __device__ static __forceinline__ u32 lower(u32 c, const CharTables16& t) { return t.lower[c]; }
-  __device__ static __forceinline__ u32 cls(u32 lc, const CharTables16& t) { return t.cls[lc] & 3u; }
+struct Chunk<u8> {
+  static constexpr int NW = 4;
+  u32 w[NW];
+  u32 L, D;
+  __device__ __forceinline__ void load(const u8* __restrict__ text, int64_t g0, u64 n_chars, const CharTables16&) {
+    if (g0 >= 0 && (u64)g0 + TK_CPT <= n_chars) {
+      uint4 v = *reinterpret_cast<const uint4*>(text + g0);
+      w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+    } else {
+#pragma unroll
+      for (int k = 0; k < NW; k++) {
+        u32 x = 0;
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+          int64_t g = g0 + k * 4 + b;
+          if (g >= 0 && (u64)g < n_chars) x |= (u32)text[g] << (8 * b);
+        }
+        w[k] = x;
+      }
+    }
+    L = D = 0;
+#pragma unroll
+    for (int k = 0; k < NW; k++) {
+      w[k] = swar_lower4(w[k]);
+      u32 lf, df;
+      swar_class4(w[k], &lf, &df);
+      L |= swar_nibble(lf) << (4 * k);
+      D |= swar_nibble(df) << (4 * k);
+    }
+  }
 };
 
-// ---- hashing ------------------------------------------------------------------------------------
+template <>
+struct Chunk<u16> {
+  static constexpr int NW = 8;
+  u32 w[NW];
+  u32 L, D;
+  __device__ __forceinline__ void load(const u16* __restrict__ text, int64_t g0, u64 n_chars, const CharTables16& tab) {
+    if (g0 >= 0 && (u64)g0 + TK_CPT <= n_chars) {
+      const uint4* q = reinterpret_cast<const uint4*>(text + g0);
+      uint4 a = q[0], b = q[1];
+      w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
+    } else {
+#pragma unroll
+      for (int k = 0; k < NW; k++) {
+        u32 x = 0;
+#pragma unroll
+        for (int b = 0; b < 2; b++) {
+          int64_t g = g0 + k * 2 + b;
+          if (g >= 0 && (u64)g < n_chars) x |= (u32)text[g] << (16 * b);
+        }
+        w[k] = x;
+      }
+    }
+    L = D = 0;
+#pragma unroll
+    for (int k = 0; k < NW; k++) {
+      u32 c0 = tab.lower[w[k] & 0xFFFFu], c1 = tab.lower[w[k] >> 16];
+      u32 k0 = tab.cls[c0], k1 = tab.cls[c1];
+      w[k] = c0 | (c1 << 16);
+      L |= ((k0 & 1u) | ((k1 & 1u) << 1)) << (2 * k);
+      D |= (((k0 >> 1) & 1u) | (((k1 >> 1) & 1u) << 1)) << (2 * k);
+    }
+  }
+};
+
+// ---- hashing (over the 32-bit words of the lower-cased string, zero padded) -------------------------
 __device__ __forceinline__ u32 fmix32(u32 h) {
   h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
   return h;
@@ -73,11 +160,12 @@ __device__ __forceinline__ u32 fmix32(u32 h) {
 struct TokHash { u32 idx, tag; };
 struct HashState {
   u32 h1, h2;
-  __device__ __forceinline__ void init(u32 len) { h1 = 0x811C9DC5u ^ len; h2 = 0x9E3779B9u + len * 0x85EBCA6Bu; }
-  __device__ __forceinline__ void add(u32 c) {
-    h1 = (h1 ^ c) * 0x01000193u;
-    h2 = (h2 + c) * 0xCC9E2D51u;
-    h2 = (h2 << 13) | (h2 >> 19);
+  __device__ __forceinline__ void init(u32 len) { h1 = 0x811C9DC5u ^ (len * 0x9E3779B1u); h2 = 0x85EBCA6Bu + len; }
+  __device__ __forceinline__ void add(u32 w) {
+    h1 = (h1 ^ w) * 0xCC9E2D51u;
+    h1 = (h1 << 15) | (h1 >> 17);
+    h2 = (h2 + w) * 0x1B873593u;
+    h2 ^= h2 >> 13;
   }
   __device__ __forceinline__ TokHash fin() const {
     TokHash r;
@@ -87,18 +175,45 @@ struct HashState {
   }
 };
 
-// ---- text sources --------------------------------------------------------------------------------
-// Position space of canonical occurrences: [0, n_chars) = the text buffer (original case),
-// [n_chars, n_chars + n_pool) = the explicit-code pool (verbatim, Builder.Add codes).
+// word k of the byte string starting at byte offset `off` of a 4-byte aligned array
+__device__ __forceinline__ u32 str_word(const u32* __restrict__ base, u64 off, u32 k, u64 n_bytes) {
+  u64 a = (off >> 2) + k;
+  u32 sh = (u32)off & 3u;
+  u32 lo = base[a];
+  if (sh == 0) return lo;
+  u32 hi = ((a + 1) << 2) < n_bytes ? base[a + 1] : 0u;
+  return __builtin_amdgcn_alignbyte(hi, lo, sh);
+}
+__device__ __forceinline__ u32 tail_mask(u32 nbytes, u32 k) {  // mask of word k of an nbytes-long string
+  u32 rem = nbytes - 4u * k;
+  return rem >= 4u ? 0xFFFFFFFFu : ((1u << (8u * rem)) - 1u);
+}
+
+// ---- canonical occurrences ------------------------------------------------------------------------
+// Position space: [0, n_chars) = the text buffer (original case), [n_chars, ...) = the explicit-code
+// pool (verbatim Builder.Add codes).  Both arrays are 4-byte aligned.
 template <typename CharT>
 struct TextView {
   const CharT* text;
   u64 n_chars;
   const CharT* pool;
+  u64 n_pool;
   CharTables16 tab;
-  __device__ __forceinline__ u32 canon_char(u64 pos) const {
-    if (pos < n_chars) return CharOps<CharT>::lower((u32)text[pos], tab);
+  __device__ __forceinline__ u32 canon_char(u64 pos) const {   // lower-cased code unit at pos
+    if (pos < n_chars) {
+      u32 c = (u32)text[pos];
+      return sizeof(CharT) == 1 ? lower_latin1(c) : (u32)tab.lower[c];
+    }
     return (u32)pool[pos - n_chars];
+  }
+  // lower-cased word k (unmasked) of the string whose first character is at `pos`
+  __device__ __forceinline__ u32 canon_word(u64 pos, u32 k) const {
+    if (pos < n_chars) {
+      u32 w = str_word(reinterpret_cast<const u32*>(text), pos * sizeof(CharT), k, n_chars * sizeof(CharT));
+      if (sizeof(CharT) == 1) return swar_lower4(w);
+      return (u32)tab.lower[w & 0xFFFFu] | ((u32)tab.lower[w >> 16] << 16);
+    }
+    return str_word(reinterpret_cast<const u32*>(pool), (pos - n_chars) * sizeof(CharT), k, n_pool * sizeof(CharT));
   }
 };
 
@@ -108,27 +223,30 @@ struct VocabTable {
   u32* overflow;   // set to 1 when a probe sequence gets too long
 };
 
-// Look up / insert the string `get(j)`, j < len, whose canonical position would be `pos`.
-// Returns the slot index (0xFFFFFFFF on table overflow).
-template <typename CharT, typename GetChar>
+// Look up / insert the string whose (masked) words are get(k), k < nw, nbytes long, `len` characters,
+// canonical position `pos`.  Returns the slot index (0xFFFFFFFF on table overflow).
+template <typename CharT, typename GetWord>
 __device__ __forceinline__ u32 vocab_lookup_insert(const VocabTable& vt, const TextView<CharT>& tv, TokHash h, u32 len, u64 pos,
-                                                   GetChar get) {
+                                                   GetWord get) {
   const u64 mine = voc_word(h.tag, len, pos);
+  const u32 nbytes = len * (u32)sizeof(CharT), nw = (nbytes + 3u) >> 2;
   u32 idx = h.idx & vt.mask;
   for (u32 probes = 0; probes < 4096u; probes++) {
-    // agent-scope relaxed load: bypasses the per-CU L1 so a slot filled by another CU is seen as
-    // soon as this XCD's L2 line is fresh; a stale "empty" is resolved by the CAS below.
-    u64 w = __hip_atomic_load(&vt.slots[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // Plain (L1-cacheable) load: hot slots (Zipf head) are served by each CU's own L1 instead of
+    // hammering one L2 channel.  A slot word only ever changes 0 -> value, so a stale read can only
+    // be a stale "empty", which the CAS below repairs (it returns the current value); a non-empty
+    // read is final.  Correct for any workgroup -> XCD placement.
+    u64 w = vt.slots[idx];
     if (w == 0) {
       u64 old = atomicCAS((unsigned long long*)&vt.slots[idx], 0ull, (unsigned long long)mine);
       if (old == 0) return idx;
       w = old;
     }
-    if ((w >> 42) == (mine >> 42)) {  // tag and length agree -> verify the characters
-      u64 cp = voc_pos(w);
+    if ((w >> 42) == (mine >> 42)) {  // tag and length agree -> verify the characters word by word
+      const u64 cp = voc_pos(w);
       bool eq = true;
-      for (u32 j = 0; j < len; j++) {
-        if (tv.canon_char(cp + j) != get(j)) { eq = false; break; }
+      for (u32 k = 0; k < nw; k++) {
+        if (((tv.canon_word(cp, k) ^ get(k)) & tail_mask(nbytes, k)) != 0u) { eq = false; break; }
       }
       if (eq) return idx;
     }
@@ -138,130 +256,112 @@ __device__ __forceinline__ u32 vocab_lookup_insert(const VocabTable& vt, const T
   return 0xFFFFFFFFu;
 }
 
-// ---- tile tokeniser --------------------------------------------------------------------------------
+// ---- tile tokeniser ----------------------------------------------------------------------------------
 struct TokParams {
   u64 n_chars;
-  const u64* page_off;   // [n_pages + 1] device, ascending, page_off[0] = 0, page_off[n_pages] = n_chars
+  const u64* page_off;     // [n_pages + 1] device, ascending (unused when uniform_page_chars != 0)
   u64 n_pages;
   u32 min_len, max_len;
-  u32 uniform_page_chars;  // != 0: pages start at every multiple of this (page_off unused)
+  u32 uniform_page_chars;  // != 0: pages start at every multiple of this
 };
 
-template <typename CharT>
+template <typename CharT, bool STAGE_TEXT>
 struct TokLds {
-  CharT txt[TK_SPAN];          // lower-cased characters, local index = global - tile_start + TK_PRE
-  u32 bnd[TK_SPAN / 32 + 2];   // bit i: a token boundary lies before local position i
-  u32 nz[TK_SPAN / 32 + 2];    // bit i: class(local i) != 0
-  u32 pg[TK_SPAN / 32 + 2];    // bit i: a page starts at local position i
-  u32 tok[TK_MAXTOK];          // compacted kept tokens: local start | len << 16
+  u16 Lm[TK_MASKS];                                              // letter mask per chunk (slot = chunk + 1)
+  u16 Dm[TK_MASKS];                                              // number mask per chunk
+  u32 pg[(TK_TILE + TK_HALO * TK_CPT) / 32 + 3];                 // page-start bitmask (non-uniform pages)
   u32 scan[TK_THREADS / 64 + 1];
+  u32 txt[STAGE_TEXT ? (TK_TILE + TK_HALO * TK_CPT) * sizeof(CharT) / 4 + 4 : 1];  // lower-cased text
+  u32 tok[STAGE_TEXT ? TK_MAXTOK : 1];                           // kept tokens: tile position | len << 16
 };
 
-// Stages one tile, finds the kept tokens and leaves them compacted in L.tok; returns their count.
-template <typename CharT>
-__device__ __forceinline__ u32 tokenize_tile(const CharT* __restrict__ text, const TokParams& P, const CharTables16& tab, u64 tile,
-                                             TokLds<CharT>& L) {
+// After this call: `keep` = 16-bit mask of kept token starts in this lane's chunk, `bnd` = 64-bit
+// boundary window whose bit 0 is the first character of the chunk.  Contains one __syncthreads
+// (two with a general page table).
+template <typename CharT, bool STAGE_TEXT>
+__device__ __forceinline__ void tokenize_chunk(const CharT* __restrict__ text, const TokParams& P, const CharTables16& tab, u64 tile,
+                                               TokLds<CharT, STAGE_TEXT>& S, u32* keep_out, u64* bnd_out) {
   const u32 tid = threadIdx.x;
-  const int64_t lo = (int64_t)(tile * TK_TILE) - TK_PRE;          // global index of local 0
-  for (u32 i = tid; i < TK_SPAN / 32 + 2; i += TK_THREADS) L.pg[i] = 0;
-  __syncthreads();
-  // page starts inside [lo, lo + TK_SPAN)
-  if (P.uniform_page_chars) {
-    const u64 S = P.uniform_page_chars;
-    u64 first = lo < 0 ? 0 : (u64)lo;
-    u64 o = (first + S - 1) / S * S + (u64)tid * S;
-    for (; (int64_t)o < lo + TK_SPAN && o <= P.n_chars; o += (u64)TK_THREADS * S) {
-      u32 li = (u32)((int64_t)o - lo);
-      atomicOr(&L.pg[li >> 5], 1u << (li & 31));
-    }
-  } else {
-    u64 first = lo < 0 ? 0 : (u64)lo;
-    u64 a = 0, b = P.n_pages + 1;  // lower_bound over page_off[0 .. n_pages]
-    while (a < b) { u64 m = (a + b) >> 1; if (P.page_off[m] < first) a = m + 1; else b = m; }
+  const u64 tile_start = tile * TK_TILE;
+  const bool general_pages = P.uniform_page_chars == 0;
+  if (general_pages) {
+    for (u32 i = tid; i < (TK_TILE + TK_HALO * TK_CPT) / 32 + 3; i += TK_THREADS) S.pg[i] = 0;
+    __syncthreads();
+    // pages starting inside [tile_start, tile_start + TILE + HALO)
+    u64 a = 0, b = P.n_pages + 1;
+    while (a < b) { u64 m = (a + b) >> 1; if (P.page_off[m] < tile_start) a = m + 1; else b = m; }
     for (u64 p = a + tid; p <= P.n_pages; p += TK_THREADS) {
       u64 o = P.page_off[p];
-      if ((int64_t)o >= lo + TK_SPAN) break;
-      u32 li = (u32)((int64_t)o - lo);
-      atomicOr(&L.pg[li >> 5], 1u << (li & 31));
+      if (o >= tile_start + TK_TILE + TK_HALO * TK_CPT) break;
+      u32 li = (u32)(o - tile_start);
+      atomicOr(&S.pg[li >> 5], 1u << (li & 31));
     }
   }
-  __syncthreads();
-  // load, lower-case, classify; chunk c covers local [16c, 16c+16)
-  for (u32 c = tid; c < TK_CHUNKS; c += TK_THREADS) {
-    int64_t g0 = lo + (int64_t)c * TK_CPT;
-    u32 ch[TK_CPT];
-    if (g0 >= 0 && (u64)g0 + TK_CPT <= P.n_chars) {
+  {
+    Chunk<CharT> c;
+    c.load(text, (int64_t)(tile_start + (u64)tid * TK_CPT), P.n_chars, tab);
+    S.Lm[tid + 1] = (u16)c.L;
+    S.Dm[tid + 1] = (u16)c.D;
+    if (STAGE_TEXT) {
+#pragma unroll
+      for (int k = 0; k < Chunk<CharT>::NW; k++) S.txt[tid * Chunk<CharT>::NW + k] = c.w[k];
+    }
+  }
+  if (tid < TK_HALO) {   // look-ahead chunks (wave 0 only)
+    Chunk<CharT> c;
+    c.load(text, (int64_t)(tile_start + TK_TILE + (u64)tid * TK_CPT), P.n_chars, tab);
+    S.Lm[TK_THREADS + 1 + tid] = (u16)c.L;
+    S.Dm[TK_THREADS + 1 + tid] = (u16)c.D;
+    if (STAGE_TEXT) {
+#pragma unroll
+      for (int k = 0; k < Chunk<CharT>::NW; k++) S.txt[(TK_THREADS + tid) * Chunk<CharT>::NW + k] = c.w[k];
+    }
+  }
+  if (tid == TK_HALO) {  // class of the character just before the tile
+    u32 Lb = 0, Db = 0;
+    if (tile_start > 0) {
+      u32 ch = (u32)text[tile_start - 1];
       if (sizeof(CharT) == 1) {
-        uint4 v = *reinterpret_cast<const uint4*>(text + g0);
-        u32 wv[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-        for (int j = 0; j < TK_CPT; j++) ch[j] = (wv[j >> 2] >> (8 * (j & 3))) & 0xFFu;
+        u32 lf, df;
+        swar_class4(swar_lower4(ch), &lf, &df);
+        Lb = (lf >> 7) & 1u; Db = (df >> 7) & 1u;
       } else {
-        const uint4* q = reinterpret_cast<const uint4*>(text + g0);
-        uint4 v0 = q[0], v1 = q[1];
-        u32 wv[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-#pragma unroll
-        for (int j = 0; j < TK_CPT; j++) ch[j] = (wv[j >> 1] >> (16 * (j & 1))) & 0xFFFFu;
-      }
-    } else {
-#pragma unroll
-      for (int j = 0; j < TK_CPT; j++) {
-        int64_t g = g0 + j;
-        ch[j] = (g >= 0 && (u64)g < P.n_chars) ? (u32)text[g] : 0u;
+        u32 k = tab.cls[tab.lower[ch]];
+        Lb = k & 1u; Db = (k >> 1) & 1u;
       }
     }
-    // class of the character just before this chunk
-    u32 prev_cls = 0;
-    if (g0 - 1 >= 0 && (u64)(g0 - 1) < P.n_chars)
-      prev_cls = CharOps<CharT>::cls(CharOps<CharT>::lower((u32)text[g0 - 1], tab), tab);
-    u32 nzm = 0, bm = 0;
-    u32 pgm = (L.pg[(c * TK_CPT) >> 5] >> ((c * TK_CPT) & 31)) & 0xFFFFu;
-#pragma unroll
-    for (int j = 0; j < TK_CPT; j++) {
-      u32 lc = CharOps<CharT>::lower(ch[j], tab);
-      u32 k = CharOps<CharT>::cls(lc, tab);
-      L.txt[c * TK_CPT + j] = (CharT)lc;
-      nzm |= (k != 0 ? 1u : 0u) << j;
-      bm |= (k != prev_cls ? 1u : 0u) << j;
-      prev_cls = k;
-    }
-    bm |= pgm;
-    reinterpret_cast<u16*>(L.bnd)[c] = (u16)bm;
-    reinterpret_cast<u16*>(L.nz)[c] = (u16)nzm;
-  }
-  if (tid < 4) {  // bits past the staged span read as "boundary" so windows terminate
-    reinterpret_cast<u16*>(L.bnd)[TK_CHUNKS + tid] = 0xFFFFu;
-    reinterpret_cast<u16*>(L.nz)[TK_CHUNKS + tid] = 0;
+    S.Lm[0] = (u16)(Lb << 15);
+    S.Dm[0] = (u16)(Db << 15);
   }
   __syncthreads();
-  // tokens starting in this thread's 16 tile positions (chunk tid + 1)
-  const u32 c = tid + TK_PRE / TK_CPT;
-  u32 starts = reinterpret_cast<u16*>(L.bnd)[c] & reinterpret_cast<u16*>(L.nz)[c];
-  // pass 1: which starts are kept (length filter, Build.cs:528); pass 2 (after the scan) writes them
-  u32 keepm = 0;
+  const u32 s = tid + 1;
+  const u64 L64 = (u64)S.Lm[s] | ((u64)S.Lm[s + 1] << 16) | ((u64)S.Lm[s + 2] << 32) | ((u64)S.Lm[s + 3] << 48);
+  const u64 D64 = (u64)S.Dm[s] | ((u64)S.Dm[s + 1] << 16) | ((u64)S.Dm[s + 2] << 32) | ((u64)S.Dm[s + 3] << 48);
+  const u64 pL = S.Lm[s - 1] >> 15, pD = S.Dm[s - 1] >> 15;
+  u64 bnd = (L64 ^ ((L64 << 1) | pL)) | (D64 ^ ((D64 << 1) | pD));
+  const u64 g0 = tile_start + (u64)tid * TK_CPT;
+  if (general_pages) {
+    u32 b0 = tid * TK_CPT;  // bit offset into S.pg, multiple of 16
+    u64 lo = ((u64)S.pg[(b0 >> 5) + 1] << 32) | S.pg[b0 >> 5];
+    u64 pgw = lo >> (b0 & 31);
+    if (b0 & 31) pgw |= (u64)S.pg[(b0 >> 5) + 2] << (64 - (b0 & 31));
+    bnd |= pgw;
+  } else {
+    const u32 Sz = P.uniform_page_chars;
+    u32 r = (u32)(g0 % Sz);
+    for (u32 o = r ? Sz - r : 0u; o < 64u; o += Sz) bnd |= 1ull << o;
+  }
+  u32 starts = (u32)(bnd & (L64 | D64)) & 0xFFFFu;
+  u32 keep = 0;
   for (u32 m = starts; m;) {
     u32 j = (u32)__builtin_ctz(m);
     m &= m - 1;
-    u32 b = c * TK_CPT + j + 1;      // first candidate end
-    u64 win = (((u64)L.bnd[(b >> 5) + 1] << 32) | L.bnd[b >> 5]) >> (b & 31);
-    if ((b & 31) != 0) win |= (u64)L.bnd[(b >> 5) + 2] << (64 - (b & 31));
-    u32 len = win ? (u32)__builtin_ctzll(win) + 1u : 65u;
-    if (len >= P.min_len && len <= P.max_len) keepm |= 1u << j;
+    u64 rest = bnd >> (j + 1);
+    u32 len = rest ? (u32)__builtin_ctzll(rest) + 1u : 99u;
+    if (len >= P.min_len && len <= P.max_len) keep |= 1u << j;
   }
-  u32 total;
-  u32 ex = block_scan_excl<u32, TK_THREADS / 64>((u32)__builtin_popcount(keepm), L.scan, &total);
-  for (u32 m = keepm; m;) {
-    u32 j = (u32)__builtin_ctz(m);
-    m &= m - 1;
-    u32 i = c * TK_CPT + j;
-    u32 b = i + 1;
-    u64 win = (((u64)L.bnd[(b >> 5) + 1] << 32) | L.bnd[b >> 5]) >> (b & 31);
-    if ((b & 31) != 0) win |= (u64)L.bnd[(b >> 5) + 2] << (64 - (b & 31));
-    u32 len = (u32)__builtin_ctzll(win) + 1u;
-    L.tok[ex++] = i | (len << 16);
-  }
-  __syncthreads();
-  return total;
+  *keep_out = keep;
+  *bnd_out = bnd;
 }
 
 }  // namespace dcd
