@@ -91,18 +91,26 @@ struct SlotUsed {
 };
 
 __global__ void k_vocab_compact(const u64* __restrict__ slots, u64 cap, const u32* __restrict__ excl, u64* __restrict__ term_word,
-                                u32* __restrict__ term_slot, u32* __restrict__ maxlen) {
+                                u32* __restrict__ term_slot) {
   u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-  u64 w = i < cap ? slots[i] : 0;
-  u32 l = 0;
+  if (i >= cap) return;
+  u64 w = slots[i];
   if (w) {
     u32 d = excl[i];
     term_word[d] = w;
     term_slot[d] = (u32)i;
-    l = voc_len(w);
   }
-  l = wave_max(l);                      // one atomic per wave, not per term
-  if (l && lane_id() == 0) atomicMax(maxlen, l);
+}
+// longest key: one atomic per workgroup over the V compacted terms (never one per term: a single
+// address takes ~88 atomics/us on this chip)
+__global__ __launch_bounds__(256) void k_max_len(const u64* __restrict__ term_word, u64 n, u32* __restrict__ maxlen) {
+  __shared__ u32 s[4];
+  u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  u32 l = i < n ? voc_len(term_word[i]) : 0u;
+  l = wave_max(l);
+  if (lane_id() == 0) s[threadIdx.x >> 6] = l;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicMax(maxlen, max(max(s[0], s[1]), max(s[2], s[3])));
 }
 
 // sort key chunk: characters [c*K, c*K+K) of the term, big-endian packed (K = 4 for bytes, 2 for
@@ -646,7 +654,8 @@ static int32_t finish_impl(dcd_build* h) {
   u32 maxlen = 0;
   if (V) {
     hipLaunchKernelGGL(k_vocab_compact, dim3((u32)div_up(cap, 256)), dim3(256), 0, st, slots.p, cap, slot_excl.p, term_word.p,
-                       term_slot.p, d_flags.p + 1);
+                       term_slot.p);
+    hipLaunchKernelGGL(k_max_len, dim3((u32)div_up(V, 256)), dim3(256), 0, st, term_word.p, V, d_flags.p + 1);
     DCD_HIP(hipMemcpyAsync(&maxlen, d_flags.p + 1, 4, hipMemcpyDeviceToHost, st));
     DCD_HIP(hipStreamSynchronize(st));
     constexpr u32 K = sizeof(CharT) == 1 ? 4 : 2;

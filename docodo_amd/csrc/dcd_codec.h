@@ -55,10 +55,15 @@ __global__ __launch_bounds__(CODEC_THREADS) void k_enc_reduce(Src src, u64 n, u6
   if (threadIdx.x == 0) partial[blockIdx.x] = (u64)lds[0] + lds[1] + lds[2] + lds[3];
 }
 
+// Writes the units of one 2048-item tile.  Items are taken in blocked order (lane t owns 8
+// consecutive items, so one block scan gives every unit offset); the units are first laid out in
+// LDS and then copied to HBM by consecutive lanes, so a wave-instruction stores 128 contiguous bytes
+// instead of 64 scattered 2-byte words.
 template <typename Src>
 __global__ __launch_bounds__(CODEC_THREADS) void k_enc_write(Src src, u64 n, const u64* __restrict__ partial,
                                                             u16* __restrict__ out) {
   __shared__ u32 lds[5];
+  __shared__ u16 s_units[CODEC_TILE * 5];
   u64 base = (u64)blockIdx.x * CODEC_TILE + (u64)threadIdx.x * CODEC_ITEMS;
   u64 d[CODEC_ITEMS];
   u32 nu[CODEC_ITEMS];
@@ -71,16 +76,27 @@ __global__ __launch_bounds__(CODEC_THREADS) void k_enc_write(Src src, u64 n, con
     s += nu[j];
   }
   u32 tot;
-  u64 off = partial[blockIdx.x] + block_scan_excl<u32, 4>(s, lds, &tot);
+  u32 loff = block_scan_excl<u32, 4>(s, lds, &tot);
+  const u64 gbase = partial[blockIdx.x];
 #pragma unroll
   for (int j = 0; j < CODEC_ITEMS; j++) {
     u64 i = base + j;
     if (i < n) {
-      src.on_item(i, off, d[j]);
-      for (u32 g = 0; g < nu[j]; g++) out[off + g] = seq_unit(d[j], g, nu[j]);
-      off += nu[j];
+      src.on_item(i, gbase + loff, d[j]);
+      for (u32 g = 0; g < nu[j]; g++) s_units[loff + g] = seq_unit(d[j], g, nu[j]);
+      loff += nu[j];
     }
   }
+  __syncthreads();
+  // coalesced copy; 32-bit stores where the destination is 4-byte aligned
+  u16* dst = out + gbase;
+  u32 head = (u32)(((uintptr_t)dst >> 1) & 1u) & (tot ? 1u : 0u);   // one leading u16 to reach alignment
+  if (threadIdx.x == 0 && head) dst[0] = s_units[0];
+  u32 npair = (tot - head) >> 1;
+  u32* dst32 = reinterpret_cast<u32*>(dst + head);
+  for (u32 k = threadIdx.x; k < npair; k += CODEC_THREADS)
+    dst32[k] = (u32)s_units[head + 2 * k] | ((u32)s_units[head + 2 * k + 1] << 16);
+  if (threadIdx.x == 0 && ((tot - head) & 1u)) dst[tot - 1] = s_units[tot - 1];
 }
 
 // Encodes n items.  partial: >= div_up(n, CODEC_TILE) + 1 u64 (grand total of units left in
