@@ -92,10 +92,21 @@ def main():
     synth.corpus_dev(text.data_ptr(), D, first_doc=first_doc, device=local_rank)
     coord_base = first_doc * synth.DOC_BYTES           # shards encode GLOBAL coordinates
 
+    from docodo_amd import dist as ddist
+    merge_ms = []
+
     def step():
         b = docodo_amd.Builder(coord_base=coord_base, device=local_rank)
         b.AddUniformPagesDev(text.data_ptr(), D, synth.DOC_BYTES, first_doc=first_doc)
         st = b.Finish()
+        if world > 1:
+            # exchange step: per-term segments travel to their owner (hash(key) % world) with RCCL
+            # all-to-all over xGMI and are merged there; part of the timed step
+            t0 = time.perf_counter()
+            owned = ddist.distributed_merge(b, device_index=local_rank)
+            torch.cuda.synchronize()
+            merge_ms.append((time.perf_counter() - t0) * 1e3)
+            owned.close()
         return b, st
 
     def fence():
@@ -156,6 +167,9 @@ def main():
             "kernel_ms_per_step": {KERNEL_NAMES[k]: round(per_step[k], 4) for k in range(8)},
             "postings_per_s": round(world * N / (dt / args.steps), 0),
         }
+        if world > 1:
+            out["exchange_merge_ms_per_step_rank0"] = round(float(np.mean(merge_ms[args.warmup:])), 3)
+            out["config"]["exchange"] = "RCCL all-to-all of per-term segments (meta, keys, units) to owner = hash(key) % world, then dcd_merge_shards"
         if world == 1 and args.cpu_docs > 0:
             out["cpu_baseline"] = cpu_baseline(min(args.cpu_docs, D))
         print(json.dumps(out), flush=True)

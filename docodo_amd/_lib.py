@@ -99,6 +99,10 @@ SIGNATURES = {
     "dcd_query_batch": (_i32, [_vp, _vp, _vp, _sz, C.POINTER(QueryOpts), C.POINTER(_vp)]),
     "dcd_results_get": (_i32, [_vp, C.POINTER(ResultsView)]),
     "dcd_results_free": (None, [_vp]),
+    "dcd_build_export_plan": (_i32, [_vp, _u32, _vp, _vp, _vp]),
+    "dcd_build_export_fill": (_i32, [_vp, _vp, _vp, _vp]),
+    "dcd_merge_shards": (_i32, [_i32, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _u64, C.POINTER(_vp)]),
+    "dcd_index_set_uniform_pages": (_i32, [_vp, _u64, _u32, _u64, _vp, _sz]),
     "dcd_synth_corpus_host": (_i32, [_vp, _u64, _u64, _u32, _u32, C.c_double, _u64]),
     "dcd_synth_corpus_dev": (_i32, [_vp, _u64, _u64, _u32, _u32, C.c_double, _u64, _i32]),
     "dcd_synth_term": (_i32, [_u32, _u32, C.c_char_p, _sz, _pz]),

@@ -10,6 +10,7 @@
 #include "dcd_scan.h"
 #include "dcd_sort.h"
 #include "dcd_tokenize.h"
+#include "dcd_vocab.h"
 
 namespace dcd {
 
@@ -85,83 +86,14 @@ __global__ void k_explicit(const u32* __restrict__ xoff, const u32* __restrict__
   tuples[i] = make_uint2(slot, xcoord[i]);
 }
 
-struct SlotUsed {
-  const u64* slots;
-  __device__ __forceinline__ u32 operator()(u64 i) const { return slots[i] != 0 ? 1u : 0u; }
-};
-
-__global__ void k_vocab_compact(const u64* __restrict__ slots, u64 cap, const u32* __restrict__ excl, u64* __restrict__ term_word,
-                                u32* __restrict__ term_slot) {
-  u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= cap) return;
-  u64 w = slots[i];
-  if (w) {
-    u32 d = excl[i];
-    term_word[d] = w;
-    term_slot[d] = (u32)i;
-  }
-}
-// longest key: one atomic per workgroup over the V compacted terms (never one per term: a single
-// address takes ~88 atomics/us on this chip)
-__global__ __launch_bounds__(256) void k_max_len(const u64* __restrict__ term_word, u64 n, u32* __restrict__ maxlen) {
-  __shared__ u32 s[4];
-  u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-  u32 l = i < n ? voc_len(term_word[i]) : 0u;
-  l = wave_max(l);
-  if (lane_id() == 0) s[threadIdx.x >> 6] = l;
-  __syncthreads();
-  if (threadIdx.x == 0) atomicMax(maxlen, max(max(s[0], s[1]), max(s[2], s[3])));
-}
-
-// sort key chunk: characters [c*K, c*K+K) of the term, big-endian packed (K = 4 for bytes, 2 for
-// UTF-16 units) so that integer order == String.CompareOrdinal order; missing characters are 0.
-template <typename CharT>
-__global__ void k_term_keys(uint2* __restrict__ perm, u64 n, const u64* __restrict__ term_word, TextView<CharT> tv, u32 chunk,
-                            bool init) {
-  u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  u32 t = init ? (u32)i : perm[i].y;
-  u64 w = term_word[t];
-  u32 len = voc_len(w);
-  u64 pos = voc_pos(w);
-  constexpr u32 K = sizeof(CharT) == 1 ? 4 : 2;
-  u32 key = 0;
-#pragma unroll
-  for (u32 j = 0; j < K; j++) {
-    u32 ci = chunk * K + j;
-    u32 ch = ci < len ? tv.canon_char(pos + ci) : 0u;
-    key = (key << (32 / K)) | ch;
-  }
-  perm[i] = make_uint2(key, t);
-}
-
-__global__ void k_assign_rank(const uint2* __restrict__ perm, u64 n, const u32* __restrict__ term_slot, const u64* __restrict__ term_word,
-                              u32* __restrict__ rank_of_slot, u64* __restrict__ rk_word) {
-  u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= n) return;
-  u32 d = perm[r].y;
-  rank_of_slot[term_slot[d]] = (u32)r;
-  rk_word[r] = term_word[d];
-}
-
-struct TermLenF {
-  const u64* rk_word;
-  __device__ __forceinline__ u32 operator()(u64 r) const { return voc_len(rk_word[r]); }
-};
-
-template <typename CharT>
-__global__ void k_term_strings(const u64* __restrict__ rk_word, u64 n, const u32* __restrict__ str_off, TextView<CharT> tv,
-                               u16* __restrict__ out) {
-  u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= n) return;
-  u64 w = rk_word[r];
-  u32 len = voc_len(w);
-  u64 pos = voc_pos(w);
-  u32 o = str_off[r];
-  for (u32 j = 0; j < len; j++) out[o + j] = (u16)tv.canon_char(pos + j);
-}
-
 __global__ void k_set_u64(u64* p, u64 v) { *p = v; }
+__global__ void k_term_first_last(const uint2* __restrict__ sorted, const u64* __restrict__ item_start, u64 n_terms, u64 base,
+                                  u64* __restrict__ first, u64* __restrict__ last) {
+  u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_terms) return;
+  first[t] = base + sorted[item_start[t]].y;
+  last[t] = base + sorted[item_start[t + 1] - 1].y;
+}
 __global__ void k_uniform_page_end(u64* out, u64 n, u64 base, u64 chars) {
   u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] = base + (i + 1) * chars;
@@ -297,6 +229,8 @@ DeviceIndex* build_take_index(dcd_build* b) {
   return &b->ix;
 }
 int build_device(dcd_build* b) { return b->device; }
+DeviceIndex* build_peek_index(dcd_build* b) { return (b->finished && !b->adopted) ? &b->ix : nullptr; }
+hipStream_t build_stream(dcd_build* b) { return b->st; }
 }  // namespace dcd
 
 static ustr mk16(const u16* p, size_t n) { return ustr((const char16_t*)p, n); }
@@ -641,38 +575,14 @@ static int32_t finish_impl(dcd_build* h) {
 
   // ---- 3. vocabulary: compact, sort the term strings ordinally -------------------------------
   DCD_TRY(t_voc.start());
-  DevBuf<u64> term_word, rk_word;
-  DevBuf<u32> term_slot, rank_of_slot, d_hist;
-  DevBuf<uint2> permA, permB;
-  DCD_TRY(term_word.alloc(dev, V ? V : 1));
-  DCD_TRY(rk_word.alloc(dev, V ? V : 1));
-  DCD_TRY(term_slot.alloc(dev, V ? V : 1));
-  DCD_TRY(rank_of_slot.alloc(dev, cap));
+  DevBuf<u32> d_hist;
   DCD_TRY(d_hist.alloc(dev, (u64)RS_MAX_BLOCKS << 10));
-  DCD_TRY(permA.alloc(dev, V ? V : 1));
-  DCD_TRY(permB.alloc(dev, V ? V : 1));
-  u32 maxlen = 0;
-  if (V) {
-    hipLaunchKernelGGL(k_vocab_compact, dim3((u32)div_up(cap, 256)), dim3(256), 0, st, slots.p, cap, slot_excl.p, term_word.p,
-                       term_slot.p);
-    hipLaunchKernelGGL(k_max_len, dim3((u32)div_up(V, 256)), dim3(256), 0, st, term_word.p, V, d_flags.p + 1);
-    DCD_HIP(hipMemcpyAsync(&maxlen, d_flags.p + 1, 4, hipMemcpyDeviceToHost, st));
-    DCD_HIP(hipStreamSynchronize(st));
-    constexpr u32 K = sizeof(CharT) == 1 ? 4 : 2;
-    const u32 nchunks = (maxlen + K - 1) / K;
-    probe_begin(DCD_K_VOCAB_SORT);
-    uint2* cur = permA.p;
-    uint2* other = permB.p;
-    for (int c = (int)nchunks - 1; c >= 0; c--) {
-      hipLaunchKernelGGL((k_term_keys<CharT>), dim3((u32)div_up(V, 256)), dim3(256), 0, st, cur, V, term_word.p, tv, (u32)c,
-                         c == (int)nchunks - 1);
-      uint2* res = rs_sort(cur, other, nullptr, V, 32, d_hist.p, scan_scr32.p, st);
-      if (res != cur) { other = cur; cur = res; }
-    }
-    hipLaunchKernelGGL(k_assign_rank, dim3((u32)div_up(V, 256)), dim3(256), 0, st, cur, V, term_slot.p, term_word.p, rank_of_slot.p,
-                       rk_word.p);
-    probe_end();
-  }
+  VocabRanks vr;
+  probe_begin(DCD_K_VOCAB_SORT);
+  DCD_TRY(vocab_rank<CharT>(dev, st, slots.p, cap, slot_excl.p, V, tv, d_hist.p, scan_scr32.p, d_flags.p + 1, &vr));
+  probe_end();
+  DevBuf<u32>& rank_of_slot = vr.rank_of_slot;
+  DevBuf<u64>& rk_word = vr.rk_word;
   DCD_TRY(t_voc.stop());
 
   // ---- 4. sort the tuples by term (stable; explicit postings first need coordinate order) ----
@@ -727,11 +637,15 @@ static int32_t finish_impl(dcd_build* h) {
   DCD_TRY(ix.units.alloc(dev, U ? U : 1));
   if (N) {
     probe_begin(DCD_K_ENC_WRITE);
-    hipLaunchKernelGGL((k_enc_write<EncSrcPairs>), dim3((u32)enb), dim3(CODEC_THREADS), 0, st, src, N, enc_part.p, ix.units.p);
+    hipLaunchKernelGGL(k_pack_write, dim3((u32)enb), dim3(CODEC_THREADS), 0, st, src, N, enc_part.p, ix.units.p);
     probe_end();
   }
   hipLaunchKernelGGL(k_set_u64, dim3(1), dim3(1), 0, st, ix.term_unit_start.p + V, U);
   hipLaunchKernelGGL(k_set_u64, dim3(1), dim3(1), 0, st, ix.term_item_start.p + V, N);
+  DCD_TRY(ix.term_first.alloc(dev, V ? V : 1));
+  DCD_TRY(ix.term_last.alloc(dev, V ? V : 1));
+  if (V) hipLaunchKernelGGL(k_term_first_last, dim3((u32)div_up(V, 256)), dim3(256), 0, st, sorted, ix.term_item_start.p, V,
+                            h->opts.coord_base, ix.term_first.p, ix.term_last.p);
   DCD_TRY(t_pack.stop());
 
   // ---- 6. keys + ".index" image -----------------------------------------------------------------

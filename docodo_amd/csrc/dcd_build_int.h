@@ -48,6 +48,7 @@ struct DeviceIndex {
   DevBuf<u16> term_chars;        // keys, UTF-16 code units, back to back
   DevBuf<u32> term_str_off;      // [n_terms + 1]
   DevBuf<u64> page_end;          // [n_pages] END coordinates (device copy of PageTable::end)
+  DevBuf<u64> term_first, term_last;  // [n_terms] first / last absolute coordinate per term (shard merge)
   // host mirrors (small): keys for dcd_index_find, offsets
   std::vector<u16> h_term_chars;
   std::vector<u32> h_term_str_off;

@@ -55,6 +55,57 @@ __global__ void k_add_inplace(u64* __restrict__ excl, const u64* __restrict__ de
   if (i < n) excl[i] += deltas[i];
 }
 
+__global__ __launch_bounds__(CODEC_THREADS) void k_pack_write(EncSrcPairs src, u64 n, const u64* __restrict__ partial, u16* __restrict__ out) {
+  __shared__ u32 lds[5];
+  __shared__ union { uint2 pairs[CODEC_TILE + 1]; u16 units[CODEC_TILE * 5]; } sh;
+  const u64 t0 = (u64)blockIdx.x * CODEC_TILE;
+  const u32 cnt = (u32)min((u64)CODEC_TILE, n - t0);
+  // pairs[0] = item before the tile
+  for (u32 k = threadIdx.x; k < cnt + 1; k += CODEC_THREADS) {
+    u64 i = t0 + k;   // pairs[k] = p[i - 1]
+    sh.pairs[k] = i ? src.p[i - 1] : make_uint2(0xFFFFFFFFu, 0u);
+  }
+  __syncthreads();
+  u64 d[CODEC_ITEMS];
+  u32 nu[CODEC_ITEMS], term[CODEC_ITEMS];
+  bool hd[CODEC_ITEMS];
+  u32 s = 0;
+  const u32 l0 = threadIdx.x * CODEC_ITEMS;
+#pragma unroll
+  for (int j = 0; j < CODEC_ITEMS; j++) {
+    u32 li = l0 + j;
+    d[j] = 0; nu[j] = 0; term[j] = 0; hd[j] = false;
+    if (li < cnt) {
+      uint2 q = sh.pairs[li], c = sh.pairs[li + 1];
+      hd[j] = (t0 + li == 0) || q.x != c.x;
+      term[j] = c.x;
+      d[j] = hd[j] ? src.base + c.y : (u64)c.y - (u64)q.y;
+      nu[j] = seq_nunits(d[j]);
+      s += nu[j];
+    }
+  }
+  u32 tot;
+  u32 loff = block_scan_excl<u32, 4>(s, lds, &tot);   // (contains barriers: all pair reads are done)
+  const u64 gbase = partial[blockIdx.x];
+#pragma unroll
+  for (int j = 0; j < CODEC_ITEMS; j++) {
+    if (l0 + j < cnt) {
+      if (hd[j]) { src.term_unit_start[term[j]] = gbase + loff; src.term_item_start[term[j]] = t0 + l0 + j; }
+      for (u32 g = 0; g < nu[j]; g++) sh.units[loff + g] = seq_unit(d[j], g, nu[j]);
+      loff += nu[j];
+    }
+  }
+  __syncthreads();
+  u16* dst = out + gbase;
+  u32 head = (u32)(((uintptr_t)dst >> 1) & 1u) & (tot ? 1u : 0u);
+  if (threadIdx.x == 0 && head) dst[0] = sh.units[0];
+  u32 npair = (tot - head) >> 1;
+  u32* dst32 = reinterpret_cast<u32*>(dst + head);
+  for (u32 k = threadIdx.x; k < npair; k += CODEC_THREADS)
+    dst32[k] = (u32)sh.units[head + 2 * k] | ((u32)sh.units[head + 2 * k + 1] << 16);
+  if (threadIdx.x == 0 && ((tot - head) & 1u)) dst[tot - 1] = sh.units[tot - 1];
+}
+
 void decode_count_launch(const u16* units, u64 n, u64* partial, hipStream_t st) {
   u64 nb = div_up(n ? n : 1, CODEC_TILE);
   hipLaunchKernelGGL(k_dec_count, dim3((u32)nb), dim3(CODEC_THREADS), 0, st, units, n, partial);

@@ -1,0 +1,389 @@
+// dcd_merge.hip -- doc-range shard merge ("reduce by key over xGMI").
+//
+// Reference behaviour being replaced: MergeFiles / MergeIndexes with shift_coords (Index.cs:577-752):
+// equal terms' IndexSequences are concatenated in shard order; every appended sequence has its first
+// value re-coded relative to the previous shard's last value (Shift + AddRange, Index.cs:665-674).
+// Shards here carry GLOBAL coordinates already (coord_base = text length of the previous shards,
+// which also avoids the reference's "shift by last word start" quirk), so the
+// merge only re-codes 1..5 head units per (term, shard) segment and copies the rest verbatim.
+//
+// Export (per shard):  owner(term) = hash(key) % n_owners; terms are grouped by owner (stable, so
+// ordinal order survives inside an owner) and three buffers are filled: metadata, keys, units.
+// Merge (per owner): keys of all incoming segments go through the same exact hash table as the
+// build's vocabulary, the union vocabulary is sorted ordinally, segments are stably sorted by term
+// (source order = coordinate order is kept), head units are re-coded, output offsets come from a scan
+// and one copy kernel writes the merged posting lists.  The library never communicates: the caller
+// (bench.py / docodo_amd.dist) moves the buffers with RCCL all-to-all.
+#include <algorithm>
+#include <map>
+#include <memory>
+#include <mutex>
+
+#include "dcd_codec.h"
+#include "dcd_index_int.h"
+#include "dcd_scan.h"
+#include "dcd_sort.h"
+#include "dcd_tokenize.h"
+#include "dcd_vocab.h"
+
+struct dcd_build;
+namespace dcd {
+DeviceIndex* build_peek_index(dcd_build* b);
+hipStream_t build_stream(dcd_build* b);
+int build_device(dcd_build* b);
+
+__device__ __forceinline__ u32 key_hash16(const u16* s, u32 n) {
+  u32 h = 0x811C9DC5u;
+  for (u32 i = 0; i < n; i++) h = (h ^ s[i]) * 0x01000193u;
+  return fmix32(h ^ n);
+}
+
+// ---- export ------------------------------------------------------------------------------------
+__global__ void k_owner_pairs(const u16* __restrict__ chars, const u32* __restrict__ str_off, u64 n_terms, u32 n_owners,
+                              uint2* __restrict__ pairs) {
+  u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_terms) return;
+  u32 o = key_hash16(chars + str_off[t], str_off[t + 1] - str_off[t]) % n_owners;
+  pairs[t] = make_uint2(o, (u32)t);
+}
+
+struct PermUnitsF {   // units of the term at export position j
+  const uint2* perm; const u64* unit_start;
+  __device__ u64 operator()(u64 j) const { u32 t = perm[j].y; return unit_start[t + 1] - unit_start[t]; }
+};
+struct PermKeyLenF {
+  const uint2* perm; const u32* str_off;
+  __device__ u64 operator()(u64 j) const { u32 t = perm[j].y; return (u64)(str_off[t + 1] - str_off[t]); }
+};
+
+// per-owner totals: [owner][0] terms, [1] key units, [2] posting units
+__global__ __launch_bounds__(256) void k_owner_totals(const uint2* __restrict__ perm, u64 n_terms, const u64* __restrict__ unit_start,
+                                                     const u32* __restrict__ str_off, u32 n_owners, unsigned long long* __restrict__ totals) {
+  __shared__ unsigned long long s[64 * 3];
+  for (u32 i = threadIdx.x; i < n_owners * 3; i += blockDim.x) s[i] = 0;
+  __syncthreads();
+  u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < n_terms) {
+    uint2 p = perm[j];
+    atomicAdd(&s[p.x * 3 + 0], 1ull);
+    atomicAdd(&s[p.x * 3 + 1], (unsigned long long)(str_off[p.y + 1] - str_off[p.y]));
+    atomicAdd(&s[p.x * 3 + 2], (unsigned long long)(unit_start[p.y + 1] - unit_start[p.y]));
+  }
+  __syncthreads();
+  for (u32 i = threadIdx.x; i < n_owners * 3; i += blockDim.x)
+    if (s[i]) atomicAdd(&totals[i], s[i]);
+}
+
+__global__ void k_export_meta(const uint2* __restrict__ perm, u64 n_terms, const u64* __restrict__ unit_start, const u64* __restrict__ item_start,
+                              const u32* __restrict__ str_off, const u16* __restrict__ chars, const u64* __restrict__ first,
+                              const u64* __restrict__ last, const u64* __restrict__ key_dst, dcd_term_meta* __restrict__ meta,
+                              u16* __restrict__ keys) {
+  u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n_terms) return;
+  u32 t = perm[j].y;
+  dcd_term_meta m;
+  m.first = first[t];
+  m.last = last[t];
+  m.n_values = item_start[t + 1] - item_start[t];
+  m.n_units = (u32)(unit_start[t + 1] - unit_start[t]);
+  m.key_len = str_off[t + 1] - str_off[t];
+  meta[j] = m;
+  const u16* s = chars + str_off[t];
+  u16* d = keys + key_dst[j];
+  for (u32 i = 0; i < m.key_len; i++) d[i] = s[i];
+}
+
+// segmented copy: dst_off[j] .. dst_off[j+1] <- src[src_start(j) ..]; 8 units per thread
+constexpr int CP_UPT = 8;
+__global__ void k_export_units(const uint2* __restrict__ perm, u64 n_terms, const u64* __restrict__ dst_off, u64 total_units,
+                               const u64* __restrict__ unit_start, const u16* __restrict__ units, u16* __restrict__ out) {
+  u64 u0 = ((u64)blockIdx.x * blockDim.x + threadIdx.x) * CP_UPT;
+  if (u0 >= total_units) return;
+  u64 a = 0, b = n_terms;  // last j with dst_off[j] <= u0
+  while (a + 1 < b) { u64 m = (a + b) >> 1; if (dst_off[m] <= u0) a = m; else b = m; }
+  u64 j = a;
+  u64 next = j + 1 < n_terms ? dst_off[j + 1] : total_units;
+  u64 src = unit_start[perm[j].y] + (u0 - dst_off[j]);
+  for (int k = 0; k < CP_UPT; k++) {
+    u64 u = u0 + k;
+    if (u >= total_units) break;
+    while (u >= next) { j++; next = j + 1 < n_terms ? dst_off[j + 1] : total_units; src = unit_start[perm[j].y]; }
+    out[u] = units[src++];
+  }
+}
+
+// ---- merge ---------------------------------------------------------------------------------------
+struct MetaKeyLenF { const dcd_term_meta* m; __device__ u64 operator()(u64 j) const { return m[j].key_len; } };
+struct MetaUnitsF { const dcd_term_meta* m; __device__ u64 operator()(u64 j) const { return m[j].n_units; } };
+
+__global__ void k_insert_keys(const dcd_term_meta* __restrict__ meta, const u64* __restrict__ key_off, u64 n, TextView<u16> tv, VocabTable vt,
+                              uint2* __restrict__ pairs) {
+  u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  const u32 len = meta[j].key_len, nbytes = len * 2u, nw = (nbytes + 3u) >> 2;
+  const u32* pool32 = reinterpret_cast<const u32*>(tv.pool);
+  const u64 boff = key_off[j] * 2u, pbytes = tv.n_pool * 2u;
+  auto word = [pool32, boff, pbytes, nbytes](u32 q) -> u32 { return str_word(pool32, boff, q, pbytes) & tail_mask(nbytes, q); };
+  HashState hs;
+  hs.init(len);
+  for (u32 q = 0; q < nw; q++) hs.add(word(q));
+  u32 slot = vocab_lookup_insert<u16>(vt, tv, hs.fin(), len, key_off[j], word);
+  pairs[j] = make_uint2(slot, (u32)j);
+}
+
+// per sorted segment q: new head delta and output size
+struct SegPlan {
+  const uint2* sorted;          // x = term rank, y = segment index
+  const dcd_term_meta* meta;
+  __device__ __forceinline__ bool head(u64 q) const { return q == 0 || sorted[q].x != sorted[q - 1].x; }
+  __device__ __forceinline__ u64 new_delta(u64 q) const {
+    const dcd_term_meta& m = meta[sorted[q].y];
+    return head(q) ? m.first : m.first - meta[sorted[q - 1].y].last;
+  }
+  __device__ __forceinline__ u64 out_units(u64 q) const {
+    const dcd_term_meta& m = meta[sorted[q].y];
+    return (u64)m.n_units - seq_nunits(m.first) + seq_nunits(new_delta(q));
+  }
+};
+struct SegUnitsF { SegPlan p; __device__ u64 operator()(u64 q) const { return p.out_units(q); } };
+struct SegValuesF { SegPlan p; __device__ u64 operator()(u64 q) const { return p.meta[p.sorted[q].y].n_values; } };
+
+__global__ void k_merge_heads(SegPlan p, u64 n_seg, const u64* __restrict__ dst_off, const u64* __restrict__ val_off,
+                              u64* __restrict__ term_unit_start, u64* __restrict__ term_item_start) {
+  u64 q = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= n_seg) return;
+  if (p.head(q)) { term_unit_start[p.sorted[q].x] = dst_off[q]; term_item_start[p.sorted[q].x] = val_off[q]; }
+}
+
+__global__ void k_merge_copy(SegPlan p, u64 n_seg, const u64* __restrict__ dst_off, u64 total_units, const u64* __restrict__ src_off,
+                             const u16* __restrict__ units, u16* __restrict__ out) {
+  u64 u0 = ((u64)blockIdx.x * blockDim.x + threadIdx.x) * CP_UPT;
+  if (u0 >= total_units) return;
+  u64 a = 0, b = n_seg;
+  while (a + 1 < b) { u64 m = (a + b) >> 1; if (dst_off[m] <= u0) a = m; else b = m; }
+  u64 q = a;
+  for (int k = 0; k < CP_UPT; k++) {
+    u64 u = u0 + k;
+    if (u >= total_units) break;
+    while (q + 1 < n_seg && u >= dst_off[q + 1]) q++;
+    const dcd_term_meta& m = p.meta[p.sorted[q].y];
+    u64 nd = p.new_delta(q);
+    u32 newlen = seq_nunits(nd), oldlen = seq_nunits(m.first);
+    u64 r = u - dst_off[q];
+    out[u] = r < newlen ? seq_unit(nd, (u32)r, newlen) : units[src_off[p.sorted[q].y] + oldlen + (r - newlen)];
+  }
+}
+
+}  // namespace dcd
+
+using namespace dcd;
+
+struct ExportPlan {
+  u32 n_owners = 0;
+  DevBuf<uint2> perm;
+  DevBuf<u64> key_dst, unit_dst;
+  u64 n_terms = 0, total_keys = 0, total_units = 0;
+};
+static std::map<dcd_build*, std::unique_ptr<ExportPlan>>& export_plans() {
+  static std::map<dcd_build*, std::unique_ptr<ExportPlan>> m;
+  return m;
+}
+static std::mutex g_export_mu;
+
+extern "C" {
+
+int32_t dcd_build_export_plan(dcd_build* h, uint32_t n_owners, uint64_t* term_count, uint64_t* key_count, uint64_t* unit_count) {
+  if (!h || !term_count || !key_count || !unit_count) DCD_FAIL(DCD_E_BADARG, "dcd_build_export_plan: NULL argument");
+  if (n_owners == 0 || n_owners > 64) DCD_FAIL(DCD_E_BADARG, "n_owners must be in [1, 64]");
+  DeviceIndex* ix = build_peek_index(h);
+  if (!ix) DCD_FAIL(DCD_E_STATE, "build is not finished (or its index was adopted)");
+  const int dev = ix->device;
+  hipStream_t st = build_stream(h);
+  DCD_TRY(ensure_device(dev));
+  const u64 V = ix->n_terms;
+  std::unique_ptr<ExportPlan> ep(new ExportPlan());
+  ep->n_owners = n_owners;
+  ep->n_terms = V;
+  DevBuf<uint2> pa, pb;
+  DevBuf<u32> hist, sscr;
+  DevBuf<u64> sscr64;
+  DevBuf<unsigned long long> totals;
+  DCD_TRY(pa.alloc(dev, V ? V : 1)); DCD_TRY(pb.alloc(dev, V ? V : 1));
+  DCD_TRY(hist.alloc(dev, (u64)RS_MAX_BLOCKS << 10));
+  DCD_TRY(sscr.alloc(dev, scan_scratch_elems((u64)RS_MAX_BLOCKS << 10)));
+  DCD_TRY(sscr64.alloc(dev, scan_scratch_elems(V ? V : 1)));
+  DCD_TRY(totals.alloc(dev, 64 * 3));
+  DCD_TRY(ep->key_dst.alloc(dev, V + 1)); DCD_TRY(ep->unit_dst.alloc(dev, V + 1));
+  DCD_HIP(hipMemsetAsync(totals.p, 0, 64 * 3 * 8, st));
+  std::vector<unsigned long long> tot(64 * 3, 0);
+  if (V) {
+    hipLaunchKernelGGL(k_owner_pairs, dim3((u32)div_up(V, 256)), dim3(256), 0, st, ix->term_chars.p, ix->term_str_off.p, V, n_owners, pa.p);
+    uint2* sorted = rs_sort(pa.p, pb.p, nullptr, V, 6, hist.p, sscr.p, st);
+    if (sorted == pa.p) ep->perm = std::move(pa); else ep->perm = std::move(pb);
+    hipLaunchKernelGGL(k_owner_totals, dim3((u32)div_up(V, 256)), dim3(256), 0, st, ep->perm.p, V, ix->term_unit_start.p, ix->term_str_off.p,
+                       n_owners, totals.p);
+    scan_exclusive_f<PermKeyLenF, u64>(PermKeyLenF{ep->perm.p, ix->term_str_off.p}, ep->key_dst.p, V, sscr64.p, st);
+    DCD_HIP(hipMemcpyAsync(&ep->total_keys, sscr64.p + scan_nblocks(V), 8, hipMemcpyDeviceToHost, st));
+    DCD_HIP(hipStreamSynchronize(st));
+    scan_exclusive_f<PermUnitsF, u64>(PermUnitsF{ep->perm.p, ix->term_unit_start.p}, ep->unit_dst.p, V, sscr64.p, st);
+    DCD_HIP(hipMemcpyAsync(&ep->total_units, sscr64.p + scan_nblocks(V), 8, hipMemcpyDeviceToHost, st));
+    DCD_HIP(hipMemcpyAsync(tot.data(), totals.p, 64 * 3 * 8, hipMemcpyDeviceToHost, st));
+    DCD_HIP(hipStreamSynchronize(st));
+    DCD_HIP(hipGetLastError());
+  }
+  for (u32 o = 0; o < n_owners; o++) { term_count[o] = tot[o * 3]; key_count[o] = tot[o * 3 + 1]; unit_count[o] = tot[o * 3 + 2]; }
+  std::lock_guard<std::mutex> g(g_export_mu);
+  export_plans()[h] = std::move(ep);
+  return DCD_OK;
+}
+
+int32_t dcd_build_export_fill(dcd_build* h, void* meta_dev, uint16_t* keys_dev, uint16_t* units_dev) {
+  if (!h) DCD_FAIL(DCD_E_BADARG, "dcd_build_export_fill: NULL handle");
+  std::unique_ptr<ExportPlan> ep;
+  {
+    std::lock_guard<std::mutex> g(g_export_mu);
+    auto it = export_plans().find(h);
+    if (it == export_plans().end()) DCD_FAIL(DCD_E_STATE, "dcd_build_export_plan must run first");
+    ep = std::move(it->second);
+    export_plans().erase(it);
+  }
+  DeviceIndex* ix = build_peek_index(h);
+  if (!ix) DCD_FAIL(DCD_E_STATE, "build is not finished (or its index was adopted)");
+  const u64 V = ep->n_terms;
+  if (V && (!meta_dev || (!keys_dev && ep->total_keys) || (!units_dev && ep->total_units))) DCD_FAIL(DCD_E_BADARG, "dcd_build_export_fill: NULL buffer");
+  hipStream_t st = build_stream(h);
+  DCD_TRY(ensure_device(ix->device));
+  if (V) {
+    hipLaunchKernelGGL(k_export_meta, dim3((u32)div_up(V, 256)), dim3(256), 0, st, ep->perm.p, V, ix->term_unit_start.p, ix->term_item_start.p,
+                       ix->term_str_off.p, ix->term_chars.p, ix->term_first.p, ix->term_last.p, ep->key_dst.p, (dcd_term_meta*)meta_dev, keys_dev);
+    if (ep->total_units)
+      hipLaunchKernelGGL(k_export_units, dim3((u32)div_up(div_up(ep->total_units, CP_UPT), 256)), dim3(256), 0, st, ep->perm.p, V, ep->unit_dst.p,
+                         ep->total_units, ix->term_unit_start.p, ix->units.p, units_dev);
+  }
+  DCD_HIP(hipStreamSynchronize(st));
+  DCD_HIP(hipGetLastError());
+  return DCD_OK;
+}
+
+int32_t dcd_merge_shards(int32_t device, uint32_t n_sources, const uint64_t* term_count, const uint64_t* key_count,
+                         const uint64_t* unit_count, const void* meta_dev, const uint16_t* keys_dev, const uint16_t* units_dev,
+                         uint64_t max_coord, dcd_index** out) {
+  if (!term_count || !key_count || !unit_count || !out) DCD_FAIL(DCD_E_BADARG, "dcd_merge_shards: NULL argument");
+  DCD_TRY(ensure_device(device));
+  u64 M = 0, K = 0, U = 0;
+  for (u32 s = 0; s < n_sources; s++) { M += term_count[s]; K += key_count[s]; U += unit_count[s]; }
+  if (M && (!meta_dev || (!keys_dev && K) || (!units_dev && U))) DCD_FAIL(DCD_E_BADARG, "dcd_merge_shards: NULL buffer");
+  if (((uintptr_t)keys_dev & 3) != 0) DCD_FAIL(DCD_E_BADARG, "keys buffer must be 4-byte aligned");
+  if (M >= (1ull << 32)) DCD_FAIL(DCD_E_OVERFLOW, "too many segments");
+  std::unique_ptr<dcd_index> h(new dcd_index());
+  DCD_HIP(hipStreamCreateWithFlags(&h->st, hipStreamNonBlocking));
+  hipStream_t st = h->st;
+  DeviceIndex& ix = h->ix;
+  ix.device = device;
+  ix.max_coord = max_coord;
+  const dcd_term_meta* meta = (const dcd_term_meta*)meta_dev;
+
+  DevBuf<u64> key_off, src_off, sscr64;
+  DCD_TRY(key_off.alloc(device, M + 1)); DCD_TRY(src_off.alloc(device, M + 1));
+  DCD_TRY(sscr64.alloc(device, scan_scratch_elems(M ? M : 1)));
+  u64 V = 0;
+  VocabRanks vr;
+  DevBuf<u64> slots;
+  DevBuf<u32> flags, slot_excl, hist, sscr32;
+  DevBuf<uint2> pa, pb;
+  DCD_TRY(flags.alloc(device, 4));
+  DCD_TRY(hist.alloc(device, (u64)RS_MAX_BLOCKS << 10));
+  DCD_TRY(pa.alloc(device, M ? M : 1)); DCD_TRY(pb.alloc(device, M ? M : 1));
+  TextView<u16> tv;
+  tv.text = nullptr; tv.n_chars = 0; tv.pool = keys_dev; tv.n_pool = K; tv.tab = CharTables16{nullptr, nullptr};
+  uint2* sorted = pa.p;
+  u64 cap = 0;
+  if (M) {
+    scan_exclusive_f<MetaKeyLenF, u64>(MetaKeyLenF{meta}, key_off.p, M, sscr64.p, st);
+    scan_exclusive_f<MetaUnitsF, u64>(MetaUnitsF{meta}, src_off.p, M, sscr64.p, st);
+    u32 cap_log2 = log2_ceil(M * 2 + 1);
+    if (cap_log2 < 12) cap_log2 = 12;
+    cap = 1ull << cap_log2;
+    DCD_TRY(slots.alloc(device, cap));
+    DCD_TRY(slot_excl.alloc(device, cap));
+    DCD_TRY(sscr32.alloc(device, std::max<u64>(scan_scratch_elems(cap), scan_scratch_elems((u64)RS_MAX_BLOCKS << 10))));
+    DCD_HIP(hipMemsetAsync(slots.p, 0, cap * 8, st));
+    DCD_HIP(hipMemsetAsync(flags.p, 0, 16, st));
+    VocabTable vt;
+    vt.slots = slots.p; vt.mask = (u32)(cap - 1); vt.overflow = flags.p;
+    hipLaunchKernelGGL(k_insert_keys, dim3((u32)div_up(M, 256)), dim3(256), 0, st, meta, key_off.p, M, tv, vt, pa.p);
+    scan_exclusive_f<SlotUsed, u32>(SlotUsed{slots.p}, slot_excl.p, cap, sscr32.p, st);
+    u32 v32 = 0, fl[4] = {0, 0, 0, 0};
+    DCD_HIP(hipMemcpyAsync(&v32, sscr32.p + scan_nblocks(cap), 4, hipMemcpyDeviceToHost, st));
+    DCD_HIP(hipMemcpyAsync(fl, flags.p, 16, hipMemcpyDeviceToHost, st));
+    DCD_HIP(hipStreamSynchronize(st));
+    if (fl[0]) DCD_FAIL(DCD_E_OVERFLOW, "merge vocabulary table overflow");
+    V = v32;
+    DCD_TRY(vocab_rank<u16>(device, st, slots.p, cap, slot_excl.p, V, tv, hist.p, sscr32.p, flags.p + 1, &vr));
+    sorted = rs_sort(pa.p, pb.p, vr.rank_of_slot.p, M, (int)log2_ceil(V ? V : 1), hist.p, sscr32.p, st);
+  }
+  // output offsets
+  DevBuf<u64> dst_off, val_off;
+  DCD_TRY(dst_off.alloc(device, M + 1)); DCD_TRY(val_off.alloc(device, M + 1));
+  DCD_TRY(ix.term_unit_start.alloc(device, V + 1));
+  DCD_TRY(ix.term_item_start.alloc(device, V + 1));
+  u64 Uout = 0, Nout = 0;
+  SegPlan sp{sorted, meta};
+  if (M) {
+    scan_exclusive_f<SegUnitsF, u64>(SegUnitsF{sp}, dst_off.p, M, sscr64.p, st);
+    DCD_HIP(hipMemcpyAsync(&Uout, sscr64.p + scan_nblocks(M), 8, hipMemcpyDeviceToHost, st));
+    DCD_HIP(hipStreamSynchronize(st));
+    scan_exclusive_f<SegValuesF, u64>(SegValuesF{sp}, val_off.p, M, sscr64.p, st);
+    DCD_HIP(hipMemcpyAsync(&Nout, sscr64.p + scan_nblocks(M), 8, hipMemcpyDeviceToHost, st));
+    DCD_HIP(hipStreamSynchronize(st));
+    hipLaunchKernelGGL(k_merge_heads, dim3((u32)div_up(M, 256)), dim3(256), 0, st, sp, M, dst_off.p, val_off.p, ix.term_unit_start.p,
+                       ix.term_item_start.p);
+  }
+  DCD_HIP(hipMemcpyAsync(ix.term_unit_start.p + V, &Uout, 8, hipMemcpyHostToDevice, st));
+  DCD_HIP(hipMemcpyAsync(ix.term_item_start.p + V, &Nout, 8, hipMemcpyHostToDevice, st));
+  DCD_TRY(ix.units.alloc(device, Uout ? Uout : 1));
+  if (Uout)
+    hipLaunchKernelGGL(k_merge_copy, dim3((u32)div_up(div_up(Uout, CP_UPT), 256)), dim3(256), 0, st, sp, M, dst_off.p, Uout, src_off.p, units_dev,
+                       ix.units.p);
+  // keys in rank order
+  DCD_TRY(ix.term_str_off.alloc(device, V + 1));
+  u32 total_chars = 0;
+  if (V) {
+    DevBuf<u32> s32;
+    DCD_TRY(s32.alloc(device, scan_scratch_elems(V)));
+    scan_exclusive_f<TermLenF, u32>(TermLenF{vr.rk_word.p}, ix.term_str_off.p, V, s32.p, st);
+    DCD_HIP(hipMemcpyAsync(&total_chars, s32.p + scan_nblocks(V), 4, hipMemcpyDeviceToHost, st));
+    DCD_HIP(hipStreamSynchronize(st));
+  }
+  DCD_HIP(hipMemcpyAsync(ix.term_str_off.p + V, &total_chars, 4, hipMemcpyHostToDevice, st));
+  DCD_TRY(ix.term_chars.alloc(device, total_chars ? total_chars : 1));
+  if (V) hipLaunchKernelGGL((k_term_strings<u16>), dim3((u32)div_up(V, 256)), dim3(256), 0, st, vr.rk_word.p, V, ix.term_str_off.p, tv, ix.term_chars.p);
+  DCD_HIP(hipStreamSynchronize(st));
+  DCD_HIP(hipGetLastError());
+  ix.n_terms = V; ix.n_units = Uout; ix.n_postings = Nout;
+  ix.h_term_chars.resize(total_chars);
+  ix.h_term_str_off.resize(V + 1);
+  ix.h_term_unit_start.resize(V + 1);
+  ix.h_term_item_start.resize(V + 1);
+  if (total_chars) DCD_HIP(hipMemcpy(ix.h_term_chars.data(), ix.term_chars.p, (size_t)total_chars * 2, hipMemcpyDeviceToHost));
+  DCD_HIP(hipMemcpy(ix.h_term_str_off.data(), ix.term_str_off.p, (V + 1) * 4, hipMemcpyDeviceToHost));
+  DCD_HIP(hipMemcpy(ix.h_term_unit_start.data(), ix.term_unit_start.p, (V + 1) * 8, hipMemcpyDeviceToHost));
+  DCD_HIP(hipMemcpy(ix.h_term_item_start.data(), ix.term_item_start.p, (V + 1) * 8, hipMemcpyDeviceToHost));
+  *out = h.release();
+  return DCD_OK;
+}
+
+int32_t dcd_index_set_uniform_pages(dcd_index* h, uint64_t n_pages, uint32_t page_chars, uint64_t first_doc, const uint16_t* source,
+                                    size_t source_len) {
+  if (!h || (!source && source_len)) DCD_FAIL(DCD_E_BADARG, "dcd_index_set_uniform_pages: NULL argument");
+  if (page_chars == 0) DCD_FAIL(DCD_E_BADARG, "page_chars must be positive");
+  PageTable& pt = h->ix.pages;
+  pt = PageTable();
+  pt.uniform = true; pt.uni_n = n_pages; pt.uni_chars = page_chars; pt.uni_base = 0;
+  pt.doc_per_page = true; pt.first_doc = first_doc; pt.uniform_id = u"1";
+  pt.source = source_len ? ustr((const char16_t*)source, source_len) : ustr(u"syn");
+  h->ix.page_end.reset();   // rebuilt on the next query
+  return DCD_OK;
+}
+
+}  // extern "C"

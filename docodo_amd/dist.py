@@ -1,0 +1,125 @@
+"""Doc-range sharded build: the exchange step between GPUs.
+
+Each rank builds the index of its document range with GLOBAL coordinates (`Builder(coord_base=...)`),
+exports its per-term segments grouped by owner = hash(key) % world, the three export buffers travel
+with ONE all-to-all each (RCCL over xGMI on GPUs; gloo in the CPU plumbing tests), and every owner
+merges what it received with `dcd_merge_shards` (re-codes the first delta of each appended segment:
+IndexSequence.Shift + AddRange semantics of MergeFiles, Index.cs:665-674).  The result is a
+hash-partitioned index: every rank holds the complete posting lists of the terms it owns.
+
+The library itself never communicates; this module is the only place that calls torch.distributed.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import check, lib
+from .index import Index, _u16
+
+META_BYTES = 32  # sizeof(dcd_term_meta)
+
+
+class ShardExport:
+    """Export buffers of one shard: uint8 tensors on the builder's device + per-owner counts."""
+
+    def __init__(self, term_count, key_count, unit_count, meta, keys, units, max_coord):
+        self.term_count, self.key_count, self.unit_count = term_count, key_count, unit_count
+        self.meta, self.keys, self.units, self.max_coord = meta, keys, units, max_coord
+
+    def byte_splits(self):
+        return (self.term_count * META_BYTES).tolist(), (self.key_count * 2).tolist(), (self.unit_count * 2).tolist()
+
+
+def export_shard(builder, n_owners, device=None):
+    """dcd_build_export_plan + dcd_build_export_fill into torch-owned device buffers."""
+    tc = np.zeros(n_owners, np.uint64)
+    kc = np.zeros(n_owners, np.uint64)
+    uc = np.zeros(n_owners, np.uint64)
+    check(lib().dcd_build_export_plan(builder.h, n_owners, tc.ctypes.data, kc.ctypes.data, uc.ctypes.data))
+    dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+    meta = torch.empty(int(tc.sum()) * META_BYTES, dtype=torch.uint8, device=dev)
+    keys = torch.empty(int(kc.sum()) * 2, dtype=torch.uint8, device=dev)
+    units = torch.empty(int(uc.sum()) * 2, dtype=torch.uint8, device=dev)
+    check(lib().dcd_build_export_fill(builder.h, meta.data_ptr() if meta.numel() else None,
+                                      keys.data_ptr() if keys.numel() else None, units.data_ptr() if units.numel() else None))
+    return ShardExport(tc, kc, uc, meta, keys, units, builder.stats.max_coord)
+
+
+def merge_received(term_count, key_count, unit_count, meta, keys, units, max_coord, device_index=0):
+    """dcd_merge_shards on buffers that hold the sources' contributions back to back (source order)."""
+    tc = np.ascontiguousarray(term_count, np.uint64)
+    kc = np.ascontiguousarray(key_count, np.uint64)
+    uc = np.ascontiguousarray(unit_count, np.uint64)
+    h = C.c_void_p()
+    check(lib().dcd_merge_shards(device_index, tc.size, tc.ctypes.data, kc.ctypes.data, uc.ctypes.data,
+                                 meta.data_ptr() if meta.numel() else None, keys.data_ptr() if keys.numel() else None,
+                                 units.data_ptr() if units.numel() else None, int(max_coord), C.byref(h)))
+    return Index(h)
+
+
+def _split_offsets(counts):
+    off = np.zeros(len(counts) + 1, np.int64)
+    off[1:] = np.cumsum(np.asarray(counts, np.int64))
+    return off
+
+
+def local_merge(exports, owner, device_index=0):
+    """Single-process stand-in for the all-to-all: gathers, from every shard's export, the slice that
+    belongs to `owner` (in shard order) and merges it.  Used by the single-GPU tests: G fake shards on
+    one device must reproduce the one-shot build."""
+    G = len(exports)
+    metas, keyss, unitss = [], [], []
+    tc, kc, uc = np.zeros(G, np.uint64), np.zeros(G, np.uint64), np.zeros(G, np.uint64)
+    for s, e in enumerate(exports):
+        mo, ko, uo = (_split_offsets(x) for x in e.byte_splits())
+        metas.append(e.meta[mo[owner]:mo[owner + 1]])
+        keyss.append(e.keys[ko[owner]:ko[owner + 1]])
+        unitss.append(e.units[uo[owner]:uo[owner + 1]])
+        tc[s], kc[s], uc[s] = e.term_count[owner], e.key_count[owner], e.unit_count[owner]
+    meta, keys, units = torch.cat(metas), torch.cat(keyss), torch.cat(unitss)
+    return merge_received(tc, kc, uc, meta, keys, units, max(e.max_coord for e in exports), device_index)
+
+
+def exchange(export, group=None):
+    """All-to-all of the three export buffers.  Works on CUDA tensors with the nccl (= RCCL) backend
+    and on CPU tensors with gloo (plumbing tests).  Returns (term_count, key_count, unit_count per
+    SOURCE, meta, keys, units received, global max_coord)."""
+    import torch.distributed as dist
+    G = dist.get_world_size(group)
+    dev = export.meta.device
+    counts = torch.tensor(np.stack([export.term_count, export.key_count, export.unit_count], 1).astype(np.int64), device=dev)
+    rcounts = torch.empty_like(counts)
+    dist.all_to_all_single(rcounts, counts, group=group)          # row s = what source s sends to me
+    rc = rcounts.cpu().numpy().astype(np.uint64)
+    mx = torch.tensor([int(export.max_coord)], dtype=torch.int64, device=dev)
+    dist.all_reduce(mx, op=dist.ReduceOp.MAX, group=group)
+    out = []
+    for buf, send, recv in ((export.meta, export.term_count * META_BYTES, rc[:, 0] * META_BYTES),
+                            (export.keys, export.key_count * 2, rc[:, 1] * 2),
+                            (export.units, export.unit_count * 2, rc[:, 2] * 2)):
+        r = torch.empty(int(recv.sum()), dtype=torch.uint8, device=dev)
+        dist.all_to_all_single(r, buf, output_split_sizes=[int(x) for x in recv], input_split_sizes=[int(x) for x in send],
+                               group=group)
+        out.append(r)
+    if dev.type == "cuda":
+        # the collectives ran on torch's stream; the library works on its own streams
+        torch.cuda.current_stream(dev).synchronize()
+    return rc[:, 0].copy(), rc[:, 1].copy(), rc[:, 2].copy(), out[0], out[1], out[2], int(mx.item())
+
+
+def distributed_merge(builder, group=None, device_index=None):
+    """export -> all-to-all (RCCL) -> merge.  Returns this rank's owned sub-index."""
+    import torch.distributed as dist
+    G = dist.get_world_size(group)
+    if device_index is None:
+        device_index = torch.cuda.current_device()
+    e = export_shard(builder, G)
+    tc, kc, uc, meta, keys, units, mx = exchange(e, group)
+    return merge_received(tc, kc, uc, meta, keys, units, mx, device_index)
+
+
+def set_uniform_pages(index, n_pages, page_chars, first_doc=0, source="syn"):
+    a, p, n = _u16(source)
+    check(lib().dcd_index_set_uniform_pages(index.h, n_pages, page_chars, first_doc, p, n))

@@ -222,6 +222,37 @@ int32_t dcd_results_get(dcd_results* r, dcd_results_view* out);
 void dcd_results_free(dcd_results* r);
 
 /* ------------------------------------------------------------------------------------------
+ * Doc-range shard merge ("reduce by key"): the device-side equivalent of MergeFiles/MergeIndexes
+ * with shift_coords (Index.cs:577-752): equal terms' sequences are concatenated in shard order and
+ * the first value of every appended sequence is re-coded against the previous shard's last value
+ * (IndexSequence.Shift + AddRange semantics, Index.cs:665-674).  Shards were built with
+ * dcd_build_opts.coord_base = text length of all previous shards, so coordinates are already global.
+ * A term is owned by shard-merge participant  hash(key) % n_owners;  the caller moves the three
+ * export buffers between GPUs (RCCL all-to-all over xGMI) -- this library never communicates.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct dcd_term_meta {
+  uint64_t first, last;   /* first / last absolute coordinate of this shard's postings of the term */
+  uint64_t n_values;
+  uint32_t n_units;
+  uint32_t key_len;       /* UTF-16 code units */
+} dcd_term_meta;
+/* Sizes of the export, per owner (host arrays of n_owners entries each). */
+int32_t dcd_build_export_plan(dcd_build* h, uint32_t n_owners, uint64_t* term_count, uint64_t* key_count, uint64_t* unit_count);
+/* Fills caller-allocated DEVICE buffers: meta (dcd_term_meta per term), keys (UTF-16 units) and
+ * posting units, all grouped by owner (owner 0 first) and in ordinal term order inside an owner. */
+int32_t dcd_build_export_fill(dcd_build* h, void* meta_dev, uint16_t* keys_dev, uint16_t* units_dev);
+/* Merges what n_sources shards sent to this owner.  The three device buffers hold the sources'
+ * contributions back to back in source (= coordinate) order; *_count are host arrays [n_sources].
+ * The result is an index over the owned terms (hash-partitioned sub-index). */
+int32_t dcd_merge_shards(int32_t device, uint32_t n_sources, const uint64_t* term_count, const uint64_t* key_count,
+                         const uint64_t* unit_count, const void* meta_dev, const uint16_t* keys_dev, const uint16_t* units_dev,
+                         uint64_t max_coord, dcd_index** out);
+/* Page table of an index whose pages are uniform (synthetic corpora): n_pages pages of page_chars
+ * characters starting at coordinate 0, one document per page named first_doc + p under `source`. */
+int32_t dcd_index_set_uniform_pages(dcd_index* h, uint64_t n_pages, uint32_t page_chars, uint64_t first_doc,
+                                    const uint16_t* source, size_t source_len);
+
+/* ------------------------------------------------------------------------------------------
  * Measurement support (bench.py / tests): the synthetic corpus of SURVEY.md Appendix F.
  * ------------------------------------------------------------------------------------------ */
 /* n_docs documents of exactly doc_bytes ASCII bytes each, Zipf(s) over vocab terms, per-doc

@@ -1,0 +1,56 @@
+"""Worker of tests/test_dist_cpu.py: world_size-2 gloo run of docodo_amd.dist.exchange on CPU tensors.
+Every rank fabricates an export whose bytes encode (source rank, owner, kind, index) and checks that
+what it receives is exactly the slices addressed to it, in source order."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+os.environ["DOCODO_NO_TORCH"] = "0"
+
+
+def fake_export(rank, world):
+    from docodo_amd.dist import META_BYTES, ShardExport
+    rng = np.random.default_rng(100 + rank)
+    tc = rng.integers(0, 6, world).astype(np.uint64)            # ragged, zeros allowed
+    kc = (tc * rng.integers(3, 9, world).astype(np.uint64))
+    uc = (tc * rng.integers(1, 50, world).astype(np.uint64))
+
+    def fill(counts, scale, kind):
+        parts = []
+        for owner in range(world):
+            n = int(counts[owner]) * scale
+            parts.append(((np.arange(n) * 7 + rank * 31 + owner * 13 + kind * 5) % 251).astype(np.uint8))
+        return torch.from_numpy(np.concatenate(parts) if parts else np.empty(0, np.uint8))
+
+    return ShardExport(tc, kc, uc, fill(tc, META_BYTES, 0), fill(kc, 2, 1), fill(uc, 2, 2), 1000 + rank)
+
+
+def main():
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from docodo_amd.dist import META_BYTES, exchange
+    mine = fake_export(rank, world)
+    tc, kc, uc, meta, keys, units, mx = exchange(mine)
+    assert mx == 1000 + world - 1
+    exp = [fake_export(s, world) for s in range(world)]
+    for got, kind, scale, cnt in ((meta, 0, META_BYTES, tc), (keys, 1, 2, kc), (units, 2, 2, uc)):
+        want = []
+        for s in range(world):
+            counts = (exp[s].term_count, exp[s].key_count, exp[s].unit_count)[kind]
+            assert int(cnt[s]) == int(counts[rank])
+            n = int(counts[rank]) * scale
+            want.append(((np.arange(n) * 7 + s * 31 + rank * 13 + kind * 5) % 251).astype(np.uint8))
+        want = np.concatenate(want) if want else np.empty(0, np.uint8)
+        assert np.array_equal(got.numpy(), want), (rank, kind)
+    dist.barrier()
+    dist.destroy_process_group()
+    print("rank %d ok" % rank)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,81 @@
+"""Doc-range shard merge on one device: G fake shards (each built with its global coord_base), exported,
+routed like the all-to-all would, merged per owner -- must reproduce the one-shot build's posting lists
+bit for bit (and therefore the oracle's, which the one-shot build is checked against)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _build(text, n_docs, first_doc=0):
+    import docodo_amd
+    from docodo_amd import synth
+    off = np.arange(n_docs + 1, dtype=np.uint64) * synth.DOC_BYTES
+    b = docodo_amd.Builder(coord_base=first_doc * synth.DOC_BYTES)
+    b.AddPages(text, off, docs_per_page=True, first_doc=first_doc)
+    b.Finish()
+    return b
+
+
+@pytest.mark.parametrize("G,n_docs", [(1, 500), (2, 3000), (3, 6001), (8, 4000)])
+def test_fake_shards_equal_one_shot_build(oracle_mod, G, n_docs):
+    import docodo_amd
+    from docodo_amd import dist, synth
+    text = synth.corpus_host(n_docs)
+    full = _build(text, n_docs)
+    full_img, full_lst = full.index_image(), full.list_image()
+    ref = full.Build()
+    bounds = [n_docs * g // G for g in range(G + 1)]
+    shards = [_build(text[bounds[g] * 1024:bounds[g + 1] * 1024], bounds[g + 1] - bounds[g], first_doc=bounds[g]) for g in range(G)]
+    exports = [dist.export_shard(b, G) for b in shards]
+    owned = [dist.local_merge(exports, o) for o in range(G)]
+    assert sum(ix.Count for ix in owned) == ref.Count
+    assert all(ix.MaxCoord == ref.MaxCoord for ix in owned)
+    seen = 0
+    for ix in owned:
+        prev = None
+        for t in range(ix.Count):
+            k = ix.key(t)
+            assert prev is None or prev < k          # ordinal order inside an owner (ASCII keys)
+            prev = k
+            rt = ref.find(k)
+            assert rt is not None
+            if t % 37 == 0 or ix.term_count(t) > 1000:   # all big terms, a sample of the rest
+                assert np.array_equal(ix.get(t).units, ref.get(rt).units), k
+            assert ix.term_count(t) == ref.term_count(rt)
+            seen += 1
+    assert seen == ref.Count
+    # and the one-shot build is the oracle's
+    oix = oracle_mod.Index(stemmers=[])
+    ob = oracle_mod.Builder(oix)
+    ob.index_docs_latin1(text, np.arange(n_docs + 1, dtype=np.uint64) * 1024)
+    oi, ol = ob.save()
+    assert full_img == oi and full_lst == ol
+
+
+def test_merged_index_answers_queries(oracle_mod):
+    """A merged (hash-partitioned) sub-index + the global page table answers its terms like the oracle."""
+    import docodo_amd
+    from docodo_amd import dist, synth
+    n_docs, G = 5000, 4
+    text = synth.corpus_host(n_docs)
+    bounds = [n_docs * g // G for g in range(G + 1)]
+    shards = [_build(text[bounds[g] * 1024:bounds[g + 1] * 1024], bounds[g + 1] - bounds[g], first_doc=bounds[g]) for g in range(G)]
+    exports = [dist.export_shard(b, G) for b in shards]
+    oix = oracle_mod.Index(stemmers=[])
+    ob = oracle_mod.Builder(oix)
+    ob.index_docs_latin1(text, np.arange(n_docs + 1, dtype=np.uint64) * 1024)
+    oix.load(*ob.save())
+    ix = dist.local_merge(exports, 1)
+    dist.set_uniform_pages(ix, n_docs, 1024)
+    checked = 0
+    for t in range(0, ix.Count, max(1, ix.Count // 25)):
+        w = ix.key(t)
+        res = ix.query_batch([docodo_amd.DCD_OP_TERM, t, 255 + len(w)], [0, 3])
+        o = oix.search(w)
+        pages = res.pages(0)
+        assert len(pages) == len(o.foundPages)
+        for (pi, pos, rank), op in zip(pages, o.foundPages):
+            assert pi == op.page_index and np.array_equal(pos, op.pos) and abs(rank - op.rank) <= 1e-5 * max(1, abs(op.rank))
+        checked += 1
+    assert checked >= 20
