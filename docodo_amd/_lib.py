@@ -13,7 +13,7 @@ DCD_OK = 0
 DCD_E_BADARG, DCD_E_OVERFLOW, DCD_E_IO, DCD_E_HIP, DCD_E_RCCL = -1, -2, -3, -4, -5
 DCD_E_UNSUPPORTED, DCD_E_NOTFOUND, DCD_E_NOMEM, DCD_E_STATE = -6, -7, -8, -9
 DCD_ENC_LATIN1, DCD_ENC_UTF16LE = 1, 2
-DCD_OP_TERM, DCD_OP_AND, DCD_OP_OR = 0, 1, 2
+DCD_OP_TERM, DCD_OP_AND, DCD_OP_OR, DCD_OP_SETR = 0, 1, 2, 3
 
 
 class DocodoError(RuntimeError):

@@ -64,7 +64,13 @@ __global__ __launch_bounds__(TK_THREADS) void k_tok_emit(const CharT* __restrict
     for (u32 q = 0; q < nw; q++) hs.add(word(q));
     const u64 gpos = tile_start + i;
     u32 slot = vocab_lookup_insert<CharT>(vt, tv, hs.fin(), len, gpos, word);
-    tuples[obase + k] = make_uint2(slot, (u32)gpos);
+    u32 coord = (u32)gpos;
+    if (P.n_runs) {
+      u32 a = 0, b = P.n_runs;   // last run with run_off <= gpos
+      while (a + 1 < b) { u32 m = (a + b) >> 1; if (P.run_off[m] <= (u32)gpos) a = m; else b = m; }
+      coord += P.run_delta[a];
+    }
+    tuples[obase + k] = make_uint2(slot, coord);
   }
 }
 
@@ -202,8 +208,10 @@ struct dcd_build {
   const void* text_dev = nullptr;
   bool text_borrowed = false;
   u64 n_chars = 0, text_cap = 0;
-  std::vector<u64> page_off;  // [n_pages + 1]
+  std::vector<u64> page_off;  // [n_pages + 1] text-buffer offsets of the BODY pages staged on the device
   PageTable pages;
+  u64 coord_cursor = 0;       // global coordinate of the next character (IndexTask's `coord`, Build.cs:459)
+  std::vector<u32> run_off, run_delta;  // coordinate runs: text index -> local coordinate offset (header pages)
   // explicit postings
   std::vector<u16> xpool;     // code characters (UTF-16 units; narrowed for Latin-1 builds)
   std::vector<ExplicitPosting> xps;
@@ -223,6 +231,7 @@ struct dcd_build {
 namespace dcd {
 // UTF-16 class/lower tables on the device (built lazily per device from dcd_unicode.cpp)
 int32_t get_char_tables16(int device, CharTables16* out);
+void host_char_tables16(const u8** cls, const u16** lower);
 DeviceIndex* build_take_index(dcd_build* b) {
   if (!b->finished || b->adopted) return nullptr;
   b->adopted = true;
@@ -234,6 +243,24 @@ hipStream_t build_stream(dcd_build* b) { return b->st; }
 }  // namespace dcd
 
 static ustr mk16(const u16* p, size_t n) { return ustr((const char16_t*)p, n); }
+
+static int32_t add_explicit(dcd_build* h, const u16* code, size_t len, u64 coord) {
+  if (len == 0 || len > MAX_CODE_LEN) DCD_FAIL(DCD_E_UNSUPPORTED, "index codes must be 1..%u UTF-16 units long", MAX_CODE_LEN);
+  if (coord < h->opts.coord_base || coord - h->opts.coord_base >= (1ull << 32))
+    DCD_FAIL(DCD_E_OVERFLOW, "explicit coordinate outside this segment's 2^32 window");
+  if (h->opts.encoding == DCD_ENC_LATIN1)
+    for (size_t i = 0; i < len; i++)
+      if (code[i] > 0xFF) DCD_FAIL(DCD_E_UNSUPPORTED, "code unit > 0xFF in a LATIN1 build; create the build with DCD_ENC_UTF16LE");
+  ExplicitPosting x;
+  x.off = (u32)h->xpool.size();
+  x.len = (u32)len;
+  x.coord = coord;
+  h->xpool.insert(h->xpool.end(), code, code + len);
+  h->xps.push_back(x);
+  h->last_is_explicit = true;
+  h->last_explicit_coord = coord;
+  return DCD_OK;
+}
 
 extern "C" {
 
@@ -264,6 +291,7 @@ int32_t dcd_build_create(const dcd_build_opts* opts, dcd_build** out) {
   hipError_t e = hipStreamCreateWithFlags(&h->st, hipStreamNonBlocking);
   if (e != hipSuccess) { delete h; DCD_FAIL(DCD_E_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
   h->page_off.push_back(0);
+  h->coord_cursor = o.coord_base;
   *out = h;
   return DCD_OK;
 }
@@ -287,11 +315,59 @@ int32_t dcd_build_add_doc(dcd_build* h, const uint16_t* source, size_t source_le
   return DCD_OK;
 }
 
-static int32_t append_pages_meta(dcd_build* h, const uint64_t* page_off, size_t n_pages, u64 n_chars, const uint16_t* page_ids,
-                                 const uint64_t* ids_off, int32_t docs_per_page, uint64_t first_doc, const uint16_t* source,
-                                 size_t source_len) {
+static int32_t add_explicit(dcd_build* h, const u16* code, size_t len, u64 coord);
+
+// Header page (id "0"), Build.cs:485-524: one "name=value" per line; every \w-run of the value
+// yields Add("&" + name, (uint)(coord + dc - 1)) and AddWord(word.ToLower(), coord + dc); the
+// coordinate advances by line.Length + 1 per line.  A line with a long-enough name but no '='
+// throws in the reference (fields[1]) and aborts the page WITHOUT EndPage; reproduced.
+static int32_t host_header_page(dcd_build* h, const u16* text, size_t n, bool* ended) {
+  const u8* cls; const u16* lower;
+  host_char_tables16(&cls, &lower);
+  u64 coord = h->coord_cursor;
+  size_t p = 0;
+  *ended = true;
+  while (p < n) {
+    size_t e = p;
+    while (e < n && text[e] != u'\n' && text[e] != u'\r') e++;
+    ustr line(e - p, u' ');
+    for (size_t i = p; i < e; i++) line[i - p] = (char16_t)lower[text[i]];
+    p = e;
+    if (p < n) { if (text[p] == u'\r' && p + 1 < n && text[p + 1] == u'\n') p += 2; else p += 1; }
+    size_t q = line.find(u'=');
+    size_t f0 = q == ustr::npos ? line.size() : q;
+    if ((int)f0 >= h->opts.min_word_length) {
+      if (q == ustr::npos) { *ended = false; break; }
+      size_t q2 = line.find(u'=', q + 1);
+      ustr v = line.substr(q + 1, q2 == ustr::npos ? ustr::npos : q2 - q - 1);
+      ustr marker = u"&" + line.substr(0, f0);
+      u64 dc = f0 + 1;
+      size_t i = 0;
+      while (i < v.size()) {
+        size_t j = i;
+        bool w = (cls[(u16)v[i]] & 4) != 0;
+        while (j < v.size() && ((cls[(u16)v[j]] & 4) != 0) == w) j++;
+        if (w) {
+          DCD_TRY(add_explicit(h, (const u16*)marker.data(), marker.size(), (u64)(u32)(coord + dc - 1)));   // (uint) cast, Build.cs:509
+          DCD_TRY(add_explicit(h, (const u16*)v.data() + i, j - i, coord + dc));                            // AddWord, identity codes
+        }
+        dc += j - i;
+        i = j;
+      }
+    }
+    coord += line.size() + 1;
+  }
+  h->coord_cursor = coord;
+  return DCD_OK;
+}
+
+// Book-keeping + staging of one batch of pages.  Body pages are copied to the device text buffer
+// (contiguous ranges in one hipMemcpy each); header pages are tokenised here.
+static int32_t add_pages_impl(dcd_build* h, const void* text, u64 n_chars, const uint64_t* page_off, size_t n_pages,
+                              const uint16_t* page_ids, const uint64_t* ids_off, int32_t docs_per_page, uint64_t first_doc,
+                              const uint16_t* source, size_t source_len, bool device_text) {
   if (docs_per_page) {
-    if (!h->pages.docs.empty() || (!h->pages.end.empty() && !h->pages.doc_per_page))
+    if (!h->pages.docs.empty() || (h->pages.n_pages() && !h->pages.doc_per_page))
       DCD_FAIL(DCD_E_STATE, "cannot mix docs_per_page with explicit documents");
     if (h->pages.end.empty()) {
       h->pages.doc_per_page = true;
@@ -304,34 +380,82 @@ static int32_t append_pages_meta(dcd_build* h, const uint64_t* page_off, size_t 
     DCD_FAIL(DCD_E_STATE, "dcd_build_add_doc must precede pages (Build.cs:345-347)");
   }
   if (page_off[0] != 0 || page_off[n_pages] != n_chars) DCD_FAIL(DCD_E_BADARG, "page_off must start at 0 and end at n_chars");
-  bool uniform = ids_off == nullptr;
+  const bool uniform = ids_off == nullptr;
   if (uniform) {
     if (!h->pages.ids.empty()) DCD_FAIL(DCD_E_STATE, "cannot mix uniform and explicit page ids");
     h->pages.uniform_id = u"1";
   } else if (h->pages.ids.empty() && !h->pages.end.empty()) {
     DCD_FAIL(DCD_E_STATE, "cannot mix uniform and explicit page ids");
   }
-  u64 base = h->n_chars;
+  const int cs = h->csize();
+  // pending contiguous body range of the caller's buffer: [r0, r1)
+  u64 r0 = 0, r1 = 0;
+  auto flush = [&]() -> int32_t {
+    if (r1 == r0 || device_text) { r0 = r1; return DCD_OK; }
+    u64 len = r1 - r0;
+    u64 need = (h->n_chars + len) * cs + 64;
+    if (need > h->text_cap) {
+      u64 ncap = std::max<u64>(need, h->text_cap * 2);
+      DevBuf<u8> nb;
+      DCD_TRY(nb.alloc(h->device, ncap));
+      if (h->n_chars) DCD_HIP(hipMemcpyAsync(nb.p, h->text_own.p, h->n_chars * cs, hipMemcpyDeviceToDevice, h->st));
+      DCD_HIP(hipStreamSynchronize(h->st));
+      h->text_own = std::move(nb);
+      h->text_cap = ncap;
+    }
+    DCD_HIP(hipMemcpyAsync(h->text_own.p + h->n_chars * cs, (const u8*)text + r0 * cs, len * cs, hipMemcpyHostToDevice, h->st));
+    h->n_chars += len;
+    h->text_dev = h->text_own.p;
+    r0 = r1;
+    return DCD_OK;
+  };
+  u64 staged = h->n_chars;   // text index the next body character will get
   for (size_t p = 0; p < n_pages; p++) {
     if (page_off[p + 1] < page_off[p]) DCD_FAIL(DCD_E_BADARG, "page_off must be ascending");
-    u64 len = page_off[p + 1] - page_off[p];
-    if (len == 0) continue;  // empty pages are skipped entirely (Build.cs:483)
-    if (!uniform) {
-      ustr id = mk16(page_ids + ids_off[p], (size_t)(ids_off[p + 1] - ids_off[p]));
-      if (id == u"0") DCD_FAIL(DCD_E_UNSUPPORTED, "header pages (id \"0\", Build.cs:485-524) are not handled by this entry point yet");
-      h->pages.ids.push_back(id);
+    const u64 len = page_off[p + 1] - page_off[p];
+    if (len == 0) {                                   // empty pages are skipped entirely (Build.cs:483)
+      if (docs_per_page) DCD_FAIL(DCD_E_BADARG, "docs_per_page requires non-empty pages");
+      if (r1 == page_off[p]) r1 = page_off[p + 1];
+      continue;
     }
-    h->page_off.push_back(base + page_off[p + 1]);
-    h->pages.end.push_back(h->opts.coord_base + base + page_off[p + 1]);
+    ustr id;
+    if (!uniform) id = mk16(page_ids + ids_off[p], (size_t)(ids_off[p + 1] - ids_off[p]));
+    if (!uniform && id == u"0") {
+      if (device_text) DCD_FAIL(DCD_E_UNSUPPORTED, "header pages need host text (dcd_build_add_pages)");
+      if (r1 != page_off[p]) { DCD_TRY(flush()); }
+      DCD_TRY(flush());
+      r0 = r1 = page_off[p + 1];
+      std::vector<u16> wide(len);
+      if (cs == 1) for (u64 i = 0; i < len; i++) wide[i] = ((const u8*)text)[page_off[p] + i];
+      else memcpy(wide.data(), (const u16*)text + page_off[p], len * 2);
+      bool ended = true;
+      DCD_TRY(host_header_page(h, wide.data(), len, &ended));
+      if (ended) {
+        h->pages.ids.push_back(id);
+        h->pages.end.push_back(h->coord_cursor);
+        h->pages.page_doc.push_back((u32)(h->pages.docs.size() - 1));
+      }
+      // the coordinate jumped without text: open a new run for the body characters that follow
+      u64 delta = (h->coord_cursor - h->opts.coord_base) - staged;
+      if (delta >= (1ull << 32)) DCD_FAIL(DCD_E_OVERFLOW, "coordinate window of the segment exceeded");
+      if (h->run_off.empty()) { h->run_off.push_back(0); h->run_delta.push_back(0); }
+      if (h->run_off.back() == (u32)staged) h->run_delta.back() = (u32)delta;
+      else { h->run_off.push_back((u32)staged); h->run_delta.push_back((u32)delta); }
+      continue;
+    }
+    if (r1 != page_off[p]) { DCD_TRY(flush()); r0 = page_off[p]; }
+    r1 = page_off[p + 1];
+    staged += len;
+    h->coord_cursor += len;                            // coord += c.Length (Build.cs:531)
+    if (!uniform) h->pages.ids.push_back(id);
+    h->page_off.push_back(staged);
+    h->pages.end.push_back(h->coord_cursor);           // EndPage(page.id, coord) (Build.cs:532)
     if (!docs_per_page) h->pages.page_doc.push_back((u32)(h->pages.docs.size() - 1));
+    h->last_is_explicit = false;
   }
-  if (docs_per_page) {
-    // every page is its own document: empty pages would break the numbering
-    if (h->pages.end.size() != (h->page_off.size() - 1)) DCD_FAIL(DCD_E_BADARG, "internal page bookkeeping");
-    for (size_t p = 0; p < n_pages; p++)
-      if (page_off[p + 1] == page_off[p]) DCD_FAIL(DCD_E_BADARG, "docs_per_page requires non-empty pages");
-  }
-  h->last_is_explicit = false;
+  DCD_TRY(flush());
+  if (!device_text) DCD_HIP(hipStreamSynchronize(h->st));   // the caller may reuse `text` as soon as we return
+  if (staged - (h->n_chars) != 0 && !device_text) DCD_FAIL(DCD_E_BADARG, "internal staging mismatch");
   return DCD_OK;
 }
 
@@ -343,24 +467,8 @@ int32_t dcd_build_add_pages(dcd_build* h, const void* text, uint64_t n_chars, co
   if (h->text_borrowed) DCD_FAIL(DCD_E_STATE, "cannot append host text after dcd_build_add_pages_dev");
   if (ids_off && !page_ids) DCD_FAIL(DCD_E_BADARG, "ids_off without page_ids");
   if (h->n_chars + n_chars >= (1ull << 32)) DCD_FAIL(DCD_E_OVERFLOW, "one build segment holds < 2^32 characters; shard larger corpora");
-  DCD_TRY(append_pages_meta(h, page_off, n_pages, n_chars, page_ids, ids_off, docs_per_page, first_doc, source, source_len));
   DCD_TRY(ensure_device(h->device));
-  const int cs = h->csize();
-  u64 need = (h->n_chars + n_chars) * cs + 64;
-  if (need > h->text_cap) {
-    u64 ncap = std::max<u64>(need, h->text_cap * 2);
-    DevBuf<u8> nb;
-    DCD_TRY(nb.alloc(h->device, ncap));
-    if (h->n_chars) DCD_HIP(hipMemcpyAsync(nb.p, h->text_own.p, h->n_chars * cs, hipMemcpyDeviceToDevice, h->st));
-    DCD_HIP(hipStreamSynchronize(h->st));
-    h->text_own = std::move(nb);
-    h->text_cap = ncap;
-  }
-  if (n_chars) DCD_HIP(hipMemcpyAsync(h->text_own.p + h->n_chars * cs, text, n_chars * cs, hipMemcpyHostToDevice, h->st));
-  DCD_HIP(hipStreamSynchronize(h->st));  // the caller may reuse `text` as soon as we return
-  h->n_chars += n_chars;
-  h->text_dev = h->text_own.p;
-  return DCD_OK;
+  return add_pages_impl(h, text, n_chars, page_off, n_pages, page_ids, ids_off, docs_per_page, first_doc, source, source_len, false);
 }
 
 int32_t dcd_build_add_pages_dev(dcd_build* h, const void* text_dev, uint64_t n_chars, const uint64_t* page_off_host, size_t n_pages,
@@ -370,7 +478,7 @@ int32_t dcd_build_add_pages_dev(dcd_build* h, const void* text_dev, uint64_t n_c
   if (h->n_chars) DCD_FAIL(DCD_E_STATE, "dcd_build_add_pages_dev must be the only text batch of its build");
   if (((uintptr_t)text_dev & 15) != 0) DCD_FAIL(DCD_E_BADARG, "device text must be 16-byte aligned");
   if (n_chars >= (1ull << 32)) DCD_FAIL(DCD_E_OVERFLOW, "one build segment holds < 2^32 characters; shard larger corpora");
-  DCD_TRY(append_pages_meta(h, page_off_host, n_pages, n_chars, nullptr, nullptr, docs_per_page, first_doc, source, source_len));
+  DCD_TRY(add_pages_impl(h, nullptr, n_chars, page_off_host, n_pages, nullptr, nullptr, docs_per_page, first_doc, source, source_len, true));
   h->text_dev = text_dev;
   h->text_borrowed = true;
   h->n_chars = n_chars;
@@ -393,6 +501,7 @@ int32_t dcd_build_add_uniform_pages_dev(dcd_build* h, const void* text_dev, uint
   h->text_dev = text_dev;
   h->text_borrowed = true;
   h->n_chars = n_chars;
+  h->coord_cursor = h->opts.coord_base + n_chars;
   h->last_is_explicit = false;
   return DCD_OK;
 }
@@ -400,21 +509,7 @@ int32_t dcd_build_add_uniform_pages_dev(dcd_build* h, const void* text_dev, uint
 int32_t dcd_build_add(dcd_build* h, const uint16_t* code, size_t len, uint64_t coord) {
   if (!h || (!code && len)) DCD_FAIL(DCD_E_BADARG, "dcd_build_add: NULL argument");
   if (h->finished) DCD_FAIL(DCD_E_STATE, "build already finished");
-  if (len == 0 || len > MAX_CODE_LEN) DCD_FAIL(DCD_E_UNSUPPORTED, "index codes must be 1..%u UTF-16 units long", MAX_CODE_LEN);
-  if (coord < h->opts.coord_base || coord - h->opts.coord_base >= (1ull << 32))
-    DCD_FAIL(DCD_E_OVERFLOW, "explicit coordinate outside this segment's 2^32 window");
-  if (h->opts.encoding == DCD_ENC_LATIN1)
-    for (size_t i = 0; i < len; i++)
-      if (code[i] > 0xFF) DCD_FAIL(DCD_E_UNSUPPORTED, "code unit > 0xFF in a LATIN1 build; create the build with DCD_ENC_UTF16LE");
-  ExplicitPosting x;
-  x.off = (u32)h->xpool.size();
-  x.len = (u32)len;
-  x.coord = coord;
-  h->xpool.insert(h->xpool.end(), code, code + len);
-  h->xps.push_back(x);
-  h->last_is_explicit = true;
-  h->last_explicit_coord = coord;
-  return DCD_OK;
+  return add_explicit(h, code, len, coord);
 }
 
 int32_t dcd_build_end_page(dcd_build* h, const uint16_t* id, size_t len) {
@@ -502,6 +597,16 @@ static int32_t finish_impl(dcd_build* h) {
   P.min_len = (u32)h->opts.min_word_length;
   P.max_len = (u32)h->opts.max_word_length;
   P.uniform_page_chars = uniform ? (u32)h->pages.uni_chars : 0u;
+  DevBuf<u32> d_run_off, d_run_delta;
+  P.run_off = nullptr; P.run_delta = nullptr; P.n_runs = 0;
+  if (!h->run_off.empty()) {
+    DCD_TRY(d_run_off.alloc(dev, h->run_off.size()));
+    DCD_TRY(d_run_delta.alloc(dev, h->run_delta.size()));
+    DCD_HIP(hipMemcpyAsync(d_run_off.p, h->run_off.data(), h->run_off.size() * 4, hipMemcpyHostToDevice, st));
+    DCD_HIP(hipMemcpyAsync(d_run_delta.p, h->run_delta.data(), h->run_delta.size() * 4, hipMemcpyHostToDevice, st));
+    DCD_HIP(hipStreamSynchronize(st));
+    P.run_off = d_run_off.p; P.run_delta = d_run_delta.p; P.n_runs = (u32)h->run_off.size();
+  }
   DevBuf<u32> tile_count;
   DevBuf<u64> tile_off, scan_scr64;
   u64 n_text_tok = 0;

@@ -541,6 +541,10 @@ static int32_t run_batch(dcd_index* h, const int32_t* prog, const u64* prog_off,
         rounds[r.round - 1].push_back(p);
         stk.push_back(r);
         i += 1;
+      } else if (opc == DCD_OP_SETR) {
+        if (i + 2 > prog_off[q + 1] || stk.empty()) DCD_FAIL(DCD_E_BADARG, "query %zu: bad SETR", q);
+        stk.back().R = prog[i + 1];
+        i += 2;
       } else {
         DCD_FAIL(DCD_E_BADARG, "query %zu: unknown opcode %d", q, opc);
       }

@@ -258,6 +258,11 @@ __device__ __forceinline__ u32 vocab_lookup_insert(const VocabTable& vt, const T
 
 // ---- tile tokeniser ----------------------------------------------------------------------------------
 struct TokParams {
+  // coordinate runs: characters [run_off[r], run_off[r+1]) have local coordinate = index + run_delta[r]
+  // (header pages advance the coordinate without contributing text, Build.cs:485-524)
+  const u32* run_off;
+  const u32* run_delta;
+  u32 n_runs;              // <= 1: coordinate == index (+ run_delta[0] if n_runs == 1)
   u64 n_chars;
   const u64* page_off;     // [n_pages + 1] device, ascending (unused when uniform_page_chars != 0)
   u64 n_pages;

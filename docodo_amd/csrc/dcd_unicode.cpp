@@ -16,8 +16,10 @@ void host_char_tables16(const u8** cls, const u16** lower) {
     c.assign(65536, 0);
     l.resize(65536);
     for (u32 i = 0; i < 65536; i++) l[i] = (u16)i;
-    for (auto& r : kLetterRanges) for (u32 i = r[0]; i <= r[1]; i++) c[i] = 1;
-    for (auto& r : kNumberRanges) for (u32 i = r[0]; i <= r[1]; i++) c[i] = 2;
+    // bit0 = \\p{L}, bit1 = \\p{N}, bit2 = \\w (L | Mn | Nd | Pc, as .NET Regex defines it)
+    for (auto& r : kLetterRanges) for (u32 i = r[0]; i <= r[1]; i++) c[i] = 1 | 4;
+    for (auto& r : kNumberRanges) for (u32 i = r[0]; i <= r[1]; i++) c[i] |= 2;
+    for (auto& r : kWordExtraRanges) for (u32 i = r[0]; i <= r[1]; i++) c[i] |= 4;
     for (auto& p : kLowerPairs) l[p[0]] = p[1];
   });
   *cls = c.data();

@@ -1,0 +1,237 @@
+"""Index.Search front end (reference: Docodo.NET/Search.cs:192-260, 302-363, 437-617).
+
+Host-side string work that stays with the host (the C# shim keeps its own PrepareSearchRequest):
+the request string is rewritten exactly as the reference does, every word becomes a term lookup
+with the R of SearchSequence.d(), and the expression is compiled to ONE postfix program that the
+GPU evaluates (`dcd_query_batch`).  GetWordCodes is the identity (no stemmer / vocabulary / stop
+words: the parity configuration); a host with linguistics supplies `get_word_codes`.
+Snippets/headers (Search.cs:560-595) are out of scope.
+"""
+import regex
+
+from . import _lib
+
+_W = r"\p{L}\p{Mn}\p{Nd}\p{Pc}"                                        # .NET \w
+_B = rf"(?:(?<=[{_W}])(?![{_W}])|(?<![{_W}])(?=[{_W}]))"               # .NET \b
+MAX_LIKE_WORDS = 100                                                   # Search.cs:158
+
+
+def _upper(s):
+    return "".join(c.upper() if len(c.upper()) == 1 else c for c in s)
+
+
+def _lower(s):
+    return "".join(c.lower() if len(c.lower()) == 1 else ("i" if c == "İ" else c) for c in s)
+
+
+class SearchResult:  # Search.cs:20-56
+    def __init__(self, success=True, error=""):
+        self.Success, self.Error = success, error
+        self.foundPages = []   # (page index, page id, positions ndarray, rank)
+        self.foundDocs = []    # (doc index, doc name, rank, n pages), ascending rank
+        self.words = []        # (word, nFound)
+
+
+class Search:
+    def __init__(self, index, get_word_codes=None, stop_words=(), keep_forms=True):
+        self.ix = index
+        self.get_word_codes = get_word_codes or (lambda w: [w] if w else None)
+        self.stop_words = list(stop_words)
+        self.keep_forms = keep_forms
+        self._keys = None
+
+    # -- SearchWord, Search.cs:192-260: returns (postfix program for the OR of the codes, exact flag)
+    def _keys_list(self):
+        if self._keys is None:
+            self._keys = [self.ix.key(t) for t in range(self.ix.Count)]
+        return self._keys
+
+    def _search_word(self, word):
+        exact = _upper(word) == word and self.keep_forms
+        word = _lower(word)
+        words = [word]
+        if "_" in word:
+            if not self.keep_forms:
+                return [], False, 0
+            exact = True
+            words = []
+            if len(word) >= 2:                                             # GetLikeWords, Search.cs:160-167
+                pat = regex.compile(word.replace("_", ".*"))
+                for k in self._keys_list():
+                    if k and regex.match(r"\p{L}", k[0]) and pat.search(k):
+                        words.append(k)
+                        if len(words) >= MAX_LIKE_WORDS:
+                            break
+        prog, n, nfound = [], 0, 0
+        for w in words:
+            codes = self.get_word_codes(w)
+            if not codes:
+                continue
+            selfcodes = [c for c in codes if regex.match(rf"[{_W}]", c[0])]
+            know = [c for c in dict.fromkeys(codes) if c not in selfcodes]
+            use = know if (not exact and know) else selfcodes[:1]
+            for code in use:
+                t = self.ix.find(code)
+                if t is None:
+                    continue
+                prog += [_lib.DCD_OP_TERM, t, 0]
+                if n:
+                    prog.append(_lib.DCD_OP_OR)
+                n += 1
+        return prog, exact, n
+
+    # -- PrepareSearchRequest, Search.cs:319-363 (literal regex pipeline)
+    def _prepare(self, req, funcs, field=None, keepshort=False):
+        req = regex.sub(rf'[^{_W}(){{}}=~?|"]|_+', " ", req)
+        f = [""]
+
+        def field_cb(m):
+            l, _ = self._prepare(m.group(2), funcs, field=m.group(1), keepshort=True)
+            f[0] += ("*" if f[0] else "") + "(" + l + ")"
+            return ""
+
+        req = regex.sub(rf"{{*([{_W}]+)[ ]*=([{_W}|() ]+)}}", field_cb, req)
+        fields = f[0]
+        req = regex.sub(r"{.*}", "", req)
+        req = req.replace("?", "_")
+        if not keepshort:
+            req = regex.sub(rf"{_B}[{_W}]{{1,2}}{_B}", " ", req)
+        for st in self.stop_words:
+            req = regex.sub(rf"{_B}{st}{_B}", "", req)
+        req = regex.sub(r'"(.*)"', lambda m: "(" + _upper(m.group(1)) + ")", req)
+        req = req.replace("|", "+")
+        req = regex.sub(rf"({_B}|\))(\s+)({_B}|\()", lambda m: regex.sub(m.group(2), "*", m.group(0)), req)
+
+        def var_cb(m):
+            funcs.append({"word": m.group(0), "field": field})
+            return "\x00%d\x00" % (len(funcs) - 1)
+
+        req = regex.sub(rf"{_B}([{_W}]+){_B}", var_cb, req)
+        return req, fields
+
+    # -- SearchSequence.d(), Search.cs:302-312, compiled to postfix
+    def _d(self, fn, dist):
+        word = fn["word"]
+        if fn["field"] is None:
+            prog, exact, n = self._search_word(word)
+            R0 = -1 if exact else 0
+        else:                                                                  # SearchField, Search.cs:126-140
+            t = self.ix.find("&" + _lower(fn["field"]))
+            vprog, vexact, n = self._search_word(_lower(word))
+            if t is None or n == 0:
+                prog, n, R0 = [], 0, 0
+            else:
+                vR = -1 if vexact else 0
+                prog = [_lib.DCD_OP_TERM, t, -1] + vprog + [_lib.DCD_OP_SETR, vR, _lib.DCD_OP_AND]
+                R0 = -1 if vR < 0 else 1
+        wl = len(word)
+        R = (-wl - 4) if R0 < 0 else dist + wl
+        fn["n"] = n
+        if n == 0:
+            return None, R                                                     # empty IndexSequence
+        return prog + [_lib.DCD_OP_SETR, R], R
+
+    def _compile(self, expr, funcs, dist):
+        toks = regex.findall(r"\x00\d+\x00|[*+()]|\S", expr)
+        pos = [0]
+
+        def peek():
+            return toks[pos[0]] if pos[0] < len(toks) else None
+
+        # a value is (program or None for the empty sequence, R)
+        def combine(a, b, op):
+            absR = max(abs(a[1]), abs(b[1]))
+            R = -absR if (a[1] < 0 and b[1] < 0) else absR
+            if op == _lib.DCD_OP_AND:
+                if a[0] is None or b[0] is None:
+                    return None, R                                             # nothing can contain both operands
+                return a[0] + b[0] + [op], R
+            if a[0] is None and b[0] is None:
+                return None, R
+            if a[0] is None:
+                return b[0] + [_lib.DCD_OP_SETR, R], R
+            if b[0] is None:
+                return a[0] + [_lib.DCD_OP_SETR, R], R
+            return a[0] + b[0] + [op], R
+
+        def factor():
+            t = peek()
+            if t is None:
+                raise SyntaxError("eof")
+            pos[0] += 1
+            if t == "(":
+                v = expr_()
+                if peek() != ")":
+                    raise SyntaxError(")")
+                pos[0] += 1
+                return v
+            if t[0] == "\x00":
+                return self._d(funcs[int(t[1:-1])], dist)
+            raise SyntaxError(t)
+
+        def term():
+            v = factor()
+            while peek() == "*":
+                pos[0] += 1
+                v = combine(v, factor(), _lib.DCD_OP_AND)
+            return v
+
+        def expr_():
+            v = term()
+            while peek() == "+":
+                pos[0] += 1
+                v = combine(v, term(), _lib.DCD_OP_OR)
+            return v
+
+        v = expr_()
+        if pos[0] != len(toks):
+            raise SyntaxError("trailing")
+        return v
+
+    def __call__(self, req, opt=None):
+        """Index.Search(req, opt), Search.cs:437-617."""
+        try:
+            req = _lower(req)
+            fpat = r"\B-filter:([\w\*\?\\.()+{}/]+,?)+"
+            if regex.search(fpat, req):
+                return SearchResult(False, "Error: -filter: is evaluated by the host shim; not supported by this front end")
+            funcs = []
+            req, fields = self._prepare(req, funcs)
+            dist = 255 if opt is None else opt.dist                            # Search.cs:472-473
+            try:
+                res = self._compile(req, funcs, dist) if len(req) > 0 else None
+                resf = self._compile(fields, funcs, dist) if len(fields) > 0 else None
+            except SyntaxError:
+                return SearchResult(False, "Syntax Error in search request")
+            if res is None:
+                res = resf
+            if res is None:
+                return SearchResult()
+            out = SearchResult()
+            out.words = [(f["word"], None) for f in funcs]
+            progs = [p[0] for p in (res, resf) if p is not None]
+            if progs[0] is None:
+                return out                                                     # empty result sequence
+            flat, off = [], [0]
+            for p in progs:
+                flat += (p if p is not None else [])
+                off.append(len(flat))
+            if len(progs) == 2 and progs[1] is None:
+                off = off[:2]
+            r = self.ix.query_batch(flat, off)
+            if r.status[0] != 0:
+                return SearchResult(False, "Error: coordinate beyond the last page")
+            keep = None
+            if resf is not None:                                               # CombineSearchResults, Search.cs:423-428
+                keep = set()
+                if r.n_queries == 2 and r.status[1] == 0:
+                    keep = {self.ix.doc_name(d) for d, _, _ in r.docs(1)}
+            for pi, pos, rank in r.pages(0):
+                out.foundPages.append((pi, self.ix.page_info(pi)[2], pos, rank))
+            for d, rank, npg in r.docs(0):
+                name = self.ix.doc_name(d)
+                if keep is None or name in keep:
+                    out.foundDocs.append((d, name, rank, npg))
+            return out
+        except _lib.DocodoError as e:
+            return SearchResult(False, "Error: %s" % e)

@@ -189,6 +189,8 @@ int32_t dcd_index_doc_name(dcd_index* h, uint32_t doc, uint16_t* out, size_t cap
 #define DCD_OP_TERM 0
 #define DCD_OP_AND 1
 #define DCD_OP_OR 2
+#define DCD_OP_SETR 3   /* DCD_OP_SETR, R: overwrite IndexSequence.R of the top of the stack (what
+                           SearchSequence.d() does to the result of SearchWord / SearchField, Search.cs:308) */
 typedef struct dcd_query_opts {
   int32_t max_found_pages;   /* Index.MAX_FOUND_PAGES, Index.cs:101 (30000) */
   int32_t max_found_docs;    /* Index.MAX_FOUND_DOCS, Index.cs:102 (500) */

@@ -1,0 +1,143 @@
+"""The reference's own known-answer tests (XUnitDocodoTest/IndexTest.cs) replayed
+through the GPU path: header pages + body pages through dcd_build_add_pages, request strings through
+the host front end docodo_amd.Search, evaluation by dcd_query_batch."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _corpus(text, headers, n_pages):
+    docs = []
+    for name in ("Sample", "Dump"):
+        pages = [("0", headers + "Name=%s\n" % name), ("1", text)] + [(str(q + 2), text) for q in range(n_pages - 1)]
+        docs.append((name, pages))
+    return docs
+
+
+def _gpu_index(docs):
+    import docodo_amd
+    b = docodo_amd.Builder(encoding=docodo_amd.DCD_ENC_UTF16LE)
+    for name, pages in docs:
+        b.AddDoc("Test", name)
+        texts = [t for _, t in pages]
+        off = np.zeros(len(texts) + 1, np.uint64)
+        off[1:] = np.cumsum([len(t.encode("utf-16-le")) // 2 for t in texts])
+        b.AddPages("".join(texts), off, page_ids=[i for i, _ in pages])
+    b.Finish()
+    return b
+
+
+def _oracle_index(o, docs, stemmers):
+    ix = o.Index(stemmers=stemmers)
+    ob = o.Builder(ix)
+    for name, pages in docs:
+        ob.add_doc("Test", name)
+        for pid, t in pages:
+            ob.index_page(pid, t)
+    img, lst = ob.save()
+    ix.load(img, lst)
+    return ix, img, lst
+
+
+@pytest.fixture(scope="module")
+def gpu_nostem(oracle_mod, testtext1, testheaders1):
+    docs = _corpus(testtext1, testheaders1, 60)
+    b = _gpu_index(docs)
+    oix, oimg, olst = _oracle_index(oracle_mod, docs, [])
+    return b, b.index_image(), b.list_image(), oix, oimg, olst
+
+
+def test_header_pages_images_equal_oracle(gpu_nostem):
+    """Header page path (Build.cs:485-524): &field markers, value words, coordinate accounting."""
+    b, img, lst, oix, oimg, olst = gpu_nostem
+    assert lst == olst
+    assert img == oimg
+
+
+def _same(res, ores):
+    assert res.Success == ores.Success, (res.Error, ores.Error)
+    assert len(res.foundPages) == len(ores.foundPages)
+    for (pi, pid, pos, rank), op in zip(res.foundPages, ores.foundPages):
+        assert pi == op.page_index and pid == op.id and np.array_equal(pos, op.pos)
+        assert abs(rank - op.rank) <= 1e-5 * max(1.0, abs(op.rank))
+    assert len(res.foundDocs) == len(ores.foundDocs)
+    for (d, name, rank, npg), od in zip(res.foundDocs, ores.foundDocs):
+        assert name == od.name and npg == od.n_pages and abs(rank - od.rank) <= 1e-5 * max(1.0, abs(od.rank))
+
+
+def test_D1_coord_and_D2_D3_on_gpu(gpu_nostem, known, oracle_mod):
+    import docodo_amd
+    b, _, _, oix, _, _ = gpu_nostem
+    ix = docodo_amd.Index.from_images(b.index_image(), b.list_image())
+    S = docodo_amd.Search(ix)
+    for w, pos in known["D1_coord"]["words"].items():                     # IndexTest.cs:140-157
+        r = S(w)
+        assert r.Success and len(r.foundPages) == 2 * 60
+        for _, pid, p, _ in r.foundPages:
+            assert list(p) == pos
+        _same(r, oix.search(w))
+    r = S(known["D2"]["req"])                                             # IndexTest.cs:180-185
+    assert len(r.foundDocs) == 2 and all(d[3] == 60 for d in r.foundDocs)
+    _same(r, oix.search(known["D2"]["req"]))
+    r = S(known["D3"]["req"])                                             # IndexTest.cs:187-196
+    assert len(r.foundDocs) == 1 and r.foundDocs[0][1] == "Test:Dump" and r.foundDocs[0][3] == 60
+    assert all(len(p[2]) == 42 for p in r.foundPages) and len(r.foundPages) == 120
+    _same(r, oix.search(known["D3"]["req"]))
+
+
+@pytest.mark.parametrize("key", ["D6", "D7", "D9a", "D9b", "D10", "D11"])
+def test_exact_phrases_and_wildcard_on_gpu(gpu_nostem, known, oracle_mod, key):
+    """IndexTest.cs:205-220 (dist = 40): the answers that do not depend on the third-party stemmer."""
+    import docodo_amd
+    b, _, _, oix, _, _ = gpu_nostem
+    S = docodo_amd.Search(b_index(b))
+    ka = known[key]
+    r = S(ka["req"], docodo_amd.SearchOptions(dist=ka["dist"]))
+    assert r.Success, r.Error
+    if "n_found_pages" in ka:
+        assert len(r.foundPages) == ka["n_found_pages"]
+    else:
+        assert len(r.foundPages[0][2]) == ka["pos_page0"]
+    _same(r, oix.search(ka["req"], oracle_mod.SearchOptions(dist=ka["dist"])))
+
+
+_IX_CACHE = {}
+
+
+def b_index(b):
+    import docodo_amd
+    if id(b) not in _IX_CACHE:
+        _IX_CACHE[id(b)] = docodo_amd.Index.from_images(b.index_image(), b.list_image())
+    return _IX_CACHE[id(b)]
+
+
+@pytest.mark.parametrize("key", ["D4", "D5", "D8"])
+def test_stemmer_dependent_answers_via_explicit_codes(oracle_mod, known, testtext1, testheaders1, key):
+    """IndexTest.cs:198-210.  These depend on the host's stemmer ($ladi = lady + ladies): the host computes
+    the codes (GetWordCodes, Build.cs:175-247 -- here the oracle's restatement) and feeds (code, coord) through
+    the explicit API (Builder.Add), the GPU does vocabulary / sort / pack and evaluates the query."""
+    import docodo_amd
+    from oracle import porter2
+    stem = [("0-9", None), ("а-яё", None), ("a-z", porter2.stem), ("a-zẞäüö", None), ("a-zéâàêèëçîïôûùüÿ", None)]
+    docs = _corpus(testtext1, testheaders1, 3)
+    oix, oimg, olst = _oracle_index(oracle_mod, docs, stem)
+    # replay the oracle index through Builder.Add: every (key, coordinate) pair, coordinate-ascending
+    posts = []
+    for k in oix.keys():
+        for c in oracle_mod.seq_decode(oix.get(k)).tolist():
+            posts.append((c, k))
+    posts.sort()
+    b = docodo_amd.Builder(encoding=docodo_amd.DCD_ENC_UTF16LE)
+    b.AddDoc("Test", "all")
+    for c, k in posts:
+        b.Add(k, c)
+    b.EndPage("1")
+    b.Finish()
+    # posting lists are the oracle's; page table comes from the oracle images
+    ix = docodo_amd.Index.from_images(b.index_image(), olst)
+    S = docodo_amd.Search(ix, get_word_codes=oix.get_word_codes)
+    ka = known[key]
+    r = S(ka["req"], docodo_amd.SearchOptions(dist=ka["dist"]))
+    assert r.Success and len(r.foundPages[0][2]) == ka["pos_page0"]
+    _same(r, oix.search(ka["req"], oracle_mod.SearchOptions(dist=ka["dist"])))
