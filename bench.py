@@ -60,6 +60,48 @@ def cpu_baseline(n_docs_sample):
                       % (n_docs_sample, text.size / 1e6, dt)}
 
 
+def query_bench(ix, n_single, n_and3, cpu_sample, img=None, lst=None):
+    """configs[1] query leg (10 k single-term queries over ranks 101..100k, Appendix F) plus a batch of
+    3-term AND queries (opt == null -> Dist = 255).  Device time of dcd_query_batch (HIP events), results
+    produced on the device; the D2H copy of the result arrays is excluded.  CPU: oracle, 1 thread, bounded."""
+    import docodo_amd
+    from docodo_amd import synth
+    T, A = docodo_amd.DCD_OP_TERM, docodo_amd.DCD_OP_AND
+    out = {}
+    for name, nq, nt in (("single_term", n_single, 1), ("and3", n_and3, 3)):
+        ranks = synth.query_ranks(nq, nt)
+        prog, off, npost, words = [], [0], 0, []
+        for row in ranks:
+            ws = [synth.term(int(k)) for k in row]
+            ts = [ix.find(w) for w in ws]
+            if any(t is None for t in ts):
+                continue
+            for k, (w, t) in enumerate(zip(ws, ts)):
+                prog += [T, t, 255 + len(w)]
+                npost += ix.term_count(t)
+                if k:
+                    prog.append(A)
+            off.append(len(prog))
+            words.append(ts)
+        prog, off = np.array(prog, np.int32), np.array(off, np.uint64)
+        ix.query_batch(prog[:off[min(8, off.size - 1)]], off[:min(9, off.size)], keep_handle=True)   # warm-up (decodes the index once)
+        ms = min(ix.query_batch(prog, off, keep_handle=True) for _ in range(3))
+        nq_eff = off.size - 1
+        out[name] = {"queries": nq_eff, "postings_in": int(npost), "device_ms": round(ms, 3),
+                     "queries_per_s": round(nq_eff / (ms / 1e3), 0), "gpostings_per_s": round(npost / 1e9 / (ms / 1e3), 2)}
+        if cpu_sample and img is not None:
+            import oracle
+            oix = oracle.Index(stemmers=[])
+            oix.load(img, lst)
+            k = min(cpu_sample, nq_eff)
+            t0 = time.perf_counter()
+            oix.query_batch(prog[:off[k]], off[:k + 1])
+            dt = time.perf_counter() - t0
+            out[name]["cpu_baseline_queries_per_s"] = round(k / dt, 1)
+            out[name]["cpu_baseline_sample"] = "first %d queries, oracle 1 thread, %.1f s" % (k, dt)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -67,6 +109,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--docs", type=int, default=1_000_000, help="documents per GPU (1 KiB each)")
     ap.add_argument("--cpu-docs", type=int, default=200_000, help="documents in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--queries", type=int, default=10_000, help="single-term queries of configs[1] (0 = skip the query leg)")
+    ap.add_argument("--and3", type=int, default=2_000, help="3-term AND queries in the extra query batch")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -172,6 +216,14 @@ def main():
             out["config"]["exchange"] = "RCCL all-to-all of per-term segments (meta, keys, units) to owner = hash(key) % world, then dcd_merge_shards"
         if world == 1 and args.cpu_docs > 0:
             out["cpu_baseline"] = cpu_baseline(min(args.cpu_docs, D))
+        if world == 1 and args.queries > 0:
+            # query leg of configs[1], outside the timed build steps
+            bq, _ = step()
+            img, lst = (bq.index_image(), bq.list_image()) if args.cpu_docs > 0 else (None, None)
+            ixq = bq.Build()
+            out["queries"] = query_bench(ixq, args.queries, args.and3, 200 if args.cpu_docs > 0 else 0, img, lst)
+            ixq.close()
+            bq.close()
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

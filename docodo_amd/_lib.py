@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdocodo_hip.so")
+LIB_PATH = os.environ.get("DOCODO_HIP_LIB") or os.path.join(_HERE, "libdocodo_hip.so")   # override: A/B builds of the library
 
 DCD_OK = 0
 DCD_E_BADARG, DCD_E_OVERFLOW, DCD_E_IO, DCD_E_HIP, DCD_E_RCCL = -1, -2, -3, -4, -5

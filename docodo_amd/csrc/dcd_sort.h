@@ -21,7 +21,10 @@ namespace dcd {
 
 constexpr int RS_THREADS = 256;
 constexpr int RS_WAVES = RS_THREADS / 64;
-constexpr int RS_ROWS = 8;                          // 64-item rows per wave and tile
+#ifndef DCD_RS_ROWS
+#define DCD_RS_ROWS 8
+#endif
+constexpr int RS_ROWS = DCD_RS_ROWS;               // 64-item rows per wave and tile
 constexpr int RS_TILE = RS_THREADS * RS_ROWS;       // 2048 items
 constexpr int RS_MAX_BLOCKS = 2048;
 
