@@ -79,10 +79,146 @@ struct PoState {
   u32 ca, cb, last_first_excl;
 };
 
+// ---- sparse operands: galloping ----------------------------------------------------------------------
+// When one operand is much shorter than the other and the long one is sparse relative to absR, almost
+// every element of the long list lies in a chain of its own that cannot contain both operands.  Instead of
+// merging, every element s of the SHORT list finds its neighbourhood in the long list by binary search and
+// walks its gap chain outwards (the chain is the same set the merge would build: maximal runs of the union
+// with consecutive gaps <= absR); the first short-list element of a chain ("leader") emits the chain if it
+// satisfies the both-operands / ordered-prefix rule.  Exactly the same output as the streaming merge.
+constexpr u32 GAL_RATIO = 16;     // gallop when 16 * |short| <= |long|
+constexpr u32 GAL_CHUNK = 1024;   // short-list elements per workgroup iteration
+
+struct GalRec { u32 b_lo, d_hi; u32 c_hi, cnt; };   // L range [b_lo, d_hi) (relative to lbase), S range [i, c_hi]
+
+__device__ __forceinline__ u64 lower_bound_u64(const u64* __restrict__ a, u64 n, u64 v) {
+  u64 lo = 0, hi = n;
+  while (lo < hi) { u64 m = (lo + hi) >> 1; if (a[m] < v) lo = m + 1; else hi = m; }
+  return lo;
+}
+
+// merged, de-duplicated walk over S[si..se] and L[li..le); calls f(value) in ascending order
+template <typename F>
+__device__ __forceinline__ u32 gal_merge(const u64* __restrict__ Sv, u64 si, u64 se_incl, const u64* __restrict__ Lv, u64 li, u64 le, F f) {
+  u32 n = 0;
+  u64 i = si, j = li;
+  while (i <= se_incl || j < le) {
+    bool hs = i <= se_incl, hl = j < le;
+    u64 v;
+    if (hs && hl) {
+      u64 a = Sv[i], b = Lv[j];
+      if (a == b) { v = a; i++; j++; }
+      else if (a < b) { v = a; i++; }
+      else { v = b; j++; }
+    } else if (hs) { v = Sv[i++]; }
+    else { v = Lv[j++]; }
+    f(v);
+    n++;
+  }
+  return n;
+}
+
+// S = short operand (ns), L = long operand (nl); s_is_a: the short one is the LEFT operand of '*'
+__device__ void pair_gallop(const u64* __restrict__ Sv, u64 ns, const u64* __restrict__ Lv, u64 nl, bool s_is_a, u32 absR, bool ordered,
+                            u64* __restrict__ out, u64* __restrict__ out_count, u32* s_scan, u32* rec_lds /* >= GAL_CHUNK * 6 u32 */) {
+  const u32 tid = threadIdx.x;
+  __shared__ u64 g_cursor;
+  if (tid == 0) g_cursor = 0;
+  __syncthreads();
+  u64* r_b = reinterpret_cast<u64*>(rec_lds);                 // [GAL_CHUNK] first L index of the emitted part
+  u32* r_d = rec_lds + 2 * GAL_CHUNK;                         // [GAL_CHUNK] number of L elements emitted from r_b
+  u32* r_s0 = rec_lds + 3 * GAL_CHUNK;                        // [GAL_CHUNK] first S index emitted (relative to chunk base)
+  u32* r_s1 = rec_lds + 4 * GAL_CHUNK;                        // [GAL_CHUNK] last S index emitted (inclusive, absolute - i0)
+  u32* r_n = rec_lds + 5 * GAL_CHUNK;                         // [GAL_CHUNK] emitted values (0 = not a leader / nothing)
+  for (u64 i0 = 0; i0 < ns; i0 += GAL_CHUNK) {
+    const u32 cn = (u32)min((u64)GAL_CHUNK, ns - i0);
+    for (u32 k = tid; k < cn; k += blockDim.x) {
+      const u64 i = i0 + k;
+      const u64 s = Sv[i];
+      const u64 il = lower_bound_u64(Lv, nl, s);               // first L >= s
+      // left walk over the union
+      u64 a = i, b = il, cur = s;
+      for (;;) {
+        bool hs = a > 0, hl = b > 0;
+        if (!hs && !hl) break;
+        u64 cs = hs ? Sv[a - 1] : 0, cl = hl ? Lv[b - 1] : 0;
+        bool takeS = hs && (!hl || cs >= cl);
+        u64 cand = takeS ? cs : cl;
+        if (cur - cand > (u64)absR) break;
+        if (takeS) a--; else b--;
+        cur = cand;
+        if (a < i) break;   // an earlier short-list element is in this chain: not the leader
+      }
+      u32 n = 0;
+      u64 eb = 0, es0 = i, es1 = i;
+      u32 ed = 0;
+      if (a == i) {
+        // right walk
+        u64 c = i, d = il;
+        cur = s;
+        for (;;) {
+          bool hs = c + 1 < ns, hl = d < nl;
+          if (!hs && !hl) break;
+          u64 cs = hs ? Sv[c + 1] : 0, cl = hl ? Lv[d] : 0;
+          bool takeS = hs && (!hl || cs <= cl);
+          u64 cand = takeS ? cs : cl;
+          if (cand - cur > (u64)absR) break;
+          if (takeS) c++; else d++;
+          cur = cand;
+        }
+        // chain = S[i..c] u L[b..d)
+        u64 lb = b, ld = d, sb = i;
+        bool ok = d > b;                                      // needs an element of the long operand
+        if (ok && ordered) {
+          if (s_is_a) {                                       // first A element = s: drop L elements before it
+            lb = il;
+            ok = d > il;                                      // a B element at or after the first A
+          } else {                                            // A is the long operand: first A = L[b]
+            u64 fa = Lv[b];
+            while (sb <= c && Sv[sb] < fa) sb++;             // drop B-only prefix
+            ok = sb <= c;
+          }
+        }
+        if (ok) {
+          eb = lb; ed = (u32)(ld - lb); es0 = sb; es1 = c;
+          n = gal_merge(Sv, sb, c, Lv, lb, ld, [](u64) {});
+        }
+      }
+      r_b[k] = eb; r_d[k] = ed; r_s0[k] = (u32)(es0 - i0); r_s1[k] = (u32)(es1 - i0); r_n[k] = n;
+    }
+    __syncthreads();
+    // offsets: scan r_n over the chunk (GAL_CHUNK / blockDim per thread, blocked)
+    constexpr u32 PER = GAL_CHUNK / PO_THREADS;
+    u32 mine = 0;
+    for (u32 q = 0; q < PER; q++) { u32 k = tid * PER + q; if (k < cn) mine += r_n[k]; }
+    u32 total;
+    u32 ex = block_scan_excl<u32, PO_THREADS / 64>(mine, s_scan, &total);
+    const u64 base = g_cursor;
+    for (u32 q = 0; q < PER; q++) {
+      u32 k = tid * PER + q;
+      if (k < cn && r_n[k]) {
+        u64 o = base + ex;
+        gal_merge(Sv, i0 + r_s0[k], i0 + r_s1[k], Lv, r_b[k], r_b[k] + r_d[k], [&](u64 v) { out[o++] = v; });
+        ex += r_n[k];
+      }
+    }
+    __syncthreads();
+    if (tid == 0) g_cursor = base + total;
+    __syncthreads();
+  }
+  if (tid == 0) *out_count = g_cursor;
+  __syncthreads();
+}
+
 __global__ __launch_bounds__(PO_THREADS) void k_pair_ops(const PairOp* __restrict__ ops, u32 n_ops, const u64* __restrict__ idx_values,
                                                         u64* __restrict__ pool, u64* __restrict__ counts) {
-  __shared__ u64 sA[PO_TILE], sB[PO_TILE];
-  __shared__ u32 s_firstA[PO_TILE + 2], s_hasEB[PO_TILE + 2];
+  // one LDS arena, used either by the streaming merge (sA, sB, s_firstA, s_hasEB) or by the gallop records
+  __shared__ __attribute__((aligned(16))) u32 s_raw[GAL_CHUNK * 6 + 16];
+  u64* sA = reinterpret_cast<u64*>(s_raw);
+  u64* sB = sA + PO_TILE;
+  u32* s_firstA = s_raw + 4 * PO_TILE;
+  u32* s_hasEB = s_firstA + PO_TILE + 4;
+  u32* s_gal = s_raw;
   __shared__ u32 s_scan[PO_THREADS / 64 + 1];
   __shared__ PoState S;
   const u32 tid = threadIdx.x;
@@ -96,6 +232,17 @@ __global__ __launch_bounds__(PO_THREADS) void k_pair_ops(const PairOp* __restric
     const u32 absR = (u32)max(abs(op.Ra), abs(op.Rb));
     const bool ordered = op.Ra < 0 && op.Rb < 0 && absR != 0;   // R = -absR < 0  (IndexSequence.cs:221-222)
     const bool is_or = op.op == DCD_OP_OR;
+    // sparse, skewed operands: gallop from the short side (block-uniform decision)
+    if (!is_or && absR != 0 && na && nb) {
+      const bool a_short = na <= nb;
+      const u64 ns = a_short ? na : nb, nl = a_short ? nb : na;
+      const u64* Sv = a_short ? A : B;
+      const u64* Lv = a_short ? B : A;
+      if (ns * GAL_RATIO <= nl && (Lv[nl - 1] - Lv[0]) / nl > 4ull * absR) {
+        pair_gallop(Sv, ns, Lv, nl, a_short, absR, ordered, out, &counts[op.out_cnt_ref], s_scan, s_gal);
+        continue;
+      }
+    }
     if (tid == 0) {
       S.ia = S.ib = S.cursor = S.out_start = S.prev_val = 0;
       S.have_prev = S.prev_src = S.open = S.committed = S.seenA = S.seenEB = 0;
@@ -247,12 +394,19 @@ struct ResParams {
   u64 n_pages;
   u32 max_pages, max_docs;
   float doc_mult;
+  u32 uniform_chars;     // != 0: page p ends at uniform_base + (p + 1) * uniform_chars
+  u64 uniform_base;
 };
 struct QCounts { u64 n_pages, n_pos, n_docs; int32_t status; u32 pad; };
 
 constexpr int RS_T = 256;
 
 __device__ __forceinline__ u64 page_of(const ResParams& P, u64 c) {  // first page with end > c
+  if (P.uniform_chars) {
+    if (c < P.uniform_base + P.uniform_chars) return 0;   // everything below the first page end belongs to page 0
+    u64 p = (c - P.uniform_base) / P.uniform_chars;
+    return p < P.n_pages ? p : P.n_pages;
+  }
   u64 a = 0, b = P.n_pages;
   while (a < b) { u64 m = (a + b) >> 1; if (P.page_end[m] > c) b = m; else a = m + 1; }
   return a;
@@ -459,6 +613,8 @@ static int32_t make_res_params(dcd_index* h, const dcd_query_opts& o, PageDev& p
   P->doc_mult = o.doc_rank_multiply;
   P->page_doc = nullptr;
   P->page_hdr = nullptr;
+  P->uniform_chars = pt.uniform ? (u32)pt.uni_chars : 0u;
+  P->uniform_base = pt.uniform ? pt.uni_base : 0ull;
   if (np && !ix.page_end.p) {
     std::vector<u64> e(np);
     for (u64 p = 0; p < np; p++) e[p] = pt.end_at(p);

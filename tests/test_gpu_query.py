@@ -17,7 +17,10 @@ def _ops_cases():
     cases = []
     for na, nb, ga, gb in [(0, 0, 10, 10), (0, 5, 10, 10), (7, 0, 10, 10), (1, 1, 5, 5), (50, 60, 40, 30), (1000, 1200, 300, 250),
                            (5000, 300, 50, 4000), (3000, 3000, 3, 3), (20000, 17000, 700, 900), (4096, 4096, 2, 2),
-                           (100000, 2500, 60, 2400)]:
+                           (100000, 2500, 60, 2400),
+                           # sparse + skewed: the galloping path (16 |short| <= |long|, mean gap of the long list > 4 absR)
+                           (300, 30000, 300000, 3000), (20000, 700, 2000, 60000), (5, 4000, 9000000, 12000), (1, 2000, 10, 5000),
+                           (1500, 60000, 40, 1500)]:
         a, b = _rand_seq(rng, na, ga), _rand_seq(rng, nb, gb)
         # force shared values (double-tagged elements)
         if na and nb:
