@@ -14,7 +14,10 @@
 
 namespace dcd {
 
-constexpr u32 MAX_CODE_LEN = 63;  // explicit index codes (Builder.Add); text tokens are <= 32
+constexpr u32 MAX_CODE_LEN = 63;
+#ifndef DCD_CAPDIV
+#define DCD_CAPDIV 64
+#endif  // explicit index codes (Builder.Add); text tokens are <= 32
 
 // ================================================================================================
 // kernels
@@ -52,13 +55,12 @@ __global__ __launch_bounds__(TK_THREADS) void k_tok_emit(const CharT* __restrict
   const u64 tile_start = (u64)blockIdx.x * TK_TILE;
   const u64 obase = tile_off[blockIdx.x];
   constexpr u32 CS = sizeof(CharT);
-  constexpr u64 LDS_TXT_BYTES = (u64)(TK_TILE + TK_HALO * TK_CPT) * CS + 16;
   for (u32 k = threadIdx.x; k < total; k += TK_THREADS) {
     const u32 t = S.tok[k];
     const u32 i = t & 0xFFFFu, len = t >> 16;
     const u32 nbytes = len * CS, nw = (nbytes + 3u) >> 2;
     const u32* txt = S.txt;
-    auto word = [txt, i, nbytes](u32 q) -> u32 { return str_word(txt, (u64)i * CS, q, LDS_TXT_BYTES) & tail_mask(nbytes, q); };
+    auto word = [txt, i, nbytes](u32 q) -> u32 { return lds_word(txt, i * CS, q) & tail_mask(nbytes, q); };
     HashState hs;
     hs.init(len);
     for (u32 q = 0; q < nw; q++) hs.add(word(q));
@@ -630,8 +632,9 @@ static int32_t finish_impl(dcd_build* h) {
   DCD_TRY(tupB.alloc(dev, N ? N : 1));
   u32 cap_log2 = h->opts.vocab_capacity_log2;
   if (cap_log2 == 0) {
-    // first guess: one slot per 16 postings (grown x4 and the emit re-run if the load exceeds 1/2)
-    cap_log2 = log2_ceil((N ? N : 1) / 16 + 1);
+    // first guess: one slot per 64 postings -- small enough to stay close to the caches (every probe of a
+    // tail term is a random access); grown x4 and the emit re-run if the load exceeds 1/2
+    cap_log2 = log2_ceil((N ? N : 1) / DCD_CAPDIV + 1);
     if (cap_log2 < 12) cap_log2 = 12;
     if (cap_log2 > 24) cap_log2 = 24;
   }

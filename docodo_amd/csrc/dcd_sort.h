@@ -26,7 +26,10 @@ constexpr int RS_WAVES = RS_THREADS / 64;
 #endif
 constexpr int RS_ROWS = DCD_RS_ROWS;               // 64-item rows per wave and tile
 constexpr int RS_TILE = RS_THREADS * RS_ROWS;       // 2048 items
-constexpr int RS_MAX_BLOCKS = 2048;
+#ifndef DCD_RS_MAX_BLOCKS
+#define DCD_RS_MAX_BLOCKS 2048
+#endif
+constexpr int RS_MAX_BLOCKS = DCD_RS_MAX_BLOCKS;
 
 struct RsPlan {
   u64 n;

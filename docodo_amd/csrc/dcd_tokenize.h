@@ -184,6 +184,11 @@ __device__ __forceinline__ u32 str_word(const u32* __restrict__ base, u64 off, u
   u32 hi = ((a + 1) << 2) < n_bytes ? base[a + 1] : 0u;
   return __builtin_amdgcn_alignbyte(hi, lo, sh);
 }
+// same for an LDS array (32-bit offsets, the array is padded so the second word always exists)
+__device__ __forceinline__ u32 lds_word(const u32* base, u32 off, u32 k) {
+  u32 a = (off >> 2) + k;
+  return __builtin_amdgcn_alignbyte(base[a + 1], base[a], off & 3u);
+}
 __device__ __forceinline__ u32 tail_mask(u32 nbytes, u32 k) {  // mask of word k of an nbytes-long string
   u32 rem = nbytes - 4u * k;
   return rem >= 4u ? 0xFFFFFFFFu : ((1u << (8u * rem)) - 1u);
@@ -352,8 +357,10 @@ __device__ __forceinline__ void tokenize_chunk(const CharT* __restrict__ text, c
     if (b0 & 31) pgw |= (u64)S.pg[(b0 >> 5) + 2] << (64 - (b0 & 31));
     bnd |= pgw;
   } else {
+    // segment < 2^32 characters: 32-bit arithmetic; power-of-two page sizes need no division
     const u32 Sz = P.uniform_page_chars;
-    u32 r = (u32)(g0 % Sz);
+    const u32 g32 = (u32)g0;
+    u32 r = (Sz & (Sz - 1u)) == 0u ? (g32 & (Sz - 1u)) : (g32 % Sz);
     for (u32 o = r ? Sz - r : 0u; o < 64u; o += Sz) bnd |= 1ull << o;
   }
   u32 starts = (u32)(bnd & (L64 | D64)) & 0xFFFFu;
