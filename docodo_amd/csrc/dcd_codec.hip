@@ -57,13 +57,16 @@ __global__ void k_add_inplace(u64* __restrict__ excl, const u64* __restrict__ de
 
 __global__ __launch_bounds__(CODEC_THREADS) void k_pack_write(EncSrcPairs src, u64 n, const u64* __restrict__ partial, u16* __restrict__ out) {
   __shared__ u32 lds[5];
-  __shared__ union { uint2 pairs[CODEC_TILE + 1]; u16 units[CODEC_TILE * 5]; } sh;
+  // pairs are read back in blocked order (lane t reads elements 8t .. 8t+8): one element of padding per
+  // 8 keeps those 64-bit LDS reads conflict-free (stride 72 B instead of 64 B)
+  __shared__ union { uint2 pairs[(CODEC_TILE + 1) + (CODEC_TILE + 1) / 8 + 1]; u16 units[CODEC_TILE * 5]; } sh;
+  auto pad = [](u32 k) -> u32 { return k + (k >> 3); };
   const u64 t0 = (u64)blockIdx.x * CODEC_TILE;
   const u32 cnt = (u32)min((u64)CODEC_TILE, n - t0);
   // pairs[0] = item before the tile
   for (u32 k = threadIdx.x; k < cnt + 1; k += CODEC_THREADS) {
     u64 i = t0 + k;   // pairs[k] = p[i - 1]
-    sh.pairs[k] = i ? src.p[i - 1] : make_uint2(0xFFFFFFFFu, 0u);
+    sh.pairs[pad(k)] = i ? src.p[i - 1] : make_uint2(0xFFFFFFFFu, 0u);
   }
   __syncthreads();
   u64 d[CODEC_ITEMS];
@@ -76,7 +79,7 @@ __global__ __launch_bounds__(CODEC_THREADS) void k_pack_write(EncSrcPairs src, u
     u32 li = l0 + j;
     d[j] = 0; nu[j] = 0; term[j] = 0; hd[j] = false;
     if (li < cnt) {
-      uint2 q = sh.pairs[li], c = sh.pairs[li + 1];
+      uint2 q = sh.pairs[pad(li)], c = sh.pairs[pad(li + 1)];
       hd[j] = (t0 + li == 0) || q.x != c.x;
       term[j] = c.x;
       d[j] = hd[j] ? src.base + c.y : (u64)c.y - (u64)q.y;

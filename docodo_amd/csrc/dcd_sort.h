@@ -58,9 +58,32 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const uint2* __restrict_
   __syncthreads();
   const u32 w = threadIdx.x >> 6;
   u64 beg = (u64)blockIdx.x * ipb, end = beg + ipb < n ? beg + ipb : n;
-  for (u64 i = beg + threadIdx.x; i < end; i += RS_THREADS) {
-    u32 d = (rs_key(in[i].x, remap) >> shift) & (NB - 1);
-    atomicAdd(&h[w][d], 1u);
+  // Zipf keys: a plain per-item LDS atomic serialises on the hot digit (13.5 % of all items carry the
+  // top term).  Lanes holding the same digit are found with 64-lane ballots (match-any) and only the
+  // lowest of them adds the group's size.  Four independent loads are issued before the first use so a
+  // wave keeps several HBM requests in flight.
+  constexpr int UN = 4;
+  const u64 span = end > beg ? end - beg : 0;
+  for (u64 o = 0; o < span; o += (u64)RS_THREADS * UN) {
+    u32 key[UN];
+    bool valid[UN];
+#pragma unroll
+    for (int u = 0; u < UN; u++) {
+      u64 i = beg + o + (u64)u * RS_THREADS + threadIdx.x;
+      valid[u] = i < end;
+      key[u] = valid[u] ? in[i].x : 0u;
+    }
+#pragma unroll
+    for (int u = 0; u < UN; u++) {
+      u32 d = valid[u] ? (rs_key(key[u], remap) >> shift) & (NB - 1) : 0u;
+      u64 peers = ballot64(valid[u]);
+#pragma unroll
+      for (int b = 0; b < BITS; b++) {
+        u64 m = ballot64((d >> b) & 1u);
+        peers &= ((d >> b) & 1u) ? m : ~m;
+      }
+      if (valid[u] && mbcnt(peers) == 0) atomicAdd(&h[w][d], popc64(peers));
+    }
   }
   __syncthreads();
   for (int d = threadIdx.x; d < NB; d += RS_THREADS) {

@@ -181,3 +181,25 @@ def test_explicit_postings_builder_api(oracle_mod, known):
     b.Finish()
     assert b.list_image() == ol
     assert b.index_image() == oi
+
+
+def test_vocabulary_table_growth(oracle_mod):
+    """Every token distinct: the vocabulary hash table starts far too small (one slot per 64 postings) and
+    must be re-grown (x4 per round, emit re-run) until the load drops below 1/2 -- results stay exact."""
+    import docodo_amd
+
+    def word(k):
+        s = ""
+        for _ in range(5):
+            s += chr(97 + k % 26)
+            k //= 26
+        return s
+
+    n = 150_000
+    text = " ".join(word(k) for k in range(n))
+    pages = [text[i:i + 50_000] for i in range(0, len(text), 50_000)]
+    (oi, ol), ob = _oracle_images(oracle_mod, pages, docs=[("s", "d", len(pages))], ids=[str(i + 1) for i in range(len(pages))])
+    (gi, gl), gb, st = _gpu_images(pages, docs=[("s", "d", len(pages))], ids=[str(i + 1) for i in range(len(pages))])
+    assert st.n_terms == ob.n_terms and st.n_terms > 100_000
+    assert st.vocab_capacity_log2 >= 18
+    assert gi == oi and gl == ol
