@@ -42,6 +42,21 @@ def algorithmic_bytes(kernel, T, N, U):
     }.get(kernel, 0)
 
 
+def measured_traffic(kernel, T, N, U):
+    """HBM bytes per launch from the PMC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes,
+    stored in profiles/r01_final_traffic.json; FETCH_SIZE doubled per the gfx950 correction of
+    MI355X_MICROARCH.md).  Only valid for the configuration it was measured on; None otherwise."""
+    path = os.path.join(ROOT, "profiles", "r01_final_traffic.json")
+    if not os.path.exists(path):
+        return None
+    tr = json.load(open(path))
+    if (tr.get("T"), tr.get("N"), tr.get("U")) != (T, N, U):
+        return None
+    names = {"k_rs_scatter": "k_rs_scatter<9>", "k_rs_hist": "k_rs_hist<9>", "k_enc_write": "k_pack_write"}
+    k = tr["kernels"].get(names.get(kernel, kernel))
+    return None if k is None else int(k["fetch_bytes_x2"] + k["write_bytes"])
+
+
 def cpu_baseline(n_docs_sample):
     """Reference-faithful CPU restatement (oracle/, single thread) on a bounded sample of the same
     corpus: text bytes / (index + serialise) seconds.  Baseline, not the target."""
@@ -204,7 +219,9 @@ def main():
             "roofline": {"bound": "hbm", "kernel": name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "frac_of_measured_copy": round(achieved / HBM_COPY_GBS, 4),
                          "algorithmic_bytes_per_launch": int(abytes), "avg_launch_ms": round(avg_ms, 4),
-                         "launches_per_step": round(kcnt[dom] / args.steps, 2), "traffic": None},
+                         "launches_per_step": round(kcnt[dom] / args.steps, 2), "traffic": measured_traffic(name, T, int(N), int(U))},
+            "roofline_all": {KERNEL_NAMES[k]: round(algorithmic_bytes(KERNEL_NAMES[k], T, N, U) / 1e9 /
+                                                    (max(ksum[k], 1e-9) / max(1.0, kcnt[k]) / 1e3) / HBM_PEAK_GBS, 4) for k in range(7)},
             "device_ms_per_step": {"tokenize": round(stage[0] / args.steps, 3), "vocab": round(stage[1] / args.steps, 3),
                                    "sort": round(stage[2] / args.steps, 3), "pack": round(stage[3] / args.steps, 3),
                                    "image": round(stage[4] / args.steps, 3), "total": round(stage[5] / args.steps, 3)},
