@@ -49,10 +49,10 @@ __global__ __launch_bounds__(TK_THREADS) void k_tok_emit(const CharT* __restrict
     u32 j = (u32)__builtin_ctz(m);
     m &= m - 1;
     u32 len = (u32)__builtin_ctzll(bnd >> (j + 1)) + 1u;
-    S.tok[ex++] = (threadIdx.x * TK_CPT + j) | (len << 16);
+    S.tok[ex++] = (threadIdx.x * TK_CPT + j) | (len << 16);   // staged position
   }
   __syncthreads();
-  const u64 tile_start = (u64)blockIdx.x * TK_TILE;
+  const int64_t org = tile_origin(blockIdx.x);
   const u64 obase = tile_off[blockIdx.x];
   constexpr u32 CS = sizeof(CharT);
   for (u32 k = threadIdx.x; k < total; k += TK_THREADS) {
@@ -64,7 +64,7 @@ __global__ __launch_bounds__(TK_THREADS) void k_tok_emit(const CharT* __restrict
     HashState hs;
     hs.init(len);
     for (u32 q = 0; q < nw; q++) hs.add(word(q));
-    const u64 gpos = tile_start + i;
+    const u64 gpos = (u64)(org + (int64_t)i);
     u32 slot = vocab_lookup_insert<CharT>(vt, tv, hs.fin(), len, gpos, word);
     u32 coord = (u32)gpos;
     if (P.n_runs) {

@@ -23,11 +23,18 @@
 
 namespace dcd {
 
+// Geometry: every one of the 256 lanes loads exactly ONE 16-character chunk.  Lane 0 holds the chunk
+// before the tile (only the class of its last character is used), lanes 1..251 own the tile's chunks,
+// lanes 252..255 hold the look-ahead (a token may run 32 characters past its start).  Tiles therefore
+// advance by 251 * 16 = 4016 characters and no lane ever runs the classification code twice.
 constexpr int TK_THREADS = 256;
 constexpr int TK_CPT = 16;                       // characters per lane
-constexpr int TK_TILE = TK_THREADS * TK_CPT;     // 4096
+constexpr int TK_PRE = 1;                        // chunks before the tile
 constexpr int TK_HALO = 4;                       // look-ahead chunks after the tile (>= 33 characters)
-constexpr int TK_MASKS = TK_THREADS + TK_HALO + 1 + 11;  // slot 0 = chunk before the tile; padded
+constexpr int TK_OWN = TK_THREADS - TK_PRE - TK_HALO;   // 251 chunks
+constexpr int TK_TILE = TK_OWN * TK_CPT;         // 4016 characters per tile
+constexpr int TK_SPAN = TK_THREADS * TK_CPT;     // 4096 characters staged per tile
+constexpr int TK_MASKS = TK_THREADS + 8;
 constexpr int TK_MAXTOK = TK_TILE / 2 + 1;       // tokens of length 1 separated by one character
 
 // vocabulary slot word: [63:48] tag  [47:42] length (1..63)  [41:0] position of the canonical occurrence
@@ -47,10 +54,11 @@ __device__ __forceinline__ u32 swar_eq7(u32 x7, u32 k) {   // bit7 set where the
   u32 y = x7 ^ k;
   return ~((y + 0x7F7F7F7Fu) | y) & 0x80808080u;
 }
+template <bool LATIN = true>
 __device__ __forceinline__ u32 swar_lower4(u32 w) {
   const u32 hi = w & 0x80808080u, x = w & 0x7F7F7F7Fu;
   u32 up = ((x + 0x3F3F3F3Fu) & ~(x + 0x25252525u)) & 0x80808080u & ~hi;        // 'A'..'Z'
-  if (hi) {
+  if (LATIN && hi) {
     u32 lat = ((x + 0x40404040u) & ~(x + 0x21212121u)) & hi;                    // 0xC0..0xDE
     u32 y = x ^ 0x57575757u;                                                    // except 0xD7
     up |= lat & (((y + 0x7F7F7F7Fu) | y) & 0x80808080u);
@@ -58,11 +66,12 @@ __device__ __forceinline__ u32 swar_lower4(u32 w) {
   return w + (up >> 2);  // + 0x20 where upper case
 }
 // class flags of already lower-cased bytes: *Lf letters, *Df numbers (bit 7 per byte)
+template <bool LATIN = true>
 __device__ __forceinline__ void swar_class4(u32 lw, u32* Lf, u32* Df) {
   const u32 hi = lw & 0x80808080u, x = lw & 0x7F7F7F7Fu;
   u32 L = ((x + 0x1F1F1F1Fu) & ~(x + 0x05050505u)) & 0x80808080u & ~hi;         // 'a'..'z'
   u32 D = ((x + 0x50505050u) & ~(x + 0x46464646u)) & 0x80808080u & ~hi;         // '0'..'9'
-  if (hi) {
+  if (LATIN && hi) {
     u32 y = x ^ 0x77777777u;                                                    // >= 0xDF except 0xF7
     L |= (x + 0x21212121u) & hi & (((y + 0x7F7F7F7Fu) | y) & 0x80808080u);
     L |= (swar_eq7(x, 0x2A2A2A2Au) | swar_eq7(x, 0x35353535u) | swar_eq7(x, 0x3A3A3A3Au)) & hi;   // ª µ º
@@ -90,8 +99,9 @@ struct Chunk<u8> {
   static constexpr int NW = 4;
   u32 w[NW];
   u32 L, D;
-  __device__ __forceinline__ void load(const u8* __restrict__ text, int64_t g0, u64 n_chars, const CharTables16&) {
-    if (g0 >= 0 && (u64)g0 + TK_CPT <= n_chars) {
+  // `inside`: the whole staged span of the tile lies inside the text (workgroup-uniform) -> no guards
+  __device__ __forceinline__ void load(const u8* __restrict__ text, int64_t g0, u64 n_chars, const CharTables16&, bool inside) {
+    if (inside || (g0 >= 0 && (u64)g0 + TK_CPT <= n_chars)) {
       uint4 v = *reinterpret_cast<const uint4*>(text + g0);
       w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
     } else {
@@ -107,13 +117,25 @@ struct Chunk<u8> {
       }
     }
     L = D = 0;
+    // pure-ASCII waves (the common case) skip the Latin-1 ranges with ONE wave-uniform branch
+    if (__any(((w[0] | w[1] | w[2] | w[3]) & 0x80808080u) != 0u)) {
 #pragma unroll
-    for (int k = 0; k < NW; k++) {
-      w[k] = swar_lower4(w[k]);
-      u32 lf, df;
-      swar_class4(w[k], &lf, &df);
-      L |= swar_nibble(lf) << (4 * k);
-      D |= swar_nibble(df) << (4 * k);
+      for (int k = 0; k < NW; k++) {
+        w[k] = swar_lower4<true>(w[k]);
+        u32 lf, df;
+        swar_class4<true>(w[k], &lf, &df);
+        L |= swar_nibble(lf) << (4 * k);
+        D |= swar_nibble(df) << (4 * k);
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < NW; k++) {
+        w[k] = swar_lower4<false>(w[k]);
+        u32 lf, df;
+        swar_class4<false>(w[k], &lf, &df);
+        L |= swar_nibble(lf) << (4 * k);
+        D |= swar_nibble(df) << (4 * k);
+      }
     }
   }
 };
@@ -123,8 +145,8 @@ struct Chunk<u16> {
   static constexpr int NW = 8;
   u32 w[NW];
   u32 L, D;
-  __device__ __forceinline__ void load(const u16* __restrict__ text, int64_t g0, u64 n_chars, const CharTables16& tab) {
-    if (g0 >= 0 && (u64)g0 + TK_CPT <= n_chars) {
+  __device__ __forceinline__ void load(const u16* __restrict__ text, int64_t g0, u64 n_chars, const CharTables16& tab, bool inside) {
+    if (inside || (g0 >= 0 && (u64)g0 + TK_CPT <= n_chars)) {
       const uint4* q = reinterpret_cast<const uint4*>(text + g0);
       uint4 a = q[0], b = q[1];
       w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
@@ -215,7 +237,7 @@ struct TextView {
   __device__ __forceinline__ u32 canon_word(u64 pos, u32 k) const {
     if (pos < n_chars) {
       u32 w = str_word(reinterpret_cast<const u32*>(text), pos * sizeof(CharT), k, n_chars * sizeof(CharT));
-      if (sizeof(CharT) == 1) return swar_lower4(w);
+      if (sizeof(CharT) == 1) return swar_lower4<true>(w);
       return (u32)tab.lower[w & 0xFFFFu] | ((u32)tab.lower[w >> 16] << 16);
     }
     return str_word(reinterpret_cast<const u32*>(pool), (pos - n_chars) * sizeof(CharT), k, n_pool * sizeof(CharT));
@@ -277,100 +299,83 @@ struct TokParams {
 
 template <typename CharT, bool STAGE_TEXT>
 struct TokLds {
-  u16 Lm[TK_MASKS];                                              // letter mask per chunk (slot = chunk + 1)
-  u16 Dm[TK_MASKS];                                              // number mask per chunk
-  u32 pg[(TK_TILE + TK_HALO * TK_CPT) / 32 + 3];                 // page-start bitmask (non-uniform pages)
+  u16 Lm[TK_MASKS];                                              // letter mask per staged chunk (index = lane)
+  u16 Dm[TK_MASKS];                                              // number mask per staged chunk
+  u32 pg[TK_SPAN / 32 + 3];                                      // page-start bitmask (non-uniform pages)
   u32 scan[TK_THREADS / 64 + 1];
-  u32 txt[STAGE_TEXT ? (TK_TILE + TK_HALO * TK_CPT) * sizeof(CharT) / 4 + 4 : 1];  // lower-cased text
-  u32 tok[STAGE_TEXT ? TK_MAXTOK : 1];                           // kept tokens: tile position | len << 16
+  u32 txt[STAGE_TEXT ? TK_SPAN * sizeof(CharT) / 4 + 4 : 1];     // lower-cased staged text (index 0 = staged position 0)
+  u32 tok[STAGE_TEXT ? TK_MAXTOK : 1];                           // kept tokens: staged position | len << 16
 };
 
-// After this call: `keep` = 16-bit mask of kept token starts in this lane's chunk, `bnd` = 64-bit
-// boundary window whose bit 0 is the first character of the chunk.  Contains one __syncthreads
-// (two with a general page table).
+// staged position p of tile t  <->  text index  t * TK_TILE - TK_PRE * TK_CPT + p
+__device__ __forceinline__ int64_t tile_origin(u64 tile) { return (int64_t)(tile * TK_TILE) - TK_PRE * TK_CPT; }
+
+// After this call: `keep` = 16-bit mask of kept token starts in this lane's chunk (0 for the lanes that
+// only hold context), `bnd` = 64-bit boundary window whose bit 0 is the first character of the chunk.
+// Contains one __syncthreads (two with a general page table).
 template <typename CharT, bool STAGE_TEXT>
 __device__ __forceinline__ void tokenize_chunk(const CharT* __restrict__ text, const TokParams& P, const CharTables16& tab, u64 tile,
                                                TokLds<CharT, STAGE_TEXT>& S, u32* keep_out, u64* bnd_out) {
   const u32 tid = threadIdx.x;
-  const u64 tile_start = tile * TK_TILE;
+  const int64_t org = tile_origin(tile);
+  const bool inside = org >= 0 && (u64)org + TK_SPAN <= P.n_chars;   // workgroup-uniform
   const bool general_pages = P.uniform_page_chars == 0;
   if (general_pages) {
-    for (u32 i = tid; i < (TK_TILE + TK_HALO * TK_CPT) / 32 + 3; i += TK_THREADS) S.pg[i] = 0;
+    for (u32 i = tid; i < TK_SPAN / 32 + 3; i += TK_THREADS) S.pg[i] = 0;
     __syncthreads();
-    // pages starting inside [tile_start, tile_start + TILE + HALO)
+    // pages starting inside the staged span
+    const u64 lo = org < 0 ? 0 : (u64)org;
     u64 a = 0, b = P.n_pages + 1;
-    while (a < b) { u64 m = (a + b) >> 1; if (P.page_off[m] < tile_start) a = m + 1; else b = m; }
+    while (a < b) { u64 m = (a + b) >> 1; if (P.page_off[m] < lo) a = m + 1; else b = m; }
     for (u64 p = a + tid; p <= P.n_pages; p += TK_THREADS) {
       u64 o = P.page_off[p];
-      if (o >= tile_start + TK_TILE + TK_HALO * TK_CPT) break;
-      u32 li = (u32)(o - tile_start);
+      if ((int64_t)o >= org + TK_SPAN) break;
+      u32 li = (u32)((int64_t)o - org);
       atomicOr(&S.pg[li >> 5], 1u << (li & 31));
     }
   }
+  const int64_t g0 = org + (int64_t)tid * TK_CPT;
   {
     Chunk<CharT> c;
-    c.load(text, (int64_t)(tile_start + (u64)tid * TK_CPT), P.n_chars, tab);
-    S.Lm[tid + 1] = (u16)c.L;
-    S.Dm[tid + 1] = (u16)c.D;
+    c.load(text, g0, P.n_chars, tab, inside);
+    S.Lm[tid] = (u16)c.L;
+    S.Dm[tid] = (u16)c.D;
     if (STAGE_TEXT) {
 #pragma unroll
       for (int k = 0; k < Chunk<CharT>::NW; k++) S.txt[tid * Chunk<CharT>::NW + k] = c.w[k];
     }
   }
-  if (tid < TK_HALO) {   // look-ahead chunks (wave 0 only)
-    Chunk<CharT> c;
-    c.load(text, (int64_t)(tile_start + TK_TILE + (u64)tid * TK_CPT), P.n_chars, tab);
-    S.Lm[TK_THREADS + 1 + tid] = (u16)c.L;
-    S.Dm[TK_THREADS + 1 + tid] = (u16)c.D;
-    if (STAGE_TEXT) {
-#pragma unroll
-      for (int k = 0; k < Chunk<CharT>::NW; k++) S.txt[(TK_THREADS + tid) * Chunk<CharT>::NW + k] = c.w[k];
-    }
-  }
-  if (tid == TK_HALO) {  // class of the character just before the tile
-    u32 Lb = 0, Db = 0;
-    if (tile_start > 0) {
-      u32 ch = (u32)text[tile_start - 1];
-      if (sizeof(CharT) == 1) {
-        u32 lf, df;
-        swar_class4(swar_lower4(ch), &lf, &df);
-        Lb = (lf >> 7) & 1u; Db = (df >> 7) & 1u;
-      } else {
-        u32 k = tab.cls[tab.lower[ch]];
-        Lb = k & 1u; Db = (k >> 1) & 1u;
-      }
-    }
-    S.Lm[0] = (u16)(Lb << 15);
-    S.Dm[0] = (u16)(Db << 15);
-  }
+  if (tid < 8) { S.Lm[TK_THREADS + tid] = 0; S.Dm[TK_THREADS + tid] = 0; }
   __syncthreads();
-  const u32 s = tid + 1;
-  const u64 L64 = (u64)S.Lm[s] | ((u64)S.Lm[s + 1] << 16) | ((u64)S.Lm[s + 2] << 32) | ((u64)S.Lm[s + 3] << 48);
-  const u64 D64 = (u64)S.Dm[s] | ((u64)S.Dm[s + 1] << 16) | ((u64)S.Dm[s + 2] << 32) | ((u64)S.Dm[s + 3] << 48);
-  const u64 pL = S.Lm[s - 1] >> 15, pD = S.Dm[s - 1] >> 15;
-  u64 bnd = (L64 ^ ((L64 << 1) | pL)) | (D64 ^ ((D64 << 1) | pD));
-  const u64 g0 = tile_start + (u64)tid * TK_CPT;
-  if (general_pages) {
-    u32 b0 = tid * TK_CPT;  // bit offset into S.pg, multiple of 16
-    u64 lo = ((u64)S.pg[(b0 >> 5) + 1] << 32) | S.pg[b0 >> 5];
-    u64 pgw = lo >> (b0 & 31);
-    if (b0 & 31) pgw |= (u64)S.pg[(b0 >> 5) + 2] << (64 - (b0 & 31));
-    bnd |= pgw;
-  } else {
-    // segment < 2^32 characters: 32-bit arithmetic; power-of-two page sizes need no division
-    const u32 Sz = P.uniform_page_chars;
-    const u32 g32 = (u32)g0;
-    u32 r = (Sz & (Sz - 1u)) == 0u ? (g32 & (Sz - 1u)) : (g32 % Sz);
-    for (u32 o = r ? Sz - r : 0u; o < 64u; o += Sz) bnd |= 1ull << o;
-  }
-  u32 starts = (u32)(bnd & (L64 | D64)) & 0xFFFFu;
   u32 keep = 0;
-  for (u32 m = starts; m;) {
-    u32 j = (u32)__builtin_ctz(m);
-    m &= m - 1;
-    u64 rest = bnd >> (j + 1);
-    u32 len = rest ? (u32)__builtin_ctzll(rest) + 1u : 99u;
-    if (len >= P.min_len && len <= P.max_len) keep |= 1u << j;
+  u64 bnd = 0;
+  if (tid >= TK_PRE && tid < TK_PRE + TK_OWN) {
+    const u32 s = tid;
+    const u64 L64 = (u64)S.Lm[s] | ((u64)S.Lm[s + 1] << 16) | ((u64)S.Lm[s + 2] << 32) | ((u64)S.Lm[s + 3] << 48);
+    const u64 D64 = (u64)S.Dm[s] | ((u64)S.Dm[s + 1] << 16) | ((u64)S.Dm[s + 2] << 32) | ((u64)S.Dm[s + 3] << 48);
+    const u64 pL = S.Lm[s - 1] >> 15, pD = S.Dm[s - 1] >> 15;
+    bnd = (L64 ^ ((L64 << 1) | pL)) | (D64 ^ ((D64 << 1) | pD));
+    if (general_pages) {
+      u32 b0 = tid * TK_CPT;  // bit offset into S.pg, multiple of 16
+      u64 lo = ((u64)S.pg[(b0 >> 5) + 1] << 32) | S.pg[b0 >> 5];
+      u64 pgw = lo >> (b0 & 31);
+      if (b0 & 31) pgw |= (u64)S.pg[(b0 >> 5) + 2] << (64 - (b0 & 31));
+      bnd |= pgw;
+    } else {
+      // segment < 2^32 characters: 32-bit arithmetic; power-of-two page sizes need no division
+      const u32 Sz = P.uniform_page_chars;
+      const u32 g32 = (u32)g0;   // g0 >= 0 for the owning lanes
+      u32 r = (Sz & (Sz - 1u)) == 0u ? (g32 & (Sz - 1u)) : (g32 % Sz);
+      for (u32 o = r ? Sz - r : 0u; o < 64u; o += Sz) bnd |= 1ull << o;
+    }
+    u32 starts = (u32)(bnd & (L64 | D64)) & 0xFFFFu;
+    for (u32 m = starts; m;) {
+      u32 j = (u32)__builtin_ctz(m);
+      m &= m - 1;
+      u64 rest = bnd >> (j + 1);
+      u32 len = rest ? (u32)__builtin_ctzll(rest) + 1u : 99u;
+      if (len >= P.min_len && len <= P.max_len) keep |= 1u << j;
+    }
   }
   *keep_out = keep;
   *bnd_out = bnd;
