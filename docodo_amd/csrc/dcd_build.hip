@@ -22,40 +22,47 @@ constexpr u32 MAX_CODE_LEN = 63;
 // ================================================================================================
 // kernels
 // ================================================================================================
+// One wave per 944-character tile; the four waves of a workgroup are independent (no s_barrier).
 template <typename CharT>
 __global__ __launch_bounds__(TK_THREADS) void k_tok_count(const CharT* __restrict__ text, TokParams P, CharTables16 tab,
-                                                         u32* __restrict__ tile_count) {
-  __shared__ TokLds<CharT, false> S;
+                                                         u32* __restrict__ tile_count, u64 n_tiles) {
+  __shared__ TokLds<CharT, false> SW[TK_WAVES];
+  const u64 tile = (u64)blockIdx.x * TK_WAVES + (threadIdx.x >> 6);
+  if (tile >= n_tiles) return;
   u32 keep;
   u64 bnd;
-  tokenize_chunk<CharT, false>(text, P, tab, blockIdx.x, S, &keep, &bnd);
+  tokenize_chunk<CharT, false>(text, P, tab, tile, SW[threadIdx.x >> 6], &keep, &bnd);
   u32 c = wave_sum((u32)__builtin_popcount(keep));
-  if (lane_id() == 0) S.scan[threadIdx.x >> 6] = c;
-  __syncthreads();
-  if (threadIdx.x == 0) tile_count[blockIdx.x] = S.scan[0] + S.scan[1] + S.scan[2] + S.scan[3];
+  if (lane_id() == 0) tile_count[tile] = c;
 }
 
 template <typename CharT>
 __global__ __launch_bounds__(TK_THREADS) void k_tok_emit(const CharT* __restrict__ text, TokParams P, CharTables16 tab,
                                                         TextView<CharT> tv, VocabTable vt, const u64* __restrict__ tile_off,
-                                                        uint2* __restrict__ tuples) {
-  __shared__ TokLds<CharT, true> S;
+                                                        uint2* __restrict__ tuples, u64 n_tiles) {
+  __shared__ TokLds<CharT, true> SW[TK_WAVES];
+  const u64 tile = (u64)blockIdx.x * TK_WAVES + (threadIdx.x >> 6);
+  if (tile >= n_tiles) return;
+  TokLds<CharT, true>& S = SW[threadIdx.x >> 6];
+  const u32 lane = lane_id();
   u32 keep;
   u64 bnd;
-  tokenize_chunk<CharT, true>(text, P, tab, blockIdx.x, S, &keep, &bnd);
-  u32 total;
-  u32 ex = block_scan_excl<u32, TK_THREADS / 64>((u32)__builtin_popcount(keep), S.scan, &total);
+  tokenize_chunk<CharT, true>(text, P, tab, tile, S, &keep, &bnd);
+  const u32 mine = (u32)__builtin_popcount(keep);
+  const u32 incl = wave_scan_incl(mine);
+  const u32 total = __shfl(incl, 63, 64);
+  u32 ex = incl - mine;
   for (u32 m = keep; m;) {
     u32 j = (u32)__builtin_ctz(m);
     m &= m - 1;
     u32 len = (u32)__builtin_ctzll(bnd >> (j + 1)) + 1u;
-    S.tok[ex++] = (threadIdx.x * TK_CPT + j) | (len << 16);   // staged position
+    S.tok[ex++] = (lane * TK_CPT + j) | (len << 16);   // staged position
   }
-  __syncthreads();
-  const int64_t org = tile_origin(blockIdx.x);
-  const u64 obase = tile_off[blockIdx.x];
+  wave_sync();
+  const int64_t org = tile_origin(tile);
+  const u64 obase = tile_off[tile];
   constexpr u32 CS = sizeof(CharT);
-  for (u32 k = threadIdx.x; k < total; k += TK_THREADS) {
+  for (u32 k = lane; k < total; k += 64) {
     const u32 t = S.tok[k];
     const u32 i = t & 0xFFFFu, len = t >> 16;
     const u32 nbytes = len * CS, nw = (nbytes + 3u) >> 2;
@@ -617,7 +624,8 @@ static int32_t finish_impl(dcd_build* h) {
     DCD_TRY(tile_off.alloc(dev, n_tiles));
     DCD_TRY(scan_scr64.alloc(dev, scan_scratch_elems(n_tiles)));
     probe_begin(DCD_K_TOK_COUNT);
-    hipLaunchKernelGGL((k_tok_count<CharT>), dim3((u32)n_tiles), dim3(TK_THREADS), 0, st, text, P, tab, tile_count.p);
+    hipLaunchKernelGGL((k_tok_count<CharT>), dim3((u32)div_up(n_tiles, TK_WAVES)), dim3(TK_THREADS), 0, st, text, P, tab, tile_count.p,
+                       n_tiles);
     probe_end();
     scan_exclusive<u32, u64>(tile_count.p, tile_off.p, n_tiles, scan_scr64.p, st);
     DCD_HIP(hipMemcpyAsync(&n_text_tok, scan_scr64.p + scan_nblocks(n_tiles), 8, hipMemcpyDeviceToHost, st));
@@ -656,7 +664,8 @@ static int32_t finish_impl(dcd_build* h) {
     vt.slots = slots.p; vt.mask = (u32)(cap - 1); vt.overflow = d_flags.p;
     if (n_tiles) {
       probe_begin(DCD_K_TOK_EMIT);
-      hipLaunchKernelGGL((k_tok_emit<CharT>), dim3((u32)n_tiles), dim3(TK_THREADS), 0, st, text, P, tab, tv, vt, tile_off.p, tupA.p);
+      hipLaunchKernelGGL((k_tok_emit<CharT>), dim3((u32)div_up(n_tiles, TK_WAVES)), dim3(TK_THREADS), 0, st, text, P, tab, tv, vt,
+                         tile_off.p, tupA.p, n_tiles);
       probe_end();
     }
     if (n_x)

@@ -23,19 +23,28 @@
 
 namespace dcd {
 
-// Geometry: every one of the 256 lanes loads exactly ONE 16-character chunk.  Lane 0 holds the chunk
-// before the tile (only the class of its last character is used), lanes 1..251 own the tile's chunks,
-// lanes 252..255 hold the look-ahead (a token may run 32 characters past its start).  Tiles therefore
-// advance by 251 * 16 = 4016 characters and no lane ever runs the classification code twice.
+// Geometry: the unit of work is ONE WAVE (64 lanes), every lane loads exactly one 16-character chunk.
+// Lane 0 holds the chunk before the tile (only the class of its last character is used), lanes 1..59
+// own the tile's chunks, lanes 60..63 hold the look-ahead (a token may run 32 characters past its
+// start).  Wave tiles advance by 59 * 16 = 944 characters.  Nothing in the tokeniser needs a workgroup
+// barrier: neighbour masks travel by 64-lane shuffles, the staged text and the token list live in a
+// wave-private slice of LDS (ordered by a wavefront-scope fence), so the four waves of a workgroup run
+// completely independently and a stalled wave never holds the other three at an s_barrier.
 constexpr int TK_THREADS = 256;
+constexpr int TK_WAVES = TK_THREADS / 64;
 constexpr int TK_CPT = 16;                       // characters per lane
 constexpr int TK_PRE = 1;                        // chunks before the tile
 constexpr int TK_HALO = 4;                       // look-ahead chunks after the tile (>= 33 characters)
-constexpr int TK_OWN = TK_THREADS - TK_PRE - TK_HALO;   // 251 chunks
-constexpr int TK_TILE = TK_OWN * TK_CPT;         // 4016 characters per tile
-constexpr int TK_SPAN = TK_THREADS * TK_CPT;     // 4096 characters staged per tile
-constexpr int TK_MASKS = TK_THREADS + 8;
+constexpr int TK_OWN = 64 - TK_PRE - TK_HALO;    // 59 chunks
+constexpr int TK_TILE = TK_OWN * TK_CPT;         // 944 characters per wave tile
+constexpr int TK_SPAN = 64 * TK_CPT;             // 1024 characters staged per wave tile
 constexpr int TK_MAXTOK = TK_TILE / 2 + 1;       // tokens of length 1 separated by one character
+
+// orders a wave's LDS writes before its later LDS reads of other lanes' data (no s_barrier involved)
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
 
 // vocabulary slot word: [63:48] tag  [47:42] length (1..63)  [41:0] position of the canonical occurrence
 constexpr u64 VOC_POS_MASK = (1ull << 42) - 1;
@@ -298,65 +307,64 @@ struct TokParams {
 };
 
 template <typename CharT, bool STAGE_TEXT>
-struct TokLds {
-  u16 Lm[TK_MASKS];                                              // letter mask per staged chunk (index = lane)
-  u16 Dm[TK_MASKS];                                              // number mask per staged chunk
+struct TokLds {                                                  // one per WAVE
   u32 pg[TK_SPAN / 32 + 3];                                      // page-start bitmask (non-uniform pages)
-  u32 scan[TK_THREADS / 64 + 1];
   u32 txt[STAGE_TEXT ? TK_SPAN * sizeof(CharT) / 4 + 4 : 1];     // lower-cased staged text (index 0 = staged position 0)
-  u32 tok[STAGE_TEXT ? TK_MAXTOK : 1];                           // kept tokens: staged position | len << 16
+  u32 tok[STAGE_TEXT ? TK_MAXTOK + 3 : 1];                       // kept tokens: staged position | len << 16
 };
 
-// staged position p of tile t  <->  text index  t * TK_TILE - TK_PRE * TK_CPT + p
+// staged position p of wave tile t  <->  text index  t * TK_TILE - TK_PRE * TK_CPT + p
 __device__ __forceinline__ int64_t tile_origin(u64 tile) { return (int64_t)(tile * TK_TILE) - TK_PRE * TK_CPT; }
 
 // After this call: `keep` = 16-bit mask of kept token starts in this lane's chunk (0 for the lanes that
 // only hold context), `bnd` = 64-bit boundary window whose bit 0 is the first character of the chunk.
-// Contains one __syncthreads (two with a general page table).
+// Wave-synchronous: no workgroup barrier.
 template <typename CharT, bool STAGE_TEXT>
 __device__ __forceinline__ void tokenize_chunk(const CharT* __restrict__ text, const TokParams& P, const CharTables16& tab, u64 tile,
                                                TokLds<CharT, STAGE_TEXT>& S, u32* keep_out, u64* bnd_out) {
-  const u32 tid = threadIdx.x;
+  const u32 lane = lane_id();
   const int64_t org = tile_origin(tile);
-  const bool inside = org >= 0 && (u64)org + TK_SPAN <= P.n_chars;   // workgroup-uniform
+  const bool inside = org >= 0 && (u64)org + TK_SPAN <= P.n_chars;   // wave-uniform
   const bool general_pages = P.uniform_page_chars == 0;
   if (general_pages) {
-    for (u32 i = tid; i < TK_SPAN / 32 + 3; i += TK_THREADS) S.pg[i] = 0;
-    __syncthreads();
+    for (u32 i = lane; i < TK_SPAN / 32 + 3; i += 64) S.pg[i] = 0;
+    wave_sync();
     // pages starting inside the staged span
     const u64 lo = org < 0 ? 0 : (u64)org;
     u64 a = 0, b = P.n_pages + 1;
     while (a < b) { u64 m = (a + b) >> 1; if (P.page_off[m] < lo) a = m + 1; else b = m; }
-    for (u64 p = a + tid; p <= P.n_pages; p += TK_THREADS) {
+    for (u64 p = a + lane; p <= P.n_pages; p += 64) {
       u64 o = P.page_off[p];
       if ((int64_t)o >= org + TK_SPAN) break;
       u32 li = (u32)((int64_t)o - org);
       atomicOr(&S.pg[li >> 5], 1u << (li & 31));
     }
   }
-  const int64_t g0 = org + (int64_t)tid * TK_CPT;
+  const int64_t g0 = org + (int64_t)lane * TK_CPT;
+  u32 Lc, Dc;
   {
     Chunk<CharT> c;
     c.load(text, g0, P.n_chars, tab, inside);
-    S.Lm[tid] = (u16)c.L;
-    S.Dm[tid] = (u16)c.D;
+    Lc = c.L; Dc = c.D;
     if (STAGE_TEXT) {
 #pragma unroll
-      for (int k = 0; k < Chunk<CharT>::NW; k++) S.txt[tid * Chunk<CharT>::NW + k] = c.w[k];
+      for (int k = 0; k < Chunk<CharT>::NW; k++) S.txt[lane * Chunk<CharT>::NW + k] = c.w[k];
     }
   }
-  if (tid < 8) { S.Lm[TK_THREADS + tid] = 0; S.Dm[TK_THREADS + tid] = 0; }
-  __syncthreads();
+  if (general_pages || STAGE_TEXT) wave_sync();
+  // neighbour masks by shuffle: chunks lane+1 .. lane+3 (look-ahead) and the last bit of chunk lane-1
+  const u32 L1 = __shfl_down(Lc, 1, 64), L2 = __shfl_down(Lc, 2, 64), L3 = __shfl_down(Lc, 3, 64);
+  const u32 D1 = __shfl_down(Dc, 1, 64), D2 = __shfl_down(Dc, 2, 64), D3 = __shfl_down(Dc, 3, 64);
+  const u32 Lp = __shfl_up(Lc, 1, 64), Dp = __shfl_up(Dc, 1, 64);
   u32 keep = 0;
   u64 bnd = 0;
-  if (tid >= TK_PRE && tid < TK_PRE + TK_OWN) {
-    const u32 s = tid;
-    const u64 L64 = (u64)S.Lm[s] | ((u64)S.Lm[s + 1] << 16) | ((u64)S.Lm[s + 2] << 32) | ((u64)S.Lm[s + 3] << 48);
-    const u64 D64 = (u64)S.Dm[s] | ((u64)S.Dm[s + 1] << 16) | ((u64)S.Dm[s + 2] << 32) | ((u64)S.Dm[s + 3] << 48);
-    const u64 pL = S.Lm[s - 1] >> 15, pD = S.Dm[s - 1] >> 15;
+  if (lane >= TK_PRE && lane < TK_PRE + TK_OWN) {
+    const u64 L64 = (u64)Lc | ((u64)L1 << 16) | ((u64)L2 << 32) | ((u64)L3 << 48);
+    const u64 D64 = (u64)Dc | ((u64)D1 << 16) | ((u64)D2 << 32) | ((u64)D3 << 48);
+    const u64 pL = (Lp >> 15) & 1u, pD = (Dp >> 15) & 1u;
     bnd = (L64 ^ ((L64 << 1) | pL)) | (D64 ^ ((D64 << 1) | pD));
     if (general_pages) {
-      u32 b0 = tid * TK_CPT;  // bit offset into S.pg, multiple of 16
+      u32 b0 = lane * TK_CPT;  // bit offset into S.pg, multiple of 16
       u64 lo = ((u64)S.pg[(b0 >> 5) + 1] << 32) | S.pg[b0 >> 5];
       u64 pgw = lo >> (b0 & 31);
       if (b0 & 31) pgw |= (u64)S.pg[(b0 >> 5) + 2] << (64 - (b0 & 31));
