@@ -400,11 +400,14 @@ struct ResParams {
 struct QCounts { u64 n_pages, n_pos, n_docs; int32_t status; u32 pad; };
 
 constexpr int RS_T = 256;
+constexpr int RS_I = 4;                 // coordinates per thread
+constexpr int RS_TILE = RS_T * RS_I;    // 1024 coordinates per workgroup iteration
 
 __device__ __forceinline__ u64 page_of(const ResParams& P, u64 c) {  // first page with end > c
   if (P.uniform_chars) {
     if (c < P.uniform_base + P.uniform_chars) return 0;   // everything below the first page end belongs to page 0
-    u64 p = (c - P.uniform_base) / P.uniform_chars;
+    u64 d = c - P.uniform_base;
+    u64 p = (P.uniform_chars & (P.uniform_chars - 1u)) == 0u ? d >> (31 - __builtin_clz(P.uniform_chars)) : d / P.uniform_chars;
     return p < P.n_pages ? p : P.n_pages;
   }
   u64 a = 0, b = P.n_pages;
@@ -412,7 +415,11 @@ __device__ __forceinline__ u64 page_of(const ResParams& P, u64 c) {  // first pa
   return a;
 }
 
-// One workgroup per query.  FILL = false: counts only.  FILL = true: writes the CSR arrays.
+// One workgroup per query, 1024 coordinates per iteration (4 consecutive ones per lane).
+// FILL = false: counts only.  FILL = true: writes the CSR arrays.
+// The walk stops after the coordinate that makes foundPages.Count > MAX_FOUND_PAGES (Search.cs:409):
+// validity is a prefix property, so one scan (page starts) + one min-reduction (first coordinate past
+// the cap) + one scan (document starts among the valid ones) per iteration is enough.
 template <bool FILL>
 __global__ __launch_bounds__(RS_T) void k_result(const FinalSeq* __restrict__ fin, u32 nq, const u64* __restrict__ idx_values,
                                                 const u64* __restrict__ pool, const u64* __restrict__ counts, ResParams P,
@@ -420,7 +427,8 @@ __global__ __launch_bounds__(RS_T) void k_result(const FinalSeq* __restrict__ fi
                                                 const u64* __restrict__ doc_base, u32* __restrict__ o_page_index, u64* __restrict__ o_pos_off,
                                                 int32_t* __restrict__ o_pos, u32* __restrict__ o_doc_index, u32* __restrict__ o_doc_first_page) {
   __shared__ u32 s_scan[RS_T / 64 + 1];
-  __shared__ u64 s_page[RS_T];
+  __shared__ u64 s_last[RS_T];          // page of each lane's last coordinate
+  __shared__ u32 s_min[RS_T / 64];
   __shared__ u64 c_prev_page;
   __shared__ u32 c_pages, c_docs, c_err, c_done;
   __shared__ u64 c_pos;
@@ -429,56 +437,117 @@ __global__ __launch_bounds__(RS_T) void k_result(const FinalSeq* __restrict__ fi
   const Seg sg = fin[q].s;
   const u64* V = seg_ptr(sg, idx_values, pool);
   const u64 n = seg_cnt(sg, counts);
+  if (FILL && qc[q].status != DCD_OK) return;   // the count pass found a coordinate beyond the last page: no output
   if (tid == 0) { c_prev_page = ~0ull; c_pages = 0; c_docs = 0; c_err = 0; c_done = 0; c_pos = 0; }
   __syncthreads();
   const u64 pb = FILL ? page_base[q] : 0, sb = FILL ? pos_base[q] : 0, db = FILL ? doc_base[q] : 0;
-  for (u64 t0 = 0; t0 < n && !c_done; t0 += RS_T) {
-    u64 i = t0 + tid;
-    bool in = i < n;
-    u64 c = in ? V[i] : 0;
-    u64 p = in ? page_of(P, c) : 0;
-    s_page[tid] = p;
+  for (u64 t0 = 0; t0 < n && !c_done; t0 += RS_TILE) {
+    const u64 i0 = t0 + (u64)tid * RS_I;
+    u64 c[RS_I], p[RS_I];
+    u32 np_mine = 0;
+#pragma unroll
+    for (int k = 0; k < RS_I; k++) {
+      bool in = i0 + k < n;
+      c[k] = in ? V[i0 + k] : 0;
+      p[k] = in ? page_of(P, c[k]) : ~0ull;
+    }
+    // last valid page of this lane (for the next lane's first comparison)
+    {
+      u64 lp = ~0ull;
+#pragma unroll
+      for (int k = 0; k < RS_I; k++) if (i0 + k < n) lp = p[k];
+      s_last[tid] = lp;
+    }
     __syncthreads();
-    u64 pprev = tid == 0 ? c_prev_page : s_page[tid - 1];
-    bool err = in && p >= P.n_pages;
-    bool newp = in && (pprev == ~0ull || p != pprev);
+    u64 pprev = tid == 0 ? c_prev_page : s_last[tid - 1];   // every earlier lane is full unless it is past n
+    bool newp[RS_I];
+#pragma unroll
+    for (int k = 0; k < RS_I; k++) {
+      bool in = i0 + k < n;
+      newp[k] = in && (pprev == ~0ull || p[k] != pprev);
+      if (in) pprev = p[k];
+      np_mine += newp[k] ? 1u : 0u;
+    }
     u32 tot_np;
-    u32 ord = c_pages + block_scan_excl<u32, RS_T / 64>(newp ? 1u : 0u, s_scan, &tot_np) + (newp ? 1u : 0u) - 1u;  // page ordinal of element
-    // the loop breaks after the coordinate that makes foundPages.Count > MAX (Search.cs:409)
-    bool valid = in && (ord < P.max_pages || (ord == P.max_pages && newp));
-    // a coordinate beyond the last page is an error only if it is reached (before truncation)
-    u32 docp = 0, docprev = 0;
-    bool newd = false;
-    if (valid && newp && !err) {
-      docp = P.page_doc ? P.page_doc[p] : (u32)p;
-      if (pprev != ~0ull && pprev < P.n_pages) docprev = P.page_doc ? P.page_doc[pprev] : (u32)pprev;
-      newd = pprev == ~0ull || docp != docprev;
+    u32 ord0 = c_pages + block_scan_excl<u32, RS_T / 64>(np_mine, s_scan, &tot_np);   // pages started before this lane's items
+    // page ordinal per item and the first item past the cap
+    u32 ord[RS_I];
+    u32 first_bad = 0xFFFFFFFFu;
+    {
+      u32 o = ord0;
+#pragma unroll
+      for (int k = 0; k < RS_I; k++) {
+        bool in = i0 + k < n;
+        o += newp[k] ? 1u : 0u;
+        ord[k] = o - 1u;                                     // ordinal of the page this item belongs to
+        bool valid = in && (ord[k] < P.max_pages || (ord[k] == P.max_pages && newp[k]));
+        if (in && !valid && first_bad == 0xFFFFFFFFu) first_bad = tid * RS_I + k;
+      }
+    }
+    // block minimum of first_bad
+    {
+      u32 m = first_bad;
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) { u32 t = __shfl_xor(m, d, 64); m = t < m ? t : m; }
+      if (lane_id() == 0) s_min[tid >> 6] = m;
+    }
+    __syncthreads();
+    const u32 cut = min(min(s_min[0], s_min[1]), min(s_min[2], s_min[3]));   // items [0, cut) of this tile are valid
+    const u32 tile_n = (u32)min((u64)RS_TILE, n - t0);
+    const u32 nvalid = min(cut, tile_n);
+    u32 nd_mine = 0, vnp_mine = 0;
+    bool newd[RS_I];
+    u32 docp[RS_I];
+    u64 prevp = tid == 0 ? c_prev_page : s_last[tid - 1];
+#pragma unroll
+    for (int k = 0; k < RS_I; k++) {
+      const u32 li = tid * RS_I + k;
+      const bool valid = li < nvalid;
+      newd[k] = false;
+      docp[k] = 0;
+      if (valid && p[k] >= P.n_pages) atomicOr(&c_err, 1u);   // coordinate beyond the last page (reached)
+      if (valid && newp[k] && p[k] < P.n_pages) {
+        docp[k] = P.page_doc ? P.page_doc[p[k]] : (u32)p[k];
+        u32 docprev = 0;
+        bool hasprev = prevp != ~0ull && prevp < P.n_pages;
+        if (hasprev) docprev = P.page_doc ? P.page_doc[prevp] : (u32)prevp;
+        newd[k] = !hasprev || docp[k] != docprev;
+      }
+      if (valid && newp[k]) vnp_mine++;
+      if (newd[k]) nd_mine++;
+      if (i0 + k < n) prevp = p[k];
     }
     u32 tot_nd;
-    u32 dord = c_docs + block_scan_excl<u32, RS_T / 64>(newd ? 1u : 0u, s_scan, &tot_nd);
-    u32 tot_valid;
-    (void)block_scan_excl<u32, RS_T / 64>(valid ? 1u : 0u, s_scan, &tot_valid);
-    if (valid && err) atomicOr(&c_err, 1u);
-    if (FILL && valid && !err) {
-      u64 base = p == 0 ? 0ull : P.page_end[p - 1];
-      o_pos[sb + i] = (int32_t)(c - base);
-      if (newp) { o_page_index[pb + ord] = (u32)p; o_pos_off[pb + ord] = sb + i; }
-      if (newd && dord <= P.max_docs) {          // one extra entry marks the end of the last found doc
-        if (dord < P.max_docs) o_doc_index[db + dord] = docp;
-        o_doc_first_page[db + q + dord] = ord;   // (max_docs + 1 slots per query, see host side)
+    u32 dord0 = c_docs + block_scan_excl<u32, RS_T / 64>(nd_mine, s_scan, &tot_nd);
+    u32 tot_vnp;
+    (void)block_scan_excl<u32, RS_T / 64>(vnp_mine, s_scan, &tot_vnp);
+    if (FILL && !c_err) {
+      u32 dord = dord0;
+#pragma unroll
+      for (int k = 0; k < RS_I; k++) {
+        const u32 li = tid * RS_I + k;
+        if (li < nvalid && p[k] < P.n_pages) {
+          const u64 i = i0 + k;
+          u64 base = p[k] == 0 ? 0ull : (P.uniform_chars ? P.uniform_base + p[k] * (u64)P.uniform_chars : P.page_end[p[k] - 1]);
+          o_pos[sb + i] = (int32_t)(c[k] - base);
+          if (newp[k]) { o_page_index[pb + ord[k]] = (u32)p[k]; o_pos_off[pb + ord[k]] = sb + i; }
+          if (newd[k]) {
+            if (dord <= P.max_docs) {                    // one extra entry marks the end of the last found doc
+              if (dord < P.max_docs) o_doc_index[db + dord] = docp[k];
+              o_doc_first_page[db + q + dord] = ord[k];
+            }
+            dord++;
+          }
+        }
       }
     }
     __syncthreads();
-    // totals among valid elements only (a page that starts beyond the cap must not count)
-    u32 tot_vnp, tot_vnd;
-    (void)block_scan_excl<u32, RS_T / 64>((valid && newp) ? 1u : 0u, s_scan, &tot_vnp);
-    (void)block_scan_excl<u32, RS_T / 64>((valid && newd) ? 1u : 0u, s_scan, &tot_vnd);
     if (tid == 0) {
       c_pages += tot_vnp;
-      c_docs += tot_vnd;
-      c_pos += tot_valid;
-      if (tot_valid < min((u64)RS_T, n - t0) || c_pages > P.max_pages) c_done = 1;
-      c_prev_page = s_page[min((u64)RS_T, n - t0) - 1];
+      c_docs += tot_nd;
+      c_pos += nvalid;
+      if (nvalid < tile_n || c_pages > P.max_pages) c_done = 1;
+      c_prev_page = s_last[(tile_n - 1) / RS_I];
     }
     __syncthreads();
   }
