@@ -1,0 +1,65 @@
+// P/Invoke surface of libdocodo_hip.so for Docodo.NET (see INTEGRATION.md).  Source only: the build image has no
+// .NET toolchain, so this file is not compiled here; it mirrors include/docodo_hip.h one to one.
+using System;
+using System.Runtime.InteropServices;
+
+namespace Docodo
+{
+    internal static unsafe class Native
+    {
+        const string Lib = "docodo_hip";   // libdocodo_hip.so next to Docodo.NET.dll or on LD_LIBRARY_PATH
+
+        [StructLayout(LayoutKind.Sequential)]
+        public struct BuildOpts { public int device, min_word_length, max_word_length, encoding;
+                                  public ulong coord_base; public uint vocab_capacity_log2, reserved; }
+        [StructLayout(LayoutKind.Sequential)]
+        public struct QueryOpts { public int max_found_pages, max_found_docs; public float doc_rank_multiply; public int want_sequences; }
+        [StructLayout(LayoutKind.Sequential)]
+        public struct ResultsView { public ulong n_queries; public int* status; public ulong* page_off; public uint* page_index;
+                                    public float* page_rank; public ulong* pos_off; public int* pos; public ulong* doc_off;
+                                    public uint* doc_index; public float* doc_rank; public uint* doc_n_pages;
+                                    public ulong* seq_off; public ushort* seq_units; public int* seq_R; public float ms_device; }
+
+        [DllImport(Lib)] public static extern int dcd_last_error(byte* buf, UIntPtr cap);
+
+        // IndexSequence.cs
+        [DllImport(Lib)] public static extern int dcd_seq_encode(ulong* values, UIntPtr n, ushort* outp, UIntPtr cap, out UIntPtr nUnits);
+        [DllImport(Lib)] public static extern int dcd_seq_decode(ushort* units, UIntPtr nUnits, ulong* outp, UIntPtr cap, out UIntPtr n);
+        [DllImport(Lib)] public static extern int dcd_seq_count(ushort* units, UIntPtr nUnits, out UIntPtr nValues);
+        [DllImport(Lib)] public static extern int dcd_seq_shift(ushort* units, UIntPtr nUnits, ulong shift, ushort* outp, UIntPtr cap, out UIntPtr nOut);
+        [DllImport(Lib)] public static extern int dcd_seq_and(ushort* a, UIntPtr na, int Ra, ushort* b, UIntPtr nb, int Rb,
+                                                              ushort* outp, UIntPtr cap, out UIntPtr nOut, out int R);
+        [DllImport(Lib)] public static extern int dcd_seq_or(ushort* a, UIntPtr na, int Ra, ushort* b, UIntPtr nb, int Rb,
+                                                             ushort* outp, UIntPtr cap, out UIntPtr nOut, out int R);
+        // Build.cs
+        [DllImport(Lib)] public static extern void dcd_build_default_opts(out BuildOpts o);
+        [DllImport(Lib)] public static extern int dcd_build_create(ref BuildOpts o, out IntPtr h);
+        [DllImport(Lib)] public static extern void dcd_build_free(IntPtr h);
+        [DllImport(Lib)] public static extern int dcd_build_add_doc(IntPtr h, char* src, UIntPtr srcLen, char* name, UIntPtr nameLen);
+        [DllImport(Lib)] public static extern int dcd_build_add_pages(IntPtr h, void* text, ulong nChars, ulong* pageOff, UIntPtr nPages,
+                                                                      char* pageIds, ulong* idsOff, int docsPerPage, ulong firstDoc,
+                                                                      char* src, UIntPtr srcLen);
+        [DllImport(Lib)] public static extern int dcd_build_add(IntPtr h, char* code, UIntPtr len, ulong coord);
+        [DllImport(Lib)] public static extern int dcd_build_end_page(IntPtr h, char* id, UIntPtr len);
+        [DllImport(Lib)] public static extern int dcd_build_finish(IntPtr h);
+        [DllImport(Lib)] public static extern int dcd_build_save(IntPtr h, [MarshalAs(UnmanagedType.LPUTF8Str)] string dir);
+        // Index.cs / Search.cs
+        [DllImport(Lib)] public static extern int dcd_index_open([MarshalAs(UnmanagedType.LPUTF8Str)] string dir, int device, out IntPtr h);
+        [DllImport(Lib)] public static extern int dcd_index_from_build(IntPtr build, out IntPtr h);
+        [DllImport(Lib)] public static extern void dcd_index_free(IntPtr h);
+        [DllImport(Lib)] public static extern int dcd_index_find(IntPtr h, char* key, UIntPtr len, out uint term);
+        [DllImport(Lib)] public static extern int dcd_index_get(IntPtr h, uint term, ushort* outp, UIntPtr cap, out UIntPtr nUnits);
+        [DllImport(Lib)] public static extern int dcd_index_term_count(IntPtr h, uint term, out ulong nValues);
+        [DllImport(Lib)] public static extern void dcd_query_default_opts(out QueryOpts o);
+        [DllImport(Lib)] public static extern int dcd_query_batch(IntPtr h, int* prog, ulong* progOff, UIntPtr nQueries, ref QueryOpts o, out IntPtr results);
+        [DllImport(Lib)] public static extern int dcd_results_get(IntPtr r, out ResultsView v);
+        [DllImport(Lib)] public static extern void dcd_results_free(IntPtr r);
+
+        public static void Check(int status) {
+            if (status == 0) return;
+            byte* buf = stackalloc byte[1024];
+            dcd_last_error(buf, (UIntPtr)1024);
+            throw new InvalidOperationException("docodo_hip " + status + ": " + Marshal.PtrToStringUTF8((IntPtr)buf));
+        }
+    }
+}

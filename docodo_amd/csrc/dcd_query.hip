@@ -4,6 +4,7 @@
 // operators * / + (IndexSequence.cs:218-322), PrepareSearchResult (Search.cs:365-420) and the page /
 // document ranks (Search.cs:99-111, 552-557, 599).
 //
+// (GAL_RATIO = 4 measured best on MI355X: 2 / 4 / 8 / 16 / 1 -> 6.45 / 6.41 / 7.00 / 7.76 / 8.02 ms for 20 k AND3 queries)
 // Shape of the computation
 //   * the posting lists are decoded once per index into absolute coordinates (HBM-resident u64,
 //     built lazily on the first query: an auxiliary structure, the .index image stays canonical);
@@ -86,7 +87,10 @@ struct PoState {
 // walks its gap chain outwards (the chain is the same set the merge would build: maximal runs of the union
 // with consecutive gaps <= absR); the first short-list element of a chain ("leader") emits the chain if it
 // satisfies the both-operands / ordered-prefix rule.  Exactly the same output as the streaming merge.
-constexpr u32 GAL_RATIO = 16;     // gallop when 16 * |short| <= |long|
+#ifndef DCD_GAL_RATIO
+#define DCD_GAL_RATIO 4
+#endif
+constexpr u32 GAL_RATIO = DCD_GAL_RATIO;   // gallop when RATIO * |short| <= |long|
 constexpr u32 GAL_CHUNK = 1024;   // short-list elements per workgroup iteration
 
 struct GalRec { u32 b_lo, d_hi; u32 c_hi, cnt; };   // L range [b_lo, d_hi) (relative to lbase), S range [i, c_hi]
