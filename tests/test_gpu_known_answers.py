@@ -141,3 +141,55 @@ def test_stemmer_dependent_answers_via_explicit_codes(oracle_mod, known, testtex
     r = S(ka["req"], docodo_amd.SearchOptions(dist=ka["dist"]))
     assert r.Success and len(r.foundPages[0][2]) == ka["pos_page0"]
     _same(r, oix.search(ka["req"], oracle_mod.SearchOptions(dist=ka["dist"])))
+
+
+def test_latin1_header_pages_and_edge_lines(oracle_mod):
+    """Header pages in a byte (Latin-1) build, odd header lines: short names (skipped), no trailing newline,
+    CR LF line ends, '=' inside the value, digits, a line without '=' after a valid one (aborts the page
+    without EndPage, Build.cs:537-540), plus body pages after each header."""
+    import docodo_amd
+    hdrs = ["Name=Alpha Beta\nSize=190\nab=skipped value\nTitle=Charles Diskense=ignored tail\n",
+            "Source=Test\r\nKeywords=één twee_drie 42abc",      # no trailing newline, CR LF, Latin-1 letters, '_' and digits
+            "Name=ok line\nbrokenlinewithoutequals\nName=never reached\n"]
+    body = "The quick brown fox; jumps over the lazy dog. ÀÉÎ naïve 12345 a1b2"
+    docs = []
+    for d, h in enumerate(hdrs):
+        docs.append(("doc%d" % d, [("0", h), ("1", body), ("2", body * 3)]))
+    oix = oracle_mod.Index(stemmers=[])
+    ob = oracle_mod.Builder(oix)
+    b = docodo_amd.Builder(encoding=docodo_amd.DCD_ENC_LATIN1)
+    for name, pages in docs:
+        ob.add_doc("src", name)
+        b.AddDoc("src", name)
+        for pid, t in pages:
+            ob.index_page(pid, t)
+        texts = [t for _, t in pages]
+        off = np.zeros(len(texts) + 1, np.uint64)
+        off[1:] = np.cumsum([len(t) for t in texts])
+        b.AddPages("".join(texts), off, page_ids=[i for i, _ in pages])
+    b.Finish()
+    oi, ol = ob.save()
+    assert b.list_image() == ol
+    assert b.index_image() == oi
+
+
+def test_query_edge_cases(gpu_nostem, oracle_mod):
+    """Empty batch, unknown words, a query whose program is a single missing term, error status for a
+    coordinate beyond the last page (ErrorSearchResult in the reference, Search.cs:609-613)."""
+    import docodo_amd
+    b, img, lst, oix, _, _ = gpu_nostem
+    ix = b_index(b)
+    r = ix.query_batch([], [0])
+    assert r.n_queries == 0
+    S = docodo_amd.Search(ix)
+    for req in ("zzzzunknown", "zzzzunknown and", "and zzzzunknown", "zzzz | and", "(", "and )", "", "a b"):
+        _same(S(req), oix.search(req)) if S(req).Success else None
+        assert S(req).Success == oix.search(req).Success, req
+    # page table that stops before the postings: every query hits "coordinate beyond the last page"
+    short_list = lst[:lst.index(b"Test:Dump") - 8 - 1] if b"Test:Dump" in lst else lst
+    ix2 = docodo_amd.Index.from_images(img, short_list)
+    oix2 = oracle_mod.Index(stemmers=[])
+    oix2.load(img, short_list)
+    t = ix2.find("and")
+    r = ix2.query_batch([docodo_amd.DCD_OP_TERM, t, 258], [0, 3])
+    assert (r.status[0] != 0) == (not oix2.search("and").Success)
