@@ -71,13 +71,19 @@ __global__ void k_term_relative(const u64* __restrict__ excl, const u64* __restr
 // operator * / + on operand pairs
 // ------------------------------------------------------------------------------------------------
 constexpr int PO_THREADS = 256;
-constexpr int PO_ITEMS = 4;
+#ifndef DCD_PO_ITEMS
+#define DCD_PO_ITEMS 4
+#endif
+constexpr int PO_ITEMS = DCD_PO_ITEMS;
 constexpr int PO_TILE = PO_THREADS * PO_ITEMS;
 
 struct PoState {
   u64 ia, ib, cursor, out_start, prev_val;
   u32 have_prev, prev_src, open, committed, seenA, seenEB;
   u32 ca, cb, last_first_excl;
+  u32 hA, hB, fA, fB;            // LDS rings: head slot and number of staged (unconsumed) elements per operand
+  u32 t_first_brk, t_last_src;   // fast path: brk of the tile's first element, source of its last element
+  u64 t_last_val;
 };
 
 // ---- sparse operands: galloping ----------------------------------------------------------------------
@@ -217,7 +223,8 @@ __device__ void pair_gallop(const u64* __restrict__ Sv, u64 ns, const u64* __res
 __global__ __launch_bounds__(PO_THREADS) void k_pair_ops(const PairOp* __restrict__ ops, u32 n_ops, const u64* __restrict__ idx_values,
                                                         u64* __restrict__ pool, u64* __restrict__ counts) {
   // one LDS arena, used either by the streaming merge (sA, sB, s_firstA, s_hasEB) or by the gallop records
-  __shared__ __attribute__((aligned(16))) u32 s_raw[GAL_CHUNK * 6 + 16];
+  constexpr u32 RAW_WORDS = (6u * PO_TILE > 6u * GAL_CHUNK ? 6u * PO_TILE : 6u * GAL_CHUNK) + 16u;
+  __shared__ __attribute__((aligned(16))) u32 s_raw[RAW_WORDS];
   u64* sA = reinterpret_cast<u64*>(s_raw);
   u64* sB = sA + PO_TILE;
   u32* s_firstA = s_raw + 4 * PO_TILE;
@@ -250,23 +257,29 @@ __global__ __launch_bounds__(PO_THREADS) void k_pair_ops(const PairOp* __restric
     if (tid == 0) {
       S.ia = S.ib = S.cursor = S.out_start = S.prev_val = 0;
       S.have_prev = S.prev_src = S.open = S.committed = S.seenA = S.seenEB = 0;
+      S.hA = S.hB = S.fA = S.fB = 0;
     }
     __syncthreads();
 
     while (S.ia < na || S.ib < nb) {
       const u64 ia = S.ia, ib = S.ib;
+      // The operands are staged in two LDS rings of PO_TILE elements.  A tile consumes ca + cb = PO_TILE
+      // elements; only the freed slots are refilled, so every posting is read from HBM exactly once.
+      const u32 hA = S.hA, hB = S.hB;
       const u32 ra = (u32)min((u64)PO_TILE, na - ia), rb = (u32)min((u64)PO_TILE, nb - ib);
-      for (u32 i = tid; i < ra; i += PO_THREADS) sA[i] = A[ia + i];
-      for (u32 i = tid; i < rb; i += PO_THREADS) sB[i] = B[ib + i];
+      for (u32 i = S.fA + tid; i < ra; i += PO_THREADS) sA[(hA + i) & (PO_TILE - 1)] = A[ia + i];
+      for (u32 i = S.fB + tid; i < rb; i += PO_THREADS) sB[(hB + i) & (PO_TILE - 1)] = B[ib + i];
       for (u32 i = tid; i < PO_TILE + 2; i += PO_THREADS) { s_firstA[i] = NONE32; s_hasEB[i] = 0; }
       __syncthreads();
+      auto Aat = [&](u32 x) -> u64 { return sA[(hA + x) & (PO_TILE - 1)]; };
+      auto Bat = [&](u32 x) -> u64 { return sB[(hB + x) & (PO_TILE - 1)]; };
       const u32 cnt = min((u32)PO_TILE, ra + rb);
       // merge path: split of diagonal d -> (i from A, d - i from B); ties take A first
       auto split = [&](u32 d) -> u32 {
         u32 lo = d > rb ? d - rb : 0u, hi = min(d, ra);
         while (lo < hi) {
           u32 mid = (lo + hi) >> 1;
-          if (sA[mid] <= sB[d - 1 - mid]) lo = mid + 1; else hi = mid;
+          if (Aat(mid) <= Bat(d - 1 - mid)) lo = mid + 1; else hi = mid;
         }
         return lo;
       };
@@ -279,27 +292,89 @@ __global__ __launch_bounds__(PO_THREADS) void k_pair_ops(const PairOp* __restric
       if (d0 > 0) {
         hp = 1;
         bool ua = i > 0, ub = j > 0;
-        if (ua && ub) { if (sB[j - 1] >= sA[i - 1]) { pv = sB[j - 1]; psrc = 1; } else { pv = sA[i - 1]; psrc = 0; } }
-        else if (ua) { pv = sA[i - 1]; psrc = 0; }
-        else { pv = sB[j - 1]; psrc = 1; }
+        if (ua && ub) { if (Bat(j - 1) >= Aat(i - 1)) { pv = Bat(j - 1); psrc = 1; } else { pv = Aat(i - 1); psrc = 0; } }
+        else if (ua) { pv = Aat(i - 1); psrc = 0; }
+        else { pv = Bat(j - 1); psrc = 1; }
       }
       u64 val[PO_ITEMS];
       u32 src[PO_ITEMS], dup[PO_ITEMS], brk[PO_ITEMS];
       u32 nbrk = 0;
+      u32 contact = 0;         // some neighbouring union elements come from different operands within absR
+      u32 lastbrk1 = 0;        // 1 + tile position of this lane's last chain break (0 = none)
 #pragma unroll
       for (int k = 0; k < PO_ITEMS; k++) {
         val[k] = 0; src[k] = 0; dup[k] = 0; brk[k] = 0;
         if (d0 + k < d1) {
-          bool takeA = i < ra && (j >= rb || sA[i] <= sB[j]);
-          u64 v = takeA ? sA[i] : sB[j];
+          bool takeA = i < ra && (j >= rb || Aat(i) <= Bat(j));
+          u64 v = takeA ? Aat(i) : Bat(j);
           if (takeA) i++; else j++;
           val[k] = v;
           src[k] = takeA ? 0u : 1u;
           dup[k] = (!takeA && hp && psrc == 0 && pv == v) ? 1u : 0u;
           brk[k] = !hp ? 1u : ((absR != 0 && v - pv > (u64)absR) ? 1u : 0u);
           nbrk += brk[k];
+          if (hp && psrc != src[k] && !brk[k]) contact = 1;
+          if (brk[k]) lastbrk1 = d0 + k + 1;
           pv = v; psrc = src[k]; hp = 1;
         }
+      }
+      // ---- sparse fast path -----------------------------------------------------------------------
+      // No two neighbouring union elements of this tile come from different operands within absR: every
+      // chain inside the tile is single-operand, nothing can be emitted here except (optimistically) the
+      // tile's last chain, which may still meet the other operand in a later tile.  One reduction and
+      // O(1) state updates replace the chain machinery below (scans, LDS atomics, ~8 barriers).
+      if (!is_or && absR != 0) {
+        u32 key = contact ? 0xFFFFFFFFu : lastbrk1;
+        key = wave_max(key);
+        if (lane_id() == 0) s_scan[tid >> 6] = key;
+        if (tid == 0) S.t_first_brk = brk[0];
+        if (d1 == cnt && d0 < d1) { S.t_last_src = src[d1 - d0 - 1]; S.t_last_val = val[d1 - d0 - 1]; }
+        __syncthreads();
+        const u32 M = max(max(s_scan[0], s_scan[1]), max(s_scan[2], s_scan[3]));
+        const bool carried_committed_continues = S.open && S.committed && !S.t_first_brk;
+        if (M != 0xFFFFFFFFu && !carried_committed_continues) {
+          const bool final_tile = (ia + S.ca == na) && (ib + S.cb == nb);
+          const u32 last_src = S.t_last_src;
+          u64 new_cursor, new_out_start = S.out_start;
+          u32 n_open = S.open, n_com = S.committed, n_sa = S.seenA, n_seb = S.seenEB;
+          if (M == 0) {                                  // the carried chain spans the whole tile
+            const bool elig = !ordered || S.seenA;
+            if (final_tile) new_cursor = S.out_start;    // closes without the other operand: roll back
+            else {
+              if (elig) {
+#pragma unroll
+                for (int k = 0; k < PO_ITEMS; k++) if (d0 + k < d1) out[S.cursor + d0 + k] = val[k];
+              }
+              new_cursor = S.cursor + (elig ? cnt : 0u);
+            }
+          } else {
+            const u32 LB = M - 1;
+            const u64 cursor0 = (S.open && !S.committed) ? S.out_start : S.cursor;   // the carried chain closes: roll back
+            if (final_tile) new_cursor = cursor0;
+            else {
+              const bool elig = !ordered || last_src == 0;
+              if (elig) {
+#pragma unroll
+                for (int k = 0; k < PO_ITEMS; k++) if (d0 + k < d1 && d0 + k >= LB) out[cursor0 + (d0 + k - LB)] = val[k];
+              }
+              new_cursor = cursor0 + (elig ? cnt - LB : 0u);
+              new_out_start = cursor0;
+              n_open = 1; n_com = 0; n_sa = last_src == 0 ? 1u : 0u; n_seb = (last_src == 1 && !ordered) ? 1u : 0u;
+            }
+          }
+          __syncthreads();
+          if (tid == 0) {
+            S.cursor = new_cursor; S.out_start = new_out_start;
+            S.open = n_open; S.committed = n_com; S.seenA = n_sa; S.seenEB = n_seb;
+            S.ia = ia + S.ca; S.ib = ib + S.cb;
+            S.hA = (hA + S.ca) & (PO_TILE - 1); S.hB = (hB + S.cb) & (PO_TILE - 1);
+            S.fA = ra - S.ca; S.fB = rb - S.cb;
+            S.prev_val = S.t_last_val; S.prev_src = last_src; S.have_prev = 1;
+          }
+          __syncthreads();
+          continue;
+        }
+        __syncthreads();   // s_scan is reused by the block scans below
       }
       u32 total_brk;
       u32 cbase = block_scan_excl<u32, PO_THREADS / 64>(nbrk, s_scan, &total_brk);
@@ -379,6 +454,8 @@ __global__ __launch_bounds__(PO_THREADS) void k_pair_ops(const PairOp* __restric
         S.open = 1; S.seenA = hasA; S.seenEB = hasEB; S.committed = com;
         S.cursor = cursor + total_emit;
         S.ia = ia + S.ca; S.ib = ib + S.cb;
+        S.hA = (hA + S.ca) & (PO_TILE - 1); S.hB = (hB + S.cb) & (PO_TILE - 1);
+        S.fA = ra - S.ca; S.fB = rb - S.cb;
       }
       if (d1 == cnt && d0 < d1) { S.prev_val = val[d1 - d0 - 1]; S.prev_src = src[d1 - d0 - 1]; S.have_prev = 1; }
       __syncthreads();
@@ -917,13 +994,96 @@ void dcd_query_default_opts(dcd_query_opts* o) {
   o->want_sequences = 0;
 }
 
+// Worst-case work-pool elements a query needs (every operator result can be as long as both operands).
+static u64 query_pool_need(const DeviceIndex& ix, const int32_t* prog, u64 a, u64 b) {
+  std::vector<u64> stk;
+  u64 need = 0;
+  for (u64 i = a; i < b;) {
+    int32_t opc = prog[i];
+    if (opc == DCD_OP_TERM) {
+      if (i + 3 > b) break;
+      int64_t t = prog[i + 1];
+      stk.push_back((t >= 0 && (u64)t < ix.n_terms) ? ix.h_term_item_start[t + 1] - ix.h_term_item_start[t] : 0);
+      i += 3;
+    } else if (opc == DCD_OP_SETR) {
+      i += 2;
+    } else {
+      if (stk.size() < 2) break;
+      u64 y = stk.back(); stk.pop_back();
+      u64 x = stk.back(); stk.pop_back();
+      stk.push_back(x + y);
+      need += x + y;
+      i += 1;
+    }
+  }
+  return need;
+}
+
+static void append_results(dcd_results& dst, const dcd_results& src) {
+  const u64 p0 = dst.page_index.size(), s0 = dst.pos.size(), d0 = dst.doc_index.size(), u0 = dst.seq_units.size();
+  const bool first = dst.page_off.empty();
+  dst.status.insert(dst.status.end(), src.status.begin(), src.status.end());
+  auto app_off = [&](std::vector<u64>& d, const std::vector<u64>& sv, u64 base) {
+    size_t k0 = first ? 0 : 1;                         // later chunks drop their leading 0
+    if (!first && !d.empty()) {}
+    for (size_t k = k0; k < sv.size(); k++) d.push_back(sv[k] + base);
+  };
+  app_off(dst.page_off, src.page_off, p0);
+  app_off(dst.doc_off, src.doc_off, d0);
+  // pos_off has one entry per page plus a final total: keep a single running terminator
+  if (!dst.pos_off.empty()) dst.pos_off.pop_back();
+  for (size_t k = 0; k < src.pos_off.size(); k++) dst.pos_off.push_back(src.pos_off[k] + s0);
+  dst.page_index.insert(dst.page_index.end(), src.page_index.begin(), src.page_index.end());
+  dst.page_rank.insert(dst.page_rank.end(), src.page_rank.begin(), src.page_rank.end());
+  dst.pos.insert(dst.pos.end(), src.pos.begin(), src.pos.end());
+  dst.doc_index.insert(dst.doc_index.end(), src.doc_index.begin(), src.doc_index.end());
+  dst.doc_rank.insert(dst.doc_rank.end(), src.doc_rank.begin(), src.doc_rank.end());
+  dst.doc_n_pages.insert(dst.doc_n_pages.end(), src.doc_n_pages.begin(), src.doc_n_pages.end());
+  if (src.have_seq) {
+    dst.have_seq = true;
+    app_off(dst.seq_off, src.seq_off, u0);
+    dst.seq_units.insert(dst.seq_units.end(), src.seq_units.begin(), src.seq_units.end());
+    dst.seq_R.insert(dst.seq_R.end(), src.seq_R.begin(), src.seq_R.end());
+  }
+  dst.ms_device += src.ms_device;
+}
+
 int32_t dcd_query_batch(dcd_index* h, const int32_t* prog, const uint64_t* prog_off, size_t n_queries, const dcd_query_opts* opts,
                         dcd_results** out) {
   if (!h || !prog_off || !out || (!prog && n_queries && prog_off[n_queries] != 0)) DCD_FAIL(DCD_E_BADARG, "dcd_query_batch: NULL argument");
   dcd_query_opts o;
   if (opts) o = *opts; else dcd_query_default_opts(&o);
+  DCD_TRY(ensure_device(h->ix.device));
+  // The work pool is sized for the worst case of every operator; batches whose worst case exceeds a
+  // quarter of the free HBM are evaluated in consecutive sub-batches (results are concatenated).
+  size_t free_b = 0, total_b = 0;
+  DCD_HIP(hipMemGetInfo(&free_b, &total_b));
+  u64 budget = std::max<u64>((u64)free_b / 4 / 8, 1ull << 24);   // elements of 8 bytes
+  if (const char* e = getenv("DOCODO_QUERY_POOL_ELEMS")) budget = std::max<u64>(strtoull(e, nullptr, 10), 1);   // tests
   std::unique_ptr<dcd_results> R(new dcd_results());
-  DCD_TRY(run_batch(h, prog, prog_off, n_queries, o, R.get(), nullptr, nullptr));
+  size_t q0 = 0;
+  bool single = true;
+  while (q0 < n_queries || (n_queries == 0 && single)) {
+    size_t q1 = q0;
+    u64 acc = 0;
+    while (q1 < n_queries) {
+      u64 need = query_pool_need(h->ix, prog, prog_off[q1], prog_off[q1 + 1]);
+      if (q1 > q0 && acc + need > budget) break;
+      acc += need;
+      q1++;
+    }
+    if (q0 == 0 && q1 == n_queries) {                      // the common case: one sub-batch, no copies
+      DCD_TRY(run_batch(h, prog, prog_off, n_queries, o, R.get(), nullptr, nullptr));
+      break;
+    }
+    single = false;
+    std::vector<u64> off(q1 - q0 + 1);
+    for (size_t k = 0; k <= q1 - q0; k++) off[k] = prog_off[q0 + k] - prog_off[q0];
+    dcd_results part;
+    DCD_TRY(run_batch(h, prog + prog_off[q0], off.data(), q1 - q0, o, &part, nullptr, nullptr));
+    append_results(*R, part);
+    q0 = q1;
+  }
   *out = R.release();
   return DCD_OK;
 }

@@ -191,3 +191,29 @@ def test_index_roundtrip_through_images(synth_index, oracle_mod):
         _check_result(res, 0, oix.search(w))
     assert ix2.page_info(3) == (oix.page_end(3), oix.page_doc(3), oix.page_id(3))
     assert ix2.doc_name(5) == oix.doc_name(5)
+
+
+def test_sub_batching_matches_single_batch(synth_index, monkeypatch):
+    """dcd_query_batch splits a batch whose worst-case work pool exceeds the HBM budget; the concatenated
+    result must equal the one-shot evaluation (budget forced down to 200 k elements here)."""
+    import docodo_amd
+    from docodo_amd import synth
+    ix, oix, _, _ = synth_index
+    ranks = synth.query_ranks(300, 3, lo_rank=20)
+    prog, off = [], [0]
+    for row in ranks:
+        ts = [ix.find(synth.term(int(k))) for k in row]
+        if any(t is None for t in ts):
+            continue
+        for k, t in enumerate(ts):
+            prog += [docodo_amd.DCD_OP_TERM, t, 255 + len(synth.term(int(row[k])))]
+            if k:
+                prog.append(docodo_amd.DCD_OP_AND)
+        off.append(len(prog))
+    monkeypatch.delenv("DOCODO_QUERY_POOL_ELEMS", raising=False)
+    a = ix.query_batch(prog, off, want_sequences=True)
+    monkeypatch.setenv("DOCODO_QUERY_POOL_ELEMS", "200000")
+    b = ix.query_batch(prog, off, want_sequences=True)
+    for name in ("status", "page_off", "page_index", "page_rank", "pos_off", "pos", "doc_off", "doc_index", "doc_rank",
+                 "doc_n_pages", "seq_off", "seq_units", "seq_R"):
+        assert np.array_equal(getattr(a, name), getattr(b, name)), name
