@@ -45,6 +45,7 @@ struct PairOp {
   u32 op;          // DCD_OP_AND / DCD_OP_OR
   u32 out_cnt_ref;
   u64 out_off;     // into the work pool; capacity = cap(a) + cap(b)
+  u64 tmp_off;     // into the round's scratch arena (same capacity)
 };
 struct FinalSeq {
   Seg s;
@@ -466,6 +467,525 @@ __global__ __launch_bounds__(PO_THREADS) void k_pair_ops(const PairOp* __restric
 }
 
 // ------------------------------------------------------------------------------------------------
+// partitioned operators: one WAVEFRONT per (operator, partition)
+// ------------------------------------------------------------------------------------------------
+// The union of both operands is cut at fixed diagonals (every PART union elements, found with a 64-ary
+// merge-path search over the operands in HBM).  Gap chains are independent of each other, so the work
+// item of partition p evaluates exactly the chains that START inside [p*PART, (p+1)*PART): it skips the
+// elements before its first chain break and FOLLOWS its last chain beyond the partition end until the
+// chain closes.  No state crosses work items.  Emitted coordinates are written compactly into a scratch
+// arena at the union index of the first owned element (owned ranges are disjoint and an item never emits
+// more than it owns, so the writes cannot collide), then one scan over the per-item counts and a gather
+// pass produce the contiguous operator result.  Every wave runs the same tile logic as one operand pair
+// did before (merge path, chain ids, "contains both operands", ordered prefix rule, optimistic write +
+// roll-back at tile borders), on 256-element tiles with wave-level scans; '+' uses the same ownership
+// rule with every element its own chain.  Skewed sparse pairs gallop from the short operand, the short
+// list spread evenly over the operator's work items.
+#ifndef DCD_PART
+#define DCD_PART 4096
+#endif
+constexpr u32 PW_T = 64;
+constexpr u32 PW_ITEMS = 4;
+constexpr u32 PW_TILE = PW_T * PW_ITEMS;
+constexpr u64 PART = DCD_PART;
+
+// orders a wave's LDS writes before its later LDS reads of other lanes' data: the work items are single
+// wavefronts, LDS executes a wave's accesses in order, so no s_barrier / s_waitcnt is needed (and the
+// outstanding HBM loads and stores are not waited for, unlike __syncthreads())
+__device__ __forceinline__ void wsync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+__device__ __forceinline__ u32 wave_min(u32 v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) { u32 t = __shfl_xor(v, d, DCD_WAVE); v = t < v ? t : v; }
+  return v;
+}
+__device__ __forceinline__ u64 shfl64(u64 v, u32 src_lane) {
+  u32 lo = __shfl((u32)v, (int)src_lane, DCD_WAVE), hi = __shfl((u32)(v >> 32), (int)src_lane, DCD_WAVE);
+  return ((u64)hi << 32) | lo;
+}
+
+// number of A elements among the first d elements of the union of A and B (ties: A first); all 64 lanes
+// probe one candidate each, so the search needs log64 rounds of dependent HBM accesses
+__device__ __forceinline__ u64 wave_split(const u64* __restrict__ A, u64 na, const u64* __restrict__ B, u64 nb, u64 d) {
+  u64 lo = d > nb ? d - nb : 0, hi = d < na ? d : na;
+  const u32 lane = lane_id();
+  while (lo < hi) {
+    const u64 step = (hi - lo + 63) >> 6;
+    const u64 p = lo + (u64)lane * step + (step - 1);
+    bool pr = false;
+    if (p < hi) pr = A[p] <= B[d - 1 - p];
+    const u32 c = popc64(ballot64(pr));          // the predicate is monotone: the true lanes form a prefix
+    const u64 nlo = lo + (u64)c * step;
+    const u64 nhi = nlo + step - 1;
+    lo = nlo;
+    hi = nhi < hi ? nhi : hi;
+  }
+  return lo;
+}
+
+// ---- galloping, one slice of the short operand per work item ------------------------------------------------
+__device__ void part_gallop(const u64* __restrict__ Sv, u64 ns, const u64* __restrict__ Lv, u64 nl, bool s_is_a, u32 absR, bool ordered,
+                            u64 i_begin, u64 i_end, u64* __restrict__ tmp_op, u32* rec_lds, u64& count_out, u64& slot_out) {
+  const u32 lane = threadIdx.x;
+  u64* r_b = reinterpret_cast<u64*>(rec_lds);                 // [PW_TILE] first L index of the emitted part
+  u32* r_d = rec_lds + 2 * PW_TILE;                           // [PW_TILE] number of L elements emitted from r_b
+  u32* r_s0 = rec_lds + 3 * PW_TILE;                          // [PW_TILE] first S index emitted (relative to i0)
+  u32* r_s1 = rec_lds + 4 * PW_TILE;                          // [PW_TILE] last S index emitted (inclusive, relative to i0)
+  u32* r_n = rec_lds + 5 * PW_TILE;                           // [PW_TILE] emitted values (0 = not a leader / nothing)
+  u64 cursor = 0, slot = 0;
+  bool have_slot = false;
+  for (u64 i0 = i_begin; i0 < i_end; i0 += PW_TILE) {
+    const u32 cn = (u32)min((u64)PW_TILE, i_end - i0);
+    for (u32 k = lane; k < cn; k += PW_T) {
+      const u64 i = i0 + k;
+      const u64 s = Sv[i];
+      const u64 il = lower_bound_u64(Lv, nl, s);               // first L >= s
+      u64 a = i, b = il, cur = s;                              // left walk over the union
+      for (;;) {
+        bool hs = a > 0, hl = b > 0;
+        if (!hs && !hl) break;
+        u64 cs = hs ? Sv[a - 1] : 0, cl = hl ? Lv[b - 1] : 0;
+        bool takeS = hs && (!hl || cs >= cl);
+        u64 cand = takeS ? cs : cl;
+        if (cur - cand > (u64)absR) break;
+        if (takeS) a--; else b--;
+        cur = cand;
+        if (a < i) break;   // an earlier short-list element is in this chain: not the leader
+      }
+      u32 n = 0;
+      u64 eb = 0, es0 = i, es1 = i;
+      u32 ed = 0;
+      if (a == i) {
+        u64 c = i, d = il;                                     // right walk
+        cur = s;
+        for (;;) {
+          bool hs = c + 1 < ns, hl = d < nl;
+          if (!hs && !hl) break;
+          u64 cs = hs ? Sv[c + 1] : 0, cl = hl ? Lv[d] : 0;
+          bool takeS = hs && (!hl || cs <= cl);
+          u64 cand = takeS ? cs : cl;
+          if (cand - cur > (u64)absR) break;
+          if (takeS) c++; else d++;
+          cur = cand;
+        }
+        // chain = S[i..c] u L[b..d)
+        u64 lb = b, ld = d, sb = i;
+        bool ok = d > b;                                      // needs an element of the long operand
+        if (ok && ordered) {
+          if (s_is_a) {                                       // first A element = s: drop L elements before it
+            lb = il;
+            ok = d > il;                                      // a B element at or after the first A
+          } else {                                            // A is the long operand: first A = L[b]
+            u64 fa = Lv[b];
+            while (sb <= c && Sv[sb] < fa) sb++;             // drop B-only prefix
+            ok = sb <= c;
+          }
+        }
+        if (ok) {
+          eb = lb; ed = (u32)(ld - lb); es0 = sb; es1 = c;
+          n = gal_merge(Sv, sb, c, Lv, lb, ld, [](u64) {});
+        }
+      }
+      r_b[k] = eb; r_d[k] = ed; r_s0[k] = (u32)(es0 - i0); r_s1[k] = (u32)(es1 - i0); r_n[k] = n;
+    }
+    __syncthreads();
+    u32 mine = 0;
+    for (u32 q = 0; q < PW_ITEMS; q++) { u32 k = lane * PW_ITEMS + q; if (k < cn) mine += r_n[k]; }
+    const u32 incl = wave_scan_incl(mine);
+    const u32 total = __shfl(incl, 63, DCD_WAVE);
+    u32 ex = incl - mine;
+    if (!have_slot && total) {
+      // scratch slot of this work item = union index (S index + L index) of its first emitted element
+      const u64 m = ballot64(mine != 0);
+      const u32 fl = (u32)__builtin_ctzll(m);
+      u64 cand = 0;
+      if (lane == fl) {
+        for (u32 q = 0; q < PW_ITEMS; q++) { u32 k = lane * PW_ITEMS + q; if (k < cn && r_n[k]) { cand = r_b[k] + i0 + r_s0[k]; break; } }
+      }
+      slot = shfl64(cand, fl);
+      have_slot = true;
+    }
+    u64* out = tmp_op + slot;
+    for (u32 q = 0; q < PW_ITEMS; q++) {
+      u32 k = lane * PW_ITEMS + q;
+      if (k < cn && r_n[k]) {
+        u64 o = cursor + ex;
+        gal_merge(Sv, i0 + r_s0[k], i0 + r_s1[k], Lv, r_b[k], r_b[k] + r_d[k], [&](u64 v) { out[o++] = v; });
+        ex += r_n[k];
+      }
+    }
+    cursor += total;
+    __syncthreads();
+  }
+  count_out = cursor;
+  slot_out = slot;
+}
+
+__global__ __launch_bounds__(PW_T) void k_pair_parts(const PairOp* __restrict__ ops, u32 n_ops, const u64* __restrict__ part_base,
+                                                    const u64* __restrict__ idx_values, const u64* __restrict__ pool,
+                                                    const u64* __restrict__ counts, u64* __restrict__ tmp, u64* __restrict__ part_count,
+                                                    u64* __restrict__ part_src) {
+  constexpr u32 RAW_WORDS = 6u * PW_TILE + 16u;
+  __shared__ __attribute__((aligned(16))) u32 s_raw[RAW_WORDS];
+  u64* sA = reinterpret_cast<u64*>(s_raw);
+  u64* sB = sA + PW_TILE;
+  u32* s_firstA = s_raw + 4 * PW_TILE;
+  u32* s_hasEB = s_firstA + PW_TILE + 4;
+  const u32 lane = threadIdx.x;
+  const u64 w = blockIdx.x;
+  u32 oi;
+  {   // operator of this work item: last op with part_base[op] <= w
+    u32 lo = 0, hi = n_ops;
+    while (lo + 1 < hi) { u32 m = (lo + hi) >> 1; if (part_base[m] <= w) lo = m; else hi = m; }
+    oi = lo;
+  }
+  const u64 p = w - part_base[oi];
+  const PairOp op = ops[oi];
+  const u64* A = seg_ptr(op.a, idx_values, pool);
+  const u64* B = seg_ptr(op.b, idx_values, pool);
+  const u64 na = seg_cnt(op.a, counts), nb = seg_cnt(op.b, counts);
+  u64* tmp_op = tmp + op.tmp_off;
+  const u32 absR = (u32)max(abs(op.Ra), abs(op.Rb));
+  const bool ordered = op.Ra < 0 && op.Rb < 0 && absR != 0;   // R = -absR < 0  (IndexSequence.cs:221-222)
+  const bool is_or = op.op == DCD_OP_OR;
+  const u64 n_union = na + nb;
+  const u64 n_act = n_union ? (n_union + PART - 1) / PART : 0;   // partitions in use (the grid is sized for the capacity)
+  u64 count = 0, slot = 0;
+  if (p < n_act) {
+    bool gallop = false;
+    if (!is_or && absR != 0 && na && nb) {
+      const bool a_short = na <= nb;
+      const u64 ns = a_short ? na : nb, nl = a_short ? nb : na;
+      const u64* Sv = a_short ? A : B;
+      const u64* Lv = a_short ? B : A;
+      if (ns * GAL_RATIO <= nl && (Lv[nl - 1] - Lv[0]) / nl > 4ull * absR) {
+        gallop = true;
+        const u64 per = (ns + n_act - 1) / n_act;
+        const u64 i_begin = min(ns, p * per), i_end = min(ns, i_begin + per);
+        if (i_begin < i_end) part_gallop(Sv, ns, Lv, nl, a_short, absR, ordered, i_begin, i_end, tmp_op, s_raw, count, slot);
+      }
+    }
+    if (!gallop) {
+      const u64 d_begin = p * PART, d_end = d_begin + PART;
+      u64 ia = wave_split(A, na, B, nb, d_begin), ib = d_begin - ia;
+      u64 prev_val = 0;
+      u32 prev_src = 0, have_prev = 0;
+      if (d_begin > 0) {
+        have_prev = 1;
+        const bool ua = ia > 0, ub = ib > 0;
+        const u64 pa = ua ? A[ia - 1] : 0, pb = ub ? B[ib - 1] : 0;
+        if (ua && ub) { if (pb >= pa) { prev_val = pb; prev_src = 1; } else { prev_val = pa; prev_src = 0; } }
+        else if (ua) { prev_val = pa; prev_src = 0; }
+        else { prev_val = pb; prev_src = 1; }
+      }
+      u64 g = d_begin;                 // union index of the next unconsumed element
+      u64 cursor = 0, out_start = 0;
+      u32 open = 0, committed = 0, seenA = 0, seenEB = 0;
+      u32 hA = 0, hB = 0;
+      bool skipping = !is_or;          // '*': nothing is owned before the first chain break of the partition
+      u64* out = tmp_op + d_begin;
+      slot = d_begin;
+      // Operands are staged in two LDS rings of PW_TILE elements.  A tile consumes ca + cb = PW_TILE elements; the
+      // refill of the freed slots is requested from HBM as soon as ca is known (a wave-wide merge-path probe) and is
+      // stored into the rings after the tile's merge has read them, so the load latency overlaps the tile's work.
+      u32 ra = (u32)min((u64)PW_TILE, na - ia), rb = (u32)min((u64)PW_TILE, nb - ib);
+      for (u32 i = lane; i < ra; i += PW_T) sA[i] = A[ia + i];
+      for (u32 i = lane; i < rb; i += PW_T) sB[i] = B[ib + i];
+      wsync();
+      while (ra + rb != 0) {
+        if (g >= d_end && (skipping || is_or)) break;
+        auto Aat = [&](u32 x) -> u64 { return sA[(hA + x) & (PW_TILE - 1)]; };
+        auto Bat = [&](u32 x) -> u64 { return sB[(hB + x) & (PW_TILE - 1)]; };
+        const u32 cnt = min((u32)PW_TILE, ra + rb);
+        auto split = [&](u32 d) -> u32 {     // merge path: ties take A first
+          u32 lo = d > rb ? d - rb : 0u, hi = min(d, ra);
+          while (lo < hi) {
+            u32 mid = (lo + hi) >> 1;
+            if (Aat(mid) <= Bat(d - 1 - mid)) lo = mid + 1; else hi = mid;
+          }
+          return lo;
+        };
+        u32 ca = ra;                         // A elements among the tile's cnt union elements
+        if (cnt != ra + rb) {
+          u32 lo = cnt > rb ? cnt - rb : 0u, hi = min(cnt, ra);
+          while (lo < hi) {                  // 64-ary probe over the staged elements: at most two rounds
+            const u32 step = (hi - lo + 63u) >> 6;
+            const u32 pp = lo + lane * step + (step - 1u);
+            bool pr = false;
+            if (pp < hi) pr = Aat(pp) <= Bat(cnt - 1u - pp);
+            const u32 c = popc64(ballot64(pr));
+            const u32 nlo = lo + c * step, nhi = nlo + step - 1u;
+            lo = nlo;
+            hi = min(hi, nhi);
+          }
+          ca = lo;
+        }
+        const u32 cb = cnt - ca;
+        // request the refill
+        const u32 keepA = ra - ca, keepB = rb - cb;
+        const u32 nra = (u32)min((u64)PW_TILE, na - ia - ca), nrb = (u32)min((u64)PW_TILE, nb - ib - cb);
+        const u32 newA = nra - keepA, newB = nrb - keepB;
+        u64 pfA[PW_ITEMS], pfB[PW_ITEMS];
+#pragma unroll
+        for (int q = 0; q < (int)PW_ITEMS; q++) {
+          const u32 x = lane + (u32)q * PW_T;
+          pfA[q] = x < newA ? A[ia + ra + x] : 0;
+          pfB[q] = x < newB ? B[ib + rb + x] : 0;
+        }
+        const u32 d0 = min(lane * PW_ITEMS, cnt), d1 = min(d0 + PW_ITEMS, cnt);
+        u32 i = split(d0), j = d0 - i;
+        u64 pv = prev_val;
+        u32 psrc = prev_src, hp = have_prev;
+        if (d0 > 0) {
+          hp = 1;
+          bool ua = i > 0, ub = j > 0;
+          if (ua && ub) { if (Bat(j - 1) >= Aat(i - 1)) { pv = Bat(j - 1); psrc = 1; } else { pv = Aat(i - 1); psrc = 0; } }
+          else if (ua) { pv = Aat(i - 1); psrc = 0; }
+          else { pv = Bat(j - 1); psrc = 1; }
+        }
+        u64 val[PW_ITEMS];
+        u32 src[PW_ITEMS], dup[PW_ITEMS], brk[PW_ITEMS], ctc[PW_ITEMS], al[PW_ITEMS];
+#pragma unroll
+        for (int k = 0; k < (int)PW_ITEMS; k++) {
+          val[k] = 0; src[k] = 0; dup[k] = 0; brk[k] = 0; ctc[k] = 0; al[k] = 0;
+          if (d0 + k < d1) {
+            bool takeA = i < ra && (j >= rb || Aat(i) <= Bat(j));
+            u64 v = takeA ? Aat(i) : Bat(j);
+            if (takeA) i++; else j++;
+            val[k] = v;
+            src[k] = takeA ? 0u : 1u;
+            dup[k] = (!takeA && hp && psrc == 0 && pv == v) ? 1u : 0u;
+            brk[k] = !hp ? 1u : ((absR != 0 && v - pv > (u64)absR) ? 1u : 0u);
+            ctc[k] = (hp && psrc != src[k] && !brk[k]) ? 1u : 0u;   // neighbours from different operands within absR
+            al[k] = 1;
+            pv = v; psrc = src[k]; hp = 1;
+          }
+        }
+        // the rings have been read: store the refill (visible to the next tile after the wsync that ends this one)
+        wsync();
+#pragma unroll
+        for (int q = 0; q < (int)PW_ITEMS; q++) {
+          const u32 x = lane + (u32)q * PW_T;
+          if (x < newA) sA[(hA + ra + x) & (PW_TILE - 1)] = pfA[q];
+          if (x < newB) sB[(hB + rb + x) & (PW_TILE - 1)] = pfB[q];
+        }
+        // the tile's last element (all lanes)
+        const u32 last_lane = (cnt - 1) / PW_ITEMS, last_k = (cnt - 1) % PW_ITEMS;
+        u64 lv = 0; u32 ls = 0;
+#pragma unroll
+        for (int k = 0; k < (int)PW_ITEMS; k++) if ((u32)k == last_k) { lv = val[k]; ls = src[k]; }
+        const u64 t_last_val = shfl64(lv, last_lane);
+        const u32 t_last_src = __shfl(ls, (int)last_lane, DCD_WAVE);
+        const bool inputs_end = (ia + ca == na) && (ib + cb == nb);
+        // ---- ownership: [t_lo, t_hi) of this tile belongs to the work item ------------------------------
+        u32 t_lo = 0, t_hi = cnt;
+        const bool may_end = g + cnt > d_end;
+        if (skipping || may_end) {
+          u32 fb = NONE32, fe = NONE32;
+#pragma unroll
+          for (int k = 0; k < (int)PW_ITEMS; k++) {
+            if (d0 + k < d1 && (is_or || brk[k])) {
+              if (fb == NONE32) fb = d0 + k;
+              if (fe == NONE32 && g + d0 + k >= d_end) fe = d0 + k;
+            }
+          }
+          fb = wave_min(fb); fe = wave_min(fe);
+          if (skipping) t_lo = min(fb, cnt);
+          if (may_end) t_hi = min(fe, cnt);
+          if (t_hi < t_lo) t_hi = t_lo;
+        }
+        const bool ends_here = t_hi < cnt;       // a chain break at or beyond the partition end: stop before it
+        auto advance = [&]() {
+          ia += ca; ib += cb;
+          hA = (hA + ca) & (PW_TILE - 1); hB = (hB + cb) & (PW_TILE - 1);
+          ra = nra; rb = nrb;
+          prev_val = t_last_val; prev_src = t_last_src; have_prev = 1;
+          g += cnt;
+        };
+        if (t_lo >= t_hi) {                      // nothing owned in this tile
+          if (ends_here) {
+            if (open && !committed) cursor = out_start;   // the carried chain closes without the other operand
+            open = 0;
+            break;
+          }
+          advance();
+          wsync();
+          continue;
+        }
+        if (skipping) { skipping = false; slot = g + t_lo; out = tmp_op + slot; }
+        const bool has_dead = t_lo > 0 || ends_here;
+        if (has_dead) {
+#pragma unroll
+          for (int k = 0; k < (int)PW_ITEMS; k++) {
+            const bool a = d0 + k < d1 && d0 + k >= t_lo && d0 + k < t_hi;
+            al[k] = a ? 1u : 0u;
+            if (!a) { brk[k] = 0; ctc[k] = 0; }
+          }
+        }
+        const bool final_tile = ends_here || inputs_end;
+        u32 nbrk = 0, contact = 0, lastbrk1 = 0;
+#pragma unroll
+        for (int k = 0; k < (int)PW_ITEMS; k++) {
+          nbrk += brk[k];
+          contact |= ctc[k];
+          if (brk[k]) lastbrk1 = d0 + k + 1;
+        }
+        // ---- sparse fast path: no two neighbouring elements from different operands within absR ------
+        if (!is_or && absR != 0 && !has_dead) {
+          const u32 M = wave_max(contact ? 0xFFFFFFFFu : lastbrk1);
+          const u32 t_first_brk = __shfl(brk[0], 0, DCD_WAVE);
+          const bool carried_committed_continues = open && committed && !t_first_brk;
+          if (M != 0xFFFFFFFFu && !carried_committed_continues) {
+            if (M == 0) {                                  // the carried chain spans the whole tile
+              const bool elig = !ordered || seenA;
+              if (final_tile) cursor = out_start;          // closes without the other operand: roll back
+              else if (elig) {
+#pragma unroll
+                for (int k = 0; k < (int)PW_ITEMS; k++) if (d0 + k < d1) out[cursor + d0 + k] = val[k];
+                cursor += cnt;
+              }
+            } else {
+              const u32 LB = M - 1;
+              const u64 cursor0 = (open && !committed) ? out_start : cursor;   // the carried chain closes: roll back
+              if (final_tile) cursor = cursor0;
+              else {
+                const bool elig = !ordered || t_last_src == 0;
+                if (elig) {
+#pragma unroll
+                  for (int k = 0; k < (int)PW_ITEMS; k++) if (d0 + k < d1 && d0 + k >= LB) out[cursor0 + (d0 + k - LB)] = val[k];
+                }
+                cursor = cursor0 + (elig ? cnt - LB : 0u);
+                out_start = cursor0;
+                open = 1; committed = 0; seenA = t_last_src == 0 ? 1u : 0u; seenEB = (t_last_src == 1 && !ordered) ? 1u : 0u;
+              }
+            }
+            advance();
+            wsync();
+            continue;
+          }
+        }
+        // ---- general path ---------------------------------------------------------------------------------
+        for (u32 x = lane; x < PW_TILE + 2; x += PW_T) { s_firstA[x] = NONE32; s_hasEB[x] = 0; }
+        wsync();
+        const u32 incl_brk = wave_scan_incl(nbrk);
+        const u32 last_cid = __shfl(incl_brk, 63, DCD_WAVE);
+        u32 cid[PW_ITEMS];
+        {
+          u32 c = incl_brk - nbrk;
+#pragma unroll
+          for (int k = 0; k < (int)PW_ITEMS; k++) { c += brk[k]; cid[k] = c; }
+        }
+#pragma unroll
+        for (int k = 0; k < (int)PW_ITEMS; k++) {   // first A element (tile position) per chain
+          if (al[k] && src[k] == 0) {
+            bool first_in_thread = true;
+            for (int q = 0; q < k; q++) if (al[q] && src[q] == 0 && cid[q] == cid[k]) first_in_thread = false;
+            if (first_in_thread) atomicMin(&s_firstA[cid[k]], d0 + k);
+          }
+        }
+        wsync();
+        u32 elig[PW_ITEMS];
+#pragma unroll
+        for (int k = 0; k < (int)PW_ITEMS; k++) {
+          elig[k] = 0;
+          if (al[k]) {
+            bool sA_ = s_firstA[cid[k]] <= d0 + k || (cid[k] == 0 && seenA);
+            elig[k] = (!ordered || sA_) ? 1u : 0u;
+            if (src[k] == 1 && elig[k]) {
+              bool first_in_thread = true;
+              for (int q = 0; q < k; q++) if (al[q] && src[q] == 1 && elig[q] && cid[q] == cid[k]) first_in_thread = false;
+              if (first_in_thread) atomicOr(&s_hasEB[cid[k]], 1u);
+            }
+          }
+        }
+        wsync();
+        auto commit_of = [&](u32 c) -> bool {
+          bool hasA = s_firstA[c] != NONE32 || (c == 0 && seenA);
+          bool hasEB = s_hasEB[c] != 0 || (c == 0 && seenEB);
+          return (hasA && hasEB) || (c == 0 && committed);
+        };
+        u32 emit[PW_ITEMS], nemit = 0;
+#pragma unroll
+        for (int k = 0; k < (int)PW_ITEMS; k++) {
+          emit[k] = 0;
+          if (al[k] && !dup[k]) {
+            if (is_or) emit[k] = 1;
+            else if (elig[k]) {
+              bool closed = cid[k] < last_cid || final_tile;
+              emit[k] = closed ? (commit_of(cid[k]) ? 1u : 0u) : 1u;
+            }
+          }
+          nemit += emit[k];
+        }
+        // roll back an open chain that closed in this tile without committing
+        if (!is_or && open && !committed && (last_cid > 0 || final_tile) && !commit_of(0)) cursor = out_start;
+        const u32 incl_emit = wave_scan_incl(nemit);
+        const u32 total_emit = __shfl(incl_emit, 63, DCD_WAVE);
+        u32 lfe1 = 0;                                 // 1 + emit offset of the first element of the tile's last chain
+        {
+          u32 e = incl_emit - nemit;
+#pragma unroll
+          for (int k = 0; k < (int)PW_ITEMS; k++) {
+            if (al[k]) {
+              if (brk[k] && cid[k] == last_cid) lfe1 = e + 1;
+              if (emit[k]) out[cursor + e] = val[k];
+              e += emit[k];
+            }
+          }
+        }
+        lfe1 = wave_max(lfe1);
+        {
+          const bool hasA = s_firstA[last_cid] != NONE32 || (last_cid == 0 && seenA);
+          const bool hasEB = s_hasEB[last_cid] != 0 || (last_cid == 0 && seenEB);
+          const bool com = (hasA && hasEB) || (last_cid == 0 && committed);
+          if (last_cid != 0 || !open) out_start = cursor + (lfe1 ? lfe1 - 1 : 0u);
+          open = 1; seenA = hasA; seenEB = hasEB; committed = com;
+          cursor += total_emit;
+        }
+        if (ends_here) { open = 0; break; }
+        advance();
+        wsync();
+      }
+      count = cursor;
+    }
+  }
+  if (lane == 0) { part_count[w] = count; part_src[w] = slot; }
+}
+
+// out[...] <- scratch: every wave looks at 64 work items at a time and copies the non-empty ones
+__global__ __launch_bounds__(256) void k_pair_gather(const PairOp* __restrict__ ops, u32 n_ops, const u64* __restrict__ part_base, u64 W,
+                                                    const u64* __restrict__ part_count, const u64* __restrict__ part_src,
+                                                    const u64* __restrict__ excl, const u64* __restrict__ tmp, u64* __restrict__ pool) {
+  const u32 lane = lane_id();
+  const u64 gw = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = ((u64)gridDim.x * blockDim.x) >> 6;
+  for (u64 base = gw * 64; base < W; base += nw * 64) {
+    const u64 w = base + lane;
+    const u64 c = w < W ? part_count[w] : 0;
+    u64 m = ballot64(c != 0);
+    while (m) {
+      const u32 b = (u32)__builtin_ctzll(m);
+      m &= m - 1;
+      const u64 ww = base + b;
+      const u64 cc = shfl64(c, b);
+      u32 lo = 0, hi = n_ops;
+      while (lo + 1 < hi) { u32 mid = (lo + hi) >> 1; if (part_base[mid] <= ww) lo = mid; else hi = mid; }
+      const u64 tmp_off = ops[lo].tmp_off, out_off = ops[lo].out_off;
+      const u64* s = tmp + tmp_off + part_src[ww];
+      u64* d = pool + out_off + (excl[ww] - excl[part_base[lo]]);
+      for (u64 k = lane; k < cc; k += 64) d[k] = s[k];
+    }
+  }
+}
+
+__global__ void k_pair_totals(const PairOp* __restrict__ ops, u32 n_ops, const u64* __restrict__ part_base, const u64* __restrict__ excl,
+                              u64* __restrict__ counts) {
+  u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_ops) counts[ops[i].out_cnt_ref] = excl[part_base[i + 1]] - excl[part_base[i]];
+}
+
+// ------------------------------------------------------------------------------------------------
 // PrepareSearchResult + ranks
 // ------------------------------------------------------------------------------------------------
 struct ResParams {
@@ -809,6 +1329,7 @@ static int32_t run_batch(dcd_index* h, const int32_t* prog, const u64* prog_off,
   std::vector<u64> final_cap(nq, 0);
   u64 pool_elems = 0;
   u32 n_counts = 0;
+  std::vector<u64> op_cap;          // capacity of every operator result, by count reference
   for (size_t q = 0; q < nq; q++) {
     std::vector<SymVal> stk;
     for (u64 i = prog_off[q]; i < prog_off[q + 1];) {
@@ -836,8 +1357,10 @@ static int32_t run_batch(dcd_index* h, const int32_t* prog, const u64* prog_off,
         PairOp p;
         p.a = a.s; p.b = b.s; p.Ra = a.R; p.Rb = b.R; p.op = (u32)opc;
         p.out_off = pool_elems; p.out_cnt_ref = n_counts++;
+        p.tmp_off = 0;                                                   // assigned per round below
         SymVal r;
         r.cap = a.cap + b.cap;
+        op_cap.push_back(r.cap);
         pool_elems += r.cap;
         r.s.kind = 1; r.s.off = p.out_off; r.s.cnt_ref = p.out_cnt_ref; r.s.cnt_imm = 0;
         int absR = std::max(std::abs(a.R), std::abs(b.R));
@@ -862,14 +1385,48 @@ static int32_t run_batch(dcd_index* h, const int32_t* prog, const u64* prog_off,
   }
   if (o.max_found_docs > 512 || o.max_found_docs < 0 || o.max_found_pages < 0) DCD_FAIL(DCD_E_BADARG, "max_found_docs must be in [0, 512]");
 
+  // work items of every round: operator i owns part_base[i+1] - part_base[i] partitions of PART union elements
+  // (sized for the operands' capacities; the device knows the real counts) and a scratch region of the
+  // same capacity as its result
+  static const bool legacy = getenv("DOCODO_QUERY_LEGACY") != nullptr;
+  std::vector<std::vector<u64>> part_base(rounds.size());
+  u64 tmp_elems = 0, max_items = 0;
+  for (size_t r = 0; r < rounds.size(); r++) {
+    u64 t = 0, wsum = 0;
+    part_base[r].resize(rounds[r].size() + 1);
+    for (size_t k = 0; k < rounds[r].size(); k++) {
+      PairOp& p = rounds[r][k];
+      p.tmp_off = t;
+      part_base[r][k] = wsum;
+      u64 ca = p.a.cnt_ref == NONE32 ? p.a.cnt_imm : op_cap[p.a.cnt_ref];
+      u64 cb = p.b.cnt_ref == NONE32 ? p.b.cnt_imm : op_cap[p.b.cnt_ref];
+      t += ca + cb;
+      wsum += std::max<u64>(1, div_up(ca + cb, PART));
+    }
+    part_base[r][rounds[r].size()] = wsum;
+    tmp_elems = std::max(tmp_elems, t);
+    max_items = std::max(max_items, wsum);
+  }
+  if (max_items >= (1ull << 31)) DCD_FAIL(DCD_E_OVERFLOW, "query batch too large: %llu work items in one round", (unsigned long long)max_items);
+
   // ---- device buffers -------------------------------------------------------------------------------
-  DevBuf<u64> pool, counts;
+  DevBuf<u64> pool, counts, tmp, d_part_count, d_part_src, d_part_excl, d_part_scr;
   DCD_TRY(pool.alloc(dev, pool_elems ? pool_elems : 1));
   DCD_TRY(counts.alloc(dev, n_counts ? n_counts : 1));
+  if (!legacy) {
+    DCD_TRY(tmp.alloc(dev, tmp_elems ? tmp_elems : 1));
+    DCD_TRY(d_part_count.alloc(dev, max_items + 1));
+    DCD_TRY(d_part_src.alloc(dev, max_items + 1));
+    DCD_TRY(d_part_excl.alloc(dev, max_items + 1));
+    DCD_TRY(d_part_scr.alloc(dev, scan_scratch_elems(max_items + 1)));
+  }
   std::vector<DevBuf<PairOp>> d_rounds(rounds.size());
+  std::vector<DevBuf<u64>> d_part_base(rounds.size());
   for (size_t r = 0; r < rounds.size(); r++) {
     DCD_TRY(d_rounds[r].alloc(dev, rounds[r].size()));
     DCD_HIP(hipMemcpyAsync(d_rounds[r].p, rounds[r].data(), rounds[r].size() * sizeof(PairOp), hipMemcpyHostToDevice, st));
+    DCD_TRY(d_part_base[r].alloc(dev, part_base[r].size()));
+    DCD_HIP(hipMemcpyAsync(d_part_base[r].p, part_base[r].data(), part_base[r].size() * 8, hipMemcpyHostToDevice, st));
   }
   DevBuf<FinalSeq> d_fin;
   DCD_TRY(d_fin.alloc(dev, nq ? nq : 1));
@@ -889,8 +1446,20 @@ static int32_t run_batch(dcd_index* h, const int32_t* prog, const u64* prog_off,
   DCD_TRY(tm.start());
   for (size_t r = 0; r < rounds.size(); r++) {
     u32 n = (u32)rounds[r].size();
-    u32 grid = n < 8192u ? n : 8192u;
-    hipLaunchKernelGGL(k_pair_ops, dim3(grid), dim3(PO_THREADS), 0, st, d_rounds[r].p, n, idx_values, pool.p, counts.p);
+    if (legacy) {
+      u32 grid = n < 8192u ? n : 8192u;
+      hipLaunchKernelGGL(k_pair_ops, dim3(grid), dim3(PO_THREADS), 0, st, d_rounds[r].p, n, idx_values, pool.p, counts.p);
+      continue;
+    }
+    const u64 W = part_base[r][n];
+    hipLaunchKernelGGL(k_pair_parts, dim3((u32)W), dim3(PW_T), 0, st, d_rounds[r].p, n, d_part_base[r].p, idx_values, pool.p, counts.p,
+                       tmp.p, d_part_count.p, d_part_src.p);
+    DCD_HIP(hipMemsetAsync(d_part_count.p + W, 0, 8, st));
+    scan_exclusive<u64, u64>(d_part_count.p, d_part_excl.p, W + 1, d_part_scr.p, st);
+    const u32 gg = (u32)std::min<u64>(div_up(div_up(W, 64), 4), 4096);
+    hipLaunchKernelGGL(k_pair_gather, dim3(gg), dim3(256), 0, st, d_rounds[r].p, n, d_part_base[r].p, W, d_part_count.p, d_part_src.p,
+                       d_part_excl.p, tmp.p, pool.p);
+    hipLaunchKernelGGL(k_pair_totals, dim3(div_up(n, 256)), dim3(256), 0, st, d_rounds[r].p, n, d_part_base[r].p, d_part_excl.p, counts.p);
   }
   u64 tot_pages = 0, tot_pos = 0, tot_docs = 0;
   if (nq) {
@@ -1012,7 +1581,7 @@ static u64 query_pool_need(const DeviceIndex& ix, const int32_t* prog, u64 a, u6
       u64 y = stk.back(); stk.pop_back();
       u64 x = stk.back(); stk.pop_back();
       stk.push_back(x + y);
-      need += x + y;
+      need += 2 * (x + y);            // result + the round's scratch region
       i += 1;
     }
   }
