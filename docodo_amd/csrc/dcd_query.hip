@@ -4,19 +4,20 @@
 // operators * / + (IndexSequence.cs:218-322), PrepareSearchResult (Search.cs:365-420) and the page /
 // document ranks (Search.cs:99-111, 552-557, 599).
 //
-// (GAL_RATIO = 4 measured best on MI355X: 2 / 4 / 8 / 16 / 1 -> 6.45 / 6.41 / 7.00 / 7.76 / 8.02 ms for 20 k AND3 queries)
 // Shape of the computation
 //   * the posting lists are decoded once per index into absolute coordinates (HBM-resident u64,
 //     built lazily on the first query: an auxiliary structure, the .index image stays canonical);
 //   * a query is a postfix program; programs advance in rounds, one binary operator per query and
-//     round, all operators of a round in ONE launch (k_pair_ops: one workgroup per operand pair);
-//   * k_pair_ops streams both operands through LDS in 1024-element tiles: merge path -> union with
-//     source tags -> gap chains -> "contains both operands" (and the ordered-mode prefix rule) ->
-//     compaction.  A chain that is still open at a tile border is written optimistically and rolled
-//     back if it closes without the other operand (exact restatement of the group logic of
-//     IndexSequence.cs:218-284);
-//   * k_result_count / k_result_fill walk the final sequence of each query (one workgroup per
-//     query): coordinate -> page by binary search over the page END table (IndexPageList.GetPage,
+//     round, all operators of a round in ONE launch of k_pair_parts: one WAVEFRONT per (operator,
+//     partition of 8192 union elements), see the comment above that kernel;
+//   * a work item streams both operands through LDS rings in 256-element tiles: merge path -> union
+//     with source tags -> gap chains -> "contains both operands" (and the ordered-mode prefix rule)
+//     -> compaction.  A chain that is still open at a tile border is written optimistically and
+//     rolled back if it closes without the other operand (exact restatement of the group logic of
+//     IndexSequence.cs:218-284); skewed sparse pairs gallop from the
+//     short operand (GAL_RATIO = 4 measured best on MI355X);
+//   * k_result<false/true> walk the final sequence of each query (one workgroup per query):
+//     coordinate -> page by binary search over the page END table (IndexPageList.GetPage,
 //     Build.cs:74-97), page-relative positions, the 30000-page / 500-document caps, ranks.
 //
 // Operand streams must be strictly ascending (true for every posting list and every operator
@@ -71,22 +72,6 @@ __global__ void k_term_relative(const u64* __restrict__ excl, const u64* __restr
 // ------------------------------------------------------------------------------------------------
 // operator * / + on operand pairs
 // ------------------------------------------------------------------------------------------------
-constexpr int PO_THREADS = 256;
-#ifndef DCD_PO_ITEMS
-#define DCD_PO_ITEMS 4
-#endif
-constexpr int PO_ITEMS = DCD_PO_ITEMS;
-constexpr int PO_TILE = PO_THREADS * PO_ITEMS;
-
-struct PoState {
-  u64 ia, ib, cursor, out_start, prev_val;
-  u32 have_prev, prev_src, open, committed, seenA, seenEB;
-  u32 ca, cb, last_first_excl;
-  u32 hA, hB, fA, fB;            // LDS rings: head slot and number of staged (unconsumed) elements per operand
-  u32 t_first_brk, t_last_src;   // fast path: brk of the tile's first element, source of its last element
-  u64 t_last_val;
-};
-
 // ---- sparse operands: galloping ----------------------------------------------------------------------
 // When one operand is much shorter than the other and the long one is sparse relative to absR, almost
 // every element of the long list lies in a chain of its own that cannot contain both operands.  Instead of
@@ -98,9 +83,6 @@ struct PoState {
 #define DCD_GAL_RATIO 4
 #endif
 constexpr u32 GAL_RATIO = DCD_GAL_RATIO;   // gallop when RATIO * |short| <= |long|
-constexpr u32 GAL_CHUNK = 1024;   // short-list elements per workgroup iteration
-
-struct GalRec { u32 b_lo, d_hi; u32 c_hi, cnt; };   // L range [b_lo, d_hi) (relative to lbase), S range [i, c_hi]
 
 __device__ __forceinline__ u64 lower_bound_u64(const u64* __restrict__ a, u64 n, u64 v) {
   u64 lo = 0, hi = n;
@@ -129,343 +111,6 @@ __device__ __forceinline__ u32 gal_merge(const u64* __restrict__ Sv, u64 si, u64
   return n;
 }
 
-// S = short operand (ns), L = long operand (nl); s_is_a: the short one is the LEFT operand of '*'
-__device__ void pair_gallop(const u64* __restrict__ Sv, u64 ns, const u64* __restrict__ Lv, u64 nl, bool s_is_a, u32 absR, bool ordered,
-                            u64* __restrict__ out, u64* __restrict__ out_count, u32* s_scan, u32* rec_lds /* >= GAL_CHUNK * 6 u32 */) {
-  const u32 tid = threadIdx.x;
-  __shared__ u64 g_cursor;
-  if (tid == 0) g_cursor = 0;
-  __syncthreads();
-  u64* r_b = reinterpret_cast<u64*>(rec_lds);                 // [GAL_CHUNK] first L index of the emitted part
-  u32* r_d = rec_lds + 2 * GAL_CHUNK;                         // [GAL_CHUNK] number of L elements emitted from r_b
-  u32* r_s0 = rec_lds + 3 * GAL_CHUNK;                        // [GAL_CHUNK] first S index emitted (relative to chunk base)
-  u32* r_s1 = rec_lds + 4 * GAL_CHUNK;                        // [GAL_CHUNK] last S index emitted (inclusive, absolute - i0)
-  u32* r_n = rec_lds + 5 * GAL_CHUNK;                         // [GAL_CHUNK] emitted values (0 = not a leader / nothing)
-  for (u64 i0 = 0; i0 < ns; i0 += GAL_CHUNK) {
-    const u32 cn = (u32)min((u64)GAL_CHUNK, ns - i0);
-    for (u32 k = tid; k < cn; k += blockDim.x) {
-      const u64 i = i0 + k;
-      const u64 s = Sv[i];
-      const u64 il = lower_bound_u64(Lv, nl, s);               // first L >= s
-      // left walk over the union
-      u64 a = i, b = il, cur = s;
-      for (;;) {
-        bool hs = a > 0, hl = b > 0;
-        if (!hs && !hl) break;
-        u64 cs = hs ? Sv[a - 1] : 0, cl = hl ? Lv[b - 1] : 0;
-        bool takeS = hs && (!hl || cs >= cl);
-        u64 cand = takeS ? cs : cl;
-        if (cur - cand > (u64)absR) break;
-        if (takeS) a--; else b--;
-        cur = cand;
-        if (a < i) break;   // an earlier short-list element is in this chain: not the leader
-      }
-      u32 n = 0;
-      u64 eb = 0, es0 = i, es1 = i;
-      u32 ed = 0;
-      if (a == i) {
-        // right walk
-        u64 c = i, d = il;
-        cur = s;
-        for (;;) {
-          bool hs = c + 1 < ns, hl = d < nl;
-          if (!hs && !hl) break;
-          u64 cs = hs ? Sv[c + 1] : 0, cl = hl ? Lv[d] : 0;
-          bool takeS = hs && (!hl || cs <= cl);
-          u64 cand = takeS ? cs : cl;
-          if (cand - cur > (u64)absR) break;
-          if (takeS) c++; else d++;
-          cur = cand;
-        }
-        // chain = S[i..c] u L[b..d)
-        u64 lb = b, ld = d, sb = i;
-        bool ok = d > b;                                      // needs an element of the long operand
-        if (ok && ordered) {
-          if (s_is_a) {                                       // first A element = s: drop L elements before it
-            lb = il;
-            ok = d > il;                                      // a B element at or after the first A
-          } else {                                            // A is the long operand: first A = L[b]
-            u64 fa = Lv[b];
-            while (sb <= c && Sv[sb] < fa) sb++;             // drop B-only prefix
-            ok = sb <= c;
-          }
-        }
-        if (ok) {
-          eb = lb; ed = (u32)(ld - lb); es0 = sb; es1 = c;
-          n = gal_merge(Sv, sb, c, Lv, lb, ld, [](u64) {});
-        }
-      }
-      r_b[k] = eb; r_d[k] = ed; r_s0[k] = (u32)(es0 - i0); r_s1[k] = (u32)(es1 - i0); r_n[k] = n;
-    }
-    __syncthreads();
-    // offsets: scan r_n over the chunk (GAL_CHUNK / blockDim per thread, blocked)
-    constexpr u32 PER = GAL_CHUNK / PO_THREADS;
-    u32 mine = 0;
-    for (u32 q = 0; q < PER; q++) { u32 k = tid * PER + q; if (k < cn) mine += r_n[k]; }
-    u32 total;
-    u32 ex = block_scan_excl<u32, PO_THREADS / 64>(mine, s_scan, &total);
-    const u64 base = g_cursor;
-    for (u32 q = 0; q < PER; q++) {
-      u32 k = tid * PER + q;
-      if (k < cn && r_n[k]) {
-        u64 o = base + ex;
-        gal_merge(Sv, i0 + r_s0[k], i0 + r_s1[k], Lv, r_b[k], r_b[k] + r_d[k], [&](u64 v) { out[o++] = v; });
-        ex += r_n[k];
-      }
-    }
-    __syncthreads();
-    if (tid == 0) g_cursor = base + total;
-    __syncthreads();
-  }
-  if (tid == 0) *out_count = g_cursor;
-  __syncthreads();
-}
-
-__global__ __launch_bounds__(PO_THREADS) void k_pair_ops(const PairOp* __restrict__ ops, u32 n_ops, const u64* __restrict__ idx_values,
-                                                        u64* __restrict__ pool, u64* __restrict__ counts) {
-  // one LDS arena, used either by the streaming merge (sA, sB, s_firstA, s_hasEB) or by the gallop records
-  constexpr u32 RAW_WORDS = (6u * PO_TILE > 6u * GAL_CHUNK ? 6u * PO_TILE : 6u * GAL_CHUNK) + 16u;
-  __shared__ __attribute__((aligned(16))) u32 s_raw[RAW_WORDS];
-  u64* sA = reinterpret_cast<u64*>(s_raw);
-  u64* sB = sA + PO_TILE;
-  u32* s_firstA = s_raw + 4 * PO_TILE;
-  u32* s_hasEB = s_firstA + PO_TILE + 4;
-  u32* s_gal = s_raw;
-  __shared__ u32 s_scan[PO_THREADS / 64 + 1];
-  __shared__ PoState S;
-  const u32 tid = threadIdx.x;
-
-  for (u32 oi = blockIdx.x; oi < n_ops; oi += gridDim.x) {
-    const PairOp op = ops[oi];
-    const u64* A = seg_ptr(op.a, idx_values, pool);
-    const u64* B = seg_ptr(op.b, idx_values, pool);
-    const u64 na = seg_cnt(op.a, counts), nb = seg_cnt(op.b, counts);
-    u64* out = pool + op.out_off;
-    const u32 absR = (u32)max(abs(op.Ra), abs(op.Rb));
-    const bool ordered = op.Ra < 0 && op.Rb < 0 && absR != 0;   // R = -absR < 0  (IndexSequence.cs:221-222)
-    const bool is_or = op.op == DCD_OP_OR;
-    // sparse, skewed operands: gallop from the short side (block-uniform decision)
-    if (!is_or && absR != 0 && na && nb) {
-      const bool a_short = na <= nb;
-      const u64 ns = a_short ? na : nb, nl = a_short ? nb : na;
-      const u64* Sv = a_short ? A : B;
-      const u64* Lv = a_short ? B : A;
-      if (ns * GAL_RATIO <= nl && (Lv[nl - 1] - Lv[0]) / nl > 4ull * absR) {
-        pair_gallop(Sv, ns, Lv, nl, a_short, absR, ordered, out, &counts[op.out_cnt_ref], s_scan, s_gal);
-        continue;
-      }
-    }
-    if (tid == 0) {
-      S.ia = S.ib = S.cursor = S.out_start = S.prev_val = 0;
-      S.have_prev = S.prev_src = S.open = S.committed = S.seenA = S.seenEB = 0;
-      S.hA = S.hB = S.fA = S.fB = 0;
-    }
-    __syncthreads();
-
-    while (S.ia < na || S.ib < nb) {
-      const u64 ia = S.ia, ib = S.ib;
-      // The operands are staged in two LDS rings of PO_TILE elements.  A tile consumes ca + cb = PO_TILE
-      // elements; only the freed slots are refilled, so every posting is read from HBM exactly once.
-      const u32 hA = S.hA, hB = S.hB;
-      const u32 ra = (u32)min((u64)PO_TILE, na - ia), rb = (u32)min((u64)PO_TILE, nb - ib);
-      for (u32 i = S.fA + tid; i < ra; i += PO_THREADS) sA[(hA + i) & (PO_TILE - 1)] = A[ia + i];
-      for (u32 i = S.fB + tid; i < rb; i += PO_THREADS) sB[(hB + i) & (PO_TILE - 1)] = B[ib + i];
-      for (u32 i = tid; i < PO_TILE + 2; i += PO_THREADS) { s_firstA[i] = NONE32; s_hasEB[i] = 0; }
-      __syncthreads();
-      auto Aat = [&](u32 x) -> u64 { return sA[(hA + x) & (PO_TILE - 1)]; };
-      auto Bat = [&](u32 x) -> u64 { return sB[(hB + x) & (PO_TILE - 1)]; };
-      const u32 cnt = min((u32)PO_TILE, ra + rb);
-      // merge path: split of diagonal d -> (i from A, d - i from B); ties take A first
-      auto split = [&](u32 d) -> u32 {
-        u32 lo = d > rb ? d - rb : 0u, hi = min(d, ra);
-        while (lo < hi) {
-          u32 mid = (lo + hi) >> 1;
-          if (Aat(mid) <= Bat(d - 1 - mid)) lo = mid + 1; else hi = mid;
-        }
-        return lo;
-      };
-      const u32 d0 = min(tid * PO_ITEMS, cnt), d1 = min(d0 + PO_ITEMS, cnt);
-      u32 i = split(d0), j = d0 - i;
-      if (tid == 0) { u32 ci = split(cnt); S.ca = ci; S.cb = cnt - ci; }
-      // element before d0
-      u64 pv = S.prev_val;
-      u32 psrc = S.prev_src, hp = S.have_prev;
-      if (d0 > 0) {
-        hp = 1;
-        bool ua = i > 0, ub = j > 0;
-        if (ua && ub) { if (Bat(j - 1) >= Aat(i - 1)) { pv = Bat(j - 1); psrc = 1; } else { pv = Aat(i - 1); psrc = 0; } }
-        else if (ua) { pv = Aat(i - 1); psrc = 0; }
-        else { pv = Bat(j - 1); psrc = 1; }
-      }
-      u64 val[PO_ITEMS];
-      u32 src[PO_ITEMS], dup[PO_ITEMS], brk[PO_ITEMS];
-      u32 nbrk = 0;
-      u32 contact = 0;         // some neighbouring union elements come from different operands within absR
-      u32 lastbrk1 = 0;        // 1 + tile position of this lane's last chain break (0 = none)
-#pragma unroll
-      for (int k = 0; k < PO_ITEMS; k++) {
-        val[k] = 0; src[k] = 0; dup[k] = 0; brk[k] = 0;
-        if (d0 + k < d1) {
-          bool takeA = i < ra && (j >= rb || Aat(i) <= Bat(j));
-          u64 v = takeA ? Aat(i) : Bat(j);
-          if (takeA) i++; else j++;
-          val[k] = v;
-          src[k] = takeA ? 0u : 1u;
-          dup[k] = (!takeA && hp && psrc == 0 && pv == v) ? 1u : 0u;
-          brk[k] = !hp ? 1u : ((absR != 0 && v - pv > (u64)absR) ? 1u : 0u);
-          nbrk += brk[k];
-          if (hp && psrc != src[k] && !brk[k]) contact = 1;
-          if (brk[k]) lastbrk1 = d0 + k + 1;
-          pv = v; psrc = src[k]; hp = 1;
-        }
-      }
-      // ---- sparse fast path -----------------------------------------------------------------------
-      // No two neighbouring union elements of this tile come from different operands within absR: every
-      // chain inside the tile is single-operand, nothing can be emitted here except (optimistically) the
-      // tile's last chain, which may still meet the other operand in a later tile.  One reduction and
-      // O(1) state updates replace the chain machinery below (scans, LDS atomics, ~8 barriers).
-      if (!is_or && absR != 0) {
-        u32 key = contact ? 0xFFFFFFFFu : lastbrk1;
-        key = wave_max(key);
-        if (lane_id() == 0) s_scan[tid >> 6] = key;
-        if (tid == 0) S.t_first_brk = brk[0];
-        if (d1 == cnt && d0 < d1) { S.t_last_src = src[d1 - d0 - 1]; S.t_last_val = val[d1 - d0 - 1]; }
-        __syncthreads();
-        const u32 M = max(max(s_scan[0], s_scan[1]), max(s_scan[2], s_scan[3]));
-        const bool carried_committed_continues = S.open && S.committed && !S.t_first_brk;
-        if (M != 0xFFFFFFFFu && !carried_committed_continues) {
-          const bool final_tile = (ia + S.ca == na) && (ib + S.cb == nb);
-          const u32 last_src = S.t_last_src;
-          u64 new_cursor, new_out_start = S.out_start;
-          u32 n_open = S.open, n_com = S.committed, n_sa = S.seenA, n_seb = S.seenEB;
-          if (M == 0) {                                  // the carried chain spans the whole tile
-            const bool elig = !ordered || S.seenA;
-            if (final_tile) new_cursor = S.out_start;    // closes without the other operand: roll back
-            else {
-              if (elig) {
-#pragma unroll
-                for (int k = 0; k < PO_ITEMS; k++) if (d0 + k < d1) out[S.cursor + d0 + k] = val[k];
-              }
-              new_cursor = S.cursor + (elig ? cnt : 0u);
-            }
-          } else {
-            const u32 LB = M - 1;
-            const u64 cursor0 = (S.open && !S.committed) ? S.out_start : S.cursor;   // the carried chain closes: roll back
-            if (final_tile) new_cursor = cursor0;
-            else {
-              const bool elig = !ordered || last_src == 0;
-              if (elig) {
-#pragma unroll
-                for (int k = 0; k < PO_ITEMS; k++) if (d0 + k < d1 && d0 + k >= LB) out[cursor0 + (d0 + k - LB)] = val[k];
-              }
-              new_cursor = cursor0 + (elig ? cnt - LB : 0u);
-              new_out_start = cursor0;
-              n_open = 1; n_com = 0; n_sa = last_src == 0 ? 1u : 0u; n_seb = (last_src == 1 && !ordered) ? 1u : 0u;
-            }
-          }
-          __syncthreads();
-          if (tid == 0) {
-            S.cursor = new_cursor; S.out_start = new_out_start;
-            S.open = n_open; S.committed = n_com; S.seenA = n_sa; S.seenEB = n_seb;
-            S.ia = ia + S.ca; S.ib = ib + S.cb;
-            S.hA = (hA + S.ca) & (PO_TILE - 1); S.hB = (hB + S.cb) & (PO_TILE - 1);
-            S.fA = ra - S.ca; S.fB = rb - S.cb;
-            S.prev_val = S.t_last_val; S.prev_src = last_src; S.have_prev = 1;
-          }
-          __syncthreads();
-          continue;
-        }
-        __syncthreads();   // s_scan is reused by the block scans below
-      }
-      u32 total_brk;
-      u32 cbase = block_scan_excl<u32, PO_THREADS / 64>(nbrk, s_scan, &total_brk);
-      u32 cid[PO_ITEMS];
-      {
-        u32 c = cbase;
-#pragma unroll
-        for (int k = 0; k < PO_ITEMS; k++) { c += brk[k]; cid[k] = c; }
-      }
-      // first A element (tile position) per chain
-#pragma unroll
-      for (int k = 0; k < PO_ITEMS; k++) {
-        if (d0 + k < d1 && src[k] == 0) {
-          bool first_in_thread = true;
-          for (int q = 0; q < k; q++) if (src[q] == 0 && cid[q] == cid[k]) first_in_thread = false;
-          if (first_in_thread) atomicMin(&s_firstA[cid[k]], d0 + k);
-        }
-      }
-      __syncthreads();
-      u32 elig[PO_ITEMS];
-#pragma unroll
-      for (int k = 0; k < PO_ITEMS; k++) {
-        elig[k] = 0;
-        if (d0 + k < d1) {
-          bool seenA = s_firstA[cid[k]] <= d0 + k || (cid[k] == 0 && S.seenA);
-          elig[k] = (!ordered || seenA) ? 1u : 0u;
-          if (src[k] == 1 && elig[k]) {
-            bool first_in_thread = true;
-            for (int q = 0; q < k; q++) if (src[q] == 1 && elig[q] && cid[q] == cid[k]) first_in_thread = false;
-            if (first_in_thread) atomicOr(&s_hasEB[cid[k]], 1u);
-          }
-        }
-      }
-      __syncthreads();
-      const u32 last_cid = total_brk;
-      const bool final_tile = (ia + S.ca == na) && (ib + S.cb == nb);
-      auto commit_of = [&](u32 c) -> bool {
-        bool hasA = s_firstA[c] != NONE32 || (c == 0 && S.seenA);
-        bool hasEB = s_hasEB[c] != 0 || (c == 0 && S.seenEB);
-        return (hasA && hasEB) || (c == 0 && S.committed);
-      };
-      u32 emit[PO_ITEMS], nemit = 0;
-#pragma unroll
-      for (int k = 0; k < PO_ITEMS; k++) {
-        emit[k] = 0;
-        if (d0 + k < d1 && !dup[k]) {
-          if (is_or) emit[k] = 1;
-          else if (elig[k]) {
-            bool closed = cid[k] < last_cid || final_tile;
-            emit[k] = closed ? (commit_of(cid[k]) ? 1u : 0u) : 1u;
-          }
-        }
-        nemit += emit[k];
-      }
-      // roll back an open chain that closed in this tile without committing
-      u64 cursor = S.cursor;
-      if (!is_or && S.open && !S.committed && (last_cid > 0 || final_tile) && !commit_of(0)) cursor = S.out_start;
-      u32 total_emit;
-      u32 ebase = block_scan_excl<u32, PO_THREADS / 64>(nemit, s_scan, &total_emit);
-      {
-        u32 e = ebase;
-#pragma unroll
-        for (int k = 0; k < PO_ITEMS; k++) {
-          if (d0 + k < d1) {
-            if (brk[k] && cid[k] == last_cid) S.last_first_excl = e;  // first element of the tile's last chain
-            if (emit[k]) out[cursor + e] = val[k];
-            e += emit[k];
-          }
-        }
-      }
-      __syncthreads();
-      if (tid == 0) {
-        bool hasA = s_firstA[last_cid] != NONE32 || (last_cid == 0 && S.seenA);
-        bool hasEB = s_hasEB[last_cid] != 0 || (last_cid == 0 && S.seenEB);
-        bool com = (hasA && hasEB) || (last_cid == 0 && S.committed);
-        if (last_cid != 0 || !S.open) S.out_start = cursor + S.last_first_excl;
-        S.open = 1; S.seenA = hasA; S.seenEB = hasEB; S.committed = com;
-        S.cursor = cursor + total_emit;
-        S.ia = ia + S.ca; S.ib = ib + S.cb;
-        S.hA = (hA + S.ca) & (PO_TILE - 1); S.hB = (hB + S.cb) & (PO_TILE - 1);
-        S.fA = ra - S.ca; S.fB = rb - S.cb;
-      }
-      if (d1 == cnt && d0 < d1) { S.prev_val = val[d1 - d0 - 1]; S.prev_src = src[d1 - d0 - 1]; S.have_prev = 1; }
-      __syncthreads();
-    }
-    if (tid == 0) counts[op.out_cnt_ref] = S.cursor;
-    __syncthreads();
-  }
-}
-
 // ------------------------------------------------------------------------------------------------
 // partitioned operators: one WAVEFRONT per (operator, partition)
 // ------------------------------------------------------------------------------------------------
@@ -481,13 +126,13 @@ __global__ __launch_bounds__(PO_THREADS) void k_pair_ops(const PairOp* __restric
 // roll-back at tile borders), on 256-element tiles with wave-level scans; '+' uses the same ownership
 // rule with every element its own chain.  Skewed sparse pairs gallop from the short operand, the short
 // list spread evenly over the operator's work items.
-#ifndef DCD_PART
-#define DCD_PART 4096
-#endif
 constexpr u32 PW_T = 64;
-constexpr u32 PW_ITEMS = 4;
+#ifndef DCD_PW_ITEMS
+#define DCD_PW_ITEMS 4
+#endif
+constexpr u32 PW_ITEMS = DCD_PW_ITEMS;
 constexpr u32 PW_TILE = PW_T * PW_ITEMS;
-constexpr u64 PART = DCD_PART;
+constexpr u64 PART_DEFAULT = 8192;   // union elements per work item (measured on MI355X: 2048 / 4096 / 8192 / 16384 -> 51.5 / 43.6 / 41.7 / 41.9 ms for 20 k AND3 queries on the 10 M-doc index)
 
 // orders a wave's LDS writes before its later LDS reads of other lanes' data: the work items are single
 // wavefronts, LDS executes a wave's accesses in order, so no s_barrier / s_waitcnt is needed (and the
@@ -626,7 +271,7 @@ __device__ void part_gallop(const u64* __restrict__ Sv, u64 ns, const u64* __res
 __global__ __launch_bounds__(PW_T) void k_pair_parts(const PairOp* __restrict__ ops, u32 n_ops, const u64* __restrict__ part_base,
                                                     const u64* __restrict__ idx_values, const u64* __restrict__ pool,
                                                     const u64* __restrict__ counts, u64* __restrict__ tmp, u64* __restrict__ part_count,
-                                                    u64* __restrict__ part_src) {
+                                                    u64* __restrict__ part_src, u64 PART) {
   constexpr u32 RAW_WORDS = 6u * PW_TILE + 16u;
   __shared__ __attribute__((aligned(16))) u32 s_raw[RAW_WORDS];
   u64* sA = reinterpret_cast<u64*>(s_raw);
@@ -1388,7 +1033,8 @@ static int32_t run_batch(dcd_index* h, const int32_t* prog, const u64* prog_off,
   // work items of every round: operator i owns part_base[i+1] - part_base[i] partitions of PART union elements
   // (sized for the operands' capacities; the device knows the real counts) and a scratch region of the
   // same capacity as its result
-  static const bool legacy = getenv("DOCODO_QUERY_LEGACY") != nullptr;
+  u64 PART = PART_DEFAULT;
+  if (const char* e = getenv("DOCODO_QUERY_PART")) PART = std::max<u64>(strtoull(e, nullptr, 10), 1);   // tests: tiny partitions
   std::vector<std::vector<u64>> part_base(rounds.size());
   u64 tmp_elems = 0, max_items = 0;
   for (size_t r = 0; r < rounds.size(); r++) {
@@ -1413,7 +1059,7 @@ static int32_t run_batch(dcd_index* h, const int32_t* prog, const u64* prog_off,
   DevBuf<u64> pool, counts, tmp, d_part_count, d_part_src, d_part_excl, d_part_scr;
   DCD_TRY(pool.alloc(dev, pool_elems ? pool_elems : 1));
   DCD_TRY(counts.alloc(dev, n_counts ? n_counts : 1));
-  if (!legacy) {
+  {
     DCD_TRY(tmp.alloc(dev, tmp_elems ? tmp_elems : 1));
     DCD_TRY(d_part_count.alloc(dev, max_items + 1));
     DCD_TRY(d_part_src.alloc(dev, max_items + 1));
@@ -1446,14 +1092,9 @@ static int32_t run_batch(dcd_index* h, const int32_t* prog, const u64* prog_off,
   DCD_TRY(tm.start());
   for (size_t r = 0; r < rounds.size(); r++) {
     u32 n = (u32)rounds[r].size();
-    if (legacy) {
-      u32 grid = n < 8192u ? n : 8192u;
-      hipLaunchKernelGGL(k_pair_ops, dim3(grid), dim3(PO_THREADS), 0, st, d_rounds[r].p, n, idx_values, pool.p, counts.p);
-      continue;
-    }
     const u64 W = part_base[r][n];
     hipLaunchKernelGGL(k_pair_parts, dim3((u32)W), dim3(PW_T), 0, st, d_rounds[r].p, n, d_part_base[r].p, idx_values, pool.p, counts.p,
-                       tmp.p, d_part_count.p, d_part_src.p);
+                       tmp.p, d_part_count.p, d_part_src.p, PART);
     DCD_HIP(hipMemsetAsync(d_part_count.p + W, 0, 8, st));
     scan_exclusive<u64, u64>(d_part_count.p, d_part_excl.p, W + 1, d_part_scr.p, st);
     const u32 gg = (u32)std::min<u64>(div_up(div_up(W, 64), 4), 4096);

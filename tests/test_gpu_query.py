@@ -47,11 +47,35 @@ def test_operators_parity(oracle_mod, Ra, Rb):
         assert np.array_equal(got.units, want), ("or", a.size, b.size)
 
 
-def test_long_chain_across_tiles(oracle_mod):
-    """One gap chain spanning many 1024-element tiles that gains its second operand only at the very
+@pytest.mark.parametrize("part", [64, 300, 1024])
+@pytest.mark.parametrize("Ra,Rb", [(258, 259), (-7, -9), (0, 0), (40, -3)])
+def test_operators_partition_sizes(oracle_mod, monkeypatch, part, Ra, Rb):
+    """Operators are evaluated by one wavefront per partition of the operand union (8192 elements by default);
+    tiny partitions put a partition border inside almost every gap chain: skipped heads, chains followed past
+    the partition end, duplicates and ties on a border, empty partitions."""
+    import docodo_amd
+    o = oracle_mod
+    monkeypatch.setenv("DOCODO_QUERY_PART", str(part))
+    for a, b in _ops_cases():
+        ua, ub = o.seq_encode(a), o.seq_encode(b)
+        sa, sb = docodo_amd.IndexSequence(ua, Ra), docodo_amd.IndexSequence(ub, Rb)
+        want, wR = o.seq_and(ua, Ra, ub, Rb)
+        got = sa * sb
+        assert got.R == wR
+        assert np.array_equal(got.units, want), ("and", a.size, b.size, Ra, Rb, part)
+        want, wR = o.seq_or(ua, Ra, ub, Rb)
+        got = sa + sb
+        assert np.array_equal(got.units, want), ("or", a.size, b.size, part)
+
+
+@pytest.mark.parametrize("part", [None, 256])
+def test_long_chain_across_tiles(oracle_mod, monkeypatch, part):
+    """One gap chain spanning many 256-element tiles (and many partitions) that gains its second operand only at the very
     end (optimistic write kept) or never (rolled back); ordered mode with a late first-A."""
     import docodo_amd
     o = oracle_mod
+    if part:
+        monkeypatch.setenv("DOCODO_QUERY_PART", str(part))
     a = np.arange(10, 10 + 5 * 6000, 5, dtype=np.uint64)          # dense: every gap 5
     for b in (np.array([a[-1] + 3], np.uint64), np.array([a[-1] + 300], np.uint64), np.array([a[0] - 3], np.uint64),
               np.array([a[3000] + 1], np.uint64)):
@@ -154,6 +178,31 @@ def test_three_term_and_queries(synth_index, oracle_mod):
     res = ix.query_batch(prog, off)
     for q, req in enumerate(reqs):
         _check_result(res, q, oix.search(req, oracle_mod.SearchOptions(dist=0)))
+
+
+def test_three_term_queries_small_partitions(synth_index, monkeypatch):
+    """Same batch evaluated with 8192-element and 200-element partitions: identical results."""
+    import docodo_amd
+    from docodo_amd import synth
+    ix, oix, _, _ = synth_index
+    ranks = synth.query_ranks(200, 3, lo_rank=1)
+    prog, off = [], [0]
+    for row in ranks:
+        ts = [ix.find(synth.term(int(k))) for k in row]
+        if any(t is None for t in ts):
+            continue
+        for k, t in enumerate(ts):
+            prog += [docodo_amd.DCD_OP_TERM, t, (255 + len(synth.term(int(row[k])))) if (len(off) & 1) else -(len(synth.term(int(row[k]))) + 4)]
+            if k:
+                prog.append(docodo_amd.DCD_OP_AND if (k == 1 or len(off) % 3) else docodo_amd.DCD_OP_OR)
+        off.append(len(prog))
+    monkeypatch.delenv("DOCODO_QUERY_PART", raising=False)
+    a = ix.query_batch(prog, off, want_sequences=True)
+    monkeypatch.setenv("DOCODO_QUERY_PART", "200")
+    b = ix.query_batch(prog, off, want_sequences=True)
+    for name in ("status", "page_off", "page_index", "page_rank", "pos_off", "pos", "doc_off", "doc_index", "doc_rank",
+                 "doc_n_pages", "seq_off", "seq_units", "seq_R"):
+        assert np.array_equal(getattr(a, name), getattr(b, name)), name
 
 
 def test_or_and_mixed_plan(synth_index):
