@@ -146,6 +146,12 @@ __device__ __forceinline__ u32 wave_min(u32 v) {
   for (int d = 32; d >= 1; d >>= 1) { u32 t = __shfl_xor(v, d, DCD_WAVE); v = t < v ? t : v; }
   return v;
 }
+// wave-uniform results as SCALARS: the compiler treats shuffle / DPP results as divergent, which would drag the
+// whole per-work-item state (cursors, previous element, chain flags) into vector registers
+__device__ __forceinline__ u32 rfl(u32 v) { return (u32)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ u64 rfl64(u64 v) { return ((u64)rfl((u32)(v >> 32)) << 32) | rfl((u32)v); }
+__device__ __forceinline__ u32 rdl(u32 v, u32 uniform_lane) { return (u32)__builtin_amdgcn_readlane((int)v, (int)uniform_lane); }
+__device__ __forceinline__ u64 rdl64(u64 v, u32 uniform_lane) { return ((u64)rdl((u32)(v >> 32), uniform_lane) << 32) | rdl((u32)v, uniform_lane); }
 __device__ __forceinline__ u64 shfl64(u64 v, u32 src_lane) {
   u32 lo = __shfl((u32)v, (int)src_lane, DCD_WAVE), hi = __shfl((u32)(v >> 32), (int)src_lane, DCD_WAVE);
   return ((u64)hi << 32) | lo;
@@ -239,7 +245,7 @@ __device__ void part_gallop(const u64* __restrict__ Sv, u64 ns, const u64* __res
     u32 mine = 0;
     for (u32 q = 0; q < PW_ITEMS; q++) { u32 k = lane * PW_ITEMS + q; if (k < cn) mine += r_n[k]; }
     const u32 incl = wave_scan_incl(mine);
-    const u32 total = __shfl(incl, 63, DCD_WAVE);
+    const u32 total = rdl(incl, 63);
     u32 ex = incl - mine;
     if (!have_slot && total) {
       // scratch slot of this work item = union index (S index + L index) of its first emitted element
@@ -249,7 +255,7 @@ __device__ void part_gallop(const u64* __restrict__ Sv, u64 ns, const u64* __res
       if (lane == fl) {
         for (u32 q = 0; q < PW_ITEMS; q++) { u32 k = lane * PW_ITEMS + q; if (k < cn && r_n[k]) { cand = r_b[k] + i0 + r_s0[k]; break; } }
       }
-      slot = shfl64(cand, fl);
+      slot = rdl64(cand, fl);
       have_slot = true;
     }
     u64* out = tmp_op + slot;
@@ -268,7 +274,10 @@ __device__ void part_gallop(const u64* __restrict__ Sv, u64 ns, const u64* __res
   slot_out = slot;
 }
 
-__global__ __launch_bounds__(PW_T) void k_pair_parts(const PairOp* __restrict__ ops, u32 n_ops, const u64* __restrict__ part_base,
+#ifndef DCD_PW_WAVES
+#define DCD_PW_WAVES 5
+#endif
+__global__ __launch_bounds__(PW_T, DCD_PW_WAVES) void k_pair_parts(const PairOp* __restrict__ ops, u32 n_ops, const u64* __restrict__ part_base,
                                                     const u64* __restrict__ idx_values, const u64* __restrict__ pool,
                                                     const u64* __restrict__ counts, u64* __restrict__ tmp, u64* __restrict__ part_count,
                                                     u64* __restrict__ part_src, u64 PART) {
@@ -421,8 +430,8 @@ __global__ __launch_bounds__(PW_T) void k_pair_parts(const PairOp* __restrict__ 
         u64 lv = 0; u32 ls = 0;
 #pragma unroll
         for (int k = 0; k < (int)PW_ITEMS; k++) if ((u32)k == last_k) { lv = val[k]; ls = src[k]; }
-        const u64 t_last_val = shfl64(lv, last_lane);
-        const u32 t_last_src = __shfl(ls, (int)last_lane, DCD_WAVE);
+        const u64 t_last_val = rdl64(lv, last_lane);
+        const u32 t_last_src = rdl(ls, last_lane);
         const bool inputs_end = (ia + ca == na) && (ib + cb == nb);
         // ---- ownership: [t_lo, t_hi) of this tile belongs to the work item ------------------------------
         u32 t_lo = 0, t_hi = cnt;
@@ -436,7 +445,7 @@ __global__ __launch_bounds__(PW_T) void k_pair_parts(const PairOp* __restrict__ 
               if (fe == NONE32 && g + d0 + k >= d_end) fe = d0 + k;
             }
           }
-          fb = wave_min(fb); fe = wave_min(fe);
+          fb = rfl(wave_min(fb)); fe = rfl(wave_min(fe));
           if (skipping) t_lo = min(fb, cnt);
           if (may_end) t_hi = min(fe, cnt);
           if (t_hi < t_lo) t_hi = t_lo;
@@ -479,8 +488,8 @@ __global__ __launch_bounds__(PW_T) void k_pair_parts(const PairOp* __restrict__ 
         }
         // ---- sparse fast path: no two neighbouring elements from different operands within absR ------
         if (!is_or && absR != 0 && !has_dead) {
-          const u32 M = wave_max(contact ? 0xFFFFFFFFu : lastbrk1);
-          const u32 t_first_brk = __shfl(brk[0], 0, DCD_WAVE);
+          const u32 M = rfl(wave_max(contact ? 0xFFFFFFFFu : lastbrk1));
+          const u32 t_first_brk = rfl(brk[0]);
           const bool carried_committed_continues = open && committed && !t_first_brk;
           if (M != 0xFFFFFFFFu && !carried_committed_continues) {
             if (M == 0) {                                  // the carried chain spans the whole tile
@@ -515,7 +524,7 @@ __global__ __launch_bounds__(PW_T) void k_pair_parts(const PairOp* __restrict__ 
         for (u32 x = lane; x < PW_TILE + 2; x += PW_T) { s_firstA[x] = NONE32; s_hasEB[x] = 0; }
         wsync();
         const u32 incl_brk = wave_scan_incl(nbrk);
-        const u32 last_cid = __shfl(incl_brk, 63, DCD_WAVE);
+        const u32 last_cid = rdl(incl_brk, 63);
         u32 cid[PW_ITEMS];
         {
           u32 c = incl_brk - nbrk;
@@ -567,7 +576,7 @@ __global__ __launch_bounds__(PW_T) void k_pair_parts(const PairOp* __restrict__ 
         // roll back an open chain that closed in this tile without committing
         if (!is_or && open && !committed && (last_cid > 0 || final_tile) && !commit_of(0)) cursor = out_start;
         const u32 incl_emit = wave_scan_incl(nemit);
-        const u32 total_emit = __shfl(incl_emit, 63, DCD_WAVE);
+        const u32 total_emit = rdl(incl_emit, 63);
         u32 lfe1 = 0;                                 // 1 + emit offset of the first element of the tile's last chain
         {
           u32 e = incl_emit - nemit;
@@ -580,7 +589,7 @@ __global__ __launch_bounds__(PW_T) void k_pair_parts(const PairOp* __restrict__ 
             }
           }
         }
-        lfe1 = wave_max(lfe1);
+        lfe1 = rfl(wave_max(lfe1));
         {
           const bool hasA = s_firstA[last_cid] != NONE32 || (last_cid == 0 && seenA);
           const bool hasEB = s_hasEB[last_cid] != 0 || (last_cid == 0 && seenEB);
