@@ -608,7 +608,8 @@ __global__ __launch_bounds__(PW_T, DCD_PW_WAVES) void k_pair_parts(const PairOp*
   if (lane == 0) { part_count[w] = count; part_src[w] = slot; }
 }
 
-// out[...] <- scratch: every wave looks at 64 work items at a time and copies the non-empty ones
+// out[...] <- scratch: every wave looks at 64 work items at a time; each lane resolves its own item (operator by
+// binary search, source and destination), then the wave copies the non-empty items one after the other
 __global__ __launch_bounds__(256) void k_pair_gather(const PairOp* __restrict__ ops, u32 n_ops, const u64* __restrict__ part_base, u64 W,
                                                     const u64* __restrict__ part_count, const u64* __restrict__ part_src,
                                                     const u64* __restrict__ excl, const u64* __restrict__ tmp, u64* __restrict__ pool) {
@@ -617,18 +618,21 @@ __global__ __launch_bounds__(256) void k_pair_gather(const PairOp* __restrict__ 
   for (u64 base = gw * 64; base < W; base += nw * 64) {
     const u64 w = base + lane;
     const u64 c = w < W ? part_count[w] : 0;
+    u64 so = 0, dof = 0;
+    if (c) {
+      u32 lo = 0, hi = n_ops;
+      while (lo + 1 < hi) { u32 mid = (lo + hi) >> 1; if (part_base[mid] <= w) lo = mid; else hi = mid; }
+      so = ops[lo].tmp_off + part_src[w];
+      dof = ops[lo].out_off + (excl[w] - excl[part_base[lo]]);
+    }
     u64 m = ballot64(c != 0);
     while (m) {
       const u32 b = (u32)__builtin_ctzll(m);
       m &= m - 1;
-      const u64 ww = base + b;
-      const u64 cc = shfl64(c, b);
-      u32 lo = 0, hi = n_ops;
-      while (lo + 1 < hi) { u32 mid = (lo + hi) >> 1; if (part_base[mid] <= ww) lo = mid; else hi = mid; }
-      const u64 tmp_off = ops[lo].tmp_off, out_off = ops[lo].out_off;
-      const u64* s = tmp + tmp_off + part_src[ww];
-      u64* d = pool + out_off + (excl[ww] - excl[part_base[lo]]);
-      for (u64 k = lane; k < cc; k += 64) d[k] = s[k];
+      const u64 cc = rdl64(c, b);
+      const u64* sp = tmp + rdl64(so, b);
+      u64* dp = pool + rdl64(dof, b);
+      for (u64 k = lane; k < cc; k += 64) dp[k] = sp[k];
     }
   }
 }
