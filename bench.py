@@ -75,7 +75,7 @@ def cpu_baseline(n_docs_sample):
                       % (n_docs_sample, text.size / 1e6, dt)}
 
 
-def query_bench(ix, n_single, n_and3, cpu_sample, img=None, lst=None):
+def query_bench(ix, n_single, n_and3, cpu_sample, img=None, lst=None, seed_offset=0):
     """configs[1] query leg (10 k single-term queries over ranks 101..100k, Appendix F) plus a batch of
     3-term AND queries (opt == null -> Dist = 255).  Device time of dcd_query_batch (HIP events), results
     produced on the device; the D2H copy of the result arrays is excluded.  CPU: oracle, 1 thread, bounded."""
@@ -84,7 +84,7 @@ def query_bench(ix, n_single, n_and3, cpu_sample, img=None, lst=None):
     T, A = docodo_amd.DCD_OP_TERM, docodo_amd.DCD_OP_AND
     out = {}
     for name, nq, nt in (("single_term", n_single, 1), ("and3", n_and3, 3)):
-        ranks = synth.query_ranks(nq, nt)
+        ranks = synth.query_ranks(nq, nt, seed=synth.SEED_QUERY + seed_offset)
         prog, off, npost, words = [], [0], 0, []
         for row in ranks:
             ws = [synth.term(int(k)) for k in row]
@@ -133,12 +133,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world > 1:
         raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
+    backend = "nccl"                                   # = RCCL on ROCm
+    if os.environ.get("DOCODO_BENCH_REHEARSAL"):       # N ranks on ONE GPU over gloo: plumbing rehearsal, not a measurement
+        local_rank, backend = 0, "gloo"
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     import docodo_amd
     from docodo_amd import synth
@@ -193,7 +199,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
@@ -241,6 +247,32 @@ def main():
             out["queries"] = query_bench(ixq, args.queries, args.and3, 200 if args.cpu_docs > 0 else 0, img, lst)
             ixq.close()
             bq.close()
+    if world > 1 and args.queries > 0:
+        # query-sharded leg: every rank holds a replica of the configs[1] index (docs 0..D) and evaluates
+        # its own batches (different query seeds per rank); no exchange.  Aggregate = all queries / slowest rank.
+        synth.corpus_dev(text.data_ptr(), D, first_doc=0, device=local_rank)
+        bq = docodo_amd.Builder(device=local_rank)
+        bq.AddUniformPagesDev(text.data_ptr(), D, synth.DOC_BYTES)
+        bq.Finish()
+        ixq = bq.Build()
+        qr = query_bench(ixq, args.queries, args.and3, 0, seed_offset=rank)
+        ixq.close()
+        bq.close()
+        agg = {}
+        for name in ("single_term", "and3"):
+            cdev = "cuda" if backend == "nccl" else "cpu"
+            v = torch.tensor([qr[name]["queries"], qr[name]["postings_in"]], dtype=torch.float64, device=cdev)
+            m = torch.tensor([qr[name]["device_ms"]], dtype=torch.float64, device=cdev)
+            dist.all_reduce(v, op=dist.ReduceOp.SUM)
+            dist.all_reduce(m, op=dist.ReduceOp.MAX)
+            ms = float(m.item())
+            agg[name] = {"queries": int(v[0].item()), "postings_in": int(v[1].item()), "device_ms_slowest_rank": round(ms, 3),
+                         "queries_per_s": round(float(v[0].item()) / (ms / 1e3), 0),
+                         "gpostings_per_s": round(float(v[1].item()) / 1e9 / (ms / 1e3), 2),
+                         "sharding": "by query, index replicated on every GPU"}
+        if rank == 0:
+            out["queries"] = agg
+    if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

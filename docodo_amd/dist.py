@@ -89,6 +89,13 @@ def exchange(export, group=None):
     import torch.distributed as dist
     G = dist.get_world_size(group)
     dev = export.meta.device
+    # gloo has no all-to-all on device tensors: stage through the host (rehearsals of the N > 1 path on one GPU)
+    staged = dev.type == "cuda" and dist.get_backend(group) == "gloo"
+    if staged:
+        host = ShardExport(export.term_count, export.key_count, export.unit_count, export.meta.cpu(), export.keys.cpu(),
+                           export.units.cpu(), export.max_coord)
+        tc, kc, uc, meta, keys, units, mx = exchange(host, group)
+        return tc, kc, uc, meta.to(dev), keys.to(dev), units.to(dev), mx
     counts = torch.tensor(np.stack([export.term_count, export.key_count, export.unit_count], 1).astype(np.int64), device=dev)
     rcounts = torch.empty_like(counts)
     dist.all_to_all_single(rcounts, counts, group=group)          # row s = what source s sends to me
