@@ -90,6 +90,14 @@ void dev_release(int device, void* p) {
   P.live.erase(it);
 }
 
+size_t dev_pool_cached_bytes(int device) {
+  Pool& P = pool(device);
+  std::lock_guard<std::mutex> g(P.mu);
+  size_t t = 0;
+  for (auto& kv : P.free_) t += kv.first;
+  return t;
+}
+
 void dev_pool_trim(int device) {
   Pool& P = pool(device);
   std::vector<void*> v;

@@ -55,6 +55,7 @@ struct Status {
 int32_t dev_alloc(int device, size_t bytes, void** out);
 void dev_release(int device, void* p);   // back to the pool
 void dev_pool_trim(int device);          // hipFree everything cached
+size_t dev_pool_cached_bytes(int device);   // bytes held by the cache (released blocks not yet returned to HIP)
 
 // RAII device buffer bound to the pool
 template <typename T>

@@ -1281,7 +1281,9 @@ int32_t dcd_query_batch(dcd_index* h, const int32_t* prog, const uint64_t* prog_
   // quarter of the free HBM are evaluated in consecutive sub-batches (results are concatenated).
   size_t free_b = 0, total_b = 0;
   DCD_HIP(hipMemGetInfo(&free_b, &total_b));
-  u64 budget = std::max<u64>((u64)free_b / 4 / 8, 1ull << 24);   // elements of 8 bytes
+  // blocks released into the library's device cache are available too (dev_alloc trims the cache when hipMalloc fails)
+  const u64 avail_b = (u64)free_b + (u64)dev_pool_cached_bytes(h->ix.device);
+  u64 budget = std::max<u64>(avail_b / 4 / 8, 1ull << 24);   // elements of 8 bytes
   if (const char* e = getenv("DOCODO_QUERY_POOL_ELEMS")) budget = std::max<u64>(strtoull(e, nullptr, 10), 1);   // tests
   std::unique_ptr<dcd_results> R(new dcd_results());
   size_t q0 = 0;

@@ -43,7 +43,7 @@ def tid(w):
     return term_cache[w]
 def run(queries, label):
     """queries: list of list of (word, R)"""
-    tot_ms, nq, npost = 0.0, 0, 0
+    tot_ms, nq, npost, per = 0.0, 0, 0, []
     for c0 in range(0, len(queries), chunk):
         prog, off = [], [0]
         for q in queries[c0:c0 + chunk]:
@@ -55,9 +55,9 @@ def run(queries, label):
             off.append(len(prog))
         if len(off) == 1: continue
         ms = ix.query_batch(np.array(prog, np.int32), np.array(off, np.uint64), keep_handle=True)
-        tot_ms += ms; nq += len(off) - 1
+        tot_ms += ms; nq += len(off) - 1; per.append(round(ms, 1))
     out[label] = {"queries": nq, "postings_in": int(npost), "device_ms": round(tot_ms, 2), "queries_per_s": round(nq / (tot_ms / 1e3), 0),
-                  "gpostings_per_s": round(npost / 1e9 / (tot_ms / 1e3), 2), "chunk": chunk}
+                  "gpostings_per_s": round(npost / 1e9 / (tot_ms / 1e3), 2), "chunk": chunk, "chunk_ms": per[:8]}
     print(label, out[label], flush=True)
 ix.query_batch([T, 0, 258], [0, 3], keep_handle=True)   # decodes the index once (auxiliary structure)
 r1 = synth.query_ranks(10000, 1)
