@@ -6,3 +6,4 @@ from .sequence import IndexSequence  # noqa: F401
 from .index import Builder, Index, SearchOptions, QueryBatchResult  # noqa: F401
 from . import synth  # noqa: F401
 from .search import Search, SearchResult  # noqa: F401
+from .wordcodes import WordCoder  # noqa: F401

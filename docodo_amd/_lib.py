@@ -76,7 +76,11 @@ SIGNATURES = {
     "dcd_build_add_uniform_pages_dev": (_i32, [_vp, _vp, _u64, _u32, _u64, _vp, _sz]),
     "dcd_build_add": (_i32, [_vp, _vp, _sz, _u64]),
     "dcd_build_end_page": (_i32, [_vp, _vp, _sz]),
+    "dcd_build_add_word": (_i32, [_vp, _vp, _sz, _u64]),
     "dcd_build_finish": (_i32, [_vp]),
+    "dcd_build_words": (_i32, [_vp, _vp, _vp]),
+    "dcd_build_words_get": (_i32, [_vp, _vp, _sz, _vp, _sz]),
+    "dcd_build_set_codes": (_i32, [_vp, _vp, _sz, _vp, _vp, _sz]),
     "dcd_build_get_stats": (_i32, [_vp, C.POINTER(BuildStats)]),
     "dcd_build_index_image": (_i32, [_vp, _vp, _sz, _pz]),
     "dcd_build_list_image": (_i32, [_vp, _vp, _sz, _pz]),

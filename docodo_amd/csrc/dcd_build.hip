@@ -4,6 +4,7 @@
 // Replaces IndexTask's page loop (Build.cs:477-541), Index.Builder.Add/Save (Build.cs:324-404)
 // and, for one coordinate space, the merge functions (Index.cs:537-752).
 #include <algorithm>
+#include <memory>
 
 #include "dcd_build_int.h"
 #include "dcd_codec.h"
@@ -205,7 +206,8 @@ using namespace dcd;
 // ================================================================================================
 // handle
 // ================================================================================================
-struct ExplicitPosting { u32 off, len; u64 coord; };
+struct ExplicitPosting { u32 off, len; u64 coord; bool is_word; };
+struct BuildMid;
 
 struct dcd_build {
   dcd_build_opts opts;
@@ -234,6 +236,7 @@ struct dcd_build {
   std::vector<u8> list_image;
   dcd_build_stats stats;
   bool adopted = false;       // DeviceIndex moved into a dcd_index
+  std::shared_ptr<BuildMid> mid;   // between dcd_build_words / phase 1 and phase 2
   int csize() const { return opts.encoding == DCD_ENC_UTF16LE ? 2 : 1; }
 };
 
@@ -253,7 +256,8 @@ hipStream_t build_stream(dcd_build* b) { return b->st; }
 
 static ustr mk16(const u16* p, size_t n) { return ustr((const char16_t*)p, n); }
 
-static int32_t add_explicit(dcd_build* h, const u16* code, size_t len, u64 coord) {
+static int32_t add_explicit(dcd_build* h, const u16* code, size_t len, u64 coord, bool is_word) {
+  if (h->mid) DCD_FAIL(DCD_E_STATE, "postings cannot be added after dcd_build_words");
   if (len == 0 || len > MAX_CODE_LEN) DCD_FAIL(DCD_E_UNSUPPORTED, "index codes must be 1..%u UTF-16 units long", MAX_CODE_LEN);
   if (coord < h->opts.coord_base || coord - h->opts.coord_base >= (1ull << 32))
     DCD_FAIL(DCD_E_OVERFLOW, "explicit coordinate outside this segment's 2^32 window");
@@ -264,6 +268,7 @@ static int32_t add_explicit(dcd_build* h, const u16* code, size_t len, u64 coord
   x.off = (u32)h->xpool.size();
   x.len = (u32)len;
   x.coord = coord;
+  x.is_word = is_word;
   h->xpool.insert(h->xpool.end(), code, code + len);
   h->xps.push_back(x);
   h->last_is_explicit = true;
@@ -324,7 +329,7 @@ int32_t dcd_build_add_doc(dcd_build* h, const uint16_t* source, size_t source_le
   return DCD_OK;
 }
 
-static int32_t add_explicit(dcd_build* h, const u16* code, size_t len, u64 coord);
+static int32_t add_explicit(dcd_build* h, const u16* code, size_t len, u64 coord, bool is_word);
 
 // Header page (id "0"), Build.cs:485-524: one "name=value" per line; every \w-run of the value
 // yields Add("&" + name, (uint)(coord + dc - 1)) and AddWord(word.ToLower(), coord + dc); the
@@ -357,8 +362,8 @@ static int32_t host_header_page(dcd_build* h, const u16* text, size_t n, bool* e
         bool w = (cls[(u16)v[i]] & 4) != 0;
         while (j < v.size() && ((cls[(u16)v[j]] & 4) != 0) == w) j++;
         if (w) {
-          DCD_TRY(add_explicit(h, (const u16*)marker.data(), marker.size(), (u64)(u32)(coord + dc - 1)));   // (uint) cast, Build.cs:509
-          DCD_TRY(add_explicit(h, (const u16*)v.data() + i, j - i, coord + dc));                            // AddWord, identity codes
+          DCD_TRY(add_explicit(h, (const u16*)marker.data(), marker.size(), (u64)(u32)(coord + dc - 1), false));   // (uint) cast, Build.cs:509
+          DCD_TRY(add_explicit(h, (const u16*)v.data() + i, j - i, coord + dc, true));                      // AddWord
         }
         dc += j - i;
         i = j;
@@ -375,6 +380,7 @@ static int32_t host_header_page(dcd_build* h, const u16* text, size_t n, bool* e
 static int32_t add_pages_impl(dcd_build* h, const void* text, u64 n_chars, const uint64_t* page_off, size_t n_pages,
                               const uint16_t* page_ids, const uint64_t* ids_off, int32_t docs_per_page, uint64_t first_doc,
                               const uint16_t* source, size_t source_len, bool device_text) {
+  if (h->mid) DCD_FAIL(DCD_E_STATE, "pages cannot be added after dcd_build_words");
   if (docs_per_page) {
     if (!h->pages.docs.empty() || (h->pages.n_pages() && !h->pages.doc_per_page))
       DCD_FAIL(DCD_E_STATE, "cannot mix docs_per_page with explicit documents");
@@ -518,7 +524,13 @@ int32_t dcd_build_add_uniform_pages_dev(dcd_build* h, const void* text_dev, uint
 int32_t dcd_build_add(dcd_build* h, const uint16_t* code, size_t len, uint64_t coord) {
   if (!h || (!code && len)) DCD_FAIL(DCD_E_BADARG, "dcd_build_add: NULL argument");
   if (h->finished) DCD_FAIL(DCD_E_STATE, "build already finished");
-  return add_explicit(h, code, len, coord);
+  return add_explicit(h, code, len, coord, false);
+}
+
+int32_t dcd_build_add_word(dcd_build* h, const uint16_t* word, size_t len, uint64_t coord) {
+  if (!h || (!word && len)) DCD_FAIL(DCD_E_BADARG, "dcd_build_add_word: NULL argument");
+  if (h->finished) DCD_FAIL(DCD_E_STATE, "build already finished");
+  return add_explicit(h, word, len, coord, true);
 }
 
 int32_t dcd_build_end_page(dcd_build* h, const uint16_t* id, size_t len) {
@@ -539,20 +551,71 @@ int32_t dcd_build_end_page(dcd_build* h, const uint16_t* id, size_t len) {
 // ================================================================================================
 // finish: the device pipeline
 // ================================================================================================
+// State that lives from the tokenise/vocabulary phase to the sort/pack phase.  Normally both phases run
+// back to back inside dcd_build_finish; dcd_build_words stops after the first one so that the host can
+// map every distinct word to its index codes (GetWordCodes, Build.cs:175-247) before the second.
+struct BuildMid {
+  bool codes_mode = false;          // phase 1 ran for dcd_build_words: explicit CODES were kept on the host
+  u64 N = 0, n_text_tok = 0, n_xdev = 0, V = 0;
+  u32 cap_log2 = 0, last_text_coord = 0;
+  DevBuf<uint2> tupA, tupB;
+  DevBuf<u8> d_pool_raw;            // explicit strings on the device (CharT units)
+  u64 n_pool = 0;
+  DevBuf<u64> slots;
+  DevBuf<u32> d_flags, slot_excl, scan_scr32, d_hist;
+  VocabRanks vr;
+  DevBuf<u64> d_page_end;
+  DevBuf<u16> word_chars;           // the distinct words in ordinal order
+  DevBuf<u32> word_str_off;
+  u32 total_chars = 0;
+  std::vector<u16> h_word_chars;    // host copies (codes mode)
+  std::vector<u32> h_word_str_off;
+  // codes handed over by dcd_build_set_codes
+  bool have_codes = false;
+  std::vector<u32> code_off;        // [V + 1]
+  std::vector<ustr> code_str;       // one string per entry
+  float ms_tok = 0, ms_voc = 0, ms_total = 0;
+  float ms_kernel[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  u32 n_launch[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+};
+
+namespace {
+struct Probes {
+  struct P { int id; hipEvent_t a, b; };
+  std::vector<P> v;
+  hipStream_t st;
+  explicit Probes(hipStream_t s) : st(s) {}
+  void begin(int id) { P p{id, nullptr, nullptr}; (void)hipEventCreate(&p.a); (void)hipEventCreate(&p.b); (void)hipEventRecord(p.a, st); v.push_back(p); }
+  void end() { (void)hipEventRecord(v.back().b, st); }
+  void collect(float* ms, u32* n) {   // after the stream was synchronised
+    for (auto& p : v) {
+      float t = 0;
+      if (hipEventElapsedTime(&t, p.a, p.b) == hipSuccess) { ms[p.id] += t; n[p.id]++; }
+      (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b);
+    }
+    v.clear();
+  }
+  ~Probes() { for (auto& p : v) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); } }
+};
+}  // namespace
+
+// ---- phase 1: tokenise -> exact vocabulary -> distinct words in ordinal order ----------------------------------
 template <typename CharT>
-static int32_t finish_impl(dcd_build* h) {
+static int32_t build_phase1(dcd_build* h, bool codes_mode) {
   const int dev = h->device;
   hipStream_t st = h->st;
   DCD_TRY(ensure_device(dev));
-  EvTimer t_all, t_tok, t_voc, t_sort, t_pack, t_img;
+  h->mid.reset(new BuildMid());
+  BuildMid& M = *h->mid;
+  M.codes_mode = codes_mode;
+  EvTimer t_all, t_tok, t_voc;
   DCD_TRY(t_all.init(st)); DCD_TRY(t_tok.init(st)); DCD_TRY(t_voc.init(st));
-  DCD_TRY(t_sort.init(st)); DCD_TRY(t_pack.init(st)); DCD_TRY(t_img.init(st));
+  Probes probes(st);
 
   const u64 n_chars = h->n_chars;
   const bool uniform = h->pages.uniform;
   const u64 n_pages_dev = uniform ? h->pages.uni_n : h->page_off.size() - 1;
   const u64 n_tiles = div_up(n_chars, TK_TILE);
-  const u64 n_x = h->xps.size();
   const CharT* text = (const CharT*)h->text_dev;
 
   CharTables16 tab{nullptr, nullptr};
@@ -564,37 +627,34 @@ static int32_t finish_impl(dcd_build* h) {
     DCD_TRY(d_page_off.alloc(dev, n_pages_dev + 1));
     DCD_HIP(hipMemcpyAsync(d_page_off.p, h->page_off.data(), (n_pages_dev + 1) * 8, hipMemcpyHostToDevice, st));
   }
-  DevBuf<CharT> d_pool;
+  // explicit postings that enter the device vocabulary: all of them, or (codes mode) only the WORDS
+  std::vector<u32> xo, xl, xc;
+  for (const ExplicitPosting& x : h->xps)
+    if (!codes_mode || x.is_word) { xo.push_back(x.off); xl.push_back(x.len); xc.push_back((u32)(x.coord - h->opts.coord_base)); }
+  const u64 n_x = xo.size();
+  M.n_xdev = n_x;
   DevBuf<u32> d_xoff, d_xlen, d_xcoord;
   if (n_x) {
     std::vector<CharT> pool((h->xpool.size() + 8) / 4 * 4, (CharT)0);   // zero padded: read as aligned 32-bit words
     for (size_t i = 0; i < h->xpool.size(); i++) pool[i] = (CharT)h->xpool[i];
-    std::vector<u32> xo(n_x), xl(n_x), xc(n_x);
-    for (u64 i = 0; i < n_x; i++) { xo[i] = h->xps[i].off; xl[i] = h->xps[i].len; xc[i] = (u32)(h->xps[i].coord - h->opts.coord_base); }
-    DCD_TRY(d_pool.alloc(dev, pool.size()));
+    M.n_pool = pool.size();
+    DCD_TRY(M.d_pool_raw.alloc(dev, pool.size() * sizeof(CharT)));
     DCD_TRY(d_xoff.alloc(dev, n_x)); DCD_TRY(d_xlen.alloc(dev, n_x)); DCD_TRY(d_xcoord.alloc(dev, n_x));
-    DCD_HIP(hipMemcpyAsync(d_pool.p, pool.data(), pool.size() * sizeof(CharT), hipMemcpyHostToDevice, st));
+    DCD_HIP(hipMemcpyAsync(M.d_pool_raw.p, pool.data(), pool.size() * sizeof(CharT), hipMemcpyHostToDevice, st));
     DCD_HIP(hipMemcpyAsync(d_xoff.p, xo.data(), n_x * 4, hipMemcpyHostToDevice, st));
     DCD_HIP(hipMemcpyAsync(d_xlen.p, xl.data(), n_x * 4, hipMemcpyHostToDevice, st));
     DCD_HIP(hipMemcpyAsync(d_xcoord.p, xc.data(), n_x * 4, hipMemcpyHostToDevice, st));
     DCD_HIP(hipStreamSynchronize(st));
   }
-  DevBuf<u64> d_page_end;
   if (uniform) {
-    DCD_TRY(d_page_end.alloc(dev, h->pages.uni_n));
-    hipLaunchKernelGGL(k_uniform_page_end, dim3((u32)div_up(h->pages.uni_n, 256)), dim3(256), 0, st, d_page_end.p, h->pages.uni_n,
+    DCD_TRY(M.d_page_end.alloc(dev, h->pages.uni_n));
+    hipLaunchKernelGGL(k_uniform_page_end, dim3((u32)div_up(h->pages.uni_n, 256)), dim3(256), 0, st, M.d_page_end.p, h->pages.uni_n,
                        h->pages.uni_base, h->pages.uni_chars);
   } else if (!h->pages.end.empty()) {
-    DCD_TRY(d_page_end.alloc(dev, h->pages.end.size()));
-    DCD_HIP(hipMemcpyAsync(d_page_end.p, h->pages.end.data(), h->pages.end.size() * 8, hipMemcpyHostToDevice, st));
+    DCD_TRY(M.d_page_end.alloc(dev, h->pages.end.size()));
+    DCD_HIP(hipMemcpyAsync(M.d_page_end.p, h->pages.end.data(), h->pages.end.size() * 8, hipMemcpyHostToDevice, st));
   }
   DCD_HIP(hipStreamSynchronize(st));
-
-  // per-kernel probes: (kernel id, begin event, end event)
-  struct Probe { int id; hipEvent_t a, b; };
-  std::vector<Probe> probes;
-  auto probe_begin = [&](int id) { Probe p{id, nullptr, nullptr}; (void)hipEventCreate(&p.a); (void)hipEventCreate(&p.b); (void)hipEventRecord(p.a, st); probes.push_back(p); };
-  auto probe_end = [&]() { (void)hipEventRecord(probes.back().b, st); };
 
   DCD_TRY(t_all.start());
   // ---- 1. tokenise: count pass -------------------------------------------------------------------
@@ -623,21 +683,21 @@ static int32_t finish_impl(dcd_build* h) {
     DCD_TRY(tile_count.alloc(dev, n_tiles));
     DCD_TRY(tile_off.alloc(dev, n_tiles));
     DCD_TRY(scan_scr64.alloc(dev, scan_scratch_elems(n_tiles)));
-    probe_begin(DCD_K_TOK_COUNT);
+    probes.begin(DCD_K_TOK_COUNT);
     hipLaunchKernelGGL((k_tok_count<CharT>), dim3((u32)div_up(n_tiles, TK_WAVES)), dim3(TK_THREADS), 0, st, text, P, tab, tile_count.p,
                        n_tiles);
-    probe_end();
+    probes.end();
     scan_exclusive<u32, u64>(tile_count.p, tile_off.p, n_tiles, scan_scr64.p, st);
     DCD_HIP(hipMemcpyAsync(&n_text_tok, scan_scr64.p + scan_nblocks(n_tiles), 8, hipMemcpyDeviceToHost, st));
     DCD_HIP(hipStreamSynchronize(st));
   }
   const u64 N = n_text_tok + n_x;
   if (N >= (1ull << 32)) DCD_FAIL(DCD_E_OVERFLOW, "more than 2^32 postings in one build segment");
+  M.N = N; M.n_text_tok = n_text_tok;
 
   // ---- 2. vocabulary table + emit ---------------------------------------------------------------
-  DevBuf<uint2> tupA, tupB;
-  DCD_TRY(tupA.alloc(dev, N ? N : 1));
-  DCD_TRY(tupB.alloc(dev, N ? N : 1));
+  DCD_TRY(M.tupA.alloc(dev, N ? N : 1));
+  DCD_TRY(M.tupB.alloc(dev, N ? N : 1));
   u32 cap_log2 = h->opts.vocab_capacity_log2;
   if (cap_log2 == 0) {
     // first guess: one slot per 64 postings -- small enough to stay close to the caches (every probe of a
@@ -646,79 +706,217 @@ static int32_t finish_impl(dcd_build* h) {
     if (cap_log2 < 12) cap_log2 = 12;
     if (cap_log2 > 24) cap_log2 = 24;
   }
-  DevBuf<u64> slots;
-  DevBuf<u32> d_flags;  // [0] overflow, [1] maxlen, [2] max coord (explicit)
-  DCD_TRY(d_flags.alloc(dev, 4));
+  DCD_TRY(M.d_flags.alloc(dev, 4));   // [0] overflow, [1] maxlen, [2] max coord (explicit)
   TextView<CharT> tv;
-  tv.text = text; tv.n_chars = n_chars; tv.pool = d_pool.p; tv.n_pool = d_pool.n; tv.tab = tab;
+  tv.text = text; tv.n_chars = n_chars; tv.pool = (const CharT*)M.d_pool_raw.p; tv.n_pool = M.n_pool; tv.tab = tab;
   u64 V = 0;
-  DevBuf<u32> slot_excl;
-  DevBuf<u32> scan_scr32;
   for (;;) {
     if (cap_log2 > 30) DCD_FAIL(DCD_E_OVERFLOW, "vocabulary does not fit a 2^30-slot table");
     const u64 cap = 1ull << cap_log2;
-    DCD_TRY(slots.alloc(dev, cap));
-    DCD_HIP(hipMemsetAsync(slots.p, 0, cap * 8, st));
-    DCD_HIP(hipMemsetAsync(d_flags.p, 0, 16, st));
+    DCD_TRY(M.slots.alloc(dev, cap));
+    DCD_HIP(hipMemsetAsync(M.slots.p, 0, cap * 8, st));
+    DCD_HIP(hipMemsetAsync(M.d_flags.p, 0, 16, st));
     VocabTable vt;
-    vt.slots = slots.p; vt.mask = (u32)(cap - 1); vt.overflow = d_flags.p;
+    vt.slots = M.slots.p; vt.mask = (u32)(cap - 1); vt.overflow = M.d_flags.p;
     if (n_tiles) {
-      probe_begin(DCD_K_TOK_EMIT);
+      probes.begin(DCD_K_TOK_EMIT);
       hipLaunchKernelGGL((k_tok_emit<CharT>), dim3((u32)div_up(n_tiles, TK_WAVES)), dim3(TK_THREADS), 0, st, text, P, tab, tv, vt,
-                         tile_off.p, tupA.p, n_tiles);
-      probe_end();
+                         tile_off.p, M.tupA.p, n_tiles);
+      probes.end();
     }
     if (n_x)
       hipLaunchKernelGGL((k_explicit<CharT>), dim3((u32)div_up(n_x, 256)), dim3(256), 0, st, d_xoff.p, d_xlen.p, d_xcoord.p,
-                         n_x, tv, vt, tupA.p + n_text_tok);
+                         n_x, tv, vt, M.tupA.p + n_text_tok);
     // compaction: dense ids for the used slots
-    DCD_TRY(slot_excl.alloc(dev, cap));
-    DCD_TRY(scan_scr32.alloc(dev, std::max<u64>(scan_scratch_elems(cap), scan_scratch_elems((u64)RS_MAX_BLOCKS << 10))));
-    scan_exclusive_f<SlotUsed, u32>(SlotUsed{slots.p}, slot_excl.p, cap, scan_scr32.p, st);
+    DCD_TRY(M.slot_excl.alloc(dev, cap));
+    DCD_TRY(M.scan_scr32.alloc(dev, std::max<u64>(scan_scratch_elems(cap), scan_scratch_elems((u64)RS_MAX_BLOCKS << 10))));
+    scan_exclusive_f<SlotUsed, u32>(SlotUsed{M.slots.p}, M.slot_excl.p, cap, M.scan_scr32.p, st);
     u32 flags[4] = {0, 0, 0, 0};
     u32 v32 = 0;
-    DCD_HIP(hipMemcpyAsync(flags, d_flags.p, 16, hipMemcpyDeviceToHost, st));
-    DCD_HIP(hipMemcpyAsync(&v32, scan_scr32.p + scan_nblocks(cap), 4, hipMemcpyDeviceToHost, st));
+    DCD_HIP(hipMemcpyAsync(flags, M.d_flags.p, 16, hipMemcpyDeviceToHost, st));
+    DCD_HIP(hipMemcpyAsync(&v32, M.scan_scr32.p + scan_nblocks(cap), 4, hipMemcpyDeviceToHost, st));
     DCD_HIP(hipStreamSynchronize(st));
     V = v32;
     if (flags[0] || V * 2 > cap) { cap_log2 += 2; continue; }  // overflow or load > 0.5: rebuild larger
     break;
   }
   const u64 cap = 1ull << cap_log2;
+  M.cap_log2 = cap_log2; M.V = V;
   DCD_TRY(t_tok.stop());
   // maxCoord = coordinate of the last posting added (Build.cs:326)
-  u32 last_text_coord = 0;
-  if (n_text_tok) DCD_HIP(hipMemcpyAsync(&last_text_coord, &tupA.p[n_text_tok - 1].y, 4, hipMemcpyDeviceToHost, st));
+  if (n_text_tok) DCD_HIP(hipMemcpyAsync(&M.last_text_coord, &M.tupA.p[n_text_tok - 1].y, 4, hipMemcpyDeviceToHost, st));
 
-  // ---- 3. vocabulary: compact, sort the term strings ordinally -------------------------------
+  // ---- 3. vocabulary: compact, sort the word strings ordinally, materialise them -------------------
   DCD_TRY(t_voc.start());
-  DevBuf<u32> d_hist;
-  DCD_TRY(d_hist.alloc(dev, (u64)RS_MAX_BLOCKS << 10));
-  VocabRanks vr;
-  probe_begin(DCD_K_VOCAB_SORT);
-  DCD_TRY(vocab_rank<CharT>(dev, st, slots.p, cap, slot_excl.p, V, tv, d_hist.p, scan_scr32.p, d_flags.p + 1, &vr));
-  probe_end();
-  DevBuf<u32>& rank_of_slot = vr.rank_of_slot;
-  DevBuf<u64>& rk_word = vr.rk_word;
+  DCD_TRY(M.d_hist.alloc(dev, (u64)RS_MAX_BLOCKS << 10));
+  probes.begin(DCD_K_VOCAB_SORT);
+  DCD_TRY(vocab_rank<CharT>(dev, st, M.slots.p, cap, M.slot_excl.p, V, tv, M.d_hist.p, M.scan_scr32.p, M.d_flags.p + 1, &M.vr));
+  DCD_TRY(M.word_str_off.alloc(dev, V + 1));
+  u32 total_chars = 0;
+  if (V) {
+    scan_exclusive_f<TermLenF, u32>(TermLenF{M.vr.rk_word.p}, M.word_str_off.p, V, M.scan_scr32.p, st);
+    DCD_HIP(hipMemcpyAsync(&total_chars, M.scan_scr32.p + scan_nblocks(V), 4, hipMemcpyDeviceToHost, st));
+    DCD_HIP(hipStreamSynchronize(st));
+  }
+  DCD_HIP(hipMemcpyAsync(M.word_str_off.p + V, &total_chars, 4, hipMemcpyHostToDevice, st));
+  DCD_TRY(M.word_chars.alloc(dev, total_chars ? total_chars : 1));
+  if (V) hipLaunchKernelGGL((k_term_strings<CharT>), dim3((u32)div_up(V, 256)), dim3(256), 0, st, M.vr.rk_word.p, V, M.word_str_off.p, tv,
+                            M.word_chars.p);
+  probes.end();
+  M.total_chars = total_chars;
   DCD_TRY(t_voc.stop());
+  DCD_TRY(t_all.stop());
+  DCD_HIP(hipStreamSynchronize(st));
+  DCD_HIP(hipGetLastError());
+  M.ms_tok = t_tok.ms(); M.ms_voc = t_voc.ms(); M.ms_total = t_all.ms();
+  probes.collect(M.ms_kernel, M.n_launch);
+  if (codes_mode) {
+    M.h_word_chars.resize(total_chars);
+    M.h_word_str_off.resize(V + 1);
+    if (total_chars) DCD_HIP(hipMemcpy(M.h_word_chars.data(), M.word_chars.p, (size_t)total_chars * 2, hipMemcpyDeviceToHost));
+    DCD_HIP(hipMemcpy(M.h_word_str_off.data(), M.word_str_off.p, (V + 1) * 4, hipMemcpyDeviceToHost));
+  }
+  return DCD_OK;
+}
 
-  // ---- 4. sort the tuples by term (stable; explicit postings first need coordinate order) ----
-  DCD_TRY(t_sort.start());
-  uint2* sorted = tupA.p;
+// one tuple per (posting, code of its word): counts, then the tuples in posting order (Builder.AddWord, Build.cs:302-316)
+__global__ void k_codes_count(const uint2* __restrict__ tup, u64 n, const u32* __restrict__ rank_of_slot, const u32* __restrict__ code_off,
+                              u32* __restrict__ cnt) {
+  u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const u32 w = rank_of_slot[tup[i].x];
+  cnt[i] = code_off[w + 1] - code_off[w];
+}
+__global__ void k_codes_expand(const uint2* __restrict__ tup, u64 n, const u32* __restrict__ rank_of_slot, const u32* __restrict__ code_off,
+                               const u32* __restrict__ code_key, const u64* __restrict__ out_off, uint2* __restrict__ out) {
+  u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint2 t = tup[i];
+  const u32 w = rank_of_slot[t.x];
+  u64 o = out_off[i];
+  for (u32 e = code_off[w]; e < code_off[w + 1]; e++) out[o++] = make_uint2(code_key[e], t.y);
+}
+
+// ---- phase 2: (word -> codes) -> stable sort by key -> var-ushort pack -> ".index" image ---------------------------
+template <typename CharT>
+static int32_t build_phase2(dcd_build* h) {
+  const int dev = h->device;
+  hipStream_t st = h->st;
+  DCD_TRY(ensure_device(dev));
+  BuildMid& M = *h->mid;
+  EvTimer t_all, t_sort, t_pack, t_img;
+  DCD_TRY(t_all.init(st)); DCD_TRY(t_sort.init(st)); DCD_TRY(t_pack.init(st)); DCD_TRY(t_img.init(st));
+  Probes probes(st);
+  DeviceIndex& ix = h->ix;
+  ix.device = dev;
+
+  u64 N = M.N, V = M.V;
+  uint2* a = M.tupA.p;
+  uint2* b = M.tupB.p;
+  const u32* remap = M.vr.rank_of_slot.p;     // tuple.x = hash slot -> key id = rank of the word
+  bool coord_sort = M.n_xdev != 0;            // mixed input is not in coordinate order
+  u32 total_chars = M.total_chars;
+  DevBuf<uint2> expA, expB;
+  u64 n_text_postings = M.n_text_tok;          // postings that came from the text (they precede the explicit ones)
+  u64 max_coord_codes = 0;
+  bool have_max_coord_codes = false;
+
+  if (M.codes_mode) {
+    // ---- host: the key table = all distinct code strings (String.CompareOrdinal order, Index.cs:142-151) ----
+    if (!M.have_codes) {   // no dcd_build_set_codes: identity codes
+      M.code_off.resize(V + 1);
+      M.code_str.resize(V);
+      for (u64 w = 0; w < V; w++) {
+        M.code_off[w] = (u32)w;
+        M.code_str[w] = ustr((const char16_t*)M.h_word_chars.data() + M.h_word_str_off[w], M.h_word_str_off[w + 1] - M.h_word_str_off[w]);
+      }
+      M.code_off[V] = (u32)V;
+    }
+    std::vector<ustr> keys(M.code_str);
+    std::vector<const ExplicitPosting*> xcodes;
+    for (const ExplicitPosting& x : h->xps)
+      if (!x.is_word) { xcodes.push_back(&x); keys.emplace_back((const char16_t*)h->xpool.data() + x.off, x.len); }
+    std::sort(keys.begin(), keys.end());
+    keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
+    auto key_id = [&](const ustr& s) -> u32 { return (u32)(std::lower_bound(keys.begin(), keys.end(), s) - keys.begin()); };
+    std::vector<u32> code_key(M.code_str.size());
+    for (size_t e = 0; e < M.code_str.size(); e++) code_key[e] = key_id(M.code_str[e]);
+    const u64 K = keys.size();
+    // ---- device: expand the word postings ----
+    DCD_TRY(t_all.start());
+    DCD_TRY(t_sort.start());
+    DevBuf<u32> d_code_off, d_code_key, d_cnt;
+    DevBuf<u64> d_off, d_scr;
+    DCD_TRY(d_code_off.alloc(dev, V + 1)); DCD_TRY(d_code_key.alloc(dev, code_key.size() + 1));
+    DCD_HIP(hipMemcpyAsync(d_code_off.p, M.code_off.data(), (V + 1) * 4, hipMemcpyHostToDevice, st));
+    if (!code_key.empty()) DCD_HIP(hipMemcpyAsync(d_code_key.p, code_key.data(), code_key.size() * 4, hipMemcpyHostToDevice, st));
+    u64 NE = 0, n_text_exp = 0;
+    if (N) {
+      DCD_TRY(d_cnt.alloc(dev, N + 1)); DCD_TRY(d_off.alloc(dev, N + 1)); DCD_TRY(d_scr.alloc(dev, scan_scratch_elems(N + 1)));
+      hipLaunchKernelGGL(k_codes_count, dim3((u32)div_up(N, 256)), dim3(256), 0, st, a, N, remap, d_code_off.p, d_cnt.p);
+      DCD_HIP(hipMemsetAsync(d_cnt.p + N, 0, 4, st));
+      scan_exclusive<u32, u64>(d_cnt.p, d_off.p, N + 1, d_scr.p, st);
+      DCD_HIP(hipMemcpyAsync(&NE, d_off.p + N, 8, hipMemcpyDeviceToHost, st));
+      DCD_HIP(hipMemcpyAsync(&n_text_exp, d_off.p + M.n_text_tok, 8, hipMemcpyDeviceToHost, st));
+      DCD_HIP(hipStreamSynchronize(st));
+    }
+    const u64 NX = xcodes.size();
+    const u64 NT = NE + NX;
+    if (NT >= (1ull << 32)) DCD_FAIL(DCD_E_OVERFLOW, "more than 2^32 postings in one build segment");
+    DCD_TRY(expA.alloc(dev, NT ? NT : 1));
+    DCD_TRY(expB.alloc(dev, NT ? NT : 1));
+    if (N) hipLaunchKernelGGL(k_codes_expand, dim3((u32)div_up(N, 256)), dim3(256), 0, st, a, N, remap, d_code_off.p, d_code_key.p, d_off.p, expA.p);
+    if (NX) {
+      std::vector<uint2> xt(NX);
+      for (u64 i = 0; i < NX; i++) {
+        xt[i].x = key_id(ustr((const char16_t*)h->xpool.data() + xcodes[i]->off, xcodes[i]->len));
+        xt[i].y = (u32)(xcodes[i]->coord - h->opts.coord_base);
+      }
+      DCD_HIP(hipMemcpyAsync(expA.p + NE, xt.data(), NX * sizeof(uint2), hipMemcpyHostToDevice, st));
+      DCD_HIP(hipStreamSynchronize(st));
+    }
+    if (n_text_exp) {
+      u32 c = 0;
+      DCD_HIP(hipMemcpyAsync(&c, &expA.p[n_text_exp - 1].y, 4, hipMemcpyDeviceToHost, st));
+      DCD_HIP(hipStreamSynchronize(st));
+      max_coord_codes = h->opts.coord_base + c;
+      have_max_coord_codes = true;
+    }
+    // the key strings replace the word strings
+    std::vector<u16> kc;
+    std::vector<u32> ko(K + 1, 0);
+    for (u64 k = 0; k < K; k++) { ko[k] = (u32)kc.size(); kc.insert(kc.end(), (const u16*)keys[k].data(), (const u16*)keys[k].data() + keys[k].size()); }
+    ko[K] = (u32)kc.size();
+    total_chars = (u32)kc.size();
+    DCD_TRY(M.word_chars.alloc(dev, kc.size() ? kc.size() : 1));
+    DCD_TRY(M.word_str_off.alloc(dev, K + 1));
+    if (!kc.empty()) DCD_HIP(hipMemcpyAsync(M.word_chars.p, kc.data(), kc.size() * 2, hipMemcpyHostToDevice, st));
+    DCD_HIP(hipMemcpyAsync(M.word_str_off.p, ko.data(), (K + 1) * 4, hipMemcpyHostToDevice, st));
+    DCD_HIP(hipStreamSynchronize(st));
+    a = expA.p; b = expB.p; remap = nullptr;
+    coord_sort = M.n_xdev != 0 || NX != 0;
+    n_text_postings = n_text_exp;
+    N = NT; V = K;
+  } else {
+    DCD_TRY(t_all.start());
+    DCD_TRY(t_sort.start());
+  }
+
+  // ---- 4. sort the tuples by key (stable; explicit postings first need coordinate order) ----
+  uint2* sorted = a;
   int passes = 0;
   std::vector<hipEvent_t> sort_events;
   if (N) {
-    uint2* a = tupA.p;
-    uint2* b = tupB.p;
-    if (n_x) {
+    if (coord_sort) {
       // mixed input is not in coordinate order: LSD over the coordinate bits first
-      hipLaunchKernelGGL(k_max_y, dim3((u32)div_up(N, 256)), dim3(256), 0, st, a, N, d_flags.p + 2);
+      DCD_HIP(hipMemsetAsync(M.d_flags.p + 2, 0, 4, st));
+      hipLaunchKernelGGL(k_max_y, dim3((u32)div_up(N, 256)), dim3(256), 0, st, a, N, M.d_flags.p + 2);
       u32 maxc = 0;
-      DCD_HIP(hipMemcpyAsync(&maxc, d_flags.p + 2, 4, hipMemcpyDeviceToHost, st));
+      DCD_HIP(hipMemcpyAsync(&maxc, M.d_flags.p + 2, 4, hipMemcpyDeviceToHost, st));
       DCD_HIP(hipStreamSynchronize(st));
       hipLaunchKernelGGL(k_swap_xy, dim3((u32)div_up(N, 256)), dim3(256), 0, st, a, N);
       int p1 = 0;
-      uint2* r = rs_sort(a, b, nullptr, N, (int)log2_ceil((u64)maxc + 1), d_hist.p, scan_scr32.p, st, &p1);
+      uint2* r = rs_sort(a, b, nullptr, N, (int)log2_ceil((u64)maxc + 1), M.d_hist.p, M.scan_scr32.p, st, &p1);
       passes += p1;
       if (r != a) { b = a; a = r; }
       hipLaunchKernelGGL(k_swap_xy, dim3((u32)div_up(N, 256)), dim3(256), 0, st, a, N);
@@ -726,15 +924,13 @@ static int32_t finish_impl(dcd_build* h) {
     int p2 = 0;
     RsProbe rp;
     rp.ev = &sort_events;
-    sorted = rs_sort(a, b, rank_of_slot.p, N, (int)log2_ceil(V ? V : 1), d_hist.p, scan_scr32.p, st, &p2, rp);
+    sorted = rs_sort(a, b, remap, N, (int)log2_ceil(V ? V : 1), M.d_hist.p, M.scan_scr32.p, st, &p2, rp);
     passes += p2;
   }
   DCD_TRY(t_sort.stop());
 
   // ---- 5. pack: deltas -> var-ushort units (IndexSequence.Builder.Add) -----------------------
   DCD_TRY(t_pack.start());
-  DeviceIndex& ix = h->ix;
-  ix.device = dev;
   DCD_TRY(ix.term_unit_start.alloc(dev, V + 1));
   DCD_TRY(ix.term_item_start.alloc(dev, V + 1));
   DevBuf<u64> enc_part;
@@ -744,18 +940,18 @@ static int32_t finish_impl(dcd_build* h) {
   EncSrcPairs src;
   src.p = sorted; src.base = h->opts.coord_base; src.term_unit_start = ix.term_unit_start.p; src.term_item_start = ix.term_item_start.p;
   if (N) {
-    probe_begin(DCD_K_ENC_REDUCE);
+    probes.begin(DCD_K_ENC_REDUCE);
     hipLaunchKernelGGL((k_enc_reduce<EncSrcPairs>), dim3((u32)enb), dim3(CODEC_THREADS), 0, st, src, N, enc_part.p);
-    probe_end();
+    probes.end();
     hipLaunchKernelGGL((k_scan_partials<u64>), dim3(1), dim3(1024), 0, st, enc_part.p, enb);
     DCD_HIP(hipMemcpyAsync(&U, enc_part.p + enb, 8, hipMemcpyDeviceToHost, st));
     DCD_HIP(hipStreamSynchronize(st));
   }
   DCD_TRY(ix.units.alloc(dev, U ? U : 1));
   if (N) {
-    probe_begin(DCD_K_ENC_WRITE);
+    probes.begin(DCD_K_ENC_WRITE);
     hipLaunchKernelGGL(k_pack_write, dim3((u32)enb), dim3(CODEC_THREADS), 0, st, src, N, enc_part.p, ix.units.p);
-    probe_end();
+    probes.end();
   }
   hipLaunchKernelGGL(k_set_u64, dim3(1), dim3(1), 0, st, ix.term_unit_start.p + V, U);
   hipLaunchKernelGGL(k_set_u64, dim3(1), dim3(1), 0, st, ix.term_item_start.p + V, N);
@@ -767,23 +963,14 @@ static int32_t finish_impl(dcd_build* h) {
 
   // ---- 6. keys + ".index" image -----------------------------------------------------------------
   DCD_TRY(t_img.start());
-  DCD_TRY(ix.term_str_off.alloc(dev, V + 1));
-  u32 total_chars = 0;
-  if (V) {
-    scan_exclusive_f<TermLenF, u32>(TermLenF{rk_word.p}, ix.term_str_off.p, V, scan_scr32.p, st);
-    DCD_HIP(hipMemcpyAsync(&total_chars, scan_scr32.p + scan_nblocks(V), 4, hipMemcpyDeviceToHost, st));
-    DCD_HIP(hipStreamSynchronize(st));
-  }
-  DCD_HIP(hipMemcpyAsync(ix.term_str_off.p + V, &total_chars, 4, hipMemcpyHostToDevice, st));
-  DCD_TRY(ix.term_chars.alloc(dev, total_chars ? total_chars : 1));
+  ix.term_str_off = std::move(M.word_str_off);
+  ix.term_chars = std::move(M.word_chars);
   DevBuf<u64> rec_off, pay_off, scr64b;
   DCD_TRY(rec_off.alloc(dev, V + 1));
   DCD_TRY(pay_off.alloc(dev, V + 1));
   DCD_TRY(scr64b.alloc(dev, scan_scratch_elems(V ? V : 1)));
   u64 rec_total = 0;
   if (V) {
-    hipLaunchKernelGGL((k_term_strings<CharT>), dim3((u32)div_up(V, 256)), dim3(256), 0, st, rk_word.p, V, ix.term_str_off.p, tv,
-                       ix.term_chars.p);
     scan_exclusive_f<RecSizeF, u64>(RecSizeF{ix.term_chars.p, ix.term_str_off.p, ix.term_unit_start.p}, rec_off.p, V, scr64b.p, st);
     DCD_HIP(hipMemcpyAsync(&rec_total, scr64b.p + scan_nblocks(V), 8, hipMemcpyDeviceToHost, st));
   }
@@ -791,9 +978,11 @@ static int32_t finish_impl(dcd_build* h) {
   u64 max_coord = 0;
   {
     // coordinate of the last Add call: the later of (last explicit posting, last text token)
-    if (h->last_is_explicit && n_x) max_coord = h->last_explicit_coord;
-    else if (n_text_tok) max_coord = h->opts.coord_base + last_text_coord;
-    else if (n_x) max_coord = h->last_explicit_coord;
+    const bool any_x = !h->xps.empty();
+    const u64 text_last = have_max_coord_codes ? max_coord_codes : h->opts.coord_base + M.last_text_coord;
+    if (h->last_is_explicit && any_x) max_coord = h->last_explicit_coord;
+    else if (n_text_postings) max_coord = text_last;
+    else if (any_x) max_coord = h->last_explicit_coord;
   }
   h->image_bytes = 8 + rec_total;
   DCD_TRY(h->image.alloc(dev, h->image_bytes));
@@ -802,10 +991,10 @@ static int32_t finish_impl(dcd_build* h) {
     hipLaunchKernelGGL(k_img_headers, dim3((u32)div_up(V, 256)), dim3(256), 0, st, ix.term_chars.p, ix.term_str_off.p,
                        ix.term_unit_start.p, rec_off.p, V, (u64)8, h->image.p, pay_off.p);
     if (U) {
-      probe_begin(DCD_K_IMG_UNITS);
+      probes.begin(DCD_K_IMG_UNITS);
       hipLaunchKernelGGL(k_img_units, dim3((u32)div_up(div_up(U, IMG_UPT), 256)), dim3(256), 0, st, ix.units.p, U, ix.term_unit_start.p, V,
                          pay_off.p, h->image.p);
-      probe_end();
+      probes.end();
     }
   }
   DCD_TRY(t_img.stop());
@@ -815,7 +1004,7 @@ static int32_t finish_impl(dcd_build* h) {
 
   // ---- host mirrors + stats ----------------------------------------------------------------------
   ix.n_terms = V; ix.n_units = U; ix.n_postings = N; ix.max_coord = max_coord;
-  ix.page_end = std::move(d_page_end);
+  ix.page_end = std::move(M.d_page_end);
   ix.h_term_chars.resize(total_chars);
   ix.h_term_str_off.resize(V + 1);
   ix.h_term_unit_start.resize(V + 1);
@@ -827,24 +1016,21 @@ static int32_t finish_impl(dcd_build* h) {
   ix.pages = h->pages;
 
   dcd_build_stats& s = h->stats;
-  s.n_chars = n_chars; s.n_pages = h->pages.n_pages(); s.n_docs = h->pages.n_docs();
+  s.n_chars = h->n_chars; s.n_pages = h->pages.n_pages(); s.n_docs = h->pages.n_docs();
   s.n_postings = N; s.n_terms = V; s.n_units = U; s.max_coord = max_coord;
   s.index_bytes = h->image_bytes; s.list_bytes = 0;  // the list image is generated on demand
-  s.ms_tokenize = t_tok.ms(); s.ms_vocab = t_voc.ms(); s.ms_sort = t_sort.ms(); s.ms_pack = t_pack.ms(); s.ms_image = t_img.ms();
-  s.ms_total = t_all.ms();
-  s.sort_passes = (u32)passes; s.vocab_capacity_log2 = cap_log2;
-  for (int k = 0; k < 8; k++) { s.ms_kernel[k] = 0; s.n_launch[k] = 0; }
-  for (auto& p : probes) {
-    float t = 0;
-    if (hipEventElapsedTime(&t, p.a, p.b) == hipSuccess) { s.ms_kernel[p.id] += t; s.n_launch[p.id]++; }
-    (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b);
-  }
+  s.ms_tokenize = M.ms_tok; s.ms_vocab = M.ms_voc; s.ms_sort = t_sort.ms(); s.ms_pack = t_pack.ms(); s.ms_image = t_img.ms();
+  s.ms_total = M.ms_total + t_all.ms();
+  s.sort_passes = (u32)passes; s.vocab_capacity_log2 = M.cap_log2;
+  for (int k = 0; k < 8; k++) { s.ms_kernel[k] = M.ms_kernel[k]; s.n_launch[k] = M.n_launch[k]; }
+  probes.collect(s.ms_kernel, s.n_launch);
   for (size_t i = 0; i + 3 < sort_events.size(); i += 4) {
     float t = 0;
     if (hipEventElapsedTime(&t, sort_events[i], sort_events[i + 1]) == hipSuccess) { s.ms_kernel[DCD_K_RS_HIST] += t; s.n_launch[DCD_K_RS_HIST]++; }
     if (hipEventElapsedTime(&t, sort_events[i + 2], sort_events[i + 3]) == hipSuccess) { s.ms_kernel[DCD_K_RS_SCATTER] += t; s.n_launch[DCD_K_RS_SCATTER]++; }
   }
   for (auto e : sort_events) (void)hipEventDestroy(e);
+  h->mid.reset();
   h->finished = true;
   return DCD_OK;
 }
@@ -854,8 +1040,53 @@ extern "C" {
 int32_t dcd_build_finish(dcd_build* h) {
   if (!h) DCD_FAIL(DCD_E_BADARG, "dcd_build_finish: NULL handle");
   if (h->finished) DCD_FAIL(DCD_E_STATE, "build already finished");
-  if (h->opts.encoding == DCD_ENC_UTF16LE) return finish_impl<u16>(h);
-  return finish_impl<u8>(h);
+  DCD_TRY(ensure_device(h->device));
+  const bool wide = h->opts.encoding == DCD_ENC_UTF16LE;
+  if (!h->mid) DCD_TRY(wide ? build_phase1<u16>(h, false) : build_phase1<u8>(h, false));
+  return wide ? build_phase2<u16>(h) : build_phase2<u8>(h);
+}
+
+int32_t dcd_build_words(dcd_build* h, size_t* n_words, size_t* n_chars) {
+  if (!h || !n_words || !n_chars) DCD_FAIL(DCD_E_BADARG, "dcd_build_words: NULL argument");
+  if (h->finished) DCD_FAIL(DCD_E_STATE, "build already finished");
+  if (!h->mid) {
+    DCD_TRY(ensure_device(h->device));
+    DCD_TRY(h->opts.encoding == DCD_ENC_UTF16LE ? build_phase1<u16>(h, true) : build_phase1<u8>(h, true));
+  }
+  *n_words = h->mid->V;
+  *n_chars = h->mid->total_chars;
+  return DCD_OK;
+}
+
+int32_t dcd_build_words_get(dcd_build* h, uint16_t* chars, size_t chars_cap, uint32_t* off, size_t off_cap) {
+  if (!h || !off || (!chars && chars_cap)) DCD_FAIL(DCD_E_BADARG, "dcd_build_words_get: NULL argument");
+  if (!h->mid || !h->mid->codes_mode) DCD_FAIL(DCD_E_STATE, "dcd_build_words_get: call dcd_build_words first");
+  const BuildMid& M = *h->mid;
+  if (chars_cap < M.h_word_chars.size() || off_cap < M.h_word_str_off.size()) return DCD_E_OVERFLOW;
+  if (!M.h_word_chars.empty()) memcpy(chars, M.h_word_chars.data(), M.h_word_chars.size() * 2);
+  memcpy(off, M.h_word_str_off.data(), M.h_word_str_off.size() * 4);
+  return DCD_OK;
+}
+
+int32_t dcd_build_set_codes(dcd_build* h, const uint32_t* code_off, size_t n_words, const uint32_t* str_off, const uint16_t* chars,
+                            size_t n_entries) {
+  if (!h || !code_off || !str_off || (!chars && n_entries && str_off[n_entries])) DCD_FAIL(DCD_E_BADARG, "dcd_build_set_codes: NULL argument");
+  if (!h->mid || !h->mid->codes_mode) DCD_FAIL(DCD_E_STATE, "dcd_build_set_codes: call dcd_build_words first");
+  BuildMid& M = *h->mid;
+  if (n_words != M.V) DCD_FAIL(DCD_E_BADARG, "dcd_build_set_codes: %zu words given, the build has %llu", n_words, (unsigned long long)M.V);
+  if (code_off[0] != 0 || code_off[n_words] != n_entries) DCD_FAIL(DCD_E_BADARG, "dcd_build_set_codes: code_off must run from 0 to n_entries");
+  for (size_t w = 0; w < n_words; w++) if (code_off[w] > code_off[w + 1]) DCD_FAIL(DCD_E_BADARG, "dcd_build_set_codes: code_off not ascending");
+  std::vector<ustr> cs(n_entries);
+  for (size_t e = 0; e < n_entries; e++) {
+    if (str_off[e] > str_off[e + 1]) DCD_FAIL(DCD_E_BADARG, "dcd_build_set_codes: str_off not ascending");
+    const size_t len = str_off[e + 1] - str_off[e];
+    if (len == 0 || len > MAX_CODE_LEN) DCD_FAIL(DCD_E_UNSUPPORTED, "index codes must be 1..%u UTF-16 units long", MAX_CODE_LEN);
+    cs[e] = ustr((const char16_t*)chars + str_off[e], len);
+  }
+  M.code_off.assign(code_off, code_off + n_words + 1);
+  M.code_str = std::move(cs);
+  M.have_codes = true;
+  return DCD_OK;
 }
 
 int32_t dcd_build_get_stats(dcd_build* h, dcd_build_stats* out) {

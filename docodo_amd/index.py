@@ -27,7 +27,10 @@ class Builder:
     """Index.Builder (Build.cs:258-437) fused with the IndexTask page loop (Build.cs:445-564)."""
 
     def __init__(self, encoding=_lib.DCD_ENC_LATIN1, coord_base=0, device=0, min_word_length=3, max_word_length=32,
-                 vocab_capacity_log2=0):
+                 vocab_capacity_log2=0, get_word_codes=None):
+        """get_word_codes: callable word -> list of index codes (GetWordCodes, Build.cs:175-247; see
+        docodo_amd.wordcodes.WordCoder).  None = identity codes (Stemmers.Clear(), no vocabulary, no stop words)."""
+        self.get_word_codes = get_word_codes
         o = BuildOpts()
         lib().dcd_build_default_opts(C.byref(o))
         o.device, o.encoding, o.coord_base = device, encoding, coord_base
@@ -93,15 +96,43 @@ class Builder:
         check(lib().dcd_build_add(self.h, p, n, int(coord)))
 
     def AddWord(self, word, coord):
-        """Build.cs:302-316 with GetWordCodes == identity (Stemmers.Clear(), no vocab, no stop words:
-        the parity configuration of SURVEY.md §8d); a host that stems passes its codes to Add()."""
-        self.Add(word, coord)
+        """Build.cs:302-316: the word is indexed under every code GetWordCodes gives it (see Finish)."""
+        a, p, n = _u16(word)
+        check(lib().dcd_build_add_word(self.h, p, n, int(coord)))
+
+    def Words(self):
+        """The distinct words of the build in ordinal order (runs tokenise + vocabulary on the device)."""
+        nw, nc = C.c_size_t(0), C.c_size_t(0)
+        check(lib().dcd_build_words(self.h, C.byref(nw), C.byref(nc)))
+        chars = np.empty(max(1, nc.value), np.uint16)
+        off = np.empty(nw.value + 1, np.uint32)
+        check(lib().dcd_build_words_get(self.h, chars.ctypes.data, chars.size, off.ctypes.data, off.size))
+        raw = chars[:nc.value].tobytes()
+        return [raw[2 * int(off[i]):2 * int(off[i + 1])].decode("utf-16-le", "surrogatepass") for i in range(nw.value)]
+
+    def SetCodes(self, codes_per_word):
+        """codes_per_word[w] = list of code strings of word w of Words() ([] / None = dropped)."""
+        code_off = np.zeros(len(codes_per_word) + 1, np.uint32)
+        strs = []
+        for w, cs in enumerate(codes_per_word):
+            cs = cs or []
+            strs += cs
+            code_off[w + 1] = code_off[w] + len(cs)
+        str_off = np.zeros(len(strs) + 1, np.uint32)
+        if strs:
+            str_off[1:] = np.cumsum([len(s.encode("utf-16-le", "surrogatepass")) // 2 for s in strs])
+        chars = np.frombuffer("".join(strs).encode("utf-16-le", "surrogatepass"), np.uint16)
+        check(lib().dcd_build_set_codes(self.h, code_off.ctypes.data, len(codes_per_word), str_off.ctypes.data,
+                                        chars.ctypes.data if chars.size else None, len(strs)))
 
     def EndPage(self, id):  # Build.cs:359
         a, p, n = _u16(id)
         check(lib().dcd_build_end_page(self.h, p, n))
 
     def Finish(self):
+        if self.get_word_codes is not None:
+            # GetWordCodes once per DISTINCT word on the host; one posting per (token, code) on the device
+            self.SetCodes([self.get_word_codes(w) for w in self.Words()])
         check(lib().dcd_build_finish(self.h))
         return self.stats
 

@@ -116,12 +116,33 @@ int32_t dcd_build_add_uniform_pages_dev(dcd_build* h, const void* text_dev, uint
                                         uint64_t first_doc, const uint16_t* source, size_t source_len);
 /* Builder.Add(code, coord), Build.cs:324-341: explicit posting for an index code */
 int32_t dcd_build_add(dcd_build* h, const uint16_t* code, size_t len, uint64_t coord);
+/* Builder.AddWord(word, coord), Build.cs:302-316: explicit posting for a WORD; it receives the word's index codes
+ * (identity unless the host supplies codes through dcd_build_words / dcd_build_set_codes) */
+int32_t dcd_build_add_word(dcd_build* h, const uint16_t* word, size_t len, uint64_t coord);
 /* Builder.EndPage(id) / EndPage(id, maxcoord), Build.cs:359-367 (explicit-posting API only) */
 int32_t dcd_build_end_page(dcd_build* h, const uint16_t* id, size_t len);
 /* Runs the device pipeline: tokenise -> vocabulary -> stable radix sort by term -> var-ushort pack
  * -> ".index" byte image, all resident in HBM.  Equivalent of Builder.Save + MergeAll/MergeIndexes
  * for one coordinate space (Build.cs:370-404, Index.cs:537-752). */
 int32_t dcd_build_finish(dcd_build* h);
+
+/* Word codes -- GetWordCodes, Build.cs:175-247 (stop words, "#HEX" vocabulary groups, "$stem" codes).  The
+ * stemmers and vocabularies stay on the host (StemmersNet / Dict.cs in the reference); the device does the
+ * per-posting work.  Optional two-step protocol between the last page and dcd_build_finish:
+ *   dcd_build_words      runs tokenise + vocabulary on the device and returns the number of DISTINCT words of
+ *                        the build (text tokens, header-page value words, dcd_build_add_word) and their total
+ *                        length; dcd_build_words_get copies them out in ordinal order (UTF-16, off[n_words+1]);
+ *   dcd_build_set_codes  gives, for word w, its codes = entries code_off[w] .. code_off[w+1], entry e being the
+ *                        string chars[str_off[e] .. str_off[e+1]).  No entries = the word is dropped (stop word).
+ *                        (GetWordCodes' `suff` member is always null in the reference, Build.cs:203/233, so the
+ *                        bKeepForms branch of AddWord, Build.cs:310-313, never adds anything.)
+ * dcd_build_finish then emits one posting per (token, code), Builder.AddWord, at the token's coordinate;
+ * postings added with dcd_build_add (explicit CODES, e.g. the "&field" markers of header pages) are unaffected.
+ * Without dcd_build_set_codes every word keeps the identity code list [word]. */
+int32_t dcd_build_words(dcd_build* h, size_t* n_words, size_t* n_chars);
+int32_t dcd_build_words_get(dcd_build* h, uint16_t* chars, size_t chars_cap, uint32_t* off, size_t off_cap);
+int32_t dcd_build_set_codes(dcd_build* h, const uint32_t* code_off, size_t n_words, const uint32_t* str_off,
+                            const uint16_t* chars, size_t n_entries);
 
 typedef struct dcd_build_stats {
   uint64_t n_chars, n_pages, n_docs;

@@ -143,6 +143,84 @@ def test_stemmer_dependent_answers_via_explicit_codes(oracle_mod, known, testtex
     _same(r, oix.search(ka["req"], oracle_mod.SearchOptions(dist=ka["dist"])))
 
 
+_STEM_RANGES = ["0-9", "а-яё", "a-z", "a-zẞäüö", "a-zéâàêèëçîïôûùüÿ"]   # Index.cs:175-181 (ranges of the default stemmers)
+
+
+def _stemmers():
+    from oracle import porter2   # the application's stemmer: here the test infrastructure's Snowball English
+    return [(r, porter2.stem if r == "a-z" else None) for r in _STEM_RANGES]
+
+
+@pytest.fixture(scope="module")
+def gpu_stemmed(oracle_mod, testtext1, testheaders1):
+    """Default configuration of the reference (stemmers on): the device tokenises and builds the vocabulary, the
+    host maps every DISTINCT word to its codes (WordCoder = GetWordCodes), the device emits one posting per
+    (token, code).  Header-page value words take the same route, "&field" markers stay explicit codes."""
+    import docodo_amd
+    docs = _corpus(testtext1, testheaders1, 5)
+    coder = docodo_amd.WordCoder(stemmers=_stemmers())
+    b = docodo_amd.Builder(encoding=docodo_amd.DCD_ENC_UTF16LE, get_word_codes=coder)
+    for name, pages in docs:
+        b.AddDoc("Test", name)
+        texts = [t for _, t in pages]
+        off = np.zeros(len(texts) + 1, np.uint64)
+        off[1:] = np.cumsum([len(t.encode("utf-16-le")) // 2 for t in texts])
+        b.AddPages("".join(texts), off, page_ids=[i for i, _ in pages])
+    b.Finish()
+    oix, oimg, olst = _oracle_index(oracle_mod, docs, _stemmers())
+    return b, coder, oix, oimg, olst
+
+
+def test_word_codes_images_equal_oracle(gpu_stemmed, oracle_mod):
+    """GetWordCodes through dcd_build_words / dcd_build_set_codes: ".index" / ".index.list" bit-exact against the
+    oracle built with the same stemmers ($stem codes shared by several words, e.g. lady + ladies -> $ladi)."""
+    b, coder, oix, oimg, olst = gpu_stemmed
+    assert b.list_image() == olst
+    assert b.index_image() == oimg
+    assert oix.get("$ladi") is not None and b.stats.n_terms == oix.count
+
+
+@pytest.mark.parametrize("key", ["D4", "D5", "D8"])
+def test_stemmer_dependent_answers_device_build(gpu_stemmed, oracle_mod, known, key):
+    """IndexTest.cs:198-210 on an index the DEVICE built with word codes."""
+    import docodo_amd
+    b, coder, oix, _, _ = gpu_stemmed
+    S = docodo_amd.Search(b_index(b), get_word_codes=coder)
+    ka = known[key]
+    r = S(ka["req"], docodo_amd.SearchOptions(dist=ka["dist"]))
+    assert r.Success and len(r.foundPages[0][2]) == ka["pos_page0"]
+    _same(r, oix.search(ka["req"], oracle_mod.SearchOptions(dist=ka["dist"])))
+
+
+def test_word_codes_stop_words_and_identity(oracle_mod):
+    """Stop words drop their postings (GetWordCodes returns an empty list, Build.cs:185); dcd_build_words without
+    dcd_build_set_codes keeps identity codes; explicit codes (Builder.Add) never pass through GetWordCodes."""
+    import docodo_amd
+    text = "the quick brown fox jumps over the lazy dog and the lazy cat"
+    oix = oracle_mod.Index(stemmers=[])
+    ob = oracle_mod.Builder(oix)
+    ob.add_doc("s", "d")
+    ob.index_page("1", text)
+    oimg, olst = ob.save()
+    b = docodo_amd.Builder(encoding=docodo_amd.DCD_ENC_UTF16LE)
+    b.AddDoc("s", "d")
+    b.AddPages(text, [0, len(text)], page_ids=["1"])
+    words = b.Words()                       # codes mode, no SetCodes -> identity
+    assert words == sorted(set(w for w in text.split() if len(w) >= 3))
+    b.Finish()
+    assert b.index_image() == oimg and b.list_image() == olst
+    # stop words + a shared extra code + an explicit code equal to a word
+    coder = docodo_amd.WordCoder(stop_words={"the", "and"}, stemmers=[("a-z", lambda w: "laz" if w == "lazy" else w)])
+    b2 = docodo_amd.Builder(encoding=docodo_amd.DCD_ENC_UTF16LE, get_word_codes=coder)
+    b2.AddDoc("s", "d")
+    b2.AddPages(text, [0, len(text)], page_ids=["1"])
+    b2.Finish()
+    ix = b2.Build()
+    assert ix.find("the") is None and ix.find("and") is None
+    assert ix.term_count(ix.find("lazy")) == 2 and ix.term_count(ix.find("$laz")) == 2
+    assert ix.find("$quick") is None and ix.term_count(ix.find("quick")) == 1
+
+
 def test_latin1_header_pages_and_edge_lines(oracle_mod):
     """Header pages in a byte (Latin-1) build, odd header lines: short names (skipped), no trailing newline,
     CR LF line ends, '=' inside the value, digits, a line without '=' after a valid one (aborts the page
