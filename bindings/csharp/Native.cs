@@ -40,7 +40,12 @@ namespace Docodo
                                                                       char* pageIds, ulong* idsOff, int docsPerPage, ulong firstDoc,
                                                                       char* src, UIntPtr srcLen);
         [DllImport(Lib)] public static extern int dcd_build_add(IntPtr h, char* code, UIntPtr len, ulong coord);
+        [DllImport(Lib)] public static extern int dcd_build_add_word(IntPtr h, char* word, UIntPtr len, ulong coord);
         [DllImport(Lib)] public static extern int dcd_build_end_page(IntPtr h, char* id, UIntPtr len);
+        // GetWordCodes (Build.cs:175-247) once per DISTINCT word: words out, codes in, then finish
+        [DllImport(Lib)] public static extern int dcd_build_words(IntPtr h, out UIntPtr nWords, out UIntPtr nChars);
+        [DllImport(Lib)] public static extern int dcd_build_words_get(IntPtr h, char* chars, UIntPtr charsCap, uint* off, UIntPtr offCap);
+        [DllImport(Lib)] public static extern int dcd_build_set_codes(IntPtr h, uint* codeOff, UIntPtr nWords, uint* strOff, char* chars, UIntPtr nEntries);
         [DllImport(Lib)] public static extern int dcd_build_finish(IntPtr h);
         [DllImport(Lib)] public static extern int dcd_build_save(IntPtr h, [MarshalAs(UnmanagedType.LPUTF8Str)] string dir);
         // Index.cs / Search.cs
