@@ -4,6 +4,7 @@
 // Replaces IndexTask's page loop (Build.cs:477-541), Index.Builder.Add/Save (Build.cs:324-404)
 // and, for one coordinate space, the merge functions (Index.cs:537-752).
 #include <algorithm>
+#include <chrono>
 #include <memory>
 
 #include "dcd_build_int.h"
@@ -252,6 +253,23 @@ DeviceIndex* build_take_index(dcd_build* b) {
 int build_device(dcd_build* b) { return b->device; }
 DeviceIndex* build_peek_index(dcd_build* b) { return (b->finished && !b->adopted) ? &b->ix : nullptr; }
 hipStream_t build_stream(dcd_build* b) { return b->st; }
+int32_t index_fetch_host(DeviceIndex& ix) {
+  if (ix.host_ready) return DCD_OK;
+  DCD_TRY(ensure_device(ix.device));
+  const u64 V = ix.n_terms;
+  u32 total_chars = 0;
+  ix.h_term_str_off.resize(V + 1);
+  ix.h_term_unit_start.resize(V + 1);
+  ix.h_term_item_start.resize(V + 1);
+  DCD_HIP(hipMemcpy(ix.h_term_str_off.data(), ix.term_str_off.p, (V + 1) * 4, hipMemcpyDeviceToHost));
+  total_chars = ix.h_term_str_off[V];
+  ix.h_term_chars.resize(total_chars);
+  if (total_chars) DCD_HIP(hipMemcpy(ix.h_term_chars.data(), ix.term_chars.p, (size_t)total_chars * 2, hipMemcpyDeviceToHost));
+  DCD_HIP(hipMemcpy(ix.h_term_unit_start.data(), ix.term_unit_start.p, (V + 1) * 8, hipMemcpyDeviceToHost));
+  DCD_HIP(hipMemcpy(ix.h_term_item_start.data(), ix.term_item_start.p, (V + 1) * 8, hipMemcpyDeviceToHost));
+  ix.host_ready = true;
+  return DCD_OK;
+}
 }  // namespace dcd
 
 static ustr mk16(const u16* p, size_t n) { return ustr((const char16_t*)p, n); }
@@ -580,6 +598,20 @@ struct BuildMid {
 };
 
 namespace {
+// DOCODO_TRACE=1: host-side wall-clock marks of the build phases on stderr (where the non-device time goes)
+struct HostTrace {
+  bool on;
+  std::vector<std::pair<const char*, double>> m;
+  HostTrace() : on(getenv("DOCODO_TRACE") != nullptr) {}
+  static double now() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+  void mark(const char* l) { if (on) m.emplace_back(l, now()); }
+  ~HostTrace() {
+    if (!on || m.empty()) return;
+    std::string o = "[docodo trace]";
+    for (size_t i = 1; i < m.size(); i++) { char b[96]; snprintf(b, sizeof b, " %s %.3f", m[i].first, m[i].second - m[i - 1].second); o += b; }
+    fprintf(stderr, "%s | total %.3f ms\n", o.c_str(), m.back().second - m.front().second);
+  }
+};
 struct Probes {
   struct P { int id; hipEvent_t a, b; };
   std::vector<P> v;
@@ -608,6 +640,8 @@ static int32_t build_phase1(dcd_build* h, bool codes_mode) {
   h->mid.reset(new BuildMid());
   BuildMid& M = *h->mid;
   M.codes_mode = codes_mode;
+  HostTrace tr;
+  tr.mark("begin");
   EvTimer t_all, t_tok, t_voc;
   DCD_TRY(t_all.init(st)); DCD_TRY(t_tok.init(st)); DCD_TRY(t_voc.init(st));
   Probes probes(st);
@@ -656,6 +690,7 @@ static int32_t build_phase1(dcd_build* h, bool codes_mode) {
   }
   DCD_HIP(hipStreamSynchronize(st));
 
+  tr.mark("setup");
   DCD_TRY(t_all.start());
   // ---- 1. tokenise: count pass -------------------------------------------------------------------
   DCD_TRY(t_tok.start());
@@ -691,6 +726,7 @@ static int32_t build_phase1(dcd_build* h, bool codes_mode) {
     DCD_HIP(hipMemcpyAsync(&n_text_tok, scan_scr64.p + scan_nblocks(n_tiles), 8, hipMemcpyDeviceToHost, st));
     DCD_HIP(hipStreamSynchronize(st));
   }
+  tr.mark("count");
   const u64 N = n_text_tok + n_x;
   if (N >= (1ull << 32)) DCD_FAIL(DCD_E_OVERFLOW, "more than 2^32 postings in one build segment");
   M.N = N; M.n_text_tok = n_text_tok;
@@ -740,6 +776,7 @@ static int32_t build_phase1(dcd_build* h, bool codes_mode) {
     if (flags[0] || V * 2 > cap) { cap_log2 += 2; continue; }  // overflow or load > 0.5: rebuild larger
     break;
   }
+  tr.mark("emit");
   const u64 cap = 1ull << cap_log2;
   M.cap_log2 = cap_log2; M.V = V;
   DCD_TRY(t_tok.stop());
@@ -768,8 +805,10 @@ static int32_t build_phase1(dcd_build* h, bool codes_mode) {
   DCD_TRY(t_all.stop());
   DCD_HIP(hipStreamSynchronize(st));
   DCD_HIP(hipGetLastError());
+  tr.mark("vocab");
   M.ms_tok = t_tok.ms(); M.ms_voc = t_voc.ms(); M.ms_total = t_all.ms();
   probes.collect(M.ms_kernel, M.n_launch);
+  tr.mark("collect");
   if (codes_mode) {
     M.h_word_chars.resize(total_chars);
     M.h_word_str_off.resize(V + 1);
@@ -804,6 +843,8 @@ static int32_t build_phase2(dcd_build* h) {
   hipStream_t st = h->st;
   DCD_TRY(ensure_device(dev));
   BuildMid& M = *h->mid;
+  HostTrace tr;
+  tr.mark("begin2");
   EvTimer t_all, t_sort, t_pack, t_img;
   DCD_TRY(t_all.init(st)); DCD_TRY(t_sort.init(st)); DCD_TRY(t_pack.init(st)); DCD_TRY(t_img.init(st));
   Probes probes(st);
@@ -928,6 +969,7 @@ static int32_t build_phase2(dcd_build* h) {
     passes += p2;
   }
   DCD_TRY(t_sort.stop());
+  tr.mark("sort-enqueue");
 
   // ---- 5. pack: deltas -> var-ushort units (IndexSequence.Builder.Add) -----------------------
   DCD_TRY(t_pack.start());
@@ -947,6 +989,7 @@ static int32_t build_phase2(dcd_build* h) {
     DCD_HIP(hipMemcpyAsync(&U, enc_part.p + enb, 8, hipMemcpyDeviceToHost, st));
     DCD_HIP(hipStreamSynchronize(st));
   }
+  tr.mark("enc-reduce");
   DCD_TRY(ix.units.alloc(dev, U ? U : 1));
   if (N) {
     probes.begin(DCD_K_ENC_WRITE);
@@ -975,6 +1018,7 @@ static int32_t build_phase2(dcd_build* h) {
     DCD_HIP(hipMemcpyAsync(&rec_total, scr64b.p + scan_nblocks(V), 8, hipMemcpyDeviceToHost, st));
   }
   DCD_HIP(hipStreamSynchronize(st));
+  tr.mark("pack");
   u64 max_coord = 0;
   {
     // coordinate of the last Add call: the later of (last explicit posting, last text token)
@@ -1001,18 +1045,12 @@ static int32_t build_phase2(dcd_build* h) {
   DCD_TRY(t_all.stop());
   DCD_HIP(hipStreamSynchronize(st));
   DCD_HIP(hipGetLastError());
+  tr.mark("image");
 
   // ---- host mirrors + stats ----------------------------------------------------------------------
   ix.n_terms = V; ix.n_units = U; ix.n_postings = N; ix.max_coord = max_coord;
   ix.page_end = std::move(M.d_page_end);
-  ix.h_term_chars.resize(total_chars);
-  ix.h_term_str_off.resize(V + 1);
-  ix.h_term_unit_start.resize(V + 1);
-  ix.h_term_item_start.resize(V + 1);
-  if (total_chars) DCD_HIP(hipMemcpy(ix.h_term_chars.data(), ix.term_chars.p, (size_t)total_chars * 2, hipMemcpyDeviceToHost));
-  DCD_HIP(hipMemcpy(ix.h_term_str_off.data(), ix.term_str_off.p, (V + 1) * 4, hipMemcpyDeviceToHost));
-  DCD_HIP(hipMemcpy(ix.h_term_unit_start.data(), ix.term_unit_start.p, (V + 1) * 8, hipMemcpyDeviceToHost));
-  DCD_HIP(hipMemcpy(ix.h_term_item_start.data(), ix.term_item_start.p, (V + 1) * 8, hipMemcpyDeviceToHost));
+  ix.host_ready = false;   // key / offset mirrors are fetched when an Index handle adopts the result
   ix.pages = h->pages;
 
   dcd_build_stats& s = h->stats;
@@ -1030,7 +1068,9 @@ static int32_t build_phase2(dcd_build* h) {
     if (hipEventElapsedTime(&t, sort_events[i + 2], sort_events[i + 3]) == hipSuccess) { s.ms_kernel[DCD_K_RS_SCATTER] += t; s.n_launch[DCD_K_RS_SCATTER]++; }
   }
   for (auto e : sort_events) (void)hipEventDestroy(e);
+  tr.mark("mirrors+stats");
   h->mid.reset();
+  tr.mark("free");
   h->finished = true;
   return DCD_OK;
 }

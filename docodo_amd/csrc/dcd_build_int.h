@@ -54,8 +54,12 @@ struct DeviceIndex {
   std::vector<u32> h_term_str_off;
   std::vector<u64> h_term_unit_start;
   std::vector<u64> h_term_item_start;
+  bool host_ready = true;        // false: the mirrors above still have to be fetched (index_fetch_host)
   PageTable pages;
 };
+// downloads the host mirrors of an index a build left on the device (done on demand: a build that is only saved
+// or exported never needs them)
+int32_t index_fetch_host(DeviceIndex& ix);
 
 void write_list_image(const PageTable& pt, std::vector<u8>& out);  // ".index.list", Build.cs:99-118
 void utf16_to_utf8(const u16* s, size_t n, std::string& out);

@@ -160,6 +160,7 @@ int32_t dcd_index_from_build(dcd_build* b, dcd_index** out) {
   if (!b || !out) DCD_FAIL(DCD_E_BADARG, "dcd_index_from_build: NULL argument");
   DeviceIndex* src = build_take_index(b);
   if (!src) DCD_FAIL(DCD_E_STATE, "build is not finished or its index was already adopted");
+  DCD_TRY(index_fetch_host(*src));
   dcd_index* h = new dcd_index();
   h->ix = std::move(*src);
   hipError_t e = hipStreamCreateWithFlags(&h->st, hipStreamNonBlocking);
