@@ -93,17 +93,43 @@ __global__ void k_export_meta(const uint2* __restrict__ perm, u64 n_terms, const
   for (u32 i = 0; i < m.key_len; i++) d[i] = s[i];
 }
 
-// segmented copy: dst_off[j] .. dst_off[j+1] <- src[src_start(j) ..]; 8 units per thread
+// segmented copy: dst_off[j] .. dst_off[j+1] <- src[src_start(j) ..].  A workgroup owns a tile of 2048 output units
+// (8 consecutive ones = 16 bytes per thread); the tile's first and last segment are found once per workgroup, every
+// thread then searches only that range; 8 units inside one segment move as one 16-byte store fed by (possibly
+// 2-byte-aligned) dword loads.
 constexpr int CP_UPT = 8;
-__global__ void k_export_units(const uint2* __restrict__ perm, u64 n_terms, const u64* __restrict__ dst_off, u64 total_units,
-                               const u64* __restrict__ unit_start, const u16* __restrict__ units, u16* __restrict__ out) {
-  u64 u0 = ((u64)blockIdx.x * blockDim.x + threadIdx.x) * CP_UPT;
+constexpr int CP_THREADS = 256;
+constexpr int CP_TILE = CP_UPT * CP_THREADS;
+typedef u32 __attribute__((aligned(2))) u32_a2;
+
+// last j in [0, n) with off[j] <= u  (off ascending, off[0] <= u)
+__device__ __forceinline__ u64 seg_of(const u64* __restrict__ off, u64 lo, u64 hi, u64 u) {
+  while (lo + 1 < hi) { u64 m = (lo + hi) >> 1; if (off[m] <= u) lo = m; else hi = m; }
+  return lo;
+}
+__device__ __forceinline__ void tile_seg_range(const u64* __restrict__ off, u64 n_seg, u64 tile_base, u64 total, u64* s_q) {
+  if (threadIdx.x == 0) s_q[0] = seg_of(off, 0, n_seg, tile_base);
+  if (threadIdx.x == 64) { u64 e = tile_base + CP_TILE; s_q[1] = seg_of(off, 0, n_seg, (e < total ? e : total) - 1); }
+  __syncthreads();
+}
+__device__ __forceinline__ void copy8(const u16* __restrict__ src, u16* __restrict__ dst) {
+  const u32_a2* sp = reinterpret_cast<const u32_a2*>(src);
+  uint4 v = make_uint4(sp[0], sp[1], sp[2], sp[3]);
+  *reinterpret_cast<uint4*>(dst) = v;
+}
+
+__global__ __launch_bounds__(CP_THREADS) void k_export_units(const uint2* __restrict__ perm, u64 n_terms, const u64* __restrict__ dst_off,
+                                                            u64 total_units, const u64* __restrict__ unit_start,
+                                                            const u16* __restrict__ units, u16* __restrict__ out) {
+  __shared__ u64 s_q[2];
+  const u64 tile_base = (u64)blockIdx.x * CP_TILE;
+  tile_seg_range(dst_off, n_terms, tile_base, total_units, s_q);
+  const u64 u0 = tile_base + (u64)threadIdx.x * CP_UPT;
   if (u0 >= total_units) return;
-  u64 a = 0, b = n_terms;  // last j with dst_off[j] <= u0
-  while (a + 1 < b) { u64 m = (a + b) >> 1; if (dst_off[m] <= u0) a = m; else b = m; }
-  u64 j = a;
+  u64 j = seg_of(dst_off, s_q[0], s_q[1] + 1, u0);
   u64 next = j + 1 < n_terms ? dst_off[j + 1] : total_units;
   u64 src = unit_start[perm[j].y] + (u0 - dst_off[j]);
+  if (u0 + CP_UPT <= next && ((reinterpret_cast<uintptr_t>(out + u0) & 15) == 0)) { copy8(units + src, out + u0); return; }
   for (int k = 0; k < CP_UPT; k++) {
     u64 u = u0 + k;
     if (u >= total_units) break;
@@ -155,13 +181,24 @@ __global__ void k_merge_heads(SegPlan p, u64 n_seg, const u64* __restrict__ dst_
   if (p.head(q)) { term_unit_start[p.sorted[q].x] = dst_off[q]; term_item_start[p.sorted[q].x] = val_off[q]; }
 }
 
-__global__ void k_merge_copy(SegPlan p, u64 n_seg, const u64* __restrict__ dst_off, u64 total_units, const u64* __restrict__ src_off,
-                             const u16* __restrict__ units, u16* __restrict__ out) {
-  u64 u0 = ((u64)blockIdx.x * blockDim.x + threadIdx.x) * CP_UPT;
+__global__ __launch_bounds__(CP_THREADS) void k_merge_copy(SegPlan p, u64 n_seg, const u64* __restrict__ dst_off, u64 total_units,
+                                                          const u64* __restrict__ src_off, const u16* __restrict__ units, u16* __restrict__ out) {
+  __shared__ u64 s_q[2];
+  const u64 tile_base = (u64)blockIdx.x * CP_TILE;
+  tile_seg_range(dst_off, n_seg, tile_base, total_units, s_q);
+  const u64 u0 = tile_base + (u64)threadIdx.x * CP_UPT;
   if (u0 >= total_units) return;
-  u64 a = 0, b = n_seg;
-  while (a + 1 < b) { u64 m = (a + b) >> 1; if (dst_off[m] <= u0) a = m; else b = m; }
-  u64 q = a;
+  u64 q = seg_of(dst_off, s_q[0], s_q[1] + 1, u0);
+  {
+    // 8 units of one segment, all behind its (re-coded) head: plain copy
+    const u64 next = q + 1 < n_seg ? dst_off[q + 1] : total_units;
+    if (u0 + CP_UPT <= next) {
+      const dcd_term_meta& m = p.meta[p.sorted[q].y];
+      const u32 newlen = seq_nunits(p.new_delta(q)), oldlen = seq_nunits(m.first);
+      const u64 r = u0 - dst_off[q];
+      if (r >= newlen) { copy8(units + src_off[p.sorted[q].y] + oldlen + (r - newlen), out + u0); return; }
+    }
+  }
   for (int k = 0; k < CP_UPT; k++) {
     u64 u = u0 + k;
     if (u >= total_units) break;
@@ -257,7 +294,7 @@ int32_t dcd_build_export_fill(dcd_build* h, void* meta_dev, uint16_t* keys_dev, 
     hipLaunchKernelGGL(k_export_meta, dim3((u32)div_up(V, 256)), dim3(256), 0, st, ep->perm.p, V, ix->term_unit_start.p, ix->term_item_start.p,
                        ix->term_str_off.p, ix->term_chars.p, ix->term_first.p, ix->term_last.p, ep->key_dst.p, (dcd_term_meta*)meta_dev, keys_dev);
     if (ep->total_units)
-      hipLaunchKernelGGL(k_export_units, dim3((u32)div_up(div_up(ep->total_units, CP_UPT), 256)), dim3(256), 0, st, ep->perm.p, V, ep->unit_dst.p,
+      hipLaunchKernelGGL(k_export_units, dim3((u32)div_up(ep->total_units, CP_TILE)), dim3(CP_THREADS), 0, st, ep->perm.p, V, ep->unit_dst.p,
                          ep->total_units, ix->term_unit_start.p, ix->units.p, units_dev);
   }
   DCD_HIP(hipStreamSynchronize(st));
@@ -343,7 +380,7 @@ int32_t dcd_merge_shards(int32_t device, uint32_t n_sources, const uint64_t* ter
   DCD_HIP(hipMemcpyAsync(ix.term_item_start.p + V, &Nout, 8, hipMemcpyHostToDevice, st));
   DCD_TRY(ix.units.alloc(device, Uout ? Uout : 1));
   if (Uout)
-    hipLaunchKernelGGL(k_merge_copy, dim3((u32)div_up(div_up(Uout, CP_UPT), 256)), dim3(256), 0, st, sp, M, dst_off.p, Uout, src_off.p, units_dev,
+    hipLaunchKernelGGL(k_merge_copy, dim3((u32)div_up(Uout, CP_TILE)), dim3(CP_THREADS), 0, st, sp, M, dst_off.p, Uout, src_off.p, units_dev,
                        ix.units.p);
   // keys in rank order
   DCD_TRY(ix.term_str_off.alloc(device, V + 1));

@@ -108,9 +108,38 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_apply_f(F f, u64 n, const
 inline u64 scan_nblocks(u64 n) { return div_up(n ? n : 1, SCAN_TILE); }
 inline u64 scan_scratch_elems(u64 n) { return scan_nblocks(n) + 1; }
 
+// small inputs: ONE workgroup does the whole scan (one launch instead of three; in == out allowed).  The many
+// short radix passes of the vocabulary sort are launch-latency bound.
+constexpr u64 SCAN_SMALL = 64 * 1024;
+template <typename F, typename T>
+__global__ __launch_bounds__(1024) void k_scan_small_f(F f, u64 n, T* __restrict__ out, T* __restrict__ total_out) {
+  __shared__ T lds[17];
+  T carry = 0;
+  constexpr u64 PER = 16;
+  for (u64 b0 = 0; b0 < n; b0 += 1024 * PER) {
+    u64 i0 = b0 + (u64)threadIdx.x * PER;
+    T v[PER];
+    T s = 0;
+#pragma unroll
+    for (u64 j = 0; j < PER; j++) { v[j] = i0 + j < n ? (T)f(i0 + j) : (T)0; s += v[j]; }
+    T tot;
+    T ex = carry + block_scan_excl<T, 16>(s, lds, &tot);
+#pragma unroll
+    for (u64 j = 0; j < PER; j++) { if (i0 + j < n) out[i0 + j] = ex; ex += v[j]; }
+    carry += tot;
+  }
+  if (threadIdx.x == 0) *total_out = carry;
+}
+template <typename TIn>
+struct ScanLoadF { const TIn* in; __device__ __forceinline__ TIn operator()(u64 i) const { return in[i]; } };
+
 template <typename TIn, typename T>
 inline void scan_exclusive(const TIn* in, T* out, u64 n, T* scratch, hipStream_t st) {
   u64 nb = scan_nblocks(n);
+  if (n <= SCAN_SMALL) {
+    hipLaunchKernelGGL((k_scan_small_f<ScanLoadF<TIn>, T>), dim3(1), dim3(1024), 0, st, ScanLoadF<TIn>{in}, n, out, scratch + nb);
+    return;
+  }
   hipLaunchKernelGGL((k_scan_reduce<TIn, T>), dim3((u32)nb), dim3(SCAN_THREADS), 0, st, in, n, scratch);
   hipLaunchKernelGGL((k_scan_partials<T>), dim3(1), dim3(1024), 0, st, scratch, nb);
   hipLaunchKernelGGL((k_scan_apply<TIn, T>), dim3((u32)nb), dim3(SCAN_THREADS), 0, st, in, n, scratch, out);
@@ -119,6 +148,10 @@ inline void scan_exclusive(const TIn* in, T* out, u64 n, T* scratch, hipStream_t
 template <typename F, typename T>
 inline void scan_exclusive_f(const F& f, T* out, u64 n, T* scratch, hipStream_t st) {
   u64 nb = scan_nblocks(n);
+  if (n <= SCAN_SMALL) {
+    hipLaunchKernelGGL((k_scan_small_f<F, T>), dim3(1), dim3(1024), 0, st, f, n, out, scratch + nb);
+    return;
+  }
   hipLaunchKernelGGL((k_scan_reduce_f<F, T>), dim3((u32)nb), dim3(SCAN_THREADS), 0, st, f, n, scratch);
   hipLaunchKernelGGL((k_scan_partials<T>), dim3(1), dim3(1024), 0, st, scratch, nb);
   hipLaunchKernelGGL((k_scan_apply_f<F, T>), dim3((u32)nb), dim3(SCAN_THREADS), 0, st, f, n, scratch, out);

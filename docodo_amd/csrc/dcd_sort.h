@@ -234,10 +234,10 @@ struct RsSchedule {
   int npass;
   int width[8];
 };
-inline RsSchedule rs_schedule(int total_bits) {
+inline RsSchedule rs_schedule(int total_bits, int max_width = 9) {
   RsSchedule s;
   if (total_bits < 1) total_bits = 1;
-  s.npass = (total_bits + 8) / 9;
+  s.npass = (total_bits + max_width - 1) / max_width;
   int rem = total_bits;
   for (int i = 0; i < s.npass; i++) {
     int wdt = (rem + (s.npass - i) - 1) / (s.npass - i);
@@ -255,8 +255,8 @@ inline RsSchedule rs_schedule(int total_bits) {
 // remapped ones (remap applied once).  hist: >= RS_MAX_BLOCKS << 10 u32; scan_scratch: >=
 // scan_scratch_elems(RS_MAX_BLOCKS << 10) u32.
 inline uint2* rs_sort(uint2* buf_a, uint2* buf_b, const u32* remap, u64 n, int total_bits, u32* hist, u32* scan_scratch,
-                      hipStream_t st, int* passes_out = nullptr, const RsProbe& pr = RsProbe()) {
-  RsSchedule sc = rs_schedule(total_bits);
+                      hipStream_t st, int* passes_out = nullptr, const RsProbe& pr = RsProbe(), int max_width = 9) {
+  RsSchedule sc = rs_schedule(total_bits, max_width);
   int shift = 0;
   uint2 *in = buf_a, *out = buf_b;
   for (int i = 0; i < sc.npass; i++) {
