@@ -13,4 +13,10 @@ struct dcd_index {
   // decoded postings (built lazily on the first query): segment-relative values per term
   dcd::DevBuf<u64> values;   // [n_postings], term t at [term_item_start[t], term_item_start[t+1])
   bool values_ready = false;
+  // cell directories of the longer posting lists (auxiliary, built with `values`): for term t with shift s,
+  // dir[dir_off[t] + c] = index (inside the term) of its first posting >= c << s; one extra entry = posting count.
+  // A galloping '*' finds the neighbourhood of a coordinate with two loads instead of a ~20-step binary search.
+  dcd::DevBuf<u32> dir;
+  std::vector<u64> h_dir_off;    // [n_terms + 1]
+  std::vector<u8> h_dir_shift;   // [n_terms]; 255 = no directory
 };

@@ -15,7 +15,7 @@
 //     -> compaction.  A chain that is still open at a tile border is written optimistically and
 //     rolled back if it closes without the other operand (exact restatement of the group logic of
 //     IndexSequence.cs:218-284); skewed sparse pairs gallop from the
-//     short operand (GAL_RATIO = 4 measured best on MI355X);
+//     short operand (GAL_RATIO = 2 measured best on MI355X);
 //   * k_result<false/true> walk the final sequence of each query (one workgroup per query):
 //     coordinate -> page by binary search over the page END table (IndexPageList.GetPage,
 //     Build.cs:74-97), page-relative positions, the 30000-page / 500-document caps, ranks.
@@ -39,6 +39,9 @@ struct Seg {       // a sequence of absolute coordinates somewhere on the device
   u64 cnt_imm;     // count when cnt_ref == NONE32
   u32 kind;
   u32 cnt_ref;     // index into the device `counts` array (results of earlier operators)
+  u64 dir_off;     // cell directory of an index term (see dcd_index), valid when dir_shift != NONE32
+  u32 dir_shift;
+  u32 pad;
 };
 struct PairOp {
   Seg a, b;
@@ -69,6 +72,25 @@ __global__ void k_term_relative(const u64* __restrict__ excl, const u64* __restr
   values[i] = excl[i] + deltas[i] - excl[item_start[a]];
 }
 
+// cell directory: posting i of a term writes the directory entries of the cells between its predecessor's cell
+// (exclusive) and its own (inclusive); the last posting also fills the cells behind it with the posting count
+__global__ void k_build_dir(const u64* __restrict__ values, u64 n, const u64* __restrict__ item_start, u64 n_terms,
+                            const u64* __restrict__ dir_off, const u8* __restrict__ dir_shift, u32* __restrict__ dir) {
+  u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  u64 a = 0, b = n_terms;  // last t with item_start[t] <= i
+  while (a + 1 < b) { u64 m = (a + b) >> 1; if (item_start[m] <= i) a = m; else b = m; }
+  const u32 sh = dir_shift[a];
+  if (sh == 255u) return;
+  const u64 li = i - item_start[a], cnt = item_start[a + 1] - item_start[a];
+  const u64 n_cells = dir_off[a + 1] - dir_off[a] - 1;
+  u32* d = dir + dir_off[a];
+  const u64 c = min(values[i] >> sh, n_cells - 1);          // (a coordinate beyond MaxCoord lands in the last cell)
+  u64 c0 = li ? min(values[i - 1] >> sh, n_cells - 1) + 1 : 0;
+  for (u64 x = c0; x <= c; x++) d[x] = (u32)li;
+  if (li + 1 == cnt) for (u64 x = c + 1; x <= n_cells; x++) d[x] = (u32)cnt;
+}
+
 // ------------------------------------------------------------------------------------------------
 // operator * / + on operand pairs
 // ------------------------------------------------------------------------------------------------
@@ -80,7 +102,7 @@ __global__ void k_term_relative(const u64* __restrict__ excl, const u64* __restr
 // with consecutive gaps <= absR); the first short-list element of a chain ("leader") emits the chain if it
 // satisfies the both-operands / ordered-prefix rule.  Exactly the same output as the streaming merge.
 #ifndef DCD_GAL_RATIO
-#define DCD_GAL_RATIO 4
+#define DCD_GAL_RATIO 2
 #endif
 constexpr u32 GAL_RATIO = DCD_GAL_RATIO;   // gallop when RATIO * |short| <= |long|
 
@@ -178,7 +200,8 @@ __device__ __forceinline__ u64 wave_split(const u64* __restrict__ A, u64 na, con
 
 // ---- galloping, one slice of the short operand per work item ------------------------------------------------
 __device__ void part_gallop(const u64* __restrict__ Sv, u64 ns, const u64* __restrict__ Lv, u64 nl, bool s_is_a, u32 absR, bool ordered,
-                            u64 i_begin, u64 i_end, u64* __restrict__ tmp_op, u32* rec_lds, u64& count_out, u64& slot_out) {
+                            u64 i_begin, u64 i_end, u64* __restrict__ tmp_op, u32* rec_lds, u64& count_out, u64& slot_out,
+                            const u32* __restrict__ ldir, u32 ldir_shift, u64 ldir_last) {
   const u32 lane = threadIdx.x;
   u64* r_b = reinterpret_cast<u64*>(rec_lds);                 // [PW_TILE] first L index of the emitted part
   u32* r_d = rec_lds + 2 * PW_TILE;                           // [PW_TILE] number of L elements emitted from r_b
@@ -189,10 +212,13 @@ __device__ void part_gallop(const u64* __restrict__ Sv, u64 ns, const u64* __res
   bool have_slot = false;
   for (u64 i0 = i_begin; i0 < i_end; i0 += PW_TILE) {
     const u32 cn = (u32)min((u64)PW_TILE, i_end - i0);
-    for (u32 k = lane; k < cn; k += PW_T) {
-      const u64 i = i0 + k;
+    // Every lane looks after PW_ITEMS short-list elements.  Their loads are issued together, phase by phase (the
+    // chain of dependent accesses -- directory cell, long-list position, neighbours -- is latency bound, so the
+    // elements of a lane overlap each other): position in the long list, then the four union neighbours.  An
+    // element without a neighbour within absR on either side is a chain of its own and emits nothing; only the
+    // others walk their chain.
+    auto general = [&](u64 i, u32 k, u64 il) {
       const u64 s = Sv[i];
-      const u64 il = lower_bound_u64(Lv, nl, s);               // first L >= s
       u64 a = i, b = il, cur = s;                              // left walk over the union
       for (;;) {
         bool hs = a > 0, hl = b > 0;
@@ -240,6 +266,58 @@ __device__ void part_gallop(const u64* __restrict__ Sv, u64 ns, const u64* __res
         }
       }
       r_b[k] = eb; r_d[k] = ed; r_s0[k] = (u32)(es0 - i0); r_s1[k] = (u32)(es1 - i0); r_n[k] = n;
+    };
+    {
+      u64 sv[PW_ITEMS], ilv[PW_ITEMS], hiv[PW_ITEMS];
+      bool act[PW_ITEMS];
+#pragma unroll
+      for (int q = 0; q < (int)PW_ITEMS; q++) {
+        const u32 k = lane + (u32)q * PW_T;
+        act[q] = k < cn;
+        sv[q] = act[q] ? Sv[i0 + k] : 0;
+      }
+      if (ldir) {                                              // cell directory: the search starts inside the cell of s
+#pragma unroll
+        for (int q = 0; q < (int)PW_ITEMS; q++) {
+          const u64 c = min(sv[q] >> ldir_shift, ldir_last);
+          ilv[q] = act[q] ? ldir[c] : 0;
+          hiv[q] = act[q] ? ldir[c + 1] : 0;
+        }
+        bool more = true;
+        while (more) {                                         // the PW_ITEMS binary searches advance in lock step
+          more = false;
+#pragma unroll
+          for (int q = 0; q < (int)PW_ITEMS; q++) {
+            if (ilv[q] < hiv[q]) {
+              const u64 m = (ilv[q] + hiv[q]) >> 1;
+              if (Lv[m] < sv[q]) ilv[q] = m + 1; else hiv[q] = m;
+              more |= ilv[q] < hiv[q];
+            }
+          }
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < (int)PW_ITEMS; q++) ilv[q] = act[q] ? lower_bound_u64(Lv, nl, sv[q]) : 0;
+      }
+      u64 lft[PW_ITEMS], rgt[PW_ITEMS];                        // nearest union neighbours (0 / ~0: none)
+#pragma unroll
+      for (int q = 0; q < (int)PW_ITEMS; q++) {
+        const u64 i = i0 + lane + (u64)q * PW_T;
+        const u64 sp = (act[q] && i > 0) ? Sv[i - 1] : 0, lp = (act[q] && ilv[q] > 0) ? Lv[ilv[q] - 1] : 0;
+        const u64 sn = (act[q] && i + 1 < ns) ? Sv[i + 1] : ~0ull, ln = (act[q] && ilv[q] < nl) ? Lv[ilv[q]] : ~0ull;
+        const bool has_l = act[q] && (i > 0 || ilv[q] > 0);
+        lft[q] = has_l ? max(sp, lp) : ~0ull;                  // ~0: no left neighbour
+        rgt[q] = min(sn, ln);
+      }
+#pragma unroll
+      for (int q = 0; q < (int)PW_ITEMS; q++) {
+        if (!act[q]) continue;
+        const u32 k = lane + (u32)q * PW_T;
+        const bool left_far = lft[q] == ~0ull || sv[q] - lft[q] > (u64)absR;
+        const bool right_far = rgt[q] == ~0ull || rgt[q] - sv[q] > (u64)absR;
+        if (left_far && right_far) { r_b[k] = 0; r_d[k] = 0; r_s0[k] = k; r_s1[k] = k; r_n[k] = 0; }
+        else general(i0 + k, k, ilv[q]);
+      }
     }
     __syncthreads();
     u32 mine = 0;
@@ -280,7 +358,8 @@ __device__ void part_gallop(const u64* __restrict__ Sv, u64 ns, const u64* __res
 __global__ __launch_bounds__(PW_T, DCD_PW_WAVES) void k_pair_parts(const PairOp* __restrict__ ops, u32 n_ops, const u64* __restrict__ part_base,
                                                     const u64* __restrict__ idx_values, const u64* __restrict__ pool,
                                                     const u64* __restrict__ counts, u64* __restrict__ tmp, u64* __restrict__ part_count,
-                                                    u64* __restrict__ part_src, u64 PART) {
+                                                    u64* __restrict__ part_src, u64 PART, const u32* __restrict__ dirs,
+                                                    u64 dir_max_coord) {
   constexpr u32 RAW_WORDS = 6u * PW_TILE + 16u;
   __shared__ __attribute__((aligned(16))) u32 s_raw[RAW_WORDS];
   u64* sA = reinterpret_cast<u64*>(s_raw);
@@ -307,7 +386,7 @@ __global__ __launch_bounds__(PW_T, DCD_PW_WAVES) void k_pair_parts(const PairOp*
   const u64 n_union = na + nb;
   const u64 n_act = n_union ? (n_union + PART - 1) / PART : 0;   // partitions in use (the grid is sized for the capacity)
   u64 count = 0, slot = 0;
-  if (p < n_act) {
+  if (p < n_act && (is_or || (na != 0 && nb != 0))) {     // '*' with an empty operand is empty: no chain holds both
     bool gallop = false;
     if (!is_or && absR != 0 && na && nb) {
       const bool a_short = na <= nb;
@@ -318,7 +397,10 @@ __global__ __launch_bounds__(PW_T, DCD_PW_WAVES) void k_pair_parts(const PairOp*
         gallop = true;
         const u64 per = (ns + n_act - 1) / n_act;
         const u64 i_begin = min(ns, p * per), i_end = min(ns, i_begin + per);
-        if (i_begin < i_end) part_gallop(Sv, ns, Lv, nl, a_short, absR, ordered, i_begin, i_end, tmp_op, s_raw, count, slot);
+        const Seg& ls = a_short ? op.b : op.a;
+        const u32* ldir = (ls.kind == 0 && ls.dir_shift != NONE32) ? dirs + ls.dir_off : nullptr;
+        if (i_begin < i_end) part_gallop(Sv, ns, Lv, nl, a_short, absR, ordered, i_begin, i_end, tmp_op, s_raw, count, slot, ldir, ls.dir_shift,
+                                         ldir ? dir_max_coord >> ls.dir_shift : 0);
       }
     }
     if (!gallop) {
@@ -914,9 +996,46 @@ static int32_t ensure_values(dcd_index* h) {
     DCD_TRY(excl.alloc(dev, N));
     DCD_TRY(sscr.alloc(dev, scan_scratch_elems(N)));
     decode_count_launch(ix.units.p, U, part.p, st);
+    {   // the posting counts of the term directory must match the unit stream (a damaged image would overrun below)
+      u64 nv = 0;
+      DCD_HIP(hipMemcpyAsync(&nv, part.p + nb, 8, hipMemcpyDeviceToHost, st));
+      DCD_HIP(hipStreamSynchronize(st));
+      if (nv != N) DCD_FAIL(DCD_E_BADARG, "index is inconsistent: %llu postings in the unit stream, %llu in the term directory",
+                            (unsigned long long)nv, (unsigned long long)N);
+    }
     hipLaunchKernelGGL(k_dec_deltas, dim3((u32)nb), dim3(CODEC_THREADS), 0, st, ix.units.p, U, part.p, deltas.p);
     scan_exclusive<u64, u64>(deltas.p, excl.p, N, sscr.p, st);
     hipLaunchKernelGGL(k_term_relative, dim3((u32)div_up(N, 256)), dim3(256), 0, st, excl.p, deltas.p, N, ix.term_item_start.p, V, h->values.p);
+    // cell directories for the longer lists: about one cell per posting (cell width 2^shift)
+    constexpr u64 DIR_MIN = 1024;
+    const u32 coord_bits = log2_ceil(ix.max_coord + 2);
+    h->h_dir_off.assign(V + 1, 0);
+    h->h_dir_shift.assign(V, 255);
+    u64 tot = 0;
+    for (u64 t = 0; t < V; t++) {
+      h->h_dir_off[t] = tot;
+      const u64 cnt = ix.h_term_item_start[t + 1] - ix.h_term_item_start[t];
+      if (cnt >= DIR_MIN) {
+        u32 lg = 0;
+        while ((2ull << lg) <= cnt) lg++;                     // floor(log2 cnt)
+        const u32 sh = coord_bits > lg ? coord_bits - lg : 0u;
+        h->h_dir_shift[t] = (u8)sh;
+        tot += (ix.max_coord >> sh) + 2;                       // cells 0 .. max_coord >> sh, plus the end entry
+      }
+    }
+    h->h_dir_off[V] = tot;
+    if (tot >= (1ull << 40)) DCD_FAIL(DCD_E_OVERFLOW, "cell directories too large");
+    DCD_TRY(h->dir.alloc(dev, tot ? tot : 1));
+    if (tot) {
+      DevBuf<u64> d_off;
+      DevBuf<u8> d_sh;
+      DCD_TRY(d_off.alloc(dev, V + 1));
+      DCD_TRY(d_sh.alloc(dev, V));
+      DCD_HIP(hipMemcpyAsync(d_off.p, h->h_dir_off.data(), (V + 1) * 8, hipMemcpyHostToDevice, st));
+      DCD_HIP(hipMemcpyAsync(d_sh.p, h->h_dir_shift.data(), V, hipMemcpyHostToDevice, st));
+      hipLaunchKernelGGL(k_build_dir, dim3((u32)div_up(N, 256)), dim3(256), 0, st, h->values.p, N, ix.term_item_start.p, V, d_off.p, d_sh.p,
+                         h->dir.p);
+    }
     DCD_HIP(hipStreamSynchronize(st));
     DCD_HIP(hipGetLastError());
   }
@@ -1002,6 +1121,9 @@ static int32_t run_batch(dcd_index* h, const int32_t* prog, const u64* prog_off,
         } else {
           if (t < 0 || (u64)t >= ix.n_terms) DCD_FAIL(DCD_E_BADARG, "query %zu: term %lld out of range", q, (long long)t);
           v.s.kind = 0; v.s.off = ix.h_term_item_start[t]; v.s.cnt_ref = NONE32;
+          v.s.dir_off = h->h_dir_off.empty() ? 0 : h->h_dir_off[t];
+          v.s.dir_shift = (h->h_dir_shift.empty() || h->h_dir_shift[t] == 255) ? NONE32 : (u32)h->h_dir_shift[t];
+          v.s.pad = 0;
           v.s.cnt_imm = ix.h_term_item_start[t + 1] - ix.h_term_item_start[t];
           v.cap = v.s.cnt_imm; v.round = 0;
         }
@@ -1021,6 +1143,7 @@ static int32_t run_batch(dcd_index* h, const int32_t* prog, const u64* prog_off,
         op_cap.push_back(r.cap);
         pool_elems += r.cap;
         r.s.kind = 1; r.s.off = p.out_off; r.s.cnt_ref = p.out_cnt_ref; r.s.cnt_imm = 0;
+        r.s.dir_off = 0; r.s.dir_shift = NONE32; r.s.pad = 0;
         int absR = std::max(std::abs(a.R), std::abs(b.R));
         r.R = (a.R < 0 && b.R < 0) ? -absR : absR;                       // IndexSequence.cs:221-222, 288-289
         r.round = std::max(a.round, b.round) + 1;
@@ -1107,7 +1230,7 @@ static int32_t run_batch(dcd_index* h, const int32_t* prog, const u64* prog_off,
     u32 n = (u32)rounds[r].size();
     const u64 W = part_base[r][n];
     hipLaunchKernelGGL(k_pair_parts, dim3((u32)W), dim3(PW_T), 0, st, d_rounds[r].p, n, d_part_base[r].p, idx_values, pool.p, counts.p,
-                       tmp.p, d_part_count.p, d_part_src.p, PART);
+                       tmp.p, d_part_count.p, d_part_src.p, PART, ext_values ? nullptr : h->dir.p, ix.max_coord);
     DCD_HIP(hipMemsetAsync(d_part_count.p + W, 0, 8, st));
     scan_exclusive<u64, u64>(d_part_count.p, d_part_excl.p, W + 1, d_part_scr.p, st);
     const u32 gg = (u32)std::min<u64>(div_up(div_up(W, 64), 4), 4096);
@@ -1373,6 +1496,7 @@ static int32_t seq_binop(int opc, const u16* a, size_t na, int32_t Ra, const u16
     if (nv[k]) decode_values_launch(du[k].p, nu[k], part[k].p, nv[k], deltas.p, vals.p + off, sscr.p, st);
     DCD_HIP(hipStreamSynchronize(st));
     leaves[k].s.kind = 0; leaves[k].s.off = off; leaves[k].s.cnt_ref = NONE32; leaves[k].s.cnt_imm = nv[k];
+    leaves[k].s.dir_off = 0; leaves[k].s.dir_shift = NONE32; leaves[k].s.pad = 0;
     leaves[k].cap = nv[k]; leaves[k].round = 0; leaves[k].R = 0;
     off += nv[k];
   }

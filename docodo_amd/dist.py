@@ -52,6 +52,9 @@ def merge_received(term_count, key_count, unit_count, meta, keys, units, max_coo
     tc = np.ascontiguousarray(term_count, np.uint64)
     kc = np.ascontiguousarray(key_count, np.uint64)
     uc = np.ascontiguousarray(unit_count, np.uint64)
+    if meta.is_cuda:
+        # the buffers may have been produced on torch's stream (torch.cat, collectives); the library works on its own
+        torch.cuda.current_stream(meta.device).synchronize()
     h = C.c_void_p()
     check(lib().dcd_merge_shards(device_index, tc.size, tc.ctypes.data, kc.ctypes.data, uc.ctypes.data,
                                  meta.data_ptr() if meta.numel() else None, keys.data_ptr() if keys.numel() else None,
