@@ -153,6 +153,7 @@ constexpr u32 PW_T = 64;
 #define DCD_PW_ITEMS 4
 #endif
 constexpr u32 PW_ITEMS = DCD_PW_ITEMS;
+static_assert(PW_ITEMS == 4, "the in-lane stages of the bitonic tile merge are written for 4 elements per lane");
 constexpr u32 PW_TILE = PW_T * PW_ITEMS;
 constexpr u64 PART_DEFAULT = 8192;   // union elements per work item (measured on MI355X: 2048 / 4096 / 8192 / 16384 -> 51.5 / 43.6 / 41.7 / 41.9 ms for 20 k AND3 queries on the 10 M-doc index)
 
@@ -174,6 +175,14 @@ __device__ __forceinline__ u32 rfl(u32 v) { return (u32)__builtin_amdgcn_readfir
 __device__ __forceinline__ u64 rfl64(u64 v) { return ((u64)rfl((u32)(v >> 32)) << 32) | rfl((u32)v); }
 __device__ __forceinline__ u32 rdl(u32 v, u32 uniform_lane) { return (u32)__builtin_amdgcn_readlane((int)v, (int)uniform_lane); }
 __device__ __forceinline__ u64 rdl64(u64 v, u32 uniform_lane) { return ((u64)rdl((u32)(v >> 32), uniform_lane) << 32) | rdl((u32)v, uniform_lane); }
+__device__ __forceinline__ u64 shfl_xor64(u64 v, int mask) {
+  u32 lo = __shfl_xor((u32)v, mask, DCD_WAVE), hi = __shfl_xor((u32)(v >> 32), mask, DCD_WAVE);
+  return ((u64)hi << 32) | lo;
+}
+__device__ __forceinline__ u64 shfl_up64(u64 v, u32 d) {
+  u32 lo = __shfl_up((u32)v, d, DCD_WAVE), hi = __shfl_up((u32)(v >> 32), d, DCD_WAVE);
+  return ((u64)hi << 32) | lo;
+}
 __device__ __forceinline__ u64 shfl64(u64 v, u32 src_lane) {
   u32 lo = __shfl((u32)v, (int)src_lane, DCD_WAVE), hi = __shfl((u32)(v >> 32), (int)src_lane, DCD_WAVE);
   return ((u64)hi << 32) | lo;
@@ -268,46 +277,62 @@ __device__ void part_gallop(const u64* __restrict__ Sv, u64 ns, const u64* __res
       r_b[k] = eb; r_d[k] = ed; r_s0[k] = (u32)(es0 - i0); r_s1[k] = (u32)(es1 - i0); r_n[k] = n;
     };
     {
+      // (all loads below are unconditional on clamped, always-valid indices: a load under a lane predicate would put
+      // a branch and a wait between the loads of the PW_ITEMS elements)
       u64 sv[PW_ITEMS], ilv[PW_ITEMS], hiv[PW_ITEMS];
       bool act[PW_ITEMS];
+      const u64 s_last = ns - 1, l_last = nl - 1;
 #pragma unroll
       for (int q = 0; q < (int)PW_ITEMS; q++) {
         const u32 k = lane + (u32)q * PW_T;
         act[q] = k < cn;
-        sv[q] = act[q] ? Sv[i0 + k] : 0;
+        sv[q] = Sv[min(i0 + k, s_last)];
       }
       if (ldir) {                                              // cell directory: the search starts inside the cell of s
 #pragma unroll
         for (int q = 0; q < (int)PW_ITEMS; q++) {
           const u64 c = min(sv[q] >> ldir_shift, ldir_last);
-          ilv[q] = act[q] ? ldir[c] : 0;
-          hiv[q] = act[q] ? ldir[c + 1] : 0;
+          const u32 e0 = ldir[c], e1 = ldir[c + 1];
+          ilv[q] = e0;
+          hiv[q] = act[q] ? e1 : e0;
         }
         bool more = true;
         while (more) {                                         // the PW_ITEMS binary searches advance in lock step
           more = false;
+          u64 mv[PW_ITEMS], lv[PW_ITEMS];
+#pragma unroll
+          for (int q = 0; q < (int)PW_ITEMS; q++) { mv[q] = (ilv[q] + hiv[q]) >> 1; lv[q] = Lv[min(mv[q], l_last)]; }
 #pragma unroll
           for (int q = 0; q < (int)PW_ITEMS; q++) {
             if (ilv[q] < hiv[q]) {
-              const u64 m = (ilv[q] + hiv[q]) >> 1;
-              if (Lv[m] < sv[q]) ilv[q] = m + 1; else hiv[q] = m;
+              if (lv[q] < sv[q]) ilv[q] = mv[q] + 1; else hiv[q] = mv[q];
               more |= ilv[q] < hiv[q];
             }
           }
+          more = ballot64(more) != 0;
         }
       } else {
 #pragma unroll
         for (int q = 0; q < (int)PW_ITEMS; q++) ilv[q] = act[q] ? lower_bound_u64(Lv, nl, sv[q]) : 0;
       }
-      u64 lft[PW_ITEMS], rgt[PW_ITEMS];                        // nearest union neighbours (0 / ~0: none)
+      u64 lft[PW_ITEMS], rgt[PW_ITEMS];                        // nearest union neighbours (~0: none)
+      {
+        u64 sp[PW_ITEMS], lp[PW_ITEMS], sn[PW_ITEMS], ln[PW_ITEMS];
 #pragma unroll
-      for (int q = 0; q < (int)PW_ITEMS; q++) {
-        const u64 i = i0 + lane + (u64)q * PW_T;
-        const u64 sp = (act[q] && i > 0) ? Sv[i - 1] : 0, lp = (act[q] && ilv[q] > 0) ? Lv[ilv[q] - 1] : 0;
-        const u64 sn = (act[q] && i + 1 < ns) ? Sv[i + 1] : ~0ull, ln = (act[q] && ilv[q] < nl) ? Lv[ilv[q]] : ~0ull;
-        const bool has_l = act[q] && (i > 0 || ilv[q] > 0);
-        lft[q] = has_l ? max(sp, lp) : ~0ull;                  // ~0: no left neighbour
-        rgt[q] = min(sn, ln);
+        for (int q = 0; q < (int)PW_ITEMS; q++) {
+          const u64 i = min(i0 + lane + (u64)q * PW_T, s_last);
+          sp[q] = Sv[i > 0 ? i - 1 : 0];
+          sn[q] = Sv[min(i + 1, s_last)];
+          lp[q] = Lv[ilv[q] > 0 ? min(ilv[q] - 1, l_last) : 0];
+          ln[q] = Lv[min(ilv[q], l_last)];
+        }
+#pragma unroll
+        for (int q = 0; q < (int)PW_ITEMS; q++) {
+          const u64 i = i0 + lane + (u64)q * PW_T;
+          const bool hsp = i > 0, hlp = ilv[q] > 0, hsn = i + 1 < ns, hln = ilv[q] < nl;
+          lft[q] = (hsp || hlp) ? max(hsp ? sp[q] : 0ull, hlp ? lp[q] : 0ull) : ~0ull;
+          rgt[q] = min(hsn ? sn[q] : ~0ull, hln ? ln[q] : ~0ull);
+        }
       }
 #pragma unroll
       for (int q = 0; q < (int)PW_ITEMS; q++) {
@@ -355,6 +380,15 @@ __device__ void part_gallop(const u64* __restrict__ Sv, u64 ns, const u64* __res
 #ifndef DCD_PW_WAVES
 #define DCD_PW_WAVES 5
 #endif
+#ifdef DCD_PROF
+// debug build only: wave-residency cycles per phase of k_pair_parts (s_memtime deltas, summed over all waves)
+__device__ unsigned long long g_prof[16];
+#define PROF_T() unsigned long long _pt = __builtin_readcyclecounter()
+#define PROF(i) do { unsigned long long _n = __builtin_readcyclecounter(); if (threadIdx.x == 0) atomicAdd(&g_prof[i], _n - _pt); _pt = _n; } while (0)
+#else
+#define PROF_T()
+#define PROF(i)
+#endif
 __global__ __launch_bounds__(PW_T, DCD_PW_WAVES) void k_pair_parts(const PairOp* __restrict__ ops, u32 n_ops, const u64* __restrict__ part_base,
                                                     const u64* __restrict__ idx_values, const u64* __restrict__ pool,
                                                     const u64* __restrict__ counts, u64* __restrict__ tmp, u64* __restrict__ part_count,
@@ -364,8 +398,7 @@ __global__ __launch_bounds__(PW_T, DCD_PW_WAVES) void k_pair_parts(const PairOp*
   __shared__ __attribute__((aligned(16))) u32 s_raw[RAW_WORDS];
   u64* sA = reinterpret_cast<u64*>(s_raw);
   u64* sB = sA + PW_TILE;
-  u32* s_firstA = s_raw + 4 * PW_TILE;
-  u32* s_hasEB = s_firstA + PW_TILE + 4;
+  PROF_T();
   const u32 lane = threadIdx.x;
   const u64 w = blockIdx.x;
   u32 oi;
@@ -374,6 +407,7 @@ __global__ __launch_bounds__(PW_T, DCD_PW_WAVES) void k_pair_parts(const PairOp*
     while (lo + 1 < hi) { u32 m = (lo + hi) >> 1; if (part_base[m] <= w) lo = m; else hi = m; }
     oi = lo;
   }
+  PROF(0);   // operator lookup
   const u64 p = w - part_base[oi];
   const PairOp op = ops[oi];
   const u64* A = seg_ptr(op.a, idx_values, pool);
@@ -403,6 +437,7 @@ __global__ __launch_bounds__(PW_T, DCD_PW_WAVES) void k_pair_parts(const PairOp*
                                          ldir ? dir_max_coord >> ls.dir_shift : 0);
       }
     }
+    PROF(1);   // operands, mode (gallop: everything)
     if (!gallop) {
       const u64 d_begin = p * PART, d_end = d_begin + PART;
       u64 ia = wave_split(A, na, B, nb, d_begin), ib = d_begin - ia;
@@ -418,7 +453,7 @@ __global__ __launch_bounds__(PW_T, DCD_PW_WAVES) void k_pair_parts(const PairOp*
       }
       u64 g = d_begin;                 // union index of the next unconsumed element
       u64 cursor = 0, out_start = 0;
-      u32 open = 0, committed = 0, seenA = 0, seenEB = 0;
+      u32 open = 0, committed = 0, seenA = 0;
       u32 hA = 0, hB = 0;
       bool skipping = !is_or;          // '*': nothing is owned before the first chain break of the partition
       u64* out = tmp_op + d_begin;
@@ -430,35 +465,35 @@ __global__ __launch_bounds__(PW_T, DCD_PW_WAVES) void k_pair_parts(const PairOp*
       for (u32 i = lane; i < ra; i += PW_T) sA[i] = A[ia + i];
       for (u32 i = lane; i < rb; i += PW_T) sB[i] = B[ib + i];
       wsync();
+      PROF(2);   // split search over HBM, first fill
       while (ra + rb != 0) {
         if (g >= d_end && (skipping || is_or)) break;
         auto Aat = [&](u32 x) -> u64 { return sA[(hA + x) & (PW_TILE - 1)]; };
         auto Bat = [&](u32 x) -> u64 { return sB[(hB + x) & (PW_TILE - 1)]; };
         const u32 cnt = min((u32)PW_TILE, ra + rb);
-        auto split = [&](u32 d) -> u32 {     // merge path: ties take A first
-          u32 lo = d > rb ? d - rb : 0u, hi = min(d, ra);
-          while (lo < hi) {
-            u32 mid = (lo + hi) >> 1;
-            if (Aat(mid) <= Bat(d - 1 - mid)) lo = mid + 1; else hi = mid;
-          }
-          return lo;
-        };
-        u32 ca = ra;                         // A elements among the tile's cnt union elements
-        if (cnt != ra + rb) {
-          u32 lo = cnt > rb ? cnt - rb : 0u, hi = min(cnt, ra);
-          while (lo < hi) {                  // 64-ary probe over the staged elements: at most two rounds
-            const u32 step = (hi - lo + 63u) >> 6;
-            const u32 pp = lo + lane * step + (step - 1u);
-            bool pr = false;
-            if (pp < hi) pr = Aat(pp) <= Bat(cnt - 1u - pp);
-            const u32 c = popc64(ballot64(pr));
-            const u32 nlo = lo + c * step, nhi = nlo + step - 1u;
-            lo = nlo;
-            hi = min(hi, nhi);
-          }
-          ca = lo;
+        // ---- tile front end: bitonic merge in registers ----------------------------------------------------------
+        // The tile is the cnt smallest of the staged elements.  Keys = (coordinate << 1) | operand, so that a left
+        // element sorts before an equal right element (ties take A first) and all keys are distinct; slots past the
+        // staged counts hold +inf.  A ascending and B REVERSED form a bitonic sequence of 512 keys; one half-cleaner
+        // step, min(A[t], B[255 - t]), leaves the 256 smallest as a bitonic sequence (and tells how many elements
+        // of each operand the tile consumes), eight compare-exchange stages sort them: distances 128 .. 4 cross lanes
+        // (shuffles), 2 and 1 stay inside a lane (element t = 4 * lane + k).  No data-dependent LDS addressing: the
+        // merge-path search per lane and the serial merge were 3/4 of the kernel's time in bank-conflicted,
+        // dependent LDS round trips.
+        constexpr u64 INF = ~0ull;
+        u64 x[PW_ITEMS];
+        u32 tookA = 0;
+#pragma unroll
+        for (int k = 0; k < (int)PW_ITEMS; k++) {
+          const u32 t = lane * PW_ITEMS + (u32)k, u = PW_TILE - 1u - t;
+          const u64 av = Aat(t), bv = Bat(u);
+          const u64 ka = t < ra ? (av << 1) : INF;
+          const u64 kb = u < rb ? ((bv << 1) | 1ull) : INF;
+          const bool ta = ka <= kb;                            // (inf <= inf only beyond the staged elements: never consumed)
+          x[k] = ta ? ka : kb;
+          tookA += (ta && t < ra) ? 1u : 0u;
         }
-        const u32 cb = cnt - ca;
+        const u32 ca = rfl(wave_sum(tookA)), cb = cnt - ca;    // A / B elements among the tile's cnt union elements
         // request the refill
         const u32 keepA = ra - ca, keepB = rb - cb;
         const u32 nra = (u32)min((u64)PW_TILE, na - ia - ca), nrb = (u32)min((u64)PW_TILE, nb - ib - cb);
@@ -466,39 +501,53 @@ __global__ __launch_bounds__(PW_T, DCD_PW_WAVES) void k_pair_parts(const PairOp*
         u64 pfA[PW_ITEMS], pfB[PW_ITEMS];
 #pragma unroll
         for (int q = 0; q < (int)PW_ITEMS; q++) {
-          const u32 x = lane + (u32)q * PW_T;
-          pfA[q] = x < newA ? A[ia + ra + x] : 0;
-          pfB[q] = x < newB ? B[ib + rb + x] : 0;
+          const u32 xx = lane + (u32)q * PW_T;
+          pfA[q] = xx < newA ? A[ia + ra + xx] : 0;
+          pfB[q] = xx < newB ? B[ib + rb + xx] : 0;
         }
-        const u32 d0 = min(lane * PW_ITEMS, cnt), d1 = min(d0 + PW_ITEMS, cnt);
-        u32 i = split(d0), j = d0 - i;
-        u64 pv = prev_val;
-        u32 psrc = prev_src, hp = have_prev;
-        if (d0 > 0) {
-          hp = 1;
-          bool ua = i > 0, ub = j > 0;
-          if (ua && ub) { if (Bat(j - 1) >= Aat(i - 1)) { pv = Bat(j - 1); psrc = 1; } else { pv = Aat(i - 1); psrc = 0; } }
-          else if (ua) { pv = Aat(i - 1); psrc = 0; }
-          else { pv = Bat(j - 1); psrc = 1; }
-        }
-        u64 val[PW_ITEMS];
-        u32 src[PW_ITEMS], dup[PW_ITEMS], brk[PW_ITEMS], ctc[PW_ITEMS], al[PW_ITEMS];
+        PROF(3);   // half-cleaner, refill request
 #pragma unroll
-        for (int k = 0; k < (int)PW_ITEMS; k++) {
-          val[k] = 0; src[k] = 0; dup[k] = 0; brk[k] = 0; ctc[k] = 0; al[k] = 0;
-          if (d0 + k < d1) {
-            bool takeA = i < ra && (j >= rb || Aat(i) <= Bat(j));
-            u64 v = takeA ? Aat(i) : Bat(j);
-            if (takeA) i++; else j++;
-            val[k] = v;
-            src[k] = takeA ? 0u : 1u;
-            dup[k] = (!takeA && hp && psrc == 0 && pv == v) ? 1u : 0u;
-            brk[k] = !hp ? 1u : ((absR != 0 && v - pv > (u64)absR) ? 1u : 0u);
-            ctc[k] = (hp && psrc != src[k] && !brk[k]) ? 1u : 0u;   // neighbours from different operands within absR
-            al[k] = 1;
-            pv = v; psrc = src[k]; hp = 1;
+        for (int m = 32; m >= 1; m >>= 1) {                    // element distance 4 * m: partner lane = lane ^ m
+          const bool keep_min = (lane & (u32)m) == 0;
+#pragma unroll
+          for (int k = 0; k < (int)PW_ITEMS; k++) {
+            const u64 y = shfl_xor64(x[k], m);
+            const bool lt = x[k] < y;
+            x[k] = (lt == keep_min) ? x[k] : y;
           }
         }
+        {                                                      // distances 2 and 1 inside the lane
+          u64 t0 = min(x[0], x[2]), t2 = max(x[0], x[2]), t1 = min(x[1], x[3]), t3 = max(x[1], x[3]);
+          x[0] = min(t0, t1); x[1] = max(t0, t1); x[2] = min(t2, t3); x[3] = max(t2, t3);
+        }
+        PROF(4);   // bitonic sort
+        const u32 d0 = min(lane * PW_ITEMS, cnt), d1 = min(d0 + PW_ITEMS, cnt);
+        u64 val[PW_ITEMS];
+        u32 src[PW_ITEMS], dup[PW_ITEMS], brk[PW_ITEMS], ctc[PW_ITEMS], al[PW_ITEMS];
+        {
+          const u64 thr = absR != 0 ? (u64)absR : INF;          // absR == 0: nothing ever breaks a chain
+          // element before this lane's first one: the previous lane's last key, or the carried element
+          const u64 pk = shfl_up64(x[PW_ITEMS - 1], 1);
+          u64 pv = lane == 0 ? prev_val : (pk >> 1);
+          u32 psrc = lane == 0 ? prev_src : (u32)(pk & 1ull);
+          u32 hp = lane == 0 ? have_prev : 1u;
+#pragma unroll
+          for (int k = 0; k < (int)PW_ITEMS; k++) {
+            const bool valid = d0 + k < d1;
+            const u64 v = x[k] >> 1;
+            const u32 sr = (u32)(x[k] & 1ull);
+            const u64 gap = v - pv;
+            const bool bk = !hp || gap > thr;
+            val[k] = valid ? v : 0;
+            src[k] = valid ? sr : 0u;
+            dup[k] = (valid && sr == 1 && hp && psrc == 0 && gap == 0) ? 1u : 0u;
+            brk[k] = (valid && bk) ? 1u : 0u;
+            ctc[k] = (valid && hp && psrc != sr && !bk) ? 1u : 0u;   // neighbours from different operands within absR
+            al[k] = valid ? 1u : 0u;
+            pv = v; psrc = sr; hp = 1;
+          }
+        }
+        PROF(5);   // merge
         // the rings have been read: store the refill (visible to the next tile after the wsync that ends this one)
         wsync();
 #pragma unroll
@@ -507,6 +556,7 @@ __global__ __launch_bounds__(PW_T, DCD_PW_WAVES) void k_pair_parts(const PairOp*
           if (x < newA) sA[(hA + ra + x) & (PW_TILE - 1)] = pfA[q];
           if (x < newB) sB[(hB + rb + x) & (PW_TILE - 1)] = pfB[q];
         }
+        PROF(6);   // refill store (waits for the HBM loads)
         // the tile's last element (all lanes)
         const u32 last_lane = (cnt - 1) / PW_ITEMS, last_k = (cnt - 1) % PW_ITEMS;
         u64 lv = 0; u32 ls = 0;
@@ -561,13 +611,13 @@ __global__ __launch_bounds__(PW_T, DCD_PW_WAVES) void k_pair_parts(const PairOp*
           }
         }
         const bool final_tile = ends_here || inputs_end;
-        u32 nbrk = 0, contact = 0, lastbrk1 = 0;
+        u32 contact = 0, lastbrk1 = 0;
 #pragma unroll
         for (int k = 0; k < (int)PW_ITEMS; k++) {
-          nbrk += brk[k];
           contact |= ctc[k];
           if (brk[k]) lastbrk1 = d0 + k + 1;
         }
+        PROF(7);   // ownership
         // ---- sparse fast path: no two neighbouring elements from different operands within absR ------
         if (!is_or && absR != 0 && !has_dead) {
           const u32 M = rfl(wave_max(contact ? 0xFFFFFFFFu : lastbrk1));
@@ -594,92 +644,132 @@ __global__ __launch_bounds__(PW_T, DCD_PW_WAVES) void k_pair_parts(const PairOp*
                 }
                 cursor = cursor0 + (elig ? cnt - LB : 0u);
                 out_start = cursor0;
-                open = 1; committed = 0; seenA = t_last_src == 0 ? 1u : 0u; seenEB = (t_last_src == 1 && !ordered) ? 1u : 0u;
+                open = 1; committed = 0; seenA = t_last_src == 0 ? 1u : 0u;
               }
             }
             advance();
             wsync();
+            PROF(8);   // fast path
             continue;
           }
         }
         // ---- general path ---------------------------------------------------------------------------------
-        for (u32 x = lane; x < PW_TILE + 2; x += PW_T) { s_firstA[x] = NONE32; s_hasEB[x] = 0; }
-        wsync();
-        const u32 incl_brk = wave_scan_incl(nbrk);
-        const u32 last_cid = rdl(incl_brk, 63);
-        u32 cid[PW_ITEMS];
-        {
-          u32 c = incl_brk - nbrk;
-#pragma unroll
-          for (int k = 0; k < (int)PW_ITEMS; k++) { c += brk[k]; cid[k] = c; }
-        }
-#pragma unroll
-        for (int k = 0; k < (int)PW_ITEMS; k++) {   // first A element (tile position) per chain
-          if (al[k] && src[k] == 0) {
-            bool first_in_thread = true;
-            for (int q = 0; q < k; q++) if (al[q] && src[q] == 0 && cid[q] == cid[k]) first_in_thread = false;
-            if (first_in_thread) atomicMin(&s_firstA[cid[k]], d0 + k);
-          }
-        }
-        wsync();
-        u32 elig[PW_ITEMS];
+        // A chain is emitted iff it holds both operands, i.e. iff two NEIGHBOURS of it come from different operands
+        // (ordered mode: an element of the right operand directly after one of the left operand -- exactly "a right
+        // element at or after the first left element").  So all a chain needs is the OR of one flag per element, and
+        // ordered mode the prefix-OR of "is left operand": segmented scans over the 256 elements, chains = segments,
+        // done in registers (lane-local over PW_ITEMS elements, then log-step shuffles across the lanes).
+        u32 xq[PW_ITEMS], aq[PW_ITEMS];
 #pragma unroll
         for (int k = 0; k < (int)PW_ITEMS; k++) {
-          elig[k] = 0;
-          if (al[k]) {
-            bool sA_ = s_firstA[cid[k]] <= d0 + k || (cid[k] == 0 && seenA);
-            elig[k] = (!ordered || sA_) ? 1u : 0u;
-            if (src[k] == 1 && elig[k]) {
-              bool first_in_thread = true;
-              for (int q = 0; q < k; q++) if (al[q] && src[q] == 1 && elig[q] && cid[q] == cid[k]) first_in_thread = false;
-              if (first_in_thread) atomicOr(&s_hasEB[cid[k]], 1u);
-            }
+          xq[k] = (ctc[k] && (!ordered || src[k] == 1)) ? 1u : 0u;      // ctc: predecessor in the same chain, other operand
+          aq[k] = (al[k] && src[k] == 0) ? 1u : 0u;
+        }
+        // first / last chain break of the tile (positions; cnt / 0 when there is none)
+        u32 fbp = NONE32;
+#pragma unroll
+        for (int k = (int)PW_ITEMS - 1; k >= 0; k--) if (brk[k]) fbp = d0 + k;
+        const u32 fb = min(rfl(wave_min(fbp)), cnt);
+        const u32 lbk = rfl(wave_max(lastbrk1));                        // 1 + position of the last break, 0 = none
+        const bool any_brk = lbk != 0;
+        // forward: F = OR of (xq, aq) from the chain start to the element
+        u32 F[PW_ITEMS];
+        u32 lane_brk = 0;
+        {
+          u32 acc = 0;
+#pragma unroll
+          for (int k = 0; k < (int)PW_ITEMS; k++) {
+            if (brk[k]) { acc = 0; lane_brk = 1; }
+            acc |= xq[k] | (aq[k] << 1);
+            F[k] = acc;
+          }
+          u32 w = (lane_brk << 2) | acc;                                // lane summary: flag + OR behind the lane's last break
+#pragma unroll
+          for (int d = 1; d < 64; d <<= 1) {
+            const u32 wp = __shfl_up(w, d, DCD_WAVE);
+            if (lane >= (u32)d) { if (!(w & 4u)) w |= wp & 3u; w |= wp & 4u; }
+          }
+          u32 inc = __shfl_up(w, 1, DCD_WAVE);
+          inc = lane == 0 ? 0u : (inc & 3u);
+          bool before = true;                                           // no break at or before the element inside this lane
+#pragma unroll
+          for (int k = 0; k < (int)PW_ITEMS; k++) {
+            if (brk[k]) before = false;
+            if (before) F[k] |= inc;
           }
         }
-        wsync();
-        auto commit_of = [&](u32 c) -> bool {
-          bool hasA = s_firstA[c] != NONE32 || (c == 0 && seenA);
-          bool hasEB = s_hasEB[c] != 0 || (c == 0 && seenEB);
-          return (hasA && hasEB) || (c == 0 && committed);
-        };
+        // backward: G = OR of xq from the element to the chain end
+        u32 G[PW_ITEMS];
+        {
+          u32 acc = 0, pre = 0;                                         // pre: OR over the lane's elements before its first break
+#pragma unroll
+          for (int k = (int)PW_ITEMS - 1; k >= 0; k--) {
+            acc |= xq[k];
+            G[k] = acc;
+            if (brk[k]) acc = 0;
+          }
+          pre = acc;                                                    // (what is left after the first break was passed going down)
+          u32 w = (lane_brk << 1) | pre;
+#pragma unroll
+          for (int d = 1; d < 64; d <<= 1) {
+            const u32 wn = __shfl_down(w, d, DCD_WAVE);
+            if (lane + (u32)d < 64u) { if (!(w & 2u)) w |= wn & 1u; w |= wn & 2u; }
+          }
+          u32 inc = __shfl_down(w, 1, DCD_WAVE);
+          inc = lane == 63 ? 0u : (inc & 1u);
+          bool after = true;                                            // no break behind the element inside this lane
+#pragma unroll
+          for (int k = (int)PW_ITEMS - 1; k >= 0; k--) {
+            if (after) G[k] |= inc;
+            if (brk[k]) after = false;
+          }
+        }
+        // the carried chain: does it commit once it closes?
+        u32 c0x = 0;
+#pragma unroll
+        for (int k = 0; k < (int)PW_ITEMS; k++) if (d0 + k < fb) c0x |= xq[k];
+        const bool chain0_commit = committed || (ballot64(c0x != 0) != 0);
+        if (!is_or && open && !committed && (any_brk || final_tile) && !chain0_commit) cursor = out_start;   // roll back
         u32 emit[PW_ITEMS], nemit = 0;
 #pragma unroll
         for (int k = 0; k < (int)PW_ITEMS; k++) {
           emit[k] = 0;
           if (al[k] && !dup[k]) {
             if (is_or) emit[k] = 1;
-            else if (elig[k]) {
-              bool closed = cid[k] < last_cid || final_tile;
-              emit[k] = closed ? (commit_of(cid[k]) ? 1u : 0u) : 1u;
+            else {
+              const u32 pos = d0 + k;
+              const bool in0 = pos < fb, inlast = !any_brk || pos + 1 >= lbk;
+              const bool sa = ((F[k] >> 1) & 1u) || (in0 && seenA);
+              const bool cm = (F[k] & 1u) || (G[k] & 1u) || (in0 && committed);
+              const bool closed = !inlast || final_tile;
+              emit[k] = ((!ordered || sa) && (closed ? cm : true)) ? 1u : 0u;
             }
           }
           nemit += emit[k];
         }
-        // roll back an open chain that closed in this tile without committing
-        if (!is_or && open && !committed && (last_cid > 0 || final_tile) && !commit_of(0)) cursor = out_start;
         const u32 incl_emit = wave_scan_incl(nemit);
         const u32 total_emit = rdl(incl_emit, 63);
-        u32 lfe1 = 0;                                 // 1 + emit offset of the first element of the tile's last chain
+        u32 lfe1 = 0, lx = 0, la = 0;                 // last chain: 1 + emit offset of its first element, its flags
         {
           u32 e = incl_emit - nemit;
 #pragma unroll
           for (int k = 0; k < (int)PW_ITEMS; k++) {
-            if (al[k]) {
-              if (brk[k] && cid[k] == last_cid) lfe1 = e + 1;
-              if (emit[k]) out[cursor + e] = val[k];
-              e += emit[k];
-            }
+            const u32 pos = d0 + k;
+            if (any_brk && pos + 1 == lbk) lfe1 = e + 1;
+            if (!any_brk || pos + 1 >= lbk) { lx |= xq[k]; la |= aq[k]; }
+            if (emit[k]) out[cursor + e] = val[k];
+            e += emit[k];
           }
         }
         lfe1 = rfl(wave_max(lfe1));
         {
-          const bool hasA = s_firstA[last_cid] != NONE32 || (last_cid == 0 && seenA);
-          const bool hasEB = s_hasEB[last_cid] != 0 || (last_cid == 0 && seenEB);
-          const bool com = (hasA && hasEB) || (last_cid == 0 && committed);
-          if (last_cid != 0 || !open) out_start = cursor + (lfe1 ? lfe1 - 1 : 0u);
-          open = 1; seenA = hasA; seenEB = hasEB; committed = com;
+          const bool com = (ballot64(lx != 0) != 0) || (!any_brk && committed);
+          const bool hasA = (ballot64(la != 0) != 0) || (!any_brk && seenA);
+          if (any_brk || !open) out_start = cursor + (lfe1 ? lfe1 - 1 : 0u);
+          open = 1; seenA = hasA ? 1u : 0u; committed = com ? 1u : 0u;
           cursor += total_emit;
         }
+        PROF(9);   // general path
         if (ends_here) { open = 0; break; }
         advance();
         wsync();
@@ -688,6 +778,7 @@ __global__ __launch_bounds__(PW_T, DCD_PW_WAVES) void k_pair_parts(const PairOp*
     }
   }
   if (lane == 0) { part_count[w] = count; part_src[w] = slot; }
+  PROF(10);
 }
 
 // out[...] <- scratch: every wave looks at 64 work items at a time; each lane resolves its own item (operator by
@@ -1330,6 +1421,13 @@ static int32_t run_batch(dcd_index* h, const int32_t* prog, const u64* prog_off,
   return DCD_OK;
 }
 
+#ifdef DCD_PROF
+extern "C" int32_t dcd_debug_prof(unsigned long long* out16, int32_t reset) {
+  if (out16) (void)hipMemcpyFromSymbol(out16, HIP_SYMBOL(dcd::g_prof), 16 * 8);
+  if (reset) { unsigned long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(dcd::g_prof), z, 16 * 8); }
+  return 0;
+}
+#endif
 extern "C" {
 
 void dcd_query_default_opts(dcd_query_opts* o) {
