@@ -380,6 +380,34 @@ __device__ void part_gallop(const u64* __restrict__ Sv, u64 ns, const u64* __res
 #ifndef DCD_PW_WAVES
 #define DCD_PW_WAVES 5
 #endif
+// Work plan of a round, computed on the device once the operand counts are known: how an operator is evaluated
+// (mode) and how many work items it needs -- ceil(union / PART) for the streaming merge, ceil(|short| / GAL_PER) when
+// it gallops, none when a '*' has an empty operand.  An exclusive scan of the item counts gives the operator of
+// every work item; the launch grid is sized on the host for the capacities, surplus wavefronts leave at once.
+constexpr u32 GAL_PER = 512;      // short-list elements per galloping work item
+constexpr u8 MODE_NONE = 0, MODE_STREAM = 1, MODE_GALLOP = 2;
+__global__ void k_pair_plan(const PairOp* __restrict__ ops, u32 n_ops, const u64* __restrict__ idx_values, const u64* __restrict__ pool,
+                            const u64* __restrict__ counts, u64 PART, u32* __restrict__ items, u8* __restrict__ mode) {
+  u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i > n_ops) return;
+  if (i == n_ops) { items[i] = 0; return; }
+  const PairOp op = ops[i];
+  const u64 na = seg_cnt(op.a, counts), nb = seg_cnt(op.b, counts);
+  const bool is_or = op.op == DCD_OP_OR;
+  const u32 absR = (u32)max(abs(op.Ra), abs(op.Rb));
+  u8 m = MODE_STREAM;
+  u64 n = (na + nb + PART - 1) / PART;
+  if (!is_or && (na == 0 || nb == 0)) { m = MODE_NONE; n = 0; }          // '*' with an empty operand is empty
+  else if (!is_or && absR != 0) {
+    const bool a_short = na <= nb;
+    const u64 ns = a_short ? na : nb, nl = a_short ? nb : na;
+    const u64* Lv = seg_ptr(a_short ? op.b : op.a, idx_values, pool);
+    if (ns * GAL_RATIO <= nl && (Lv[nl - 1] - Lv[0]) / nl > 4ull * absR) { m = MODE_GALLOP; n = (ns + GAL_PER - 1) / GAL_PER; }
+  }
+  items[i] = (u32)n;
+  mode[i] = m;
+}
+
 #ifdef DCD_PROF
 // debug build only: wave-residency cycles per phase of k_pair_parts (s_memtime deltas, summed over all waves)
 __device__ unsigned long long g_prof[16];
@@ -393,7 +421,7 @@ __global__ __launch_bounds__(PW_T, DCD_PW_WAVES) void k_pair_parts(const PairOp*
                                                     const u64* __restrict__ idx_values, const u64* __restrict__ pool,
                                                     const u64* __restrict__ counts, u64* __restrict__ tmp, u64* __restrict__ part_count,
                                                     u64* __restrict__ part_src, u64 PART, const u32* __restrict__ dirs,
-                                                    u64 dir_max_coord) {
+                                                    u64 dir_max_coord, const u8* __restrict__ op_mode) {
   constexpr u32 RAW_WORDS = 6u * PW_TILE + 16u;
   __shared__ __attribute__((aligned(16))) u32 s_raw[RAW_WORDS];
   u64* sA = reinterpret_cast<u64*>(s_raw);
@@ -401,6 +429,10 @@ __global__ __launch_bounds__(PW_T, DCD_PW_WAVES) void k_pair_parts(const PairOp*
   PROF_T();
   const u32 lane = threadIdx.x;
   const u64 w = blockIdx.x;
+  if (w >= part_base[n_ops]) {                               // surplus wavefront (the grid is sized for the capacities)
+    if (lane == 0) { part_count[w] = 0; part_src[w] = 0; }
+    return;
+  }
   u32 oi;
   {   // operator of this work item: last op with part_base[op] <= w
     u32 lo = 0, hi = n_ops;
@@ -417,25 +449,19 @@ __global__ __launch_bounds__(PW_T, DCD_PW_WAVES) void k_pair_parts(const PairOp*
   const u32 absR = (u32)max(abs(op.Ra), abs(op.Rb));
   const bool ordered = op.Ra < 0 && op.Rb < 0 && absR != 0;   // R = -absR < 0  (IndexSequence.cs:221-222)
   const bool is_or = op.op == DCD_OP_OR;
-  const u64 n_union = na + nb;
-  const u64 n_act = n_union ? (n_union + PART - 1) / PART : 0;   // partitions in use (the grid is sized for the capacity)
+  const bool gallop = op_mode[oi] == MODE_GALLOP;
   u64 count = 0, slot = 0;
-  if (p < n_act && (is_or || (na != 0 && nb != 0))) {     // '*' with an empty operand is empty: no chain holds both
-    bool gallop = false;
-    if (!is_or && absR != 0 && na && nb) {
+  {
+    if (gallop) {
       const bool a_short = na <= nb;
       const u64 ns = a_short ? na : nb, nl = a_short ? nb : na;
       const u64* Sv = a_short ? A : B;
       const u64* Lv = a_short ? B : A;
-      if (ns * GAL_RATIO <= nl && (Lv[nl - 1] - Lv[0]) / nl > 4ull * absR) {
-        gallop = true;
-        const u64 per = (ns + n_act - 1) / n_act;
-        const u64 i_begin = min(ns, p * per), i_end = min(ns, i_begin + per);
-        const Seg& ls = a_short ? op.b : op.a;
-        const u32* ldir = (ls.kind == 0 && ls.dir_shift != NONE32) ? dirs + ls.dir_off : nullptr;
-        if (i_begin < i_end) part_gallop(Sv, ns, Lv, nl, a_short, absR, ordered, i_begin, i_end, tmp_op, s_raw, count, slot, ldir, ls.dir_shift,
-                                         ldir ? dir_max_coord >> ls.dir_shift : 0);
-      }
+      const u64 i_begin = min(ns, p * (u64)GAL_PER), i_end = min(ns, i_begin + GAL_PER);
+      const Seg& ls = a_short ? op.b : op.a;
+      const u32* ldir = (ls.kind == 0 && ls.dir_shift != NONE32) ? dirs + ls.dir_off : nullptr;
+      if (i_begin < i_end) part_gallop(Sv, ns, Lv, nl, a_short, absR, ordered, i_begin, i_end, tmp_op, s_raw, count, slot, ldir, ls.dir_shift,
+                                       ldir ? dir_max_coord >> ls.dir_shift : 0);
     }
     PROF(1);   // operands, mode (gallop: everything)
     if (!gallop) {
@@ -1274,7 +1300,7 @@ static int32_t run_batch(dcd_index* h, const int32_t* prog, const u64* prog_off,
       u64 ca = p.a.cnt_ref == NONE32 ? p.a.cnt_imm : op_cap[p.a.cnt_ref];
       u64 cb = p.b.cnt_ref == NONE32 ? p.b.cnt_imm : op_cap[p.b.cnt_ref];
       t += ca + cb;
-      wsum += std::max<u64>(1, div_up(ca + cb, PART));
+      wsum += std::max<u64>(std::max<u64>(1, div_up(ca + cb, PART)), div_up(std::min(ca, cb), GAL_PER));   // upper bound of the device's plan
     }
     part_base[r][rounds[r].size()] = wsum;
     tmp_elems = std::max(tmp_elems, t);
@@ -1295,11 +1321,18 @@ static int32_t run_batch(dcd_index* h, const int32_t* prog, const u64* prog_off,
   }
   std::vector<DevBuf<PairOp>> d_rounds(rounds.size());
   std::vector<DevBuf<u64>> d_part_base(rounds.size());
+  DevBuf<u32> d_items;
+  DevBuf<u8> d_mode;
+  {
+    size_t mx = 1;
+    for (auto& rr : rounds) mx = std::max(mx, rr.size());
+    DCD_TRY(d_items.alloc(dev, mx + 1));
+    DCD_TRY(d_mode.alloc(dev, mx + 1));
+  }
   for (size_t r = 0; r < rounds.size(); r++) {
     DCD_TRY(d_rounds[r].alloc(dev, rounds[r].size()));
     DCD_HIP(hipMemcpyAsync(d_rounds[r].p, rounds[r].data(), rounds[r].size() * sizeof(PairOp), hipMemcpyHostToDevice, st));
     DCD_TRY(d_part_base[r].alloc(dev, part_base[r].size()));
-    DCD_HIP(hipMemcpyAsync(d_part_base[r].p, part_base[r].data(), part_base[r].size() * 8, hipMemcpyHostToDevice, st));
   }
   DevBuf<FinalSeq> d_fin;
   DCD_TRY(d_fin.alloc(dev, nq ? nq : 1));
@@ -1320,8 +1353,12 @@ static int32_t run_batch(dcd_index* h, const int32_t* prog, const u64* prog_off,
   for (size_t r = 0; r < rounds.size(); r++) {
     u32 n = (u32)rounds[r].size();
     const u64 W = part_base[r][n];
+    // device plan: item count + mode per operator, exclusive scan -> first work item of every operator
+    hipLaunchKernelGGL(k_pair_plan, dim3(div_up(n + 1, 256)), dim3(256), 0, st, d_rounds[r].p, n, idx_values, pool.p, counts.p, PART,
+                       d_items.p, d_mode.p);
+    scan_exclusive<u32, u64>(d_items.p, d_part_base[r].p, (u64)n + 1, d_part_scr.p, st);
     hipLaunchKernelGGL(k_pair_parts, dim3((u32)W), dim3(PW_T), 0, st, d_rounds[r].p, n, d_part_base[r].p, idx_values, pool.p, counts.p,
-                       tmp.p, d_part_count.p, d_part_src.p, PART, ext_values ? nullptr : h->dir.p, ix.max_coord);
+                       tmp.p, d_part_count.p, d_part_src.p, PART, ext_values ? nullptr : h->dir.p, ix.max_coord, d_mode.p);
     DCD_HIP(hipMemsetAsync(d_part_count.p + W, 0, 8, st));
     scan_exclusive<u64, u64>(d_part_count.p, d_part_excl.p, W + 1, d_part_scr.p, st);
     const u32 gg = (u32)std::min<u64>(div_up(div_up(W, 64), 4), 4096);
