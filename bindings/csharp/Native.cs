@@ -13,7 +13,8 @@ namespace Docodo
         public struct BuildOpts { public int device, min_word_length, max_word_length, encoding;
                                   public ulong coord_base; public uint vocab_capacity_log2, reserved; }
         [StructLayout(LayoutKind.Sequential)]
-        public struct QueryOpts { public int max_found_pages, max_found_docs; public float doc_rank_multiply; public int want_sequences; }
+        public struct QueryOpts { public int max_found_pages, max_found_docs; public float doc_rank_multiply; public int want_sequences;
+                                  public byte* doc_match; public ulong n_doc_match; }   // -filter: one byte per document, null = none
         [StructLayout(LayoutKind.Sequential)]
         public struct ResultsView { public ulong n_queries; public int* status; public ulong* page_off; public uint* page_index;
                                     public float* page_rank; public ulong* pos_off; public int* pos; public ulong* doc_off;

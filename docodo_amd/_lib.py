@@ -42,7 +42,7 @@ KERNEL_NAMES = ["k_tok_count", "k_tok_emit", "k_rs_hist", "k_rs_scatter", "k_enc
 
 class QueryOpts(C.Structure):
     _fields_ = [("max_found_pages", C.c_int32), ("max_found_docs", C.c_int32), ("doc_rank_multiply", C.c_float),
-                ("want_sequences", C.c_int32)]
+                ("want_sequences", C.c_int32), ("doc_match", C.c_void_p), ("n_doc_match", C.c_uint64)]
 
 
 class ResultsView(C.Structure):

@@ -856,7 +856,6 @@ static int32_t build_phase2(dcd_build* h) {
   uint2* b = M.tupB.p;
   const u32* remap = M.vr.rank_of_slot.p;     // tuple.x = hash slot -> key id = rank of the word
   bool coord_sort = M.n_xdev != 0;            // mixed input is not in coordinate order
-  u32 total_chars = M.total_chars;
   DevBuf<uint2> expA, expB;
   u64 n_text_postings = M.n_text_tok;          // postings that came from the text (they precede the explicit ones)
   u64 max_coord_codes = 0;
@@ -928,7 +927,6 @@ static int32_t build_phase2(dcd_build* h) {
     std::vector<u32> ko(K + 1, 0);
     for (u64 k = 0; k < K; k++) { ko[k] = (u32)kc.size(); kc.insert(kc.end(), (const u16*)keys[k].data(), (const u16*)keys[k].data() + keys[k].size()); }
     ko[K] = (u32)kc.size();
-    total_chars = (u32)kc.size();
     DCD_TRY(M.word_chars.alloc(dev, kc.size() ? kc.size() : 1));
     DCD_TRY(M.word_str_off.alloc(dev, K + 1));
     if (!kc.empty()) DCD_HIP(hipMemcpyAsync(M.word_chars.p, kc.data(), kc.size() * 2, hipMemcpyHostToDevice, st));

@@ -849,6 +849,7 @@ struct ResParams {
   const u64* page_end;   // [n_pages]
   const u32* page_doc;   // [n_pages] or null (doc == page)
   const u8* page_hdr;    // [n_pages] 1 = page id "0", or null
+  const u8* doc_match;   // [n_docs] 1 = the document passes the request's -filter: (Search.cs:386-394), or null (no filter)
   u64 n_pages;
   u32 max_pages, max_docs;
   float doc_mult;
@@ -970,6 +971,7 @@ __global__ __launch_bounds__(RS_T) void k_result(const FinalSeq* __restrict__ fi
         bool hasprev = prevp != ~0ull && prevp < P.n_pages;
         if (hasprev) docprev = P.page_doc ? P.page_doc[prevp] : (u32)prevp;
         newd[k] = !hasprev || docp[k] != docprev;
+        if (newd[k] && P.doc_match && !P.doc_match[docp[k]]) newd[k] = false;   // a filtered-out document is never added to foundDocs
       }
       if (valid && newp[k]) vnp_mine++;
       if (newd[k]) nd_mine++;
@@ -989,11 +991,8 @@ __global__ __launch_bounds__(RS_T) void k_result(const FinalSeq* __restrict__ fi
           u64 base = p[k] == 0 ? 0ull : (P.uniform_chars ? P.uniform_base + p[k] * (u64)P.uniform_chars : P.page_end[p[k] - 1]);
           o_pos[sb + i] = (int32_t)(c[k] - base);
           if (newp[k]) { o_page_index[pb + ord[k]] = (u32)p[k]; o_pos_off[pb + ord[k]] = sb + i; }
-          if (newd[k]) {
-            if (dord <= P.max_docs) {                    // one extra entry marks the end of the last found doc
-              if (dord < P.max_docs) o_doc_index[db + dord] = docp[k];
-              o_doc_first_page[db + q + dord] = ord[k];
-            }
+          if (newd[k]) {                                 // foundDocs.Count < MAX_FOUND_DOCS, Search.cs:387
+            if (dord < P.max_docs) { o_doc_index[db + dord] = docp[k]; o_doc_first_page[db + q + dord] = ord[k]; }
             dord++;
           }
         }
@@ -1018,10 +1017,6 @@ __global__ __launch_bounds__(RS_T) void k_result(const FinalSeq* __restrict__ fi
       r.n_docs = c_err ? 0 : min(c_docs, P.max_docs);
       r.pad = 0;
       qc[q] = r;
-    } else if (!c_err) {
-      // sentinel: page ordinal where the doc run after the last found doc starts
-      u32 nd = min(c_docs, P.max_docs);
-      if (c_docs <= P.max_docs) o_doc_first_page[db + q + nd] = c_pages;
     }
   }
 }
@@ -1044,7 +1039,7 @@ __global__ __launch_bounds__(256) void k_doc_rank(u32 nq, const QCounts* __restr
                                                  const u64* __restrict__ doc_base, const u32* __restrict__ doc_first_page,
                                                  const u32* __restrict__ page_index, const float* __restrict__ page_rank, const u8* __restrict__ page_hdr,
                                                  float mult, const u32* __restrict__ doc_index_in, u32* __restrict__ o_doc_index,
-                                                 float* __restrict__ o_doc_rank, u32* __restrict__ o_doc_npages) {
+                                                 float* __restrict__ o_doc_rank, u32* __restrict__ o_doc_npages, const u32* __restrict__ page_doc) {
   __shared__ float s_rank[512];
   __shared__ u32 s_np[512];
   const u32 q = blockIdx.x;
@@ -1054,9 +1049,16 @@ __global__ __launch_bounds__(256) void k_doc_rank(u32 nq, const QCounts* __restr
   const u32* fp = doc_first_page + db + q;
   {   // max_found_docs <= 512 is enforced on the host
     for (u32 d = threadIdx.x; d < nd; d += blockDim.x) {
-      u32 a = fp[d], b = fp[d + 1];
+      // the pages of a document are consecutive in foundPages: its run ends where the document of the page changes
+      // (documents removed by the -filter: sit between the found ones, so the next FOUND document does not mark the end)
+      const u32 a = fp[d], np_q = (u32)qc[q].n_pages, doc = doc_index_in[db + d];
+      u32 b = a;
       double sum = 0;
-      for (u32 j = a; j < b; j++) sum += (double)page_rank[pb + j];
+      for (; b < np_q; b++) {
+        const u32 pg = page_index[pb + b];
+        if ((page_doc ? page_doc[pg] : pg) != doc) break;
+        sum += (double)page_rank[pb + b];
+      }
       float r = (float)sum;
       r = 1 + (float)log((double)r);
       if (page_hdr && b > a && page_hdr[page_index[pb + a]]) r *= mult;
@@ -1164,6 +1166,7 @@ static int32_t ensure_values(dcd_index* h) {
 struct PageDev {
   DevBuf<u32> page_doc;
   DevBuf<u8> page_hdr;
+  DevBuf<u8> doc_match;
   DevBuf<u64> page_end;  // only when the index did not bring one (loaded from images)
 };
 
@@ -1177,6 +1180,7 @@ static int32_t make_res_params(dcd_index* h, const dcd_query_opts& o, PageDev& p
   P->doc_mult = o.doc_rank_multiply;
   P->page_doc = nullptr;
   P->page_hdr = nullptr;
+  P->doc_match = nullptr;
   P->uniform_chars = pt.uniform ? (u32)pt.uni_chars : 0u;
   P->uniform_base = pt.uniform ? pt.uni_base : 0ull;
   if (np && !ix.page_end.p) {
@@ -1200,6 +1204,13 @@ static int32_t make_res_params(dcd_index* h, const dcd_query_opts& o, PageDev& p
       DCD_HIP(hipMemcpy(pd.page_hdr.p, hdr.data(), np, hipMemcpyHostToDevice));
       P->page_hdr = pd.page_hdr.p;
     }
+  }
+  if (o.doc_match) {
+    if (o.n_doc_match != pt.n_docs()) DCD_FAIL(DCD_E_BADARG, "doc_match has %llu entries, the index has %llu documents",
+                                               (unsigned long long)o.n_doc_match, (unsigned long long)pt.n_docs());
+    DCD_TRY(pd.doc_match.alloc(ix.device, o.n_doc_match ? o.n_doc_match : 1));
+    if (o.n_doc_match) DCD_HIP(hipMemcpy(pd.doc_match.p, o.doc_match, o.n_doc_match, hipMemcpyHostToDevice));
+    P->doc_match = pd.doc_match.p;
   }
   return DCD_OK;
 }
@@ -1398,7 +1409,7 @@ static int32_t run_batch(dcd_index* h, const int32_t* prog, const u64* prog_off,
     DCD_HIP(hipMemcpyAsync(o_pos_off.p + tot_pages, &tot_pos, 8, hipMemcpyHostToDevice, st));
     if (tot_pages) hipLaunchKernelGGL(k_page_rank, dim3((u32)div_up(tot_pages, 256)), dim3(256), 0, st, o_pos_off.p, o_pos.p, tot_pages, o_page_rank.p);
     hipLaunchKernelGGL(k_doc_rank, dim3((u32)nq), dim3(256), 0, st, (u32)nq, d_qc.p, d_pbase.p, d_dbase.p, o_doc_first.p, o_page_index.p,
-                       o_page_rank.p, P.page_hdr, P.doc_mult, o_doc_index_tmp.p, o_doc_index.p, o_doc_rank.p, o_doc_np.p);
+                       o_page_rank.p, P.page_hdr, P.doc_mult, o_doc_index_tmp.p, o_doc_index.p, o_doc_rank.p, o_doc_np.p, P.page_doc);
   }
   DCD_TRY(tm.stop());
   DCD_HIP(hipStreamSynchronize(st));
@@ -1473,6 +1484,8 @@ void dcd_query_default_opts(dcd_query_opts* o) {
   o->max_found_docs = 500;      // Index.cs:102
   o->doc_rank_multiply = 10.f;  // Index.cs:115
   o->want_sequences = 0;
+  o->doc_match = nullptr;
+  o->n_doc_match = 0;
 }
 
 // Worst-case work-pool elements a query needs (every operator result can be as long as both operands).

@@ -307,13 +307,17 @@ class Index:
         return out[:n.value].tobytes().decode("utf-16-le", "surrogatepass")
 
     def query_batch(self, prog, prog_off, max_found_pages=30000, max_found_docs=500, doc_rank_multiply=10.0,
-                    want_sequences=False, keep_handle=False):
+                    want_sequences=False, keep_handle=False, doc_match=None):
+        """doc_match: optional uint8 array, one entry per document: 1 = the document passes the request's -filter:."""
         prog = np.ascontiguousarray(prog, np.int32)
         off = np.ascontiguousarray(prog_off, np.uint64)
         o = QueryOpts()
         lib().dcd_query_default_opts(C.byref(o))
         o.max_found_pages, o.max_found_docs = max_found_pages, max_found_docs
         o.doc_rank_multiply, o.want_sequences = doc_rank_multiply, 1 if want_sequences else 0
+        if doc_match is not None:
+            dm = np.ascontiguousarray(doc_match, np.uint8)
+            o.doc_match, o.n_doc_match = dm.ctypes.data, dm.size
         r = C.c_void_p()
         check(lib().dcd_query_batch(self.h, prog.ctypes.data if prog.size else None, off.ctypes.data, off.size - 1,
                                     C.byref(o), C.byref(r)))

@@ -7,6 +7,7 @@ GPU evaluates (`dcd_query_batch`).  GetWordCodes is the identity (no stemmer / v
 words: the parity configuration); a host with linguistics supplies `get_word_codes`.
 Snippets/headers (Search.cs:560-595) are out of scope.
 """
+import numpy as np
 import regex
 
 from . import _lib
@@ -18,6 +19,27 @@ MAX_LIKE_WORDS = 100                                                   # Search.
 
 def _upper(s):
     return "".join(c.upper() if len(c.upper()) == 1 else c for c in s)
+
+
+def _net_regex(pat):
+    """A -filter: item is a .NET regex (Regex.Match(doc.Name, filt), Search.cs:391); the character class the request
+    syntax admits ([\\w*?\\\\.()+{}/]) is spelled the same way for the `regex` module."""
+    return pat
+
+
+class _TwoResults:
+    """Main query evaluated with the document filter, field query without (Search.cs:543-547)."""
+
+    def __init__(self, a, b):
+        self.parts = [a] + ([b] if b is not None else [])
+        self.n_queries = len(self.parts)
+        self.status = [p.status[0] for p in self.parts]
+
+    def pages(self, q):
+        return self.parts[q].pages(0)
+
+    def docs(self, q):
+        return self.parts[q].docs(0)
 
 
 def _lower(s):
@@ -188,13 +210,28 @@ class Search:
             raise SyntaxError("trailing")
         return v
 
+    def _query(self, flat, off, doc_match, nprog):
+        if doc_match is None or len(off) == 2:
+            return self.ix.query_batch(flat, off, doc_match=doc_match)
+        a = self.ix.query_batch(flat[:off[1]], [0, off[1]], doc_match=doc_match)
+        b = self.ix.query_batch(flat[off[1]:off[2]], [0, off[2] - off[1]])
+        return _TwoResults(a, b)
+
     def __call__(self, req, opt=None):
         """Index.Search(req, opt), Search.cs:437-617."""
         try:
             req = _lower(req)
+            # search filter, Search.cs:455-466: every "item," of -filter: is a regex over the document names; the host
+            # evaluates the regexes (one byte per document), the device keeps filtered-out documents out of foundDocs
             fpat = r"\B-filter:([\w\*\?\\.()+{}/]+,?)+"
-            if regex.search(fpat, req):
-                return SearchResult(False, "Error: -filter: is evaluated by the host shim; not supported by this front end")
+            doc_match = None
+            m = regex.search(fpat, req)
+            if m:
+                filters = [c.strip(",") for c in m.captures(1)]
+                req = regex.sub(fpat, " ", req)
+                pats = [regex.compile(_net_regex(f)) for f in filters]
+                nd = self.ix.n_docs
+                doc_match = np.fromiter((1 if any(p.search(self.ix.doc_name(d)) for p in pats) else 0 for d in range(nd)), np.uint8, nd)
             funcs = []
             req, fields = self._prepare(req, funcs)
             dist = 255 if opt is None else opt.dist                            # Search.cs:472-473
@@ -218,7 +255,7 @@ class Search:
                 off.append(len(flat))
             if len(progs) == 2 and progs[1] is None:
                 off = off[:2]
-            r = self.ix.query_batch(flat, off)
+            r = self._query(flat, off, doc_match, len(progs))
             if r.status[0] != 0:
                 return SearchResult(False, "Error: coordinate beyond the last page")
             keep = None

@@ -217,6 +217,11 @@ typedef struct dcd_query_opts {
   int32_t max_found_docs;    /* Index.MAX_FOUND_DOCS, Index.cs:102 (500) */
   float doc_rank_multiply;   /* Index.DOC_RANK_MULTIPLY, Index.cs:115 (10) */
   int32_t want_sequences;    /* also return the final IndexSequence units per query */
+  /* "-filter:" of the request (Search.cs:455-466): one byte per document of the index, 1 = the document's name matches
+   * one of the filter regexes (the host evaluates them: Regex.Match(doc.Name, filt), Search.cs:389-393).  A document with
+   * 0 is never added to foundDocs (its pages stay in foundPages), PrepareSearchResult Search.cs:386-396.  NULL = no filter. */
+  const uint8_t* doc_match;
+  uint64_t n_doc_match;      /* must equal the number of documents when doc_match != NULL */
 } dcd_query_opts;
 void dcd_query_default_opts(dcd_query_opts* o);
 int32_t dcd_query_batch(dcd_index* h, const int32_t* prog, const uint64_t* prog_off, size_t n_queries,

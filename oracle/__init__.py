@@ -456,6 +456,19 @@ class Index:
         u = np.ascontiguousarray(units, np.uint16)
         return self.L.orc_prepare_result(self.h, u.ctypes.data, u.size, mask.ctypes.data if mask is not None else None)
 
+    def prepare_result_masked(self, units, mask):
+        """PrepareSearchResult (Search.cs:365-420) with an explicit per-document filter mask, then the doc ranks /
+        order of Search.cs:552-557, 599 -> [(doc, rank, n_pages)]."""
+        u = np.ascontiguousarray(units, np.uint16)
+        m = np.ascontiguousarray(mask, np.uint8)
+        r = self.L.orc_prepare_result(self.h, u.ctypes.data, u.size, m.ctypes.data)
+        try:
+            self.L.orc_result_finish(self.h, r)
+            return [(self.L.orc_result_found_doc(r, i), self.L.orc_result_found_doc_rank(r, i), self.L.orc_result_found_doc_npages(r, i))
+                    for i in range(self.L.orc_result_n_found_docs(r))]
+        finally:
+            self.L.orc_result_free(r)
+
     def search(self, req, opt=None):
         """Index.Search, Search.cs:437-617 (snippets/headers omitted: out of scope)."""
         try:

@@ -221,6 +221,49 @@ def test_word_codes_stop_words_and_identity(oracle_mod):
     assert ix.find("$quick") is None and ix.term_count(ix.find("quick")) == 1
 
 
+@pytest.mark.parametrize("req", ["and -filter:ump", "and -filter:ample,ump", "and -filter:nomatch", "(tupman | old) -filter:est:d.mp",
+                                 "and {Name=Dump} -filter:ump", "and {Name=Dump} -filter:ample", "and -filter:dump"])
+def test_doc_name_filter(gpu_nostem, oracle_mod, req):
+    """-filter: of the request (Search.cs:455-466, 386-396): regexes over the document names, evaluated by the host into
+    one byte per document; a filtered-out document never reaches foundDocs, its pages stay in foundPages; the field
+    query of CombineSearchResults is evaluated without the filter."""
+    import docodo_amd
+    b, _, _, oix, _, _ = gpu_nostem
+    S = docodo_amd.Search(b_index(b))
+    r, o = S(req), oix.search(req)
+    assert r.Success == o.Success
+    _same(r, o)
+    if "nomatch" in req or req.endswith("dump"):
+        assert len(r.foundDocs) == 0 and len(r.foundPages) > 0      # names are matched case-sensitively: "Test:Dump"
+
+
+def test_doc_filter_with_many_docs(oracle_mod):
+    """Filtered-out documents between found ones: page runs of the found documents, ranks, the 500-document cap counted
+    over FOUND documents only (query_batch level, against the oracle)."""
+    import docodo_amd
+    from docodo_amd import synth
+    n = 3000
+    text = synth.corpus_host(n)
+    off = np.arange(n + 1, dtype=np.uint64) * synth.DOC_BYTES
+    b = docodo_amd.Builder()
+    b.AddPages(text, off, docs_per_page=True)
+    b.Finish()
+    ix = b.Build()
+    oix = oracle_mod.Index(stemmers=[])
+    oix.load(b.index_image(), b.list_image())
+    w = synth.term(1)
+    t = ix.find(w)
+    for mod in (2, 3, 7):
+        mask = np.array([1 if d % mod == 0 else 0 for d in range(n)], np.uint8)
+        r = ix.query_batch([docodo_amd.DCD_OP_TERM, t, 255 + len(w)], [0, 3], doc_match=mask)
+        units, R = oix.search_word(w)
+        o = oix.prepare_result_masked(units, mask)
+        docs = r.docs(0)
+        assert len(docs) == len(o) and len(docs) == min(500, len(docs))
+        for (d, rank, npg), (od, orank, onpg) in zip(docs, o):
+            assert d == od and npg == onpg and abs(rank - orank) <= 1e-5 * max(1.0, abs(orank))
+
+
 def test_latin1_header_pages_and_edge_lines(oracle_mod):
     """Header pages in a byte (Latin-1) build, odd header lines: short names (skipped), no trailing newline,
     CR LF line ends, '=' inside the value, digits, a line without '=' after a valid one (aborts the page
