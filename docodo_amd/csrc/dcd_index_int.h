@@ -1,6 +1,7 @@
 // dcd_index_int.h -- the dcd_index handle shared by dcd_index.hip and dcd_query.hip.
 #pragma once
 #include <memory>
+#include <mutex>
 
 #include "dcd_build_int.h"
 #include "dcd_prims.h"
@@ -10,6 +11,9 @@ struct dcd_build;
 struct dcd_index {
   dcd::DeviceIndex ix;
   hipStream_t st = nullptr;
+  // Search is issued from many pool threads (server.cs:16-30) and serialised by lock(DoSearchLock) in the reference
+  // (Search.cs:448); batches on ONE index handle are serialised here the same way, different handles run concurrently
+  std::mutex mu;
   // decoded postings (built lazily on the first query): segment-relative values per term
   dcd::DevBuf<u64> values;   // [n_postings], term t at [term_item_start[t], term_item_start[t+1])
   bool values_ready = false;

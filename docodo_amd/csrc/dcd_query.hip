@@ -1547,6 +1547,7 @@ int32_t dcd_query_batch(dcd_index* h, const int32_t* prog, const uint64_t* prog_
   if (!h || !prog_off || !out || (!prog && n_queries && prog_off[n_queries] != 0)) DCD_FAIL(DCD_E_BADARG, "dcd_query_batch: NULL argument");
   dcd_query_opts o;
   if (opts) o = *opts; else dcd_query_default_opts(&o);
+  std::lock_guard<std::mutex> guard(h->mu);
   DCD_TRY(ensure_device(h->ix.device));
   // The work pool is sized for the worst case of every operator; batches whose worst case exceeds a
   // quarter of the free HBM are evaluated in consecutive sub-batches (results are concatenated).

@@ -205,6 +205,43 @@ def test_three_term_queries_small_partitions(synth_index, monkeypatch):
         assert np.array_equal(getattr(a, name), getattr(b, name)), name
 
 
+def test_concurrent_batches_on_one_index(synth_index):
+    """The reference issues Search from many pool threads (server.cs:16-30) under one lock (Search.cs:448);
+    dcd_query_batch on one handle is serialised internally: concurrent callers get the single-threaded answers."""
+    import threading
+    import docodo_amd
+    from docodo_amd import synth
+    ix, oix, _, _ = synth_index
+    ranks = synth.query_ranks(64, 3, lo_rank=1)
+    progs = []
+    for row in ranks:
+        ts = [ix.find(synth.term(int(k))) for k in row]
+        if any(t is None for t in ts):
+            continue
+        prog = []
+        for k, t in enumerate(ts):
+            prog += [docodo_amd.DCD_OP_TERM, t, 255 + len(synth.term(int(row[k])))]
+            if k:
+                prog.append(docodo_amd.DCD_OP_AND)
+        progs.append(prog)
+    want = [ix.query_batch(p, [0, len(p)], want_sequences=True) for p in progs]
+    got = [None] * len(progs)
+
+    def work(lo, hi):
+        for i in range(lo, hi):
+            got[i] = ix.query_batch(progs[i], [0, len(progs[i])], want_sequences=True)
+
+    n = len(progs)
+    th = [threading.Thread(target=work, args=(j * n // 4, (j + 1) * n // 4)) for j in range(4)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for a, b in zip(want, got):
+        for name in ("status", "page_index", "page_rank", "pos", "doc_index", "doc_rank", "seq_units"):
+            assert np.array_equal(getattr(a, name), getattr(b, name)), name
+
+
 def test_or_and_mixed_plan(synth_index):
     import docodo_amd
     from docodo_amd import synth
