@@ -426,6 +426,7 @@ __global__ __launch_bounds__(PW_T, DCD_PW_WAVES) void k_pair_parts(const PairOp*
   __shared__ __attribute__((aligned(16))) u32 s_raw[RAW_WORDS];
   u64* sA = reinterpret_cast<u64*>(s_raw);
   u64* sB = sA + PW_TILE;
+  u32* s_cm = s_raw + 4 * PW_TILE;                 // [PW_TILE + 1] chain flags of the general path
   PROF_T();
   const u32 lane = threadIdx.x;
   const u64 w = blockIdx.x;
@@ -682,80 +683,59 @@ __global__ __launch_bounds__(PW_T, DCD_PW_WAVES) void k_pair_parts(const PairOp*
         // ---- general path ---------------------------------------------------------------------------------
         // A chain is emitted iff it holds both operands, i.e. iff two NEIGHBOURS of it come from different operands
         // (ordered mode: an element of the right operand directly after one of the left operand -- exactly "a right
-        // element at or after the first left element").  So all a chain needs is the OR of one flag per element, and
-        // ordered mode the prefix-OR of "is left operand": segmented scans over the 256 elements, chains = segments,
-        // done in registers (lane-local over PW_ITEMS elements, then log-step shuffles across the lanes).
-        u32 xq[PW_ITEMS], aq[PW_ITEMS];
+        // element at or after the first left element").  Chains are numbered by a wave scan of the breaks; the few
+        // elements that carry such a contact flag their chain in a small LDS array, every element reads its chain's
+        // flag back.  Ordered mode additionally needs "a left element at or before me in my chain": a segmented
+        // prefix-OR in registers (lane-local over PW_ITEMS elements, then log-step shuffles across the lanes).
+        u32 xq[PW_ITEMS], aq[PW_ITEMS], cid[PW_ITEMS];
+        u32 nb_l = 0;
 #pragma unroll
         for (int k = 0; k < (int)PW_ITEMS; k++) {
           xq[k] = (ctc[k] && (!ordered || src[k] == 1)) ? 1u : 0u;      // ctc: predecessor in the same chain, other operand
           aq[k] = (al[k] && src[k] == 0) ? 1u : 0u;
+          nb_l += brk[k];
         }
-        // first / last chain break of the tile (positions; cnt / 0 when there is none)
-        u32 fbp = NONE32;
-#pragma unroll
-        for (int k = (int)PW_ITEMS - 1; k >= 0; k--) if (brk[k]) fbp = d0 + k;
-        const u32 fb = min(rfl(wave_min(fbp)), cnt);
-        const u32 lbk = rfl(wave_max(lastbrk1));                        // 1 + position of the last break, 0 = none
-        const bool any_brk = lbk != 0;
-        // forward: F = OR of (xq, aq) from the chain start to the element
-        u32 F[PW_ITEMS];
-        u32 lane_brk = 0;
+        const u32 incl_brk = wave_scan_incl(nb_l);
+        const u32 last_cid = rdl(incl_brk, 63);                          // chain 0 = the chain carried in from the previous tile
         {
-          u32 acc = 0;
+          u32 c = incl_brk - nb_l;
+#pragma unroll
+          for (int k = 0; k < (int)PW_ITEMS; k++) { c += brk[k]; cid[k] = c; }
+        }
+        for (u32 xx = lane; xx <= last_cid; xx += PW_T) s_cm[xx] = 0;
+        wsync();
+#pragma unroll
+        for (int k = 0; k < (int)PW_ITEMS; k++) if (xq[k]) s_cm[cid[k]] = 1;   // (same value from every writer)
+        wsync();
+        u32 sa[PW_ITEMS];                                                // ordered mode: a left element at or before me in my chain
+#pragma unroll
+        for (int k = 0; k < (int)PW_ITEMS; k++) sa[k] = 1;
+        if (ordered) {
+          u32 lane_brk = 0, acc = 0;
 #pragma unroll
           for (int k = 0; k < (int)PW_ITEMS; k++) {
             if (brk[k]) { acc = 0; lane_brk = 1; }
-            acc |= xq[k] | (aq[k] << 1);
-            F[k] = acc;
+            acc |= aq[k];
+            sa[k] = acc;
           }
-          u32 w = (lane_brk << 2) | acc;                                // lane summary: flag + OR behind the lane's last break
+          u32 w = (lane_brk << 1) | acc;                                // lane summary: flag + OR behind the lane's last break
 #pragma unroll
           for (int d = 1; d < 64; d <<= 1) {
             const u32 wp = __shfl_up(w, d, DCD_WAVE);
-            if (lane >= (u32)d) { if (!(w & 4u)) w |= wp & 3u; w |= wp & 4u; }
+            if (lane >= (u32)d) { if (!(w & 2u)) w |= wp & 1u; w |= wp & 2u; }
           }
           u32 inc = __shfl_up(w, 1, DCD_WAVE);
-          inc = lane == 0 ? 0u : (inc & 3u);
+          inc = lane == 0 ? 0u : (inc & 1u);
           bool before = true;                                           // no break at or before the element inside this lane
 #pragma unroll
           for (int k = 0; k < (int)PW_ITEMS; k++) {
             if (brk[k]) before = false;
-            if (before) F[k] |= inc;
+            if (before) sa[k] |= inc;
+            if (cid[k] == 0 && seenA) sa[k] = 1;
           }
         }
-        // backward: G = OR of xq from the element to the chain end
-        u32 G[PW_ITEMS];
-        {
-          u32 acc = 0, pre = 0;                                         // pre: OR over the lane's elements before its first break
-#pragma unroll
-          for (int k = (int)PW_ITEMS - 1; k >= 0; k--) {
-            acc |= xq[k];
-            G[k] = acc;
-            if (brk[k]) acc = 0;
-          }
-          pre = acc;                                                    // (what is left after the first break was passed going down)
-          u32 w = (lane_brk << 1) | pre;
-#pragma unroll
-          for (int d = 1; d < 64; d <<= 1) {
-            const u32 wn = __shfl_down(w, d, DCD_WAVE);
-            if (lane + (u32)d < 64u) { if (!(w & 2u)) w |= wn & 1u; w |= wn & 2u; }
-          }
-          u32 inc = __shfl_down(w, 1, DCD_WAVE);
-          inc = lane == 63 ? 0u : (inc & 1u);
-          bool after = true;                                            // no break behind the element inside this lane
-#pragma unroll
-          for (int k = (int)PW_ITEMS - 1; k >= 0; k--) {
-            if (after) G[k] |= inc;
-            if (brk[k]) after = false;
-          }
-        }
-        // the carried chain: does it commit once it closes?
-        u32 c0x = 0;
-#pragma unroll
-        for (int k = 0; k < (int)PW_ITEMS; k++) if (d0 + k < fb) c0x |= xq[k];
-        const bool chain0_commit = committed || (ballot64(c0x != 0) != 0);
-        if (!is_or && open && !committed && (any_brk || final_tile) && !chain0_commit) cursor = out_start;   // roll back
+        const bool chain0_commit = committed || s_cm[0] != 0;
+        if (!is_or && open && !committed && (last_cid > 0 || final_tile) && !chain0_commit) cursor = out_start;   // roll back
         u32 emit[PW_ITEMS], nemit = 0;
 #pragma unroll
         for (int k = 0; k < (int)PW_ITEMS; k++) {
@@ -763,35 +743,31 @@ __global__ __launch_bounds__(PW_T, DCD_PW_WAVES) void k_pair_parts(const PairOp*
           if (al[k] && !dup[k]) {
             if (is_or) emit[k] = 1;
             else {
-              const u32 pos = d0 + k;
-              const bool in0 = pos < fb, inlast = !any_brk || pos + 1 >= lbk;
-              const bool sa = ((F[k] >> 1) & 1u) || (in0 && seenA);
-              const bool cm = (F[k] & 1u) || (G[k] & 1u) || (in0 && committed);
-              const bool closed = !inlast || final_tile;
-              emit[k] = ((!ordered || sa) && (closed ? cm : true)) ? 1u : 0u;
+              const bool cm = s_cm[cid[k]] != 0 || (cid[k] == 0 && committed);
+              const bool closed = cid[k] < last_cid || final_tile;
+              emit[k] = (sa[k] && (closed ? cm : true)) ? 1u : 0u;
             }
           }
           nemit += emit[k];
         }
         const u32 incl_emit = wave_scan_incl(nemit);
         const u32 total_emit = rdl(incl_emit, 63);
-        u32 lfe1 = 0, lx = 0, la = 0;                 // last chain: 1 + emit offset of its first element, its flags
+        u32 lfe1 = 0, la = 0;                         // last chain: 1 + emit offset of its first element, "holds a left element"
         {
           u32 e = incl_emit - nemit;
 #pragma unroll
           for (int k = 0; k < (int)PW_ITEMS; k++) {
-            const u32 pos = d0 + k;
-            if (any_brk && pos + 1 == lbk) lfe1 = e + 1;
-            if (!any_brk || pos + 1 >= lbk) { lx |= xq[k]; la |= aq[k]; }
+            if (brk[k] && cid[k] == last_cid) lfe1 = e + 1;
+            if (cid[k] == last_cid) la |= aq[k];
             if (emit[k]) out[cursor + e] = val[k];
             e += emit[k];
           }
         }
         lfe1 = rfl(wave_max(lfe1));
         {
-          const bool com = (ballot64(lx != 0) != 0) || (!any_brk && committed);
-          const bool hasA = (ballot64(la != 0) != 0) || (!any_brk && seenA);
-          if (any_brk || !open) out_start = cursor + (lfe1 ? lfe1 - 1 : 0u);
+          const bool com = s_cm[last_cid] != 0 || (last_cid == 0 && committed);
+          const bool hasA = (ballot64(la != 0) != 0) || (last_cid == 0 && seenA);
+          if (last_cid != 0 || !open) out_start = cursor + (lfe1 ? lfe1 - 1 : 0u);
           open = 1; seenA = hasA ? 1u : 0u; committed = com ? 1u : 0u;
           cursor += total_emit;
         }
