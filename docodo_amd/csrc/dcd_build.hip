@@ -174,17 +174,34 @@ __global__ void k_img_headers(const u16* __restrict__ chars, const u32* __restri
   pay_off[r] = o;
 }
 
+// units -> image payloads.  A workgroup owns a tile of 2048 units (8 = 16 bytes per thread) and finds the tile's
+// first / last term once; 8 units of one term move as four dword stores at the payload's (arbitrary) byte alignment.
 constexpr int IMG_UPT = 8;  // units per thread
-__global__ void k_img_units(const u16* __restrict__ units, u64 n_units, const u64* __restrict__ unit_start, u64 n_terms,
-                            const u64* __restrict__ pay_off, u8* __restrict__ img) {
-  u64 u0 = ((u64)blockIdx.x * blockDim.x + threadIdx.x) * IMG_UPT;
+constexpr int IMG_THREADS = 256;
+constexpr int IMG_TILE = IMG_UPT * IMG_THREADS;
+typedef u32 __attribute__((aligned(1))) u32_a1;
+__device__ __forceinline__ u64 img_term_of(const u64* __restrict__ unit_start, u64 lo, u64 hi, u64 u) {   // last t in [lo, hi) with unit_start[t] <= u
+  while (lo + 1 < hi) { u64 m = (lo + hi) >> 1; if (unit_start[m] <= u) lo = m; else hi = m; }
+  return lo;
+}
+__global__ __launch_bounds__(IMG_THREADS) void k_img_units(const u16* __restrict__ units, u64 n_units, const u64* __restrict__ unit_start,
+                                                          u64 n_terms, const u64* __restrict__ pay_off, u8* __restrict__ img) {
+  __shared__ u64 s_t[2];
+  const u64 tile_base = (u64)blockIdx.x * IMG_TILE;
+  if (threadIdx.x == 0) s_t[0] = img_term_of(unit_start, 0, n_terms, tile_base);
+  if (threadIdx.x == 64) { u64 e = tile_base + IMG_TILE; s_t[1] = img_term_of(unit_start, 0, n_terms, (e < n_units ? e : n_units) - 1); }
+  __syncthreads();
+  const u64 u0 = tile_base + (u64)threadIdx.x * IMG_UPT;
   if (u0 >= n_units) return;
-  // term of unit u0: last t with unit_start[t] <= u0
-  u64 a = 0, b = n_terms;
-  while (a + 1 < b) { u64 m = (a + b) >> 1; if (unit_start[m] <= u0) a = m; else b = m; }
-  u64 t = a;
+  u64 t = img_term_of(unit_start, s_t[0], s_t[1] + 1, u0);
   u64 next = unit_start[t + 1];
   u64 dst = pay_off[t] + 2 * (u0 - unit_start[t]);
+  if (u0 + IMG_UPT <= next) {                      // units is 16-byte aligned at u0 (u0 is a multiple of 8)
+    const uint4 v = *reinterpret_cast<const uint4*>(units + u0);
+    u32_a1* d = reinterpret_cast<u32_a1*>(img + dst);
+    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    return;
+  }
   for (int k = 0; k < IMG_UPT; k++) {
     u64 u = u0 + k;
     if (u >= n_units) break;
@@ -1034,7 +1051,7 @@ static int32_t build_phase2(dcd_build* h) {
                        ix.term_unit_start.p, rec_off.p, V, (u64)8, h->image.p, pay_off.p);
     if (U) {
       probes.begin(DCD_K_IMG_UNITS);
-      hipLaunchKernelGGL(k_img_units, dim3((u32)div_up(div_up(U, IMG_UPT), 256)), dim3(256), 0, st, ix.units.p, U, ix.term_unit_start.p, V,
+      hipLaunchKernelGGL(k_img_units, dim3((u32)div_up(U, IMG_TILE)), dim3(IMG_THREADS), 0, st, ix.units.p, U, ix.term_unit_start.p, V,
                          pay_off.p, h->image.p);
       probes.end();
     }
