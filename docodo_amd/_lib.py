@@ -106,6 +106,12 @@ SIGNATURES = {
     "dcd_build_export_plan": (_i32, [_vp, _u32, _vp, _vp, _vp]),
     "dcd_build_export_fill": (_i32, [_vp, _vp, _vp, _vp]),
     "dcd_merge_shards": (_i32, [_i32, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _u64, C.POINTER(_vp)]),
+    "dcd_index_export_plan": (_i32, [_vp, C.c_uint32, _vp, _vp, _vp]),
+    "dcd_index_export_fill": (_i32, [_vp, _vp, _vp, _vp]),
+    "dcd_index_image": (_i32, [_vp, _vp, _sz, _vp]),
+    "dcd_index_list_image": (_i32, [_vp, _vp, _sz, _vp]),
+    "dcd_index_set_list_image": (_i32, [_vp, _vp, _sz]),
+    "dcd_index_save": (_i32, [_vp, C.c_char_p]),
     "dcd_index_set_uniform_pages": (_i32, [_vp, _u64, _u32, _u64, _vp, _sz]),
     "dcd_synth_corpus_host": (_i32, [_vp, _u64, _u64, _u32, _u32, C.c_double, _u64]),
     "dcd_synth_corpus_dev": (_i32, [_vp, _u64, _u64, _u32, _u32, C.c_double, _u64, _i32]),

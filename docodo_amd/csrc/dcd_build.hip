@@ -270,6 +270,33 @@ DeviceIndex* build_take_index(dcd_build* b) {
 int build_device(dcd_build* b) { return b->device; }
 DeviceIndex* build_peek_index(dcd_build* b) { return (b->finished && !b->adopted) ? &b->ix : nullptr; }
 hipStream_t build_stream(dcd_build* b) { return b->st; }
+int32_t index_make_image(const DeviceIndex& ix, hipStream_t st, DevBuf<u8>& image, u64* image_bytes) {
+  const int dev = ix.device;
+  DCD_TRY(ensure_device(dev));
+  const u64 V = ix.n_terms, U = ix.n_units;
+  DevBuf<u64> rec_off, pay_off, scr64b;
+  DCD_TRY(rec_off.alloc(dev, V + 1));
+  DCD_TRY(pay_off.alloc(dev, V + 1));
+  DCD_TRY(scr64b.alloc(dev, scan_scratch_elems(V ? V : 1)));
+  u64 rec_total = 0;
+  if (V) {
+    scan_exclusive_f<RecSizeF, u64>(RecSizeF{ix.term_chars.p, ix.term_str_off.p, ix.term_unit_start.p}, rec_off.p, V, scr64b.p, st);
+    DCD_HIP(hipMemcpyAsync(&rec_total, scr64b.p + scan_nblocks(V), 8, hipMemcpyDeviceToHost, st));
+  }
+  DCD_HIP(hipStreamSynchronize(st));
+  *image_bytes = 8 + rec_total;
+  DCD_TRY(image.alloc(dev, *image_bytes));
+  hipLaunchKernelGGL(k_put_u64_bytes, dim3(1), dim3(1), 0, st, image.p, ix.max_coord);
+  if (V) {
+    hipLaunchKernelGGL(k_img_headers, dim3((u32)div_up(V, 256)), dim3(256), 0, st, ix.term_chars.p, ix.term_str_off.p, ix.term_unit_start.p,
+                       rec_off.p, V, (u64)8, image.p, pay_off.p);
+    if (U) hipLaunchKernelGGL(k_img_units, dim3((u32)div_up(U, IMG_TILE)), dim3(IMG_THREADS), 0, st, ix.units.p, U, ix.term_unit_start.p, V,
+                              pay_off.p, image.p);
+  }
+  DCD_HIP(hipStreamSynchronize(st));
+  DCD_HIP(hipGetLastError());
+  return DCD_OK;
+}
 int32_t index_fetch_host(DeviceIndex& ix) {
   if (ix.host_ready) return DCD_OK;
   DCD_TRY(ensure_device(ix.device));

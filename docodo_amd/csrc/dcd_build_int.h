@@ -60,6 +60,8 @@ struct DeviceIndex {
 // downloads the host mirrors of an index a build left on the device (done on demand: a build that is only saved
 // or exported never needs them)
 int32_t index_fetch_host(DeviceIndex& ix);
+// exact ".index" bytes (Build.cs:375-386 / Appendix A.3) of a device-resident index, generated on the device
+int32_t index_make_image(const DeviceIndex& ix, hipStream_t st, DevBuf<u8>& image, u64* image_bytes);
 
 void write_list_image(const PageTable& pt, std::vector<u8>& out);  // ".index.list", Build.cs:99-118
 void utf16_to_utf8(const u16* s, size_t n, std::string& out);

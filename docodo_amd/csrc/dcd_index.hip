@@ -279,3 +279,62 @@ int32_t dcd_index_doc_name(dcd_index* h, uint32_t doc, uint16_t* out, size_t cap
 }
 
 }  // extern "C"
+
+extern "C" {
+
+// ".index" / ".index.list" of an index handle (an adopted build, a merged shard partition, a gathered index)
+int32_t dcd_index_image(dcd_index* h, uint8_t* out, size_t cap, size_t* n) {
+  if (!h || !n) DCD_FAIL(DCD_E_BADARG, "dcd_index_image: NULL argument");
+  std::lock_guard<std::mutex> guard(h->mu);
+  if (!h->image_bytes) DCD_TRY(index_make_image(h->ix, h->st, h->image, &h->image_bytes));
+  *n = (size_t)h->image_bytes;
+  if (!out || cap < h->image_bytes) return DCD_E_OVERFLOW;
+  DCD_TRY(ensure_device(h->ix.device));
+  DCD_HIP(hipMemcpy(out, h->image.p, h->image_bytes, hipMemcpyDeviceToHost));
+  return DCD_OK;
+}
+
+int32_t dcd_index_list_image(dcd_index* h, uint8_t* out, size_t cap, size_t* n) {
+  if (!h || !n) DCD_FAIL(DCD_E_BADARG, "dcd_index_list_image: NULL argument");
+  std::vector<u8> img;
+  write_list_image(h->ix.pages, img);
+  *n = img.size();
+  if (!out || cap < img.size()) return DCD_E_OVERFLOW;
+  if (!img.empty()) memcpy(out, img.data(), img.size());
+  return DCD_OK;
+}
+
+// attaches a page table given as ".index.list" bytes (Build.cs:99-148), e.g. the concatenation of the shards' lists
+int32_t dcd_index_set_list_image(dcd_index* h, const uint8_t* list_img, size_t n_list) {
+  if (!h || (!list_img && n_list)) DCD_FAIL(DCD_E_BADARG, "dcd_index_set_list_image: NULL argument");
+  std::lock_guard<std::mutex> guard(h->mu);
+  PageTable pt;
+  DCD_TRY(parse_list_image(list_img, n_list, pt));
+  h->ix.pages = std::move(pt);
+  h->ix.page_end.reset();   // rebuilt on the next query
+  return DCD_OK;
+}
+
+int32_t dcd_index_save(dcd_index* h, const char* dir_utf8) {
+  if (!h || !dir_utf8) DCD_FAIL(DCD_E_BADARG, "dcd_index_save: NULL argument");
+  size_t n = 0;
+  (void)dcd_index_image(h, nullptr, 0, &n);
+  std::vector<u8> img(n);
+  DCD_TRY(dcd_index_image(h, img.data(), img.size(), &n));
+  std::vector<u8> lst;
+  write_list_image(h->ix.pages, lst);
+  std::string d(dir_utf8);
+  if (!d.empty() && d.back() != '/') d.push_back('/');
+  const char* names[2] = {".index", ".index.list"};
+  const std::vector<u8>* data[2] = {&img, &lst};
+  for (int k = 0; k < 2; k++) {
+    FILE* f = fopen((d + names[k]).c_str(), "wb");
+    if (!f) DCD_FAIL(DCD_E_IO, "cannot create %s%s", d.c_str(), names[k]);
+    bool ok = fwrite(data[k]->data(), 1, data[k]->size(), f) == data[k]->size();
+    ok = fclose(f) == 0 && ok;
+    if (!ok) DCD_FAIL(DCD_E_IO, "short write to %s%s", d.c_str(), names[k]);
+  }
+  return DCD_OK;
+}
+
+}  // extern "C"

@@ -23,4 +23,7 @@ struct dcd_index {
   dcd::DevBuf<u32> dir;
   std::vector<u64> h_dir_off;    // [n_terms + 1]
   std::vector<u8> h_dir_shift;   // [n_terms]; 255 = no directory
+  // ".index" bytes of this index, generated on demand (dcd_index_image / dcd_index_save)
+  dcd::DevBuf<u8> image;
+  u64 image_bytes = 0;
 };

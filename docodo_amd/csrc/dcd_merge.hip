@@ -175,10 +175,13 @@ struct SegUnitsF { SegPlan p; __device__ u64 operator()(u64 q) const { return p.
 struct SegValuesF { SegPlan p; __device__ u64 operator()(u64 q) const { return p.meta[p.sorted[q].y].n_values; } };
 
 __global__ void k_merge_heads(SegPlan p, u64 n_seg, const u64* __restrict__ dst_off, const u64* __restrict__ val_off,
-                              u64* __restrict__ term_unit_start, u64* __restrict__ term_item_start) {
+                              u64* __restrict__ term_unit_start, u64* __restrict__ term_item_start, u64* __restrict__ term_first,
+                              u64* __restrict__ term_last) {
   u64 q = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= n_seg) return;
-  if (p.head(q)) { term_unit_start[p.sorted[q].x] = dst_off[q]; term_item_start[p.sorted[q].x] = val_off[q]; }
+  const u32 t = p.sorted[q].x;
+  if (p.head(q)) { term_unit_start[t] = dst_off[q]; term_item_start[t] = val_off[q]; term_first[t] = p.meta[p.sorted[q].y].first; }
+  if (q + 1 == n_seg || p.sorted[q + 1].x != t) term_last[t] = p.meta[p.sorted[q].y].last;   // last segment of the term
 }
 
 __global__ __launch_bounds__(CP_THREADS) void k_merge_copy(SegPlan p, u64 n_seg, const u64* __restrict__ dst_off, u64 total_units,
@@ -221,21 +224,18 @@ struct ExportPlan {
   DevBuf<u64> key_dst, unit_dst;
   u64 n_terms = 0, total_keys = 0, total_units = 0;
 };
-static std::map<dcd_build*, std::unique_ptr<ExportPlan>>& export_plans() {
-  static std::map<dcd_build*, std::unique_ptr<ExportPlan>> m;
+static std::map<const void*, std::unique_ptr<ExportPlan>>& export_plans() {
+  static std::map<const void*, std::unique_ptr<ExportPlan>> m;
   return m;
 }
 static std::mutex g_export_mu;
 
-extern "C" {
-
-int32_t dcd_build_export_plan(dcd_build* h, uint32_t n_owners, uint64_t* term_count, uint64_t* key_count, uint64_t* unit_count) {
-  if (!h || !term_count || !key_count || !unit_count) DCD_FAIL(DCD_E_BADARG, "dcd_build_export_plan: NULL argument");
+// export of a device-resident index (a finished build, or an index handle: the owned partition after a merge)
+static int32_t export_plan_impl(const void* h, DeviceIndex* ix, hipStream_t st, uint32_t n_owners, uint64_t* term_count, uint64_t* key_count,
+                                uint64_t* unit_count) {
   if (n_owners == 0 || n_owners > 64) DCD_FAIL(DCD_E_BADARG, "n_owners must be in [1, 64]");
-  DeviceIndex* ix = build_peek_index(h);
-  if (!ix) DCD_FAIL(DCD_E_STATE, "build is not finished (or its index was adopted)");
+  if (ix->n_terms && (!ix->term_first.p || !ix->term_last.p)) DCD_FAIL(DCD_E_STATE, "this index carries no first/last coordinates per term (loaded from files)");
   const int dev = ix->device;
-  hipStream_t st = build_stream(h);
   DCD_TRY(ensure_device(dev));
   const u64 V = ix->n_terms;
   std::unique_ptr<ExportPlan> ep(new ExportPlan());
@@ -274,8 +274,7 @@ int32_t dcd_build_export_plan(dcd_build* h, uint32_t n_owners, uint64_t* term_co
   return DCD_OK;
 }
 
-int32_t dcd_build_export_fill(dcd_build* h, void* meta_dev, uint16_t* keys_dev, uint16_t* units_dev) {
-  if (!h) DCD_FAIL(DCD_E_BADARG, "dcd_build_export_fill: NULL handle");
+static int32_t export_fill_impl(const void* h, DeviceIndex* ix, hipStream_t st, void* meta_dev, uint16_t* keys_dev, uint16_t* units_dev) {
   std::unique_ptr<ExportPlan> ep;
   {
     std::lock_guard<std::mutex> g(g_export_mu);
@@ -284,11 +283,8 @@ int32_t dcd_build_export_fill(dcd_build* h, void* meta_dev, uint16_t* keys_dev, 
     ep = std::move(it->second);
     export_plans().erase(it);
   }
-  DeviceIndex* ix = build_peek_index(h);
-  if (!ix) DCD_FAIL(DCD_E_STATE, "build is not finished (or its index was adopted)");
   const u64 V = ep->n_terms;
-  if (V && (!meta_dev || (!keys_dev && ep->total_keys) || (!units_dev && ep->total_units))) DCD_FAIL(DCD_E_BADARG, "dcd_build_export_fill: NULL buffer");
-  hipStream_t st = build_stream(h);
+  if (V && (!meta_dev || (!keys_dev && ep->total_keys) || (!units_dev && ep->total_units))) DCD_FAIL(DCD_E_BADARG, "export fill: NULL buffer");
   DCD_TRY(ensure_device(ix->device));
   if (V) {
     hipLaunchKernelGGL(k_export_meta, dim3((u32)div_up(V, 256)), dim3(256), 0, st, ep->perm.p, V, ix->term_unit_start.p, ix->term_item_start.p,
@@ -300,6 +296,29 @@ int32_t dcd_build_export_fill(dcd_build* h, void* meta_dev, uint16_t* keys_dev, 
   DCD_HIP(hipStreamSynchronize(st));
   DCD_HIP(hipGetLastError());
   return DCD_OK;
+}
+
+extern "C" {
+
+int32_t dcd_build_export_plan(dcd_build* h, uint32_t n_owners, uint64_t* term_count, uint64_t* key_count, uint64_t* unit_count) {
+  if (!h || !term_count || !key_count || !unit_count) DCD_FAIL(DCD_E_BADARG, "dcd_build_export_plan: NULL argument");
+  DeviceIndex* ix = build_peek_index(h);
+  if (!ix) DCD_FAIL(DCD_E_STATE, "build is not finished (or its index was adopted)");
+  return export_plan_impl(h, ix, build_stream(h), n_owners, term_count, key_count, unit_count);
+}
+int32_t dcd_build_export_fill(dcd_build* h, void* meta_dev, uint16_t* keys_dev, uint16_t* units_dev) {
+  if (!h) DCD_FAIL(DCD_E_BADARG, "dcd_build_export_fill: NULL handle");
+  DeviceIndex* ix = build_peek_index(h);
+  if (!ix) DCD_FAIL(DCD_E_STATE, "build is not finished (or its index was adopted)");
+  return export_fill_impl(h, ix, build_stream(h), meta_dev, keys_dev, units_dev);
+}
+int32_t dcd_index_export_plan(dcd_index* h, uint32_t n_owners, uint64_t* term_count, uint64_t* key_count, uint64_t* unit_count) {
+  if (!h || !term_count || !key_count || !unit_count) DCD_FAIL(DCD_E_BADARG, "dcd_index_export_plan: NULL argument");
+  return export_plan_impl(h, &h->ix, h->st, n_owners, term_count, key_count, unit_count);
+}
+int32_t dcd_index_export_fill(dcd_index* h, void* meta_dev, uint16_t* keys_dev, uint16_t* units_dev) {
+  if (!h) DCD_FAIL(DCD_E_BADARG, "dcd_index_export_fill: NULL handle");
+  return export_fill_impl(h, &h->ix, h->st, meta_dev, keys_dev, units_dev);
 }
 
 int32_t dcd_merge_shards(int32_t device, uint32_t n_sources, const uint64_t* term_count, const uint64_t* key_count,
@@ -364,6 +383,8 @@ int32_t dcd_merge_shards(int32_t device, uint32_t n_sources, const uint64_t* ter
   DCD_TRY(dst_off.alloc(device, M + 1)); DCD_TRY(val_off.alloc(device, M + 1));
   DCD_TRY(ix.term_unit_start.alloc(device, V + 1));
   DCD_TRY(ix.term_item_start.alloc(device, V + 1));
+  DCD_TRY(ix.term_first.alloc(device, V ? V : 1));
+  DCD_TRY(ix.term_last.alloc(device, V ? V : 1));
   u64 Uout = 0, Nout = 0;
   SegPlan sp{sorted, meta};
   if (M) {
@@ -374,7 +395,7 @@ int32_t dcd_merge_shards(int32_t device, uint32_t n_sources, const uint64_t* ter
     DCD_HIP(hipMemcpyAsync(&Nout, sscr64.p + scan_nblocks(M), 8, hipMemcpyDeviceToHost, st));
     DCD_HIP(hipStreamSynchronize(st));
     hipLaunchKernelGGL(k_merge_heads, dim3((u32)div_up(M, 256)), dim3(256), 0, st, sp, M, dst_off.p, val_off.p, ix.term_unit_start.p,
-                       ix.term_item_start.p);
+                       ix.term_item_start.p, ix.term_first.p, ix.term_last.p);
   }
   DCD_HIP(hipMemcpyAsync(ix.term_unit_start.p + V, &Uout, 8, hipMemcpyHostToDevice, st));
   DCD_HIP(hipMemcpyAsync(ix.term_item_start.p + V, &Nout, 8, hipMemcpyHostToDevice, st));

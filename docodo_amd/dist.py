@@ -47,6 +47,21 @@ def export_shard(builder, n_owners, device=None):
     return ShardExport(tc, kc, uc, meta, keys, units, builder.stats.max_coord)
 
 
+def export_index(index, n_owners=1, device=None):
+    """Export of an index handle (the owned partition after a merge): same buffers as export_shard."""
+    tc = np.zeros(n_owners, np.uint64)
+    kc = np.zeros(n_owners, np.uint64)
+    uc = np.zeros(n_owners, np.uint64)
+    check(lib().dcd_index_export_plan(index.h, n_owners, tc.ctypes.data, kc.ctypes.data, uc.ctypes.data))
+    dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+    meta = torch.empty(int(tc.sum()) * META_BYTES, dtype=torch.uint8, device=dev)
+    keys = torch.empty(int(kc.sum()) * 2, dtype=torch.uint8, device=dev)
+    units = torch.empty(int(uc.sum()) * 2, dtype=torch.uint8, device=dev)
+    check(lib().dcd_index_export_fill(index.h, meta.data_ptr() if meta.numel() else None,
+                                      keys.data_ptr() if keys.numel() else None, units.data_ptr() if units.numel() else None))
+    return ShardExport(tc, kc, uc, meta, keys, units, index.MaxCoord)
+
+
 def merge_received(term_count, key_count, unit_count, meta, keys, units, max_coord, device_index=0):
     """dcd_merge_shards on buffers that hold the sources' contributions back to back (source order)."""
     tc = np.ascontiguousarray(term_count, np.uint64)
@@ -128,6 +143,33 @@ def distributed_merge(builder, group=None, device_index=None):
     e = export_shard(builder, G)
     tc, kc, uc, meta, keys, units, mx = exchange(e, group)
     return merge_received(tc, kc, uc, meta, keys, units, mx, device_index)
+
+
+def local_gather(owned, device_index=0):
+    """Single-process stand-in for gather_index: all owned partitions -> one complete index."""
+    exports = [export_index(ix, 1) for ix in owned]
+    return local_merge(exports, 0, device_index)
+
+
+def gather_index(owned, dst=0, group=None, device_index=None):
+    """Gathers the hash partitions on rank `dst`: every rank exports its owned partition (one owner), the buffers travel
+    with all-to-all calls in which only `dst` receives, `dst` merges them (every term has exactly one segment) into the
+    complete index; its ".index" is then what a single builder writes for the whole corpus.  Returns the Index on `dst`,
+    None elsewhere.  (Attach the page table with Index.set_list_image or dist.set_uniform_pages.)"""
+    import torch.distributed as dist
+    G, me = dist.get_world_size(group), dist.get_rank(group)
+    if device_index is None:
+        device_index = torch.cuda.current_device()
+    e1 = export_index(owned, 1)
+    # re-label the single-owner export as "everything goes to dst"
+    z = np.zeros(G, np.uint64)
+    tc, kc, uc = z.copy(), z.copy(), z.copy()
+    tc[dst], kc[dst], uc[dst] = e1.term_count[0], e1.key_count[0], e1.unit_count[0]
+    e = ShardExport(tc, kc, uc, e1.meta, e1.keys, e1.units, e1.max_coord)
+    rtc, rkc, ruc, meta, keys, units, mx = exchange(e, group)
+    if me != dst:
+        return None
+    return merge_received(rtc, rkc, ruc, meta, keys, units, mx, device_index)
 
 
 def set_uniform_pages(index, n_pages, page_chars, first_doc=0, source="syn"):

@@ -300,6 +300,28 @@ class Index:
         check(lib().dcd_index_page_info(self.h, page, C.byref(end), C.byref(doc), out.ctypes.data, out.size, C.byref(n)))
         return end.value, doc.value, out[:n.value].tobytes().decode("utf-16-le", "surrogatepass")
 
+    def _image(self, fn):
+        n = C.c_size_t(0)
+        fn(self.h, None, 0, C.byref(n))
+        out = np.empty(max(1, n.value), np.uint8)
+        check(fn(self.h, out.ctypes.data, out.size, C.byref(n)))
+        return out[:n.value].tobytes()
+
+    def index_image(self):
+        """Exact ".index" bytes of this (possibly merged / gathered) index."""
+        return self._image(lib().dcd_index_image)
+
+    def list_image(self):
+        return self._image(lib().dcd_index_list_image)
+
+    def set_list_image(self, list_bytes):
+        """Attach a page table given as ".index.list" bytes (e.g. the shards' lists back to back)."""
+        lb = np.frombuffer(list_bytes, np.uint8)
+        check(lib().dcd_index_set_list_image(self.h, lb.ctypes.data if lb.size else None, lb.size))
+
+    def Save(self, dirpath):
+        check(lib().dcd_index_save(self.h, dirpath.encode("utf-8")))
+
     def doc_name(self, doc):
         out = np.empty(1024, np.uint16)
         n = C.c_size_t(0)

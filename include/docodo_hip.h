@@ -277,6 +277,18 @@ int32_t dcd_merge_shards(int32_t device, uint32_t n_sources, const uint64_t* ter
                          uint64_t max_coord, dcd_index** out);
 /* Page table of an index whose pages are uniform (synthetic corpora): n_pages pages of page_chars
  * characters starting at coordinate 0, one document per page named first_doc + p under `source`. */
+/* The owned partition after dcd_merge_shards can be exported again (same buffers as dcd_build_export_*), e.g. with
+ * n_owners = 1 to GATHER all partitions on one GPU: dcd_merge_shards over the gathered buffers (every term now has
+ * exactly one segment) gives the complete index, dcd_index_image / dcd_index_save its ".index" -- byte-identical to the
+ * one a single builder writes for the whole corpus.  The page table of a merged index is attached with
+ * dcd_index_set_list_image (concatenation of the shards' ".index.list" images, shards split at document borders) or
+ * dcd_index_set_uniform_pages. */
+int32_t dcd_index_export_plan(dcd_index* h, uint32_t n_owners, uint64_t* term_count, uint64_t* key_count, uint64_t* unit_count);
+int32_t dcd_index_export_fill(dcd_index* h, void* meta_dev, uint16_t* keys_dev, uint16_t* units_dev);
+int32_t dcd_index_image(dcd_index* h, uint8_t* out, size_t cap, size_t* n);
+int32_t dcd_index_list_image(dcd_index* h, uint8_t* out, size_t cap, size_t* n);
+int32_t dcd_index_set_list_image(dcd_index* h, const uint8_t* list_img, size_t n_list);
+int32_t dcd_index_save(dcd_index* h, const char* dir_utf8);
 int32_t dcd_index_set_uniform_pages(dcd_index* h, uint64_t n_pages, uint32_t page_chars, uint64_t first_doc,
                                     const uint16_t* source, size_t source_len);
 

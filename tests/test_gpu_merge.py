@@ -53,6 +53,32 @@ def test_fake_shards_equal_one_shot_build(oracle_mod, G, n_docs):
     assert full_img == oi and full_lst == ol
 
 
+@pytest.mark.parametrize("G,n_docs", [(2, 2000), (5, 6003)])
+def test_gathered_partitions_give_the_one_shot_index_file(G, n_docs):
+    """Doc-range shards -> per-owner merge (hash partitions) -> gather of the partitions on one GPU: ".index" and
+    ".index.list" are byte-identical to what a single builder writes for the whole corpus."""
+    import docodo_amd
+    from docodo_amd import dist, synth
+    text = synth.corpus_host(n_docs)
+    full = _build(text, n_docs)
+    bounds = [n_docs * g // G for g in range(G + 1)]
+    shards = [_build(text[bounds[g] * 1024:bounds[g + 1] * 1024], bounds[g + 1] - bounds[g], first_doc=bounds[g]) for g in range(G)]
+    exports = [dist.export_shard(b, G) for b in shards]
+    owned = [dist.local_merge(exports, o) for o in range(G)]
+    whole = dist.local_gather(owned)
+    assert whole.Count == full.stats.n_terms and whole.MaxCoord == full.stats.max_coord
+    assert whole.index_image() == full.index_image()
+    whole.set_list_image(b"".join(b.list_image() for b in shards))      # shards are split at document borders
+    assert whole.list_image() == full.list_image()
+    # the gathered index is searchable like the one-shot one
+    ref = full.Build()
+    w = synth.term(7)
+    a = whole.query_batch([docodo_amd.DCD_OP_TERM, whole.find(w), 255 + len(w)], [0, 3])
+    b = ref.query_batch([docodo_amd.DCD_OP_TERM, ref.find(w), 255 + len(w)], [0, 3])
+    for name in ("page_index", "pos", "page_rank", "doc_index", "doc_rank"):
+        assert np.array_equal(getattr(a, name), getattr(b, name)), name
+
+
 def test_merged_index_answers_queries(oracle_mod):
     """A merged (hash-partitioned) sub-index + the global page table answers its terms like the oracle."""
     import docodo_amd
