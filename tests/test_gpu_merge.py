@@ -79,6 +79,27 @@ def test_gathered_partitions_give_the_one_shot_index_file(G, n_docs):
         assert np.array_equal(getattr(a, name), getattr(b, name)), name
 
 
+def test_segmented_builder_equals_one_shot():
+    """SegmentedBuilder (the temp-index flush + MergeAll equivalent, Build.cs:335-340 / Index.cs:537-689): a device
+    corpus cut into 4 segments -> the one-shot ".index"."""
+    import torch
+    import docodo_amd
+    from docodo_amd import dist, synth
+    n_docs = 7000
+    d = torch.empty(n_docs * 1024, dtype=torch.uint8, device="cuda")
+    synth.corpus_dev(d.data_ptr(), n_docs)
+    full = docodo_amd.Builder()
+    full.AddUniformPagesDev(d.data_ptr(), n_docs, 1024)
+    full.Finish()
+    sb = dist.SegmentedBuilder(1024, max_segment_chars=2000 * 1024)
+    sb.add_pages_dev(d.data_ptr(), 3000)
+    sb.add_pages_dev(d.data_ptr() + 3000 * 1024, 4000)
+    assert len(sb.exports) == 4
+    ix = sb.finish()
+    assert ix.index_image() == full.index_image()
+    assert ix.list_image() == full.list_image()
+
+
 def test_merged_index_answers_queries(oracle_mod):
     """A merged (hash-partitioned) sub-index + the global page table answers its terms like the oracle."""
     import docodo_amd
