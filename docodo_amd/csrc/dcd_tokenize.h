@@ -331,8 +331,18 @@ __device__ __forceinline__ void tokenize_chunk(const CharT* __restrict__ text, c
     wave_sync();
     // pages starting inside the staged span
     const u64 lo = org < 0 ? 0 : (u64)org;
+    // first page offset >= lo: 64-ary search, every lane probes one candidate (log64 rounds of dependent loads instead of
+    // log2: the search runs once per wave tile in both tokeniser passes)
     u64 a = 0, b = P.n_pages + 1;
-    while (a < b) { u64 m = (a + b) >> 1; if (P.page_off[m] < lo) a = m + 1; else b = m; }
+    while (a < b) {
+      const u64 step = (b - a + 63) >> 6;
+      const u64 pp = a + (u64)lane * step + (step - 1);
+      const bool pr = pp < b && P.page_off[pp] < lo;
+      const u32 c = popc64(ballot64(pr));                    // monotone: the true lanes form a prefix
+      const u64 na = a + (u64)c * step, nb = na + step - 1;
+      a = na;
+      b = nb < b ? nb : b;
+    }
     for (u64 p = a + lane; p <= P.n_pages; p += 64) {
       u64 o = P.page_off[p];
       if ((int64_t)o >= org + TK_SPAN) break;
