@@ -5,5 +5,5 @@ from ._lib import (DCD_ENC_LATIN1, DCD_ENC_UTF16LE, DCD_OP_AND, DCD_OP_OR, DCD_O
 from .sequence import IndexSequence  # noqa: F401
 from .index import Builder, Index, SearchOptions, QueryBatchResult  # noqa: F401
 from . import synth  # noqa: F401
-from .search import Search, SearchResult  # noqa: F401
+from .search import MicroBatcher, Search, SearchResult  # noqa: F401
 from .wordcodes import WordCoder  # noqa: F401

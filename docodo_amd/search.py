@@ -217,58 +217,166 @@ class Search:
         b = self.ix.query_batch(flat[off[1]:off[2]], [0, off[2] - off[1]])
         return _TwoResults(a, b)
 
+    # -- one request = plan (host string work) + evaluation (device) + result assembly (host) ---------------------
+    def _plan(self, req, opt):
+        """-> SearchResult (nothing to evaluate: empty / syntax error) or a plan for _finish."""
+        req = _lower(req)
+        # search filter, Search.cs:455-466: every "item," of -filter: is a regex over the document names; the host
+        # evaluates the regexes (one byte per document), the device keeps filtered-out documents out of foundDocs
+        fpat = r"\B-filter:([\w\*\?\\.()+{}/]+,?)+"
+        doc_match = None
+        m = regex.search(fpat, req)
+        if m:
+            filters = [c.strip(",") for c in m.captures(1)]
+            req = regex.sub(fpat, " ", req)
+            pats = [regex.compile(_net_regex(f)) for f in filters]
+            nd = self.ix.n_docs
+            doc_match = np.fromiter((1 if any(p.search(self.ix.doc_name(d)) for p in pats) else 0 for d in range(nd)), np.uint8, nd)
+        funcs = []
+        req, fields = self._prepare(req, funcs)
+        dist = 255 if opt is None else opt.dist                            # Search.cs:472-473
+        try:
+            res = self._compile(req, funcs, dist) if len(req) > 0 else None
+            resf = self._compile(fields, funcs, dist) if len(fields) > 0 else None
+        except SyntaxError:
+            return SearchResult(False, "Syntax Error in search request")
+        if res is None:
+            res = resf
+        if res is None:
+            return SearchResult()
+        out = SearchResult()
+        out.words = [(f["word"], None) for f in funcs]
+        progs = [p[0] for p in (res, resf) if p is not None]
+        if progs[0] is None:
+            return out                                                     # empty result sequence
+        flat, off = [], [0]
+        for p in progs:
+            flat += (p if p is not None else [])
+            off.append(len(flat))
+        if len(progs) == 2 and progs[1] is None:
+            off = off[:2]
+        return {"flat": flat, "off": off, "doc_match": doc_match, "out": out, "fields": resf is not None}
+
+    def _finish(self, plan, r, q0, nq):
+        """r: batch result holding this request's nq (1 or 2) queries from index q0."""
+        out = plan["out"]
+        if r.status[q0] != 0:
+            return SearchResult(False, "Error: coordinate beyond the last page")
+        keep = None
+        if plan["fields"]:                                                 # CombineSearchResults, Search.cs:423-428
+            keep = set()
+            if nq == 2 and r.status[q0 + 1] == 0:
+                keep = {self.ix.doc_name(d) for d, _, _ in r.docs(q0 + 1)}
+        for pi, pos, rank in r.pages(q0):
+            out.foundPages.append((pi, self.ix.page_info(pi)[2], pos, rank))
+        for d, rank, npg in r.docs(q0):
+            name = self.ix.doc_name(d)
+            if keep is None or name in keep:
+                out.foundDocs.append((d, name, rank, npg))
+        return out
+
     def __call__(self, req, opt=None):
         """Index.Search(req, opt), Search.cs:437-617."""
         try:
-            req = _lower(req)
-            # search filter, Search.cs:455-466: every "item," of -filter: is a regex over the document names; the host
-            # evaluates the regexes (one byte per document), the device keeps filtered-out documents out of foundDocs
-            fpat = r"\B-filter:([\w\*\?\\.()+{}/]+,?)+"
-            doc_match = None
-            m = regex.search(fpat, req)
-            if m:
-                filters = [c.strip(",") for c in m.captures(1)]
-                req = regex.sub(fpat, " ", req)
-                pats = [regex.compile(_net_regex(f)) for f in filters]
-                nd = self.ix.n_docs
-                doc_match = np.fromiter((1 if any(p.search(self.ix.doc_name(d)) for p in pats) else 0 for d in range(nd)), np.uint8, nd)
-            funcs = []
-            req, fields = self._prepare(req, funcs)
-            dist = 255 if opt is None else opt.dist                            # Search.cs:472-473
-            try:
-                res = self._compile(req, funcs, dist) if len(req) > 0 else None
-                resf = self._compile(fields, funcs, dist) if len(fields) > 0 else None
-            except SyntaxError:
-                return SearchResult(False, "Syntax Error in search request")
-            if res is None:
-                res = resf
-            if res is None:
-                return SearchResult()
-            out = SearchResult()
-            out.words = [(f["word"], None) for f in funcs]
-            progs = [p[0] for p in (res, resf) if p is not None]
-            if progs[0] is None:
-                return out                                                     # empty result sequence
-            flat, off = [], [0]
-            for p in progs:
-                flat += (p if p is not None else [])
-                off.append(len(flat))
-            if len(progs) == 2 and progs[1] is None:
-                off = off[:2]
-            r = self._query(flat, off, doc_match, len(progs))
-            if r.status[0] != 0:
-                return SearchResult(False, "Error: coordinate beyond the last page")
-            keep = None
-            if resf is not None:                                               # CombineSearchResults, Search.cs:423-428
-                keep = set()
-                if r.n_queries == 2 and r.status[1] == 0:
-                    keep = {self.ix.doc_name(d) for d, _, _ in r.docs(1)}
-            for pi, pos, rank in r.pages(0):
-                out.foundPages.append((pi, self.ix.page_info(pi)[2], pos, rank))
-            for d, rank, npg in r.docs(0):
-                name = self.ix.doc_name(d)
-                if keep is None or name in keep:
-                    out.foundDocs.append((d, name, rank, npg))
-            return out
+            plan = self._plan(req, opt)
+            if isinstance(plan, SearchResult):
+                return plan
+            r = self._query(plan["flat"], plan["off"], plan["doc_match"], len(plan["off"]) - 1)
+            return self._finish(plan, r, 0, r.n_queries)
         except _lib.DocodoError as e:
             return SearchResult(False, "Error: %s" % e)
+
+    def search_many(self, requests, opt=None):
+        """Many requests, ONE dcd_query_batch: the reference serialises Search under a lock and serves requests from a
+        thread pool (Search.cs:448, server.cs:16-30); batching them is what feeds the GPU.  Requests with a -filter:
+        carry their own per-document mask and are evaluated on their own.  Returns the SearchResults in request order."""
+        results = [None] * len(requests)
+        plans = []
+        flat, off = [], [0]
+        for i, req in enumerate(requests):
+            try:
+                plan = self._plan(req, opt)
+            except _lib.DocodoError as e:
+                plan = SearchResult(False, "Error: %s" % e)
+            if isinstance(plan, SearchResult):
+                results[i] = plan
+            elif plan["doc_match"] is not None:
+                results[i] = self(req, opt)
+            else:
+                q0 = len(off) - 1
+                base = len(flat)
+                flat += plan["flat"]
+                off += [base + o for o in plan["off"][1:]]
+                plans.append((i, plan, q0, len(plan["off"]) - 1))
+        if plans:
+            try:
+                r = self.ix.query_batch(flat, off)
+                for i, plan, q0, nq in plans:
+                    results[i] = self._finish(plan, r, q0, nq)
+            except _lib.DocodoError as e:
+                for i, _, _, _ in plans:
+                    results[i] = SearchResult(False, "Error: %s" % e)
+        return results
+
+
+class MicroBatcher:
+    """Batched serving entry: callers on any thread submit requests and get futures; a worker thread
+    collects what arrives within `max_wait_ms` (or up to `max_batch` requests) and evaluates it with ONE
+    Search.search_many call -- the role of the REST server's request threads + DoSearchLock in the reference
+    (server.cs:24-34, Search.cs:448), turned into GPU-sized batches."""
+
+    def __init__(self, search, max_batch=4096, max_wait_ms=2.0):
+        import queue
+        import threading
+        self.search, self.max_batch, self.max_wait = search, max_batch, max_wait_ms / 1e3
+        self.q = queue.Queue()
+        self.batches = 0
+        self._stop = False
+        self.t = threading.Thread(target=self._run, daemon=True)
+        self.t.start()
+
+    def submit(self, req, opt=None):
+        from concurrent.futures import Future
+        f = Future()
+        self.q.put((req, opt, f))
+        return f
+
+    def close(self):
+        self._stop = True
+        self.q.put(None)
+        self.t.join()
+
+    def _run(self):
+        import queue
+        import time
+        while not self._stop:
+            item = self.q.get()
+            if item is None:
+                break
+            batch = [item]
+            deadline = time.perf_counter() + self.max_wait
+            while len(batch) < self.max_batch:
+                left = deadline - time.perf_counter()
+                if left <= 0:
+                    break
+                try:
+                    nxt = self.q.get(timeout=left)
+                except queue.Empty:
+                    break
+                if nxt is None:
+                    self._stop = True
+                    break
+                batch.append(nxt)
+            # requests with the same options share a call
+            groups = {}
+            for req, opt, f in batch:
+                groups.setdefault(None if opt is None else opt.dist, []).append((req, opt, f))
+            for _, items in groups.items():
+                try:
+                    res = self.search.search_many([r for r, _, _ in items], items[0][1])
+                    for (_, _, f), x in zip(items, res):
+                        f.set_result(x)
+                except Exception as e:   # noqa: BLE001 -- a failed batch must not kill the worker
+                    for _, _, f in items:
+                        f.set_exception(e)
+            self.batches += 1

@@ -264,6 +264,46 @@ def test_doc_filter_with_many_docs(oracle_mod):
             assert d == od and npg == onpg and abs(rank - orank) <= 1e-5 * max(1.0, abs(orank))
 
 
+def test_search_many_and_micro_batcher(gpu_nostem, known, oracle_mod):
+    """Many requests in ONE dcd_query_batch (Search.search_many) and through the serving micro-batcher: the same answers
+    as one call per request (incl. field queries, a filter, syntax errors, unknown words)."""
+    import threading
+    import docodo_amd
+    b, _, _, oix, _, _ = gpu_nostem
+    S = docodo_amd.Search(b_index(b))
+    reqs = [known["D2"]["req"], known["D3"]["req"], "and", "zzzzunknown", "(", "and -filter:ump", "tupman | old", '"mr pickwick"',
+            "and {Name=Dump}", "", "pickwick and tupman"] * 3
+    one = [S(r) for r in reqs]
+    many = S.search_many(reqs)
+
+    def same(a, b_):
+        assert a.Success == b_.Success and len(a.foundPages) == len(b_.foundPages) and len(a.foundDocs) == len(b_.foundDocs)
+        for x, y in zip(a.foundPages, b_.foundPages):
+            assert x[0] == y[0] and x[1] == y[1] and np.array_equal(x[2], y[2]) and x[3] == y[3]
+        assert [d[:2] for d in a.foundDocs] == [d[:2] for d in b_.foundDocs]
+
+    for a, m in zip(one, many):
+        same(a, m)
+    mb = docodo_amd.MicroBatcher(S, max_batch=64, max_wait_ms=20.0)
+    futs = [None] * len(reqs)
+
+    def work(lo, hi):
+        for i in range(lo, hi):
+            futs[i] = mb.submit(reqs[i])
+
+    n = len(reqs)
+    th = [threading.Thread(target=work, args=(j * n // 3, (j + 1) * n // 3)) for j in range(3)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    got = [f.result(timeout=60) for f in futs]
+    mb.close()
+    for a, g in zip(one, got):
+        same(a, g)
+    assert mb.batches < len(reqs)            # requests were grouped
+
+
 def test_latin1_header_pages_and_edge_lines(oracle_mod):
     """Header pages in a byte (Latin-1) build, odd header lines: short names (skipped), no trailing newline,
     CR LF line ends, '=' inside the value, digits, a line without '=' after a valid one (aborts the page
