@@ -52,6 +52,9 @@ namespace Docodo
         // Index.cs / Search.cs
         [DllImport(Lib)] public static extern int dcd_index_open([MarshalAs(UnmanagedType.LPUTF8Str)] string dir, int device, out IntPtr h);
         [DllImport(Lib)] public static extern int dcd_index_from_build(IntPtr build, out IntPtr h);
+        [DllImport(Lib)] public static extern int dcd_index_close_words(IntPtr h, char* word, UIntPtr len, uint n, uint* terms, out uint nOut);   // GetCloseWords
+        [DllImport(Lib)] public static extern int dcd_index_suggest(IntPtr h, char* prefix, UIntPtr len, uint n, uint* terms, out uint nOut);      // GetSuggessions
+        [DllImport(Lib)] public static extern int dcd_index_save(IntPtr h, [MarshalAs(UnmanagedType.LPUTF8Str)] string dir);
         [DllImport(Lib)] public static extern void dcd_index_free(IntPtr h);
         [DllImport(Lib)] public static extern int dcd_index_find(IntPtr h, char* key, UIntPtr len, out uint term);
         [DllImport(Lib)] public static extern int dcd_index_get(IntPtr h, uint term, ushort* outp, UIntPtr cap, out UIntPtr nUnits);

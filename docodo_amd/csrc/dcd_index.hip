@@ -4,10 +4,45 @@
 #include <algorithm>
 
 #include "dcd_index_int.h"
+#include "dcd_scan.h"
+#include "dcd_sort.h"
 
 namespace dcd {
 DeviceIndex* build_take_index(dcd_build* b);
 int build_device(dcd_build* b);
+}  // namespace dcd
+
+namespace dcd {
+// dictionary scan: Levenshtein distance (Index.cs:46-95) of every key to one word, one thread per key; the word sits in
+// constant kernel arguments (<= 32 units), the DP row in registers / local memory.  Output pairs (distance, term) are
+// stably sorted by distance afterwards (OrderBy(Levenshtein).Take(10), Search.cs:172).
+struct LevWord { u16 c[32]; u32 len; };
+__global__ void k_levenshtein(const u16* __restrict__ chars, const u32* __restrict__ str_off, u64 n_terms, LevWord w, uint2* __restrict__ out) {
+  u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_terms) return;
+  const u16* s = chars + str_off[t];
+  const u32 n = str_off[t + 1] - str_off[t], m = w.len;
+  u32 d = 0;
+  if (n == 0) d = m;
+  else if (m == 0) d = n;
+  else {
+    u32 row[33];
+    for (u32 j = 0; j <= m; j++) row[j] = j;
+    for (u32 i = 1; i <= n; i++) {
+      u32 diag = row[0];
+      row[0] = i;
+      const u16 si = s[i - 1];
+      for (u32 j = 1; j <= m; j++) {
+        const u32 cost = (w.c[j - 1] == si) ? 0u : 1u;
+        const u32 v = min(min(row[j] + 1u, row[j - 1] + 1u), diag + cost);
+        diag = row[j];
+        row[j] = v;
+      }
+    }
+    d = row[m];
+  }
+  out[t] = make_uint2(d, (u32)t);
+}
 }  // namespace dcd
 
 using namespace dcd;
@@ -334,6 +369,76 @@ int32_t dcd_index_save(dcd_index* h, const char* dir_utf8) {
     ok = fclose(f) == 0 && ok;
     if (!ok) DCD_FAIL(DCD_E_IO, "short write to %s%s", d.c_str(), names[k]);
   }
+  return DCD_OK;
+}
+
+}  // extern "C"
+
+extern "C" {
+
+// GetCloseWords, Search.cs:168-174: the n keys closest to `word` by Levenshtein distance (ties: dictionary order)
+int32_t dcd_index_close_words(dcd_index* h, const uint16_t* word, size_t len, uint32_t n, uint32_t* out_terms, uint32_t* n_out) {
+  if (!h || (!word && len) || !out_terms || !n_out) DCD_FAIL(DCD_E_BADARG, "dcd_index_close_words: NULL argument");
+  if (len > 32) DCD_FAIL(DCD_E_UNSUPPORTED, "words longer than 32 UTF-16 units are not indexed (MAX_WORD_LENGTH)");
+  std::lock_guard<std::mutex> guard(h->mu);
+  DeviceIndex& ix = h->ix;
+  const u64 V = ix.n_terms;
+  const u32 k = (u32)std::min<u64>(n, V);
+  *n_out = k;
+  if (!k) return DCD_OK;
+  const int dev = ix.device;
+  DCD_TRY(ensure_device(dev));
+  hipStream_t st = h->st;
+  LevWord w;
+  memset(&w, 0, sizeof w);
+  for (size_t i = 0; i < len; i++) w.c[i] = word[i];
+  w.len = (u32)len;
+  DevBuf<uint2> pa, pb;
+  DevBuf<u32> hist, sscr;
+  DCD_TRY(pa.alloc(dev, V)); DCD_TRY(pb.alloc(dev, V));
+  DCD_TRY(hist.alloc(dev, (u64)RS_MAX_BLOCKS << 10));
+  DCD_TRY(sscr.alloc(dev, scan_scratch_elems((u64)RS_MAX_BLOCKS << 10)));
+  hipLaunchKernelGGL(k_levenshtein, dim3((u32)div_up(V, 256)), dim3(256), 0, st, ix.term_chars.p, ix.term_str_off.p, V, w, pa.p);
+  uint2* sorted = rs_sort(pa.p, pb.p, nullptr, V, 7, hist.p, sscr.p, st);      // distances <= 64 + 32: 7 bits, stable
+  std::vector<uint2> top(k);
+  DCD_HIP(hipMemcpyAsync(top.data(), sorted, (size_t)k * sizeof(uint2), hipMemcpyDeviceToHost, st));
+  DCD_HIP(hipStreamSynchronize(st));
+  DCD_HIP(hipGetLastError());
+  for (u32 i = 0; i < k; i++) out_terms[i] = top[i].y;
+  return DCD_OK;
+}
+
+// Term selection of GetSuggessions, Search.cs:176-188: keys that start with `prefix`, are longer than it and whose first
+// unit is >= 'A', ordered by descending IndexSequence.Count (= number of ushort units; stable: dictionary order among
+// equals), the first n.  Keys are sorted ordinally, so the candidates are one contiguous range of the dictionary.
+int32_t dcd_index_suggest(dcd_index* h, const uint16_t* prefix, size_t len, uint32_t n, uint32_t* out_terms, uint32_t* n_out) {
+  if (!h || (!prefix && len) || !out_terms || !n_out) DCD_FAIL(DCD_E_BADARG, "dcd_index_suggest: NULL argument");
+  const DeviceIndex& ix = h->ix;
+  auto cmp_prefix = [&](u64 m) -> int {   // key m vs prefix, over the first len units
+    const u16* s = ix.h_term_chars.data() + ix.h_term_str_off[m];
+    const size_t sl = ix.h_term_str_off[m + 1] - ix.h_term_str_off[m];
+    for (size_t k = 0; k < len; k++) {
+      if (k >= sl) return -1;
+      if (s[k] != prefix[k]) return s[k] < prefix[k] ? -1 : 1;
+    }
+    return 0;
+  };
+  u64 a = 0, b = ix.n_terms;
+  while (a < b) { u64 m = (a + b) >> 1; if (cmp_prefix(m) < 0) a = m + 1; else b = m; }
+  const u64 lo = a;
+  b = ix.n_terms;
+  while (a < b) { u64 m = (a + b) >> 1; if (cmp_prefix(m) <= 0) a = m + 1; else b = m; }
+  const u64 hi = a;
+  std::vector<std::pair<u64, u32>> cand;   // (unit count, term)
+  for (u64 t = lo; t < hi; t++) {
+    const size_t sl = ix.h_term_str_off[t + 1] - ix.h_term_str_off[t];
+    if (sl <= len || ix.h_term_chars[ix.h_term_str_off[t]] < u'A') continue;
+    cand.emplace_back(ix.h_term_unit_start[t + 1] - ix.h_term_unit_start[t], (u32)t);
+  }
+  std::stable_sort(cand.begin(), cand.end(), [](const std::pair<u64, u32>& x, const std::pair<u64, u32>& y) { return x.first > y.first; });
+  const u32 k = (u32)std::min<u64>(n, cand.size());
+  for (u32 i = 0; i < k; i++) out_terms[i] = cand[i].second;
+  *n_out = k;
   return DCD_OK;
 }
 

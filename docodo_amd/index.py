@@ -300,6 +300,21 @@ class Index:
         check(lib().dcd_index_page_info(self.h, page, C.byref(end), C.byref(doc), out.ctypes.data, out.size, C.byref(n)))
         return end.value, doc.value, out[:n.value].tobytes().decode("utf-16-le", "surrogatepass")
 
+    def _term_list(self, fn, text, n):
+        a, p, ln = _u16(text)
+        out = np.empty(max(1, n), np.uint32)
+        k = C.c_uint32(0)
+        check(fn(self.h, p, ln, n, out.ctypes.data, C.byref(k)))
+        return [int(t) for t in out[:k.value]]
+
+    def close_words(self, word, n=10):
+        """GetCloseWords (Search.cs:168-174): terms of the n keys closest to `word` by Levenshtein distance."""
+        return self._term_list(lib().dcd_index_close_words, word, n)
+
+    def suggest(self, prefix, n=10):
+        """Term selection of GetSuggessions (Search.cs:176-188)."""
+        return self._term_list(lib().dcd_index_suggest, prefix, n)
+
     def _image(self, fn):
         n = C.c_size_t(0)
         fn(self.h, None, 0, C.byref(n))

@@ -217,6 +217,22 @@ class Search:
         b = self.ix.query_batch(flat[off[1]:off[2]], [0, off[2] - off[1]])
         return _TwoResults(a, b)
 
+    def GetCloseWords(self, word):
+        """Search.cs:168-174: the 10 keys closest to `word` (Levenshtein; a dictionary scan on the device)."""
+        return [self.ix.key(t) for t in self.ix.close_words(word, 10)]
+
+    def GetSuggessions(self, req, n=10):
+        """Search.cs:176-188: completions of the last word of `req`, most frequent (longest posting lists) first."""
+        if len(req) < 2:
+            return []
+        parts = [p for p in regex.split(r"\b", req) if len(p) > 0]
+        if not parts:
+            return []
+        last = _lower(parts[-1])
+        if len(last) < 2:
+            return []
+        return [self.ix.key(t)[len(last):] for t in self.ix.suggest(last, n)]
+
     # -- one request = plan (host string work) + evaluation (device) + result assembly (host) ---------------------
     def _plan(self, req, opt):
         """-> SearchResult (nothing to evaluate: empty / syntax error) or a plan for _finish."""

@@ -197,6 +197,12 @@ int32_t dcd_index_key(dcd_index* h, uint32_t term, uint16_t* out, size_t cap, si
 /* this[key]: the posting list's units (Index.cs:255-263) */
 int32_t dcd_index_get(dcd_index* h, uint32_t term, uint16_t* out, size_t cap, size_t* n_units);
 int32_t dcd_index_term_count(dcd_index* h, uint32_t term, uint64_t* n_values);   /* Count() */
+/* GetCloseWords, Search.cs:168-174 (Levenshtein, Index.cs:46-95): the n keys closest to `word`, ties in dictionary
+ * order -- a dictionary scan on the device (one thread per key, stable radix sort by distance) */
+int32_t dcd_index_close_words(dcd_index* h, const uint16_t* word, size_t len, uint32_t n, uint32_t* out_terms, uint32_t* n_out);
+/* term selection of GetSuggessions, Search.cs:176-188: keys starting with `prefix`, longer than it, first unit >= 'A',
+ * by descending IndexSequence.Count (ushort units), the first n */
+int32_t dcd_index_suggest(dcd_index* h, const uint16_t* prefix, size_t len, uint32_t n, uint32_t* out_terms, uint32_t* n_out);
 int32_t dcd_index_page_info(dcd_index* h, uint64_t page, uint64_t* end_coord, uint32_t* doc,
                             uint16_t* id_out, size_t id_cap, size_t* id_len);
 int32_t dcd_index_doc_name(dcd_index* h, uint32_t doc, uint16_t* out, size_t cap, size_t* len);

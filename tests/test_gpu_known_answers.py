@@ -264,6 +264,38 @@ def test_doc_filter_with_many_docs(oracle_mod):
             assert d == od and npg == onpg and abs(rank - orank) <= 1e-5 * max(1.0, abs(orank))
 
 
+def test_close_words_and_suggestions(gpu_nostem):
+    """GetCloseWords (Levenshtein scan over the dictionary, Search.cs:168-174) and GetSuggessions (Search.cs:176-188)
+    against a plain-Python restatement over the same keys."""
+    import docodo_amd
+    b, _, _, _, _, _ = gpu_nostem
+    ix = b_index(b)
+    S = docodo_amd.Search(ix)
+    keys = [ix.key(t) for t in range(ix.Count)]
+
+    def lev(s, t):
+        if not s:
+            return len(t)
+        if not t:
+            return len(s)
+        row = list(range(len(t) + 1))
+        for i in range(1, len(s) + 1):
+            diag, row[0] = row[0], i
+            for j in range(1, len(t) + 1):
+                v = min(row[j] + 1, row[j - 1] + 1, diag + (0 if s[i - 1] == t[j - 1] else 1))
+                diag, row[j] = row[j], v
+        return row[len(t)]
+
+    for w in ("pikwick", "tupmann", "ld", "", "winkle", "&nam", "zzzzzzzzzzzzzzzzzzzzzzzzzzzzzzzz"):
+        want = [k for _, _, k in sorted((lev(k, w), i, k) for i, k in enumerate(keys))[:10]]
+        assert S.GetCloseWords(w) == want, w
+    for req in ("mr pi", "the tu", "x", "snod", "and wi", "&n", "12"):
+        last = [p for p in __import__("regex").split(r"\b", req) if p][-1].lower()
+        cand = [(-(len(ix.get(t).units)), t) for t, k in enumerate(keys) if len(last) >= 2 and k[0] >= "A" and k.startswith(last) and len(k) > len(last)]
+        want = [keys[t][len(last):] for _, t in sorted(cand)[:10]] if len(req) >= 2 else []
+        assert S.GetSuggessions(req) == want, req
+
+
 def test_search_many_and_micro_batcher(gpu_nostem, known, oracle_mod):
     """Many requests in ONE dcd_query_batch (Search.search_many) and through the serving micro-batcher: the same answers
     as one call per request (incl. field queries, a filter, syntax errors, unknown words)."""
