@@ -217,6 +217,7 @@ __device__ void part_gallop(const u64* __restrict__ Sv, u64 ns, const u64* __res
   u32* r_s0 = rec_lds + 3 * PW_TILE;                          // [PW_TILE] first S index emitted (relative to i0)
   u32* r_s1 = rec_lds + 4 * PW_TILE;                          // [PW_TILE] last S index emitted (inclusive, relative to i0)
   u32* r_n = rec_lds + 5 * PW_TILE;                           // [PW_TILE] emitted values (0 = not a leader / nothing)
+  u16* g_list = reinterpret_cast<u16*>(rec_lds + 6 * PW_TILE);  // [PW_TILE] element slots of the elements that walk their chain
   u64 cursor = 0, slot = 0;
   bool have_slot = false;
   for (u64 i0 = i_begin; i0 < i_end; i0 += PW_TILE) {
@@ -334,14 +335,34 @@ __device__ void part_gallop(const u64* __restrict__ Sv, u64 ns, const u64* __res
           rgt[q] = min(hsn ? sn[q] : ~0ull, hln ? ln[q] : ~0ull);
         }
       }
+      // The few elements that do have a neighbour are compacted into a list and walked with one lane each: walking them
+      // where they stand would run the (long, divergent) chain code once per element slot with a single active lane.
+      u32 n_list = 0;
 #pragma unroll
       for (int q = 0; q < (int)PW_ITEMS; q++) {
-        if (!act[q]) continue;
         const u32 k = lane + (u32)q * PW_T;
         const bool left_far = lft[q] == ~0ull || sv[q] - lft[q] > (u64)absR;
         const bool right_far = rgt[q] == ~0ull || rgt[q] - sv[q] > (u64)absR;
-        if (left_far && right_far) { r_b[k] = 0; r_d[k] = 0; r_s0[k] = k; r_s1[k] = k; r_n[k] = 0; }
-        else general(i0 + k, k, ilv[q]);
+        const bool walk = act[q] && !(left_far && right_far);
+        if (act[q] && !walk) { r_b[k] = 0; r_d[k] = 0; r_s0[k] = k; r_s1[k] = k; r_n[k] = 0; }
+        const u64 m = ballot64(walk);
+        if (walk) g_list[n_list + mbcnt(m)] = (u16)k;
+        n_list += popc64(m);
+      }
+      wsync();
+      for (u32 b0 = 0; b0 < n_list; b0 += PW_T) {
+        if (b0 + lane < n_list) {
+          const u32 k = g_list[b0 + lane];
+          const u64 s = Sv[i0 + k];
+          u64 il;                                              // first L >= s, located again (cheaper than keeping it in LDS)
+          if (ldir) {
+            const u64 c = min(s >> ldir_shift, ldir_last);
+            u64 lo = ldir[c], hi = ldir[c + 1];
+            while (lo < hi) { u64 m = (lo + hi) >> 1; if (Lv[m] < s) lo = m + 1; else hi = m; }
+            il = lo;
+          } else il = lower_bound_u64(Lv, nl, s);
+          general(i0 + k, k, il);
+        }
       }
     }
     __syncthreads();
@@ -425,7 +446,7 @@ __global__ __launch_bounds__(PW_T, DCD_PW_WAVES) void k_pair_parts(const PairOp*
                                                     const u64* __restrict__ counts, u64* __restrict__ tmp, u64* __restrict__ part_count,
                                                     u64* __restrict__ part_src, u64 PART, const u32* __restrict__ dirs,
                                                     u64 dir_max_coord, const u8* __restrict__ op_mode) {
-  constexpr u32 RAW_WORDS = 6u * PW_TILE + 16u;
+  constexpr u32 RAW_WORDS = 6u * PW_TILE + PW_TILE / 2u + 16u;   // rings + chain flags, or the gallop records + walk list
   __shared__ __attribute__((aligned(16))) u32 s_raw[RAW_WORDS];
   u64* sA = reinterpret_cast<u64*>(s_raw);
   u64* sB = sA + PW_TILE;
