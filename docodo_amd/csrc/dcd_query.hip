@@ -814,9 +814,11 @@ __global__ __launch_bounds__(256) void k_pair_gather(const PairOp* __restrict__ 
                                                     const u64* __restrict__ excl, const u64* __restrict__ tmp, u64* __restrict__ pool) {
   const u32 lane = lane_id();
   const u64 gw = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = ((u64)gridDim.x * blockDim.x) >> 6;
-  for (u64 base = gw * 64; base < W; base += nw * 64) {
+  const u64 W_act = min(W, part_base[n_ops]);              // work items the device plan really used
+  const u32 grp = lane >> 3, sub = lane & 7u;
+  for (u64 base = gw * 64; base < W_act; base += nw * 64) {
     const u64 w = base + lane;
-    const u64 c = w < W ? part_count[w] : 0;
+    const u64 c = w < W_act ? part_count[w] : 0;
     u64 so = 0, dof = 0;
     if (c) {
       u32 lo = 0, hi = n_ops;
@@ -824,14 +826,24 @@ __global__ __launch_bounds__(256) void k_pair_gather(const PairOp* __restrict__ 
       so = ops[lo].tmp_off + part_src[w];
       dof = ops[lo].out_off + (excl[w] - excl[part_base[lo]]);
     }
-    u64 m = ballot64(c != 0);
-    while (m) {
-      const u32 b = (u32)__builtin_ctzll(m);
-      m &= m - 1;
-      const u64 cc = rdl64(c, b);
-      const u64* sp = tmp + rdl64(so, b);
-      u64* dp = pool + rdl64(dof, b);
-      for (u64 k = lane; k < cc; k += 64) dp[k] = sp[k];
+    // non-empty items are copied eight at a time, eight lanes (64 bytes per step) each
+    const u64 m = ballot64(c != 0);
+    const u32 rank = mbcnt(m), nnz = popc64(m);
+    for (u32 b0 = 0; b0 < nnz; b0 += 8) {
+      u32 src = 64;
+#pragma unroll
+      for (u32 gi = 0; gi < 8; gi++) {
+        const u64 mg = ballot64(c != 0 && rank == b0 + gi);
+        const u32 l = mg ? (u32)__builtin_ctzll(mg) : 64u;
+        if (grp == gi) src = l;
+      }
+      const bool have = src < 64;
+      const u64 cc = shfl64(c, have ? src : 0), so_ = shfl64(so, have ? src : 0), dof_ = shfl64(dof, have ? src : 0);
+      if (have) {
+        const u64* sp = tmp + so_;
+        u64* dp = pool + dof_;
+        for (u64 k = sub; k < cc; k += 8) dp[k] = sp[k];
+      }
     }
   }
 }
