@@ -88,3 +88,53 @@ def test_full_size_shards_merge_equals_one_shot(full_build):
         assert merged.term_count(t) == ref.term_count(t)
         total += merged.term_count(t)
     assert total == st.n_postings
+
+
+def test_medium_index_queries_against_oracle(oracle_mod):
+    """200 k docs (27 M postings): three-term AND queries that include the most frequent terms (multi-partition streaming
+    merges, galloping through the cell directories) and exact two-word phrases, all against the oracle's batch evaluation:
+    found pages / positions / documents counts for every query, complete results (positions, ranks) for a sample."""
+    import docodo_amd
+    from docodo_amd import synth
+    n = 200_000
+    text = synth.corpus_host(n)
+    off = np.arange(n + 1, dtype=np.uint64) * synth.DOC_BYTES
+    b = docodo_amd.Builder()
+    b.AddPages(text, off, docs_per_page=True)
+    b.Finish()
+    ix = b.Build()
+    oix = oracle_mod.Index(stemmers=[])
+    oix.load(b.index_image(), b.list_image())
+    T, A = docodo_amd.DCD_OP_TERM, docodo_amd.DCD_OP_AND
+    prog, poff, reqs = [], [0], []
+    for qi, row in enumerate(synth.query_ranks(120, 3, lo_rank=1)):
+        ws = [synth.term(int(k)) for k in row]
+        ts = [ix.find(w) for w in ws]
+        if any(t is None for t in ts):
+            continue
+        for k, (w, t) in enumerate(zip(ws, ts)):
+            prog += [T, t, 255 + len(w)]
+            if k:
+                prog.append(A)
+        poff.append(len(prog))
+        reqs.append((" ".join(ws), None))
+    for qi, row in enumerate(synth.query_ranks(60, 2, lo_rank=1, seed=77)):
+        ws = [synth.term(int(k)) for k in row]
+        ts = [ix.find(w) for w in ws]
+        if any(t is None for t in ts):
+            continue
+        for k, (w, t) in enumerate(zip(ws, ts)):
+            prog += [T, t, -(len(w) + 4)]
+            if k:
+                prog.append(A)
+        poff.append(len(prog))
+        reqs.append(('"' + " ".join(ws) + '"', oracle_mod.SearchOptions(dist=0)))
+    res = ix.query_batch(prog, poff)
+    o_pages, o_pos, o_docs, _ = oix.query_batch(prog, poff)
+    assert np.array_equal(np.diff(res.page_off), o_pages)
+    assert np.array_equal(np.diff(res.doc_off), o_docs)
+    got_pos = np.array([int(res.pos_off[int(res.page_off[q + 1])]) - int(res.pos_off[int(res.page_off[q])]) for q in range(res.n_queries)], np.uint64)
+    assert np.array_equal(got_pos, o_pos)
+    from test_gpu_query import _check_result
+    for q in range(0, len(reqs), 9):
+        _check_result(res, q, oix.search(reqs[q][0], reqs[q][1]))
