@@ -22,6 +22,8 @@ namespace Docodo
                                     public ulong* seq_off; public ushort* seq_units; public int* seq_R; public float ms_device; }
 
         [DllImport(Lib)] public static extern int dcd_last_error(byte* buf, UIntPtr cap);
+        [DllImport(Lib)] public static extern int dcd_version();
+        [DllImport(Lib)] public static extern int dcd_device_count(out int n);
 
         // IndexSequence.cs
         [DllImport(Lib)] public static extern int dcd_seq_encode(ulong* values, UIntPtr n, ushort* outp, UIntPtr cap, out UIntPtr nUnits);
@@ -49,7 +51,33 @@ namespace Docodo
         [DllImport(Lib)] public static extern int dcd_build_set_codes(IntPtr h, uint* codeOff, UIntPtr nWords, uint* strOff, char* chars, UIntPtr nEntries);
         [DllImport(Lib)] public static extern int dcd_build_finish(IntPtr h);
         [DllImport(Lib)] public static extern int dcd_build_save(IntPtr h, [MarshalAs(UnmanagedType.LPUTF8Str)] string dir);
+        [DllImport(Lib)] public static extern int dcd_build_add_pages_dev(IntPtr h, void* textDev, ulong nChars, ulong* pageOffHost, UIntPtr nPages,
+                                                                          int docsPerPage, ulong firstDoc, char* src, UIntPtr srcLen);
+        [DllImport(Lib)] public static extern int dcd_build_add_uniform_pages_dev(IntPtr h, void* textDev, ulong nPages, uint pageChars, ulong firstDoc,
+                                                                                  char* src, UIntPtr srcLen);
+        [DllImport(Lib)] public static extern int dcd_build_get_stats(IntPtr h, void* stats);   // dcd_build_stats, include/docodo_hip.h
+        [DllImport(Lib)] public static extern int dcd_build_index_image(IntPtr h, byte* outp, UIntPtr cap, out UIntPtr n);
+        [DllImport(Lib)] public static extern int dcd_build_list_image(IntPtr h, byte* outp, UIntPtr cap, out UIntPtr n);
+        // doc-range shards (Index.cs:537-752): export -> exchange (RCCL, outside the library) -> merge; gather -> one .index
+        [DllImport(Lib)] public static extern int dcd_build_export_plan(IntPtr h, uint nOwners, ulong* termCount, ulong* keyCount, ulong* unitCount);
+        [DllImport(Lib)] public static extern int dcd_build_export_fill(IntPtr h, void* metaDev, ushort* keysDev, ushort* unitsDev);
+        [DllImport(Lib)] public static extern int dcd_index_export_plan(IntPtr h, uint nOwners, ulong* termCount, ulong* keyCount, ulong* unitCount);
+        [DllImport(Lib)] public static extern int dcd_index_export_fill(IntPtr h, void* metaDev, ushort* keysDev, ushort* unitsDev);
+        [DllImport(Lib)] public static extern int dcd_merge_shards(int device, uint nSources, ulong* termCount, ulong* keyCount, ulong* unitCount,
+                                                                   void* metaDev, ushort* keysDev, ushort* unitsDev, ulong maxCoord, out IntPtr index);
         // Index.cs / Search.cs
+        [DllImport(Lib)] public static extern int dcd_index_from_images(byte* indexImg, UIntPtr nIndex, byte* listImg, UIntPtr nList, int device, out IntPtr h);
+        [DllImport(Lib)] public static extern int dcd_index_count(IntPtr h, out ulong nTerms);       // Index.Count
+        [DllImport(Lib)] public static extern int dcd_index_max_coord(IntPtr h, out ulong v);        // Index.MaxCoord
+        [DllImport(Lib)] public static extern int dcd_index_n_pages(IntPtr h, out ulong n);
+        [DllImport(Lib)] public static extern int dcd_index_n_docs(IntPtr h, out ulong n);
+        [DllImport(Lib)] public static extern int dcd_index_key(IntPtr h, uint term, char* outp, UIntPtr cap, out UIntPtr len);
+        [DllImport(Lib)] public static extern int dcd_index_page_info(IntPtr h, ulong page, out ulong endCoord, out uint doc, char* id, UIntPtr cap, out UIntPtr len);
+        [DllImport(Lib)] public static extern int dcd_index_doc_name(IntPtr h, uint doc, char* outp, UIntPtr cap, out UIntPtr len);
+        [DllImport(Lib)] public static extern int dcd_index_image(IntPtr h, byte* outp, UIntPtr cap, out UIntPtr n);
+        [DllImport(Lib)] public static extern int dcd_index_list_image(IntPtr h, byte* outp, UIntPtr cap, out UIntPtr n);
+        [DllImport(Lib)] public static extern int dcd_index_set_list_image(IntPtr h, byte* listImg, UIntPtr nList);
+        [DllImport(Lib)] public static extern int dcd_index_set_uniform_pages(IntPtr h, ulong nPages, uint pageChars, ulong firstDoc, char* src, UIntPtr srcLen);
         [DllImport(Lib)] public static extern int dcd_index_open([MarshalAs(UnmanagedType.LPUTF8Str)] string dir, int device, out IntPtr h);
         [DllImport(Lib)] public static extern int dcd_index_from_build(IntPtr build, out IntPtr h);
         [DllImport(Lib)] public static extern int dcd_index_close_words(IntPtr h, char* word, UIntPtr len, uint n, uint* terms, out uint nOut);   // GetCloseWords
