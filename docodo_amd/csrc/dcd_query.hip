@@ -549,12 +549,15 @@ __global__ __launch_bounds__(PW_T, DCD_PW_WAVES) void k_pair_parts(const PairOp*
         const u32 keepA = ra - ca, keepB = rb - cb;
         const u32 nra = (u32)min((u64)PW_TILE, na - ia - ca), nrb = (u32)min((u64)PW_TILE, nb - ib - cb);
         const u32 newA = nra - keepA, newB = nrb - keepB;
-        u64 pfA[PW_ITEMS], pfB[PW_ITEMS];
+        // newA + newB <= PW_TILE (a tile frees ca + cb slots): ONE stream of PW_ITEMS loads per lane covers both operands
+        u64 pf[PW_ITEMS];
+        const u64* srcA = A + ia + ra;
+        const u64* srcB = B + ib + rb - newA;
 #pragma unroll
         for (int q = 0; q < (int)PW_ITEMS; q++) {
           const u32 xx = lane + (u32)q * PW_T;
-          pfA[q] = xx < newA ? A[ia + ra + xx] : 0;
-          pfB[q] = xx < newB ? B[ib + rb + xx] : 0;
+          const u64* sp = xx < newA ? srcA : srcB;
+          pf[q] = xx < newA + newB ? sp[xx] : 0;
         }
         PROF(3);   // half-cleaner, refill request
 #pragma unroll
@@ -603,9 +606,9 @@ __global__ __launch_bounds__(PW_T, DCD_PW_WAVES) void k_pair_parts(const PairOp*
         wsync();
 #pragma unroll
         for (int q = 0; q < (int)PW_ITEMS; q++) {
-          const u32 x = lane + (u32)q * PW_T;
-          if (x < newA) sA[(hA + ra + x) & (PW_TILE - 1)] = pfA[q];
-          if (x < newB) sB[(hB + rb + x) & (PW_TILE - 1)] = pfB[q];
+          const u32 x = lane + (u32)q * PW_T;                 // sB = sA + PW_TILE
+          const u32 slot = x < newA ? ((hA + ra + x) & (PW_TILE - 1)) : (PW_TILE + ((hB + rb + x - newA) & (PW_TILE - 1)));
+          if (x < newA + newB) sA[slot] = pf[q];
         }
         PROF(6);   // refill store (waits for the HBM loads)
         // the tile's last element (all lanes)
