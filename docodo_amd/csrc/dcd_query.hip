@@ -1503,29 +1503,37 @@ void dcd_query_default_opts(dcd_query_opts* o) {
   o->n_doc_match = 0;
 }
 
-// Worst-case work-pool elements a query needs (every operator result can be as long as both operands).
+// Worst-case device elements a query needs: every operator result can be as long as both operands (work pool), plus
+// the scratch arena, which is shared by the operators of one round (the largest round counts).
 static u64 query_pool_need(const DeviceIndex& ix, const int32_t* prog, u64 a, u64 b) {
-  std::vector<u64> stk;
+  std::vector<std::pair<u64, int>> stk;   // (capacity, round)
+  std::vector<u64> round_cap;
   u64 need = 0;
   for (u64 i = a; i < b;) {
     int32_t opc = prog[i];
     if (opc == DCD_OP_TERM) {
       if (i + 3 > b) break;
       int64_t t = prog[i + 1];
-      stk.push_back((t >= 0 && (u64)t < ix.n_terms) ? ix.h_term_item_start[t + 1] - ix.h_term_item_start[t] : 0);
+      stk.emplace_back((t >= 0 && (u64)t < ix.n_terms) ? ix.h_term_item_start[t + 1] - ix.h_term_item_start[t] : 0, 0);
       i += 3;
     } else if (opc == DCD_OP_SETR) {
       i += 2;
     } else {
       if (stk.size() < 2) break;
-      u64 y = stk.back(); stk.pop_back();
-      u64 x = stk.back(); stk.pop_back();
-      stk.push_back(x + y);
-      need += 2 * (x + y);            // result + the round's scratch region
+      auto y = stk.back(); stk.pop_back();
+      auto x = stk.back(); stk.pop_back();
+      const int r = std::max(x.second, y.second) + 1;
+      const u64 cap = x.first + y.first;
+      stk.emplace_back(cap, r);
+      if ((int)round_cap.size() < r) round_cap.resize(r, 0);
+      round_cap[r - 1] += cap;
+      need += cap;
       i += 1;
     }
   }
-  return need;
+  u64 mx = 0;
+  for (u64 c : round_cap) mx = std::max(mx, c);
+  return need + mx;
 }
 
 static void append_results(dcd_results& dst, const dcd_results& src) {
@@ -1564,13 +1572,14 @@ int32_t dcd_query_batch(dcd_index* h, const int32_t* prog, const uint64_t* prog_
   if (opts) o = *opts; else dcd_query_default_opts(&o);
   std::lock_guard<std::mutex> guard(h->mu);
   DCD_TRY(ensure_device(h->ix.device));
-  // The work pool is sized for the worst case of every operator; batches whose worst case exceeds a
-  // quarter of the free HBM are evaluated in consecutive sub-batches (results are concatenated).
+  // The work pool and the scratch arena are sized for the worst case of every operator; a batch whose worst case exceeds
+  // three quarters of the free HBM (incl. the library's device cache) is evaluated in consecutive sub-batches (results are
+  // concatenated).  Fewer, larger sub-batches are better -- every one costs ~0.7 ms of launches and host round trips --
+  // and if a sub-batch still runs out of memory (result arrays, fragmentation) it is retried with half the budget.
   size_t free_b = 0, total_b = 0;
   DCD_HIP(hipMemGetInfo(&free_b, &total_b));
-  // blocks released into the library's device cache are available too (dev_alloc trims the cache when hipMalloc fails)
   const u64 avail_b = (u64)free_b + (u64)dev_pool_cached_bytes(h->ix.device);
-  u64 budget = std::max<u64>(avail_b / 4 / 8, 1ull << 24);   // elements of 8 bytes
+  u64 budget = std::max<u64>(avail_b / 4 * 3 / 8, 1ull << 24);   // elements of 8 bytes
   if (const char* e = getenv("DOCODO_QUERY_POOL_ELEMS")) budget = std::max<u64>(strtoull(e, nullptr, 10), 1);   // tests
   std::unique_ptr<dcd_results> R(new dcd_results());
   size_t q0 = 0;
@@ -1584,17 +1593,23 @@ int32_t dcd_query_batch(dcd_index* h, const int32_t* prog, const uint64_t* prog_
       acc += need;
       q1++;
     }
+    int32_t st;
     if (q0 == 0 && q1 == n_queries) {                      // the common case: one sub-batch, no copies
-      DCD_TRY(run_batch(h, prog, prog_off, n_queries, o, R.get(), nullptr, nullptr));
-      break;
+      R.reset(new dcd_results());
+      st = run_batch(h, prog, prog_off, n_queries, o, R.get(), nullptr, nullptr);
+      if (st == DCD_OK) break;
+    } else {
+      single = false;
+      std::vector<u64> off(q1 - q0 + 1);
+      for (size_t k = 0; k <= q1 - q0; k++) off[k] = prog_off[q0 + k] - prog_off[q0];
+      dcd_results part;
+      st = run_batch(h, prog + prog_off[q0], off.data(), q1 - q0, o, &part, nullptr, nullptr);
+      if (st == DCD_OK) { append_results(*R, part); q0 = q1; continue; }
     }
+    if (st != DCD_E_NOMEM || q1 - q0 <= 1 || budget <= (1ull << 24)) return st;
+    dev_pool_trim(h->ix.device);                           // out of memory: release the cache, halve the budget, try again
+    budget /= 2;
     single = false;
-    std::vector<u64> off(q1 - q0 + 1);
-    for (size_t k = 0; k <= q1 - q0; k++) off[k] = prog_off[q0 + k] - prog_off[q0];
-    dcd_results part;
-    DCD_TRY(run_batch(h, prog + prog_off[q0], off.data(), q1 - q0, o, &part, nullptr, nullptr));
-    append_results(*R, part);
-    q0 = q1;
   }
   *out = R.release();
   return DCD_OK;
