@@ -1370,7 +1370,7 @@ static int32_t run_batch(dcd_index* h, const int32_t* prog, const u64* prog_off,
   DevBuf<u64> d_pbase, d_sbase, d_dbase, sscr;
   DCD_TRY(d_qc.alloc(dev, nq ? nq : 1));
   DCD_TRY(d_pbase.alloc(dev, nq + 1)); DCD_TRY(d_sbase.alloc(dev, nq + 1)); DCD_TRY(d_dbase.alloc(dev, nq + 1));
-  DCD_TRY(sscr.alloc(dev, scan_scratch_elems(nq ? nq : 1)));
+  DCD_TRY(sscr.alloc(dev, 3 * scan_scratch_elems(nq ? nq : 1)));
   DCD_HIP(hipStreamSynchronize(st));
 
   EvTimer tm;
@@ -1396,19 +1396,23 @@ static int32_t run_batch(dcd_index* h, const int32_t* prog, const u64* prog_off,
   if (nq) {
     hipLaunchKernelGGL((k_result<false>), dim3((u32)nq), dim3(RS_T), 0, st, d_fin.p, (u32)nq, idx_values, pool.p, counts.p, P, d_qc.p,
                        nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+    // three scans on separate scratch, totals copied to the host together: one round trip instead of three
+    const u64 se = scan_scratch_elems(nq), sn = scan_nblocks(nq);
     scan_exclusive_f<QcPagesF, u64>(QcPagesF{d_qc.p}, d_pbase.p, nq, sscr.p, st);
-    DCD_HIP(hipMemcpyAsync(&tot_pages, sscr.p + scan_nblocks(nq), 8, hipMemcpyDeviceToHost, st));
+    scan_exclusive_f<QcPosF, u64>(QcPosF{d_qc.p}, d_sbase.p, nq, sscr.p + se, st);
+    scan_exclusive_f<QcDocsF, u64>(QcDocsF{d_qc.p}, d_dbase.p, nq, sscr.p + 2 * se, st);
+    DCD_HIP(hipMemcpyAsync(d_pbase.p + nq, sscr.p + sn, 8, hipMemcpyDeviceToDevice, st));
+    DCD_HIP(hipMemcpyAsync(d_sbase.p + nq, sscr.p + se + sn, 8, hipMemcpyDeviceToDevice, st));
+    DCD_HIP(hipMemcpyAsync(d_dbase.p + nq, sscr.p + 2 * se + sn, 8, hipMemcpyDeviceToDevice, st));
+    DCD_HIP(hipMemcpyAsync(&tot_pages, sscr.p + sn, 8, hipMemcpyDeviceToHost, st));
+    DCD_HIP(hipMemcpyAsync(&tot_pos, sscr.p + se + sn, 8, hipMemcpyDeviceToHost, st));
+    DCD_HIP(hipMemcpyAsync(&tot_docs, sscr.p + 2 * se + sn, 8, hipMemcpyDeviceToHost, st));
     DCD_HIP(hipStreamSynchronize(st));
-    scan_exclusive_f<QcPosF, u64>(QcPosF{d_qc.p}, d_sbase.p, nq, sscr.p, st);
-    DCD_HIP(hipMemcpyAsync(&tot_pos, sscr.p + scan_nblocks(nq), 8, hipMemcpyDeviceToHost, st));
-    DCD_HIP(hipStreamSynchronize(st));
-    scan_exclusive_f<QcDocsF, u64>(QcDocsF{d_qc.p}, d_dbase.p, nq, sscr.p, st);
-    DCD_HIP(hipMemcpyAsync(&tot_docs, sscr.p + scan_nblocks(nq), 8, hipMemcpyDeviceToHost, st));
-    DCD_HIP(hipStreamSynchronize(st));
+  } else {
+    DCD_HIP(hipMemsetAsync(d_pbase.p, 0, 8, st));
+    DCD_HIP(hipMemsetAsync(d_sbase.p, 0, 8, st));
+    DCD_HIP(hipMemsetAsync(d_dbase.p, 0, 8, st));
   }
-  DCD_HIP(hipMemcpyAsync(d_pbase.p + nq, &tot_pages, 8, hipMemcpyHostToDevice, st));
-  DCD_HIP(hipMemcpyAsync(d_sbase.p + nq, &tot_pos, 8, hipMemcpyHostToDevice, st));
-  DCD_HIP(hipMemcpyAsync(d_dbase.p + nq, &tot_docs, 8, hipMemcpyHostToDevice, st));
   DevBuf<u32> o_page_index, o_doc_index_tmp, o_doc_first, o_doc_index, o_doc_np;
   DevBuf<u64> o_pos_off;
   DevBuf<int32_t> o_pos;
