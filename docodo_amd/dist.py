@@ -114,12 +114,17 @@ def exchange(export, group=None):
                            export.units.cpu(), export.max_coord)
         tc, kc, uc, meta, keys, units, mx = exchange(host, group)
         return tc, kc, uc, meta.to(dev), keys.to(dev), units.to(dev), mx
-    counts = torch.tensor(np.stack([export.term_count, export.key_count, export.unit_count], 1).astype(np.int64), device=dev)
-    rcounts = torch.empty_like(counts)
-    dist.all_to_all_single(rcounts, counts, group=group)          # row s = what source s sends to me
-    rc = rcounts.cpu().numpy().astype(np.uint64)
-    mx = torch.tensor([int(export.max_coord)], dtype=torch.int64, device=dev)
-    dist.all_reduce(mx, op=dist.ReduceOp.MAX, group=group)
+    # ONE small all-gather tells every rank all the split sizes and the global MaxCoord (one collective and one host
+    # round trip instead of an all-to-all + an all-reduce with a sync each)
+    mine = np.concatenate([np.stack([export.term_count, export.key_count, export.unit_count], 1).astype(np.int64).ravel(),
+                           np.array([int(export.max_coord)], np.int64)])
+    mine_t = torch.from_numpy(mine).to(dev)
+    all_t = torch.empty(G * mine.size, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(all_t, mine_t, group=group)
+    allc = all_t.cpu().numpy().reshape(G, 3 * G + 1)
+    me = dist.get_rank(group)
+    rc = allc[:, :3 * G].reshape(G, G, 3)[:, me, :].astype(np.uint64)      # row s = what source s sends to me
+    mx_val = int(allc[:, 3 * G].max())
     out = []
     for buf, send, recv in ((export.meta, export.term_count * META_BYTES, rc[:, 0] * META_BYTES),
                             (export.keys, export.key_count * 2, rc[:, 1] * 2),
@@ -131,7 +136,7 @@ def exchange(export, group=None):
     if dev.type == "cuda":
         # the collectives ran on torch's stream; the library works on its own streams
         torch.cuda.current_stream(dev).synchronize()
-    return rc[:, 0].copy(), rc[:, 1].copy(), rc[:, 2].copy(), out[0], out[1], out[2], int(mx.item())
+    return rc[:, 0].copy(), rc[:, 1].copy(), rc[:, 2].copy(), out[0], out[1], out[2], mx_val
 
 
 def distributed_merge(builder, group=None, device_index=None):
