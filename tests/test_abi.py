@@ -81,3 +81,33 @@ def test_shift_is_host_side_and_matches_oracle(oracle_mod):
         q = docodo_amd.IndexSequence(u.copy())
         q.Shift(s)
         assert np.array_equal(q.units, o.seq_shift(u, s))
+
+
+def _build_abi_demo(tmp_path):
+    import subprocess
+    exe = str(tmp_path / "abi_demo")
+    libdir = os.path.join(ROOT, "docodo_amd")
+    subprocess.run(["gcc", "-std=c11", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "abi_demo.c"),
+                    "-L", libdir, "-ldocodo_hip", "-Wl,-rpath," + libdir, "-o", exe], check=True)
+    return exe
+
+
+def test_header_is_plain_c_and_the_demo_links(tmp_path):
+    """include/docodo_hip.h compiles as C11 and examples/abi_demo.c links against the shared library: the boundary
+    needs neither C++ nor Python nor torch on the caller's side.  Without a GPU the program fails loudly."""
+    import subprocess
+    import torch
+    exe = _build_abi_demo(tmp_path)
+    if not torch.cuda.is_available():
+        r = subprocess.run([exe, str(tmp_path)], capture_output=True, text=True)
+        assert r.returncode == 1 and "failed: status" in r.stderr     # DCD_E_HIP from the first compute call, no fallback
+
+
+@pytest.mark.gpu
+def test_abi_demo_runs_from_plain_c(tmp_path):
+    import subprocess
+    exe = _build_abi_demo(tmp_path)
+    r = subprocess.run([exe, str(tmp_path)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.strip().endswith("ok")
+    assert os.path.exists(tmp_path / ".index") and os.path.exists(tmp_path / ".index.list")
