@@ -1598,6 +1598,11 @@ int32_t dcd_query_batch(dcd_index* h, const int32_t* prog, const uint64_t* prog_
       q1++;
     }
     int32_t st;
+    const char* inj = getenv("DOCODO_QUERY_TEST_NOMEM");   // tests: pretend that sub-batches of more than n queries do not fit
+    if (inj && q1 - q0 > (size_t)atoll(inj)) {
+      set_error("injected out-of-memory (DOCODO_QUERY_TEST_NOMEM)");
+      st = DCD_E_NOMEM;
+    } else
     if (q0 == 0 && q1 == n_queries) {                      // the common case: one sub-batch, no copies
       R.reset(new dcd_results());
       st = run_batch(h, prog, prog_off, n_queries, o, R.get(), nullptr, nullptr);
@@ -1610,9 +1615,9 @@ int32_t dcd_query_batch(dcd_index* h, const int32_t* prog, const uint64_t* prog_
       st = run_batch(h, prog + prog_off[q0], off.data(), q1 - q0, o, &part, nullptr, nullptr);
       if (st == DCD_OK) { append_results(*R, part); q0 = q1; continue; }
     }
-    if (st != DCD_E_NOMEM || q1 - q0 <= 1 || budget <= (1ull << 24)) return st;
-    dev_pool_trim(h->ix.device);                           // out of memory: release the cache, halve the budget, try again
-    budget /= 2;
+    if (st != DCD_E_NOMEM || q1 - q0 <= 1) return st;
+    dev_pool_trim(h->ix.device);                           // out of memory: release the cache, halve the sub-batch, try again
+    budget = std::max<u64>(1, std::min(budget, acc) / 2);
     single = false;
   }
   *out = R.release();
