@@ -71,5 +71,29 @@ class IndexSequence:
 
     __and__ = __mul__          # operator &, IndexSequence.cs:205-215
 
+    @property
+    def order(self):  # IndexSequence.cs:161: "exact" sequence
+        return self.R < 0
+
+    @order.setter
+    def order(self, value):  # (the reference's setter keeps the sign: `(order ? -1 : 1) * Math.Abs(R)`, the VALUE is ignored)
+        self.R = (-1 if self.R < 0 else 1) * abs(self.R)
+
+    def Write(self, stream):  # IndexSequence.cs:167-173: i32 count of ushort units + the units, little endian
+        import struct
+        stream.write(struct.pack("<i", int(self.units.size)))
+        stream.write(np.ascontiguousarray(self.units, "<u2").tobytes())
+
+    def Read(self, stream):  # IndexSequence.cs:175-188 (a short read leaves the sequence unchanged, as the swallowed exception does)
+        import struct
+        head = stream.read(4)
+        if len(head) < 4:
+            return
+        n = struct.unpack("<i", head)[0]
+        data = stream.read(2 * n) if n > 0 else b""
+        if n < 0 or len(data) < 2 * n:
+            return
+        self.units = np.frombuffer(data, "<u2").astype(np.uint16)
+
     def __add__(self, other):  # operator +, IndexSequence.cs:286-322
         return self._binop(_lib.lib().dcd_seq_or, other)
