@@ -245,6 +245,20 @@ class Index:
         check(fn(self.h, C.byref(v)))
         return v.value
 
+    # -- the reference's public surface (Index.cs:124-263, Search.cs:430-437) on top of the handle ------------------
+    @property
+    def CanSearch(self):          # Index.cs: true once an index is loaded / built
+        return bool(self.h)
+
+    def Dispose(self):            # Index.cs:247-251
+        self.close()
+
+    def Search(self, req, opt=None, get_word_codes=None):   # Index.Search(string, SearchOptions), Search.cs:437
+        from .search import Search
+        if getattr(self, "_search", None) is None or get_word_codes is not None:
+            self._search = Search(self, get_word_codes=get_word_codes)
+        return self._search(req, opt)
+
     @property
     def Count(self):
         return self._u64(lib().dcd_index_count)
@@ -283,7 +297,7 @@ class Index:
         check(lib().dcd_index_get(self.h, term, out.ctypes.data, out.size, C.byref(n)))
         return IndexSequence(out[:n.value].copy())
 
-    def __getitem__(self, key):  # Index.cs:255
+    def __getitem__(self, key):  # IndexSequence this[string key], Index.cs:255-263 (SortedList indexer: a missing key throws)
         t = self.find(key)
         if t is None:
             raise KeyError(key)

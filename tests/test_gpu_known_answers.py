@@ -264,6 +264,19 @@ def test_doc_filter_with_many_docs(oracle_mod):
             assert d == od and npg == onpg and abs(rank - orank) <= 1e-5 * max(1.0, abs(orank))
 
 
+def test_index_surface_this_key_and_search(gpu_nostem, known, oracle_mod):
+    """Index.this[key] (Index.cs:255-263; the SortedList indexer throws for a missing key) and Index.Search(req)."""
+    import docodo_amd
+    b, _, _, oix, _, _ = gpu_nostem
+    ix = b_index(b)
+    assert ix.CanSearch
+    s = ix["pickwick"]
+    assert np.array_equal(s.units, oix.get("pickwick"))
+    with pytest.raises(KeyError):
+        ix["zzzzunknown"]
+    _same(ix.Search(known["D2"]["req"]), oix.search(known["D2"]["req"]))
+
+
 def test_close_words_and_suggestions(gpu_nostem):
     """GetCloseWords (Levenshtein scan over the dictionary, Search.cs:168-174) and GetSuggessions (Search.cs:176-188)
     against a plain-Python restatement over the same keys."""
