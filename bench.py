@@ -123,7 +123,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--docs", type=int, default=1_000_000, help="documents per GPU (1 KiB each)")
-    ap.add_argument("--cpu-docs", type=int, default=200_000, help="documents in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-docs", type=int, default=500_000, help="documents in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--queries", type=int, default=10_000, help="single-term queries of configs[1] (0 = skip the query leg)")
     ap.add_argument("--and3", type=int, default=20_000, help="3-term AND queries in the extra query batch")
     args = ap.parse_args()
