@@ -244,7 +244,7 @@ def main():
             bq, _ = step()
             img, lst = (bq.index_image(), bq.list_image()) if args.cpu_docs > 0 else (None, None)
             ixq = bq.Build()
-            out["queries"] = query_bench(ixq, args.queries, args.and3, 200 if args.cpu_docs > 0 else 0, img, lst)
+            out["queries"] = query_bench(ixq, args.queries, args.and3, 3000 if args.cpu_docs > 0 else 0, img, lst)
             ixq.close()
             bq.close()
     if world > 1 and args.queries > 0:
