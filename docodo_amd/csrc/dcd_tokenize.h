@@ -172,13 +172,31 @@ struct Chunk<u16> {
       }
     }
     L = D = 0;
+    // pure-ASCII waves (English text in a C# string) are classified arithmetically, two characters per 32-bit operation,
+    // with ONE wave-uniform branch; anything else goes through the Unicode tables (two gathers per character)
+    if (__any(((w[0] | w[1] | w[2] | w[3] | w[4] | w[5] | w[6] | w[7]) & 0xFF80FF80u) != 0u)) {
 #pragma unroll
-    for (int k = 0; k < NW; k++) {
-      u32 c0 = tab.lower[w[k] & 0xFFFFu], c1 = tab.lower[w[k] >> 16];
-      u32 k0 = tab.cls[c0], k1 = tab.cls[c1];
-      w[k] = c0 | (c1 << 16);
-      L |= ((k0 & 1u) | ((k1 & 1u) << 1)) << (2 * k);
-      D |= (((k0 >> 1) & 1u) | (((k1 >> 1) & 1u) << 1)) << (2 * k);
+      for (int k = 0; k < NW; k++) {
+        u32 c0 = tab.lower[w[k] & 0xFFFFu], c1 = tab.lower[w[k] >> 16];
+        u32 k0 = tab.cls[c0], k1 = tab.cls[c1];
+        w[k] = c0 | (c1 << 16);
+        L |= ((k0 & 1u) | ((k1 & 1u) << 1)) << (2 * k);
+        D |= (((k0 >> 1) & 1u) | (((k1 >> 1) & 1u) << 1)) << (2 * k);
+      }
+    } else {
+      // x >= a per 16-bit field (x, a < 0x8000): bit 15 of ((x | 0x8000) - a); no borrow crosses the fields
+      auto ge2 = [](u32 x, u32 a) -> u32 { return ((x | 0x80008000u) - a * 0x00010001u) & 0x80008000u; };
+#pragma unroll
+      for (int k = 0; k < NW; k++) {
+        const u32 x = w[k];
+        const u32 up = ge2(x, 'A') & ~ge2(x, 'Z' + 1);          // upper-case letters: + 0x20
+        const u32 l = x + (up >> 10);
+        const u32 lf = ge2(l, 'a') & ~ge2(l, 'z' + 1);
+        const u32 df = ge2(x, '0') & ~ge2(x, '9' + 1);
+        w[k] = l;
+        L |= (((lf >> 15) & 1u) | ((lf >> 30) & 2u)) << (2 * k);
+        D |= (((df >> 15) & 1u) | ((df >> 30) & 2u)) << (2 * k);
+      }
     }
   }
 };
