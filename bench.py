@@ -236,7 +236,7 @@ def main():
         }
         if world > 1:
             out["exchange_merge_ms_per_step_rank0"] = round(float(np.mean(merge_ms[args.warmup:])), 3)
-            out["config"]["exchange"] = "RCCL all-to-all of per-term segments (meta, keys, units) to owner = hash(key) % world, then dcd_merge_shards"
+            out["config"]["exchange"] = "RCCL all-to-all of per-term segments (meta, keys, units) to owner = hash(key) % world; dcd_merge_begin overlaps the unit exchange, then dcd_merge_finish"
         if world == 1 and args.cpu_docs > 0:
             out["cpu_baseline"] = cpu_baseline(min(args.cpu_docs, D))
         if world == 1 and args.queries > 0:

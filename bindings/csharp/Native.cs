@@ -65,6 +65,11 @@ namespace Docodo
         [DllImport(Lib)] public static extern int dcd_index_export_fill(IntPtr h, void* metaDev, ushort* keysDev, ushort* unitsDev);
         [DllImport(Lib)] public static extern int dcd_merge_shards(int device, uint nSources, ulong* termCount, ulong* keyCount, ulong* unitCount,
                                                                    void* metaDev, ushort* keysDev, ushort* unitsDev, ulong maxCoord, out IntPtr index);
+        // the same merge in two halves: begin needs only meta + keys and can run while the units are still in flight
+        [DllImport(Lib)] public static extern int dcd_merge_begin(int device, uint nSources, ulong* termCount, ulong* keyCount, ulong* unitCount,
+                                                                  void* metaDev, ushort* keysDev, ulong maxCoord, out IntPtr merge);
+        [DllImport(Lib)] public static extern int dcd_merge_finish(IntPtr merge, ushort* unitsDev, out IntPtr index);
+        [DllImport(Lib)] public static extern void dcd_merge_free(IntPtr merge);
         // Index.cs / Search.cs
         [DllImport(Lib)] public static extern int dcd_index_from_images(byte* indexImg, UIntPtr nIndex, byte* listImg, UIntPtr nList, int device, out IntPtr h);
         [DllImport(Lib)] public static extern int dcd_index_count(IntPtr h, out ulong nTerms);       // Index.Count

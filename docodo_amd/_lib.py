@@ -106,6 +106,9 @@ SIGNATURES = {
     "dcd_build_export_plan": (_i32, [_vp, _u32, _vp, _vp, _vp]),
     "dcd_build_export_fill": (_i32, [_vp, _vp, _vp, _vp]),
     "dcd_merge_shards": (_i32, [_i32, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _u64, C.POINTER(_vp)]),
+    "dcd_merge_begin": (_i32, [_i32, _u32, _vp, _vp, _vp, _vp, _vp, _u64, C.POINTER(_vp)]),
+    "dcd_merge_finish": (_i32, [_vp, _vp, C.POINTER(_vp)]),
+    "dcd_merge_free": (None, [_vp]),
     "dcd_index_close_words": (_i32, [_vp, _vp, _sz, C.c_uint32, _vp, _vp]),
     "dcd_index_suggest": (_i32, [_vp, _vp, _sz, C.c_uint32, _vp, _vp]),
     "dcd_index_export_plan": (_i32, [_vp, C.c_uint32, _vp, _vp, _vp]),

@@ -321,17 +321,32 @@ int32_t dcd_index_export_fill(dcd_index* h, void* meta_dev, uint16_t* keys_dev, 
   return export_fill_impl(h, &h->ix, h->st, meta_dev, keys_dev, units_dev);
 }
 
-int32_t dcd_merge_shards(int32_t device, uint32_t n_sources, const uint64_t* term_count, const uint64_t* key_count,
-                         const uint64_t* unit_count, const void* meta_dev, const uint16_t* keys_dev, const uint16_t* units_dev,
-                         uint64_t max_coord, dcd_index** out) {
-  if (!term_count || !key_count || !unit_count || !out) DCD_FAIL(DCD_E_BADARG, "dcd_merge_shards: NULL argument");
+// A merge in two halves: everything that needs only the segment table and the keys (vocabulary, ordinal ranks, output
+// layout, term strings, host mirrors), then the one kernel that touches the posting units -- so that a caller can run
+// the first half while the units are still in flight on the fabric.
+struct dcd_merge {
+  std::unique_ptr<dcd_index> h;
+  DevBuf<uint2> pa, pb;
+  DevBuf<u64> dst_off, src_off;
+  SegPlan sp{nullptr, nullptr};
+  u64 M = 0, U = 0, Uout = 0;
+};
+
+int32_t dcd_merge_begin(int32_t device, uint32_t n_sources, const uint64_t* term_count, const uint64_t* key_count,
+                        const uint64_t* unit_count, const void* meta_dev, const uint16_t* keys_dev, uint64_t max_coord,
+                        dcd_merge** out) {
+  if (!term_count || !key_count || !unit_count || !out) DCD_FAIL(DCD_E_BADARG, "dcd_merge_begin: NULL argument");
   DCD_TRY(ensure_device(device));
   u64 M = 0, K = 0, U = 0;
   for (u32 s = 0; s < n_sources; s++) { M += term_count[s]; K += key_count[s]; U += unit_count[s]; }
-  if (M && (!meta_dev || (!keys_dev && K) || (!units_dev && U))) DCD_FAIL(DCD_E_BADARG, "dcd_merge_shards: NULL buffer");
+  if (M && (!meta_dev || (!keys_dev && K))) DCD_FAIL(DCD_E_BADARG, "dcd_merge_begin: NULL buffer");
   if (((uintptr_t)keys_dev & 3) != 0) DCD_FAIL(DCD_E_BADARG, "keys buffer must be 4-byte aligned");
   if (M >= (1ull << 32)) DCD_FAIL(DCD_E_OVERFLOW, "too many segments");
-  std::unique_ptr<dcd_index> h(new dcd_index());
+  std::unique_ptr<dcd_merge> mg(new dcd_merge());
+  mg->h.reset(new dcd_index());
+  std::unique_ptr<dcd_index>& h = mg->h;
+  DevBuf<uint2>&pa = mg->pa, &pb = mg->pb;
+  DevBuf<u64>&dst_off = mg->dst_off, &src_off = mg->src_off;
   DCD_HIP(hipStreamCreateWithFlags(&h->st, hipStreamNonBlocking));
   hipStream_t st = h->st;
   DeviceIndex& ix = h->ix;
@@ -339,14 +354,13 @@ int32_t dcd_merge_shards(int32_t device, uint32_t n_sources, const uint64_t* ter
   ix.max_coord = max_coord;
   const dcd_term_meta* meta = (const dcd_term_meta*)meta_dev;
 
-  DevBuf<u64> key_off, src_off, sscr64;
+  DevBuf<u64> key_off, sscr64;
   DCD_TRY(key_off.alloc(device, M + 1)); DCD_TRY(src_off.alloc(device, M + 1));
   DCD_TRY(sscr64.alloc(device, scan_scratch_elems(M ? M : 1)));
   u64 V = 0;
   VocabRanks vr;
   DevBuf<u64> slots;
   DevBuf<u32> flags, slot_excl, hist, sscr32;
-  DevBuf<uint2> pa, pb;
   DCD_TRY(flags.alloc(device, 4));
   DCD_TRY(hist.alloc(device, (u64)RS_MAX_BLOCKS << 10));
   DCD_TRY(pa.alloc(device, M ? M : 1)); DCD_TRY(pb.alloc(device, M ? M : 1));
@@ -379,7 +393,7 @@ int32_t dcd_merge_shards(int32_t device, uint32_t n_sources, const uint64_t* ter
     sorted = rs_sort(pa.p, pb.p, vr.rank_of_slot.p, M, (int)log2_ceil(V ? V : 1), hist.p, sscr32.p, st);
   }
   // output offsets
-  DevBuf<u64> dst_off, val_off;
+  DevBuf<u64> val_off;
   DCD_TRY(dst_off.alloc(device, M + 1)); DCD_TRY(val_off.alloc(device, M + 1));
   DCD_TRY(ix.term_unit_start.alloc(device, V + 1));
   DCD_TRY(ix.term_item_start.alloc(device, V + 1));
@@ -400,9 +414,6 @@ int32_t dcd_merge_shards(int32_t device, uint32_t n_sources, const uint64_t* ter
   DCD_HIP(hipMemcpyAsync(ix.term_unit_start.p + V, &Uout, 8, hipMemcpyHostToDevice, st));
   DCD_HIP(hipMemcpyAsync(ix.term_item_start.p + V, &Nout, 8, hipMemcpyHostToDevice, st));
   DCD_TRY(ix.units.alloc(device, Uout ? Uout : 1));
-  if (Uout)
-    hipLaunchKernelGGL(k_merge_copy, dim3((u32)div_up(Uout, CP_TILE)), dim3(CP_THREADS), 0, st, sp, M, dst_off.p, Uout, src_off.p, units_dev,
-                       ix.units.p);
   // keys in rank order
   DCD_TRY(ix.term_str_off.alloc(device, V + 1));
   u32 total_chars = 0;
@@ -427,8 +438,36 @@ int32_t dcd_merge_shards(int32_t device, uint32_t n_sources, const uint64_t* ter
   DCD_HIP(hipMemcpy(ix.h_term_str_off.data(), ix.term_str_off.p, (V + 1) * 4, hipMemcpyDeviceToHost));
   DCD_HIP(hipMemcpy(ix.h_term_unit_start.data(), ix.term_unit_start.p, (V + 1) * 8, hipMemcpyDeviceToHost));
   DCD_HIP(hipMemcpy(ix.h_term_item_start.data(), ix.term_item_start.p, (V + 1) * 8, hipMemcpyDeviceToHost));
-  *out = h.release();
+  mg->sp = sp; mg->M = M; mg->U = U; mg->Uout = Uout;
+  *out = mg.release();
   return DCD_OK;
+}
+
+int32_t dcd_merge_finish(dcd_merge* m, const uint16_t* units_dev, dcd_index** out) {
+  if (!m || !out) DCD_FAIL(DCD_E_BADARG, "dcd_merge_finish: NULL argument");
+  std::unique_ptr<dcd_merge> mg(m);   // consumed whatever happens
+  if (!units_dev && mg->U) DCD_FAIL(DCD_E_BADARG, "dcd_merge_finish: NULL units buffer");
+  dcd_index* h = mg->h.get();
+  DCD_HIP(hipSetDevice(h->ix.device));
+  if (mg->Uout) {
+    hipLaunchKernelGGL(k_merge_copy, dim3((u32)div_up(mg->Uout, CP_TILE)), dim3(CP_THREADS), 0, h->st, mg->sp, mg->M, mg->dst_off.p, mg->Uout,
+                       mg->src_off.p, units_dev, h->ix.units.p);
+    DCD_HIP(hipStreamSynchronize(h->st));
+    DCD_HIP(hipGetLastError());
+  }
+  *out = mg->h.release();
+  return DCD_OK;
+}
+
+void dcd_merge_free(dcd_merge* m) { delete m; }
+
+int32_t dcd_merge_shards(int32_t device, uint32_t n_sources, const uint64_t* term_count, const uint64_t* key_count,
+                         const uint64_t* unit_count, const void* meta_dev, const uint16_t* keys_dev, const uint16_t* units_dev,
+                         uint64_t max_coord, dcd_index** out) {
+  if (!out) DCD_FAIL(DCD_E_BADARG, "dcd_merge_shards: NULL argument");
+  dcd_merge* m = nullptr;
+  DCD_TRY(dcd_merge_begin(device, n_sources, term_count, key_count, unit_count, meta_dev, keys_dev, max_coord, &m));
+  return dcd_merge_finish(m, units_dev, out);
 }
 
 int32_t dcd_index_set_uniform_pages(dcd_index* h, uint64_t n_pages, uint32_t page_chars, uint64_t first_doc, const uint16_t* source,

@@ -62,8 +62,13 @@ def export_index(index, n_owners=1, device=None):
     return ShardExport(tc, kc, uc, meta, keys, units, index.MaxCoord)
 
 
-def merge_received(term_count, key_count, unit_count, meta, keys, units, max_coord, device_index=0):
-    """dcd_merge_shards on buffers that hold the sources' contributions back to back (source order)."""
+def merge_received(term_count, key_count, unit_count, meta, keys, units, max_coord, device_index=0, two_phase=False):
+    """dcd_merge_shards on buffers that hold the sources' contributions back to back (source order);
+    two_phase=True goes through dcd_merge_begin / dcd_merge_finish instead (same result)."""
+    if two_phase:
+        if meta.is_cuda:
+            torch.cuda.current_stream(meta.device).synchronize()
+        return PendingMerge(term_count, key_count, unit_count, meta, keys, max_coord, device_index).finish(units)
     tc = np.ascontiguousarray(term_count, np.uint64)
     kc = np.ascontiguousarray(key_count, np.uint64)
     uc = np.ascontiguousarray(unit_count, np.uint64)
@@ -77,13 +82,40 @@ def merge_received(term_count, key_count, unit_count, meta, keys, units, max_coo
     return Index(h)
 
 
+class PendingMerge:
+    """dcd_merge_begin / dcd_merge_finish: vocabulary, ranks and output layout from the segment table and the keys
+    alone, then the unit copy -- the first half overlaps the all-to-all of the posting units (see `distributed_merge`)."""
+
+    def __init__(self, term_count, key_count, unit_count, meta, keys, max_coord, device_index=0):
+        tc = np.ascontiguousarray(term_count, np.uint64)
+        kc = np.ascontiguousarray(key_count, np.uint64)
+        uc = np.ascontiguousarray(unit_count, np.uint64)
+        self._keep = (meta, keys)            # the segment table is read again by finish
+        self.h = C.c_void_p()
+        check(lib().dcd_merge_begin(device_index, tc.size, tc.ctypes.data, kc.ctypes.data, uc.ctypes.data,
+                                    meta.data_ptr() if meta.numel() else None, keys.data_ptr() if keys.numel() else None,
+                                    int(max_coord), C.byref(self.h)))
+
+    def finish(self, units):
+        h, self.h = self.h, None
+        out = C.c_void_p()
+        check(lib().dcd_merge_finish(h, units.data_ptr() if units.numel() else None, C.byref(out)))
+        self._keep = None
+        return Index(out)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().dcd_merge_free(self.h)
+            self.h = None
+
+
 def _split_offsets(counts):
     off = np.zeros(len(counts) + 1, np.int64)
     off[1:] = np.cumsum(np.asarray(counts, np.int64))
     return off
 
 
-def local_merge(exports, owner, device_index=0):
+def local_merge(exports, owner, device_index=0, two_phase=False):
     """Single-process stand-in for the all-to-all: gathers, from every shard's export, the slice that
     belongs to `owner` (in shard order) and merges it.  Used by the single-GPU tests: G fake shards on
     one device must reproduce the one-shot build."""
@@ -97,10 +129,10 @@ def local_merge(exports, owner, device_index=0):
         unitss.append(e.units[uo[owner]:uo[owner + 1]])
         tc[s], kc[s], uc[s] = e.term_count[owner], e.key_count[owner], e.unit_count[owner]
     meta, keys, units = torch.cat(metas), torch.cat(keyss), torch.cat(unitss)
-    return merge_received(tc, kc, uc, meta, keys, units, max(e.max_coord for e in exports), device_index)
+    return merge_received(tc, kc, uc, meta, keys, units, max(e.max_coord for e in exports), device_index, two_phase)
 
 
-def exchange(export, group=None):
+def exchange(export, group=None, overlap=False):
     """All-to-all of the three export buffers.  Works on CUDA tensors with the nccl (= RCCL) backend
     and on CPU tensors with gloo (plumbing tests).  Returns (term_count, key_count, unit_count per
     SOURCE, meta, keys, units received, global max_coord)."""
@@ -113,7 +145,9 @@ def exchange(export, group=None):
         host = ShardExport(export.term_count, export.key_count, export.unit_count, export.meta.cpu(), export.keys.cpu(),
                            export.units.cpu(), export.max_coord)
         tc, kc, uc, meta, keys, units, mx = exchange(host, group)
-        return tc, kc, uc, meta.to(dev), keys.to(dev), units.to(dev), mx
+        res = (tc, kc, uc, meta.to(dev), keys.to(dev), units.to(dev), mx)
+        torch.cuda.current_stream(dev).synchronize()
+        return res + ((lambda: None),) if overlap else res
     # ONE small all-gather tells every rank all the split sizes and the global MaxCoord (one collective and one host
     # round trip instead of an all-to-all + an all-reduce with a sync each)
     mine = np.concatenate([np.stack([export.term_count, export.key_count, export.unit_count], 1).astype(np.int64).ravel(),
@@ -125,18 +159,34 @@ def exchange(export, group=None):
     me = dist.get_rank(group)
     rc = allc[:, :3 * G].reshape(G, G, 3)[:, me, :].astype(np.uint64)      # row s = what source s sends to me
     mx_val = int(allc[:, 3 * G].max())
-    out = []
-    for buf, send, recv in ((export.meta, export.term_count * META_BYTES, rc[:, 0] * META_BYTES),
-                            (export.keys, export.key_count * 2, rc[:, 1] * 2),
-                            (export.units, export.unit_count * 2, rc[:, 2] * 2)):
+    bufs = ((export.meta, export.term_count * META_BYTES, rc[:, 0] * META_BYTES),
+            (export.keys, export.key_count * 2, rc[:, 1] * 2),
+            (export.units, export.unit_count * 2, rc[:, 2] * 2))
+    out, works = [], []
+    for buf, send, recv in bufs:
         r = torch.empty(int(recv.sum()), dtype=torch.uint8, device=dev)
-        dist.all_to_all_single(r, buf, output_split_sizes=[int(x) for x in recv], input_split_sizes=[int(x) for x in send],
-                               group=group)
+        w = dist.all_to_all_single(r, buf, output_split_sizes=[int(x) for x in recv], input_split_sizes=[int(x) for x in send],
+                                   group=group, async_op=overlap)
         out.append(r)
+        works.append(w)
+    counts = (rc[:, 0].copy(), rc[:, 1].copy(), rc[:, 2].copy())
+    if overlap:
+        # the collectives of one communicator run in issue order: once meta and keys have landed the caller may start
+        # dcd_merge_begin while the (much larger) unit exchange is still on the fabric; `wait_units` ends it
+        _host_wait(works[0], dev)
+        _host_wait(works[1], dev)
+        return counts + (out[0], out[1], out[2], mx_val, lambda: _host_wait(works[2], dev))
     if dev.type == "cuda":
         # the collectives ran on torch's stream; the library works on its own streams
         torch.cuda.current_stream(dev).synchronize()
-    return rc[:, 0].copy(), rc[:, 1].copy(), rc[:, 2].copy(), out[0], out[1], out[2], mx_val
+    return counts + (out[0], out[1], out[2], mx_val)
+
+
+def _host_wait(work, dev):
+    """Blocks the HOST until an async collective has finished (the library's streams know nothing of torch's)."""
+    work.wait()                      # nccl: orders torch's current stream after the collective; gloo: blocks
+    if dev.type == "cuda":
+        torch.cuda.current_stream(dev).synchronize()
 
 
 def distributed_merge(builder, group=None, device_index=None):
@@ -146,8 +196,11 @@ def distributed_merge(builder, group=None, device_index=None):
     if device_index is None:
         device_index = torch.cuda.current_device()
     e = export_shard(builder, G)
-    tc, kc, uc, meta, keys, units, mx = exchange(e, group)
-    return merge_received(tc, kc, uc, meta, keys, units, mx, device_index)
+    # vocabulary / ranks / layout of the merge run while the posting units are still being exchanged
+    tc, kc, uc, meta, keys, units, mx, wait_units = exchange(e, group, overlap=True)
+    pending = PendingMerge(tc, kc, uc, meta, keys, mx, device_index)
+    wait_units()
+    return pending.finish(units)
 
 
 def local_gather(owned, device_index=0):

@@ -281,6 +281,17 @@ int32_t dcd_build_export_fill(dcd_build* h, void* meta_dev, uint16_t* keys_dev, 
 int32_t dcd_merge_shards(int32_t device, uint32_t n_sources, const uint64_t* term_count, const uint64_t* key_count,
                          const uint64_t* unit_count, const void* meta_dev, const uint16_t* keys_dev, const uint16_t* units_dev,
                          uint64_t max_coord, dcd_index** out);
+/* The same merge in two halves, so that the first one can run while the posting units are still travelling:
+ * dcd_merge_begin needs only the segment table and the keys (vocabulary, ordinal ranks, output layout, term strings);
+ * dcd_merge_finish copies the units (re-coding the first delta of every appended segment) and returns the index.
+ * meta_dev must stay valid until dcd_merge_finish; finish consumes the handle (also on error), dcd_merge_free drops a
+ * merge that will not be finished.  dcd_merge_shards == begin + finish. */
+typedef struct dcd_merge dcd_merge;
+int32_t dcd_merge_begin(int32_t device, uint32_t n_sources, const uint64_t* term_count, const uint64_t* key_count,
+                        const uint64_t* unit_count, const void* meta_dev, const uint16_t* keys_dev, uint64_t max_coord,
+                        dcd_merge** out);
+int32_t dcd_merge_finish(dcd_merge* m, const uint16_t* units_dev, dcd_index** out);
+void dcd_merge_free(dcd_merge* m);
 /* Page table of an index whose pages are uniform (synthetic corpora): n_pages pages of page_chars
  * characters starting at coordinate 0, one document per page named first_doc + p under `source`. */
 /* The owned partition after dcd_merge_shards can be exported again (same buffers as dcd_build_export_*), e.g. with

@@ -35,9 +35,23 @@ def main():
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from docodo_amd.dist import META_BYTES, exchange
     mine = fake_export(rank, world)
-    tc, kc, uc, meta, keys, units, mx = exchange(mine)
-    assert mx == 1000 + world - 1
     exp = [fake_export(s, world) for s in range(world)]
+    for overlap in (False, True):
+        check_exchange(rank, world, mine, exp, overlap)
+    dist.barrier()
+    dist.destroy_process_group()
+    print("rank %d ok" % rank)
+
+
+def check_exchange(rank, world, mine, exp, overlap):
+    from docodo_amd.dist import META_BYTES, exchange
+    if overlap:
+        # the async form distributed_merge uses: meta + keys are complete on return, the units after wait_units()
+        tc, kc, uc, meta, keys, units, mx, wait_units = exchange(mine, overlap=True)
+        wait_units()
+    else:
+        tc, kc, uc, meta, keys, units, mx = exchange(mine)
+    assert mx == 1000 + world - 1
     for got, kind, scale, cnt in ((meta, 0, META_BYTES, tc), (keys, 1, 2, kc), (units, 2, 2, uc)):
         want = []
         for s in range(world):
@@ -46,10 +60,7 @@ def main():
             n = int(counts[rank]) * scale
             want.append(((np.arange(n) * 7 + s * 31 + rank * 13 + kind * 5) % 251).astype(np.uint8))
         want = np.concatenate(want) if want else np.empty(0, np.uint8)
-        assert np.array_equal(got.numpy(), want), (rank, kind)
-    dist.barrier()
-    dist.destroy_process_group()
-    print("rank %d ok" % rank)
+        assert np.array_equal(got.numpy(), want), (rank, kind, overlap)
 
 
 if __name__ == "__main__":

@@ -126,3 +126,38 @@ def test_merged_index_answers_queries(oracle_mod):
             assert pi == op.page_index and np.array_equal(pos, op.pos) and abs(rank - op.rank) <= 1e-5 * max(1, abs(op.rank))
         checked += 1
     assert checked >= 20
+
+
+def test_two_phase_merge_equals_one_call():
+    """dcd_merge_begin (segment table + keys only) + dcd_merge_finish (units) == dcd_merge_shards; an unfinished merge
+    is dropped with dcd_merge_free."""
+    from docodo_amd import dist, synth
+    n_docs, G = 5000, 3
+    text = synth.corpus_host(n_docs)
+    bounds = [n_docs * g // G for g in range(G + 1)]
+    shards = [_build(text[bounds[g] * 1024:bounds[g + 1] * 1024], bounds[g + 1] - bounds[g], first_doc=bounds[g]) for g in range(G)]
+    exports = [dist.export_shard(b, G) for b in shards]
+    for o in range(G):
+        a = dist.local_merge(exports, o)
+        b = dist.local_merge(exports, o, two_phase=True)
+        assert a.Count == b.Count and a.MaxCoord == b.MaxCoord
+        assert a.index_image() == b.index_image()
+    e = exports[0]
+    import numpy as np
+    one = np.array([1], np.uint64)
+    pend = dist.PendingMerge(e.term_count[:1], e.key_count[:1], e.unit_count[:1], e.meta, e.keys, e.max_coord)
+    del pend                       # never finished: freed by dcd_merge_free
+    empty = dist.PendingMerge(one * 0, one * 0, one * 0, e.meta[:0], e.keys[:0], 0).finish(e.units[:0])
+    assert empty.Count == 0
+
+
+def test_distributed_merge_over_rccl_world1():
+    """The real RCCL path (nccl backend, async all-to-alls overlapped with dcd_merge_begin) with world_size 1."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", DCD_PORT="29671")
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "helpers", "rccl_world1_worker.py")], env=env, capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode == 0 and "rccl world1 ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
