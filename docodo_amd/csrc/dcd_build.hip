@@ -1025,7 +1025,10 @@ static int32_t build_phase2(dcd_build* h) {
   src.p = sorted; src.base = h->opts.coord_base; src.term_unit_start = ix.term_unit_start.p; src.term_item_start = ix.term_item_start.p;
   if (N) {
     probes.begin(DCD_K_ENC_REDUCE);
-    hipLaunchKernelGGL((k_enc_reduce<EncSrcPairs>), dim3((u32)enb), dim3(CODEC_THREADS), 0, st, src, N, enc_part.p);
+    if ((reinterpret_cast<uintptr_t>(sorted) & 15) == 0)
+      hipLaunchKernelGGL(k_pack_count, dim3((u32)enb), dim3(CODEC_THREADS), 0, st, src, N, enc_part.p);
+    else
+      hipLaunchKernelGGL((k_enc_reduce<EncSrcPairs>), dim3((u32)enb), dim3(CODEC_THREADS), 0, st, src, N, enc_part.p);
     probes.end();
     hipLaunchKernelGGL((k_scan_partials<u64>), dim3(1), dim3(1024), 0, st, enc_part.p, enb);
     DCD_HIP(hipMemcpyAsync(&U, enc_part.p + enb, 8, hipMemcpyDeviceToHost, st));

@@ -104,6 +104,7 @@ __global__ __launch_bounds__(CODEC_THREADS) void k_enc_write(Src src, u64 n, con
 // 8-byte-per-lane reads into LDS (plus the item before the tile) and the units share that LDS
 // afterwards; every HBM access of the kernel is then a full-width wave access.
 __global__ __launch_bounds__(CODEC_THREADS) void k_pack_write(EncSrcPairs src, u64 n, const u64* __restrict__ partial, u16* __restrict__ out);
+__global__ __launch_bounds__(CODEC_THREADS) void k_pack_count(EncSrcPairs src, u64 n, u64* __restrict__ partial);   // == k_enc_reduce<EncSrcPairs>
 
 // Encodes n items.  partial: >= div_up(n, CODEC_TILE) + 1 u64 (grand total of units left in
 // partial[nblocks]).  out must hold the total (<= 5 n).

@@ -55,6 +55,41 @@ __global__ void k_add_inplace(u64* __restrict__ excl, const u64* __restrict__ de
   if (i < n) excl[i] += deltas[i];
 }
 
+// Unit count of a tile of the build's sorted pairs (k_enc_reduce<EncSrcPairs> for this source): every lane reads TWO
+// pairs per 16-byte load and keeps all four loads of its tile in flight; the pair before a lane's first one comes from
+// the neighbouring lane.  Inside a term the delta of two segment-local coordinates fits 32 bits (at most 3 units);
+// only the first posting of a term carries the 64-bit base.
+__global__ __launch_bounds__(CODEC_THREADS) void k_pack_count(EncSrcPairs src, u64 n, u64* __restrict__ partial) {
+  __shared__ u32 lds[4];
+  const u64 t0 = (u64)blockIdx.x * CODEC_TILE;
+  const u32 lane = lane_id();
+  const uint4* p2 = reinterpret_cast<const uint4*>(src.p);      // t0 is even and src.p 16-byte aligned (checked by the host)
+  constexpr int NL = CODEC_ITEMS / 2;
+  uint4 kv[NL];
+  uint2 before[NL];
+#pragma unroll
+  for (int j = 0; j < NL; j++) {
+    const u64 i = t0 + 2 * ((u64)j * CODEC_THREADS + threadIdx.x);     // first item of the lane's pair
+    kv[j] = i < n ? p2[i >> 1] : make_uint4(0u, 0u, 0u, 0u);           // (the second item may lie past n: masked below)
+    before[j] = (lane == 0 && i > 0 && i < n) ? src.p[i - 1] : make_uint2(0xFFFFFFFFu, 0u);
+  }
+  u32 s = 0;
+#pragma unroll
+  for (int j = 0; j < NL; j++) {
+    const u64 i = t0 + 2 * ((u64)j * CODEC_THREADS + threadIdx.x);
+    uint2 q;
+    q.x = __shfl_up(kv[j].z, 1, DCD_WAVE);
+    q.y = __shfl_up(kv[j].w, 1, DCD_WAVE);
+    if (lane == 0) q = before[j];
+    if (i < n) s += (i == 0 || q.x != kv[j].x) ? seq_nunits(src.base + kv[j].y) : seq_nunits32(kv[j].y - q.y);
+    if (i + 1 < n) s += kv[j].x != kv[j].z ? seq_nunits(src.base + kv[j].w) : seq_nunits32(kv[j].w - kv[j].y);
+  }
+  s = wave_sum(s);
+  if (lane == 0) lds[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = (u64)lds[0] + lds[1] + lds[2] + lds[3];
+}
+
 __global__ __launch_bounds__(CODEC_THREADS) void k_pack_write(EncSrcPairs src, u64 n, const u64* __restrict__ partial, u16* __restrict__ out) {
   __shared__ u32 lds[5];
   // pairs are read back in blocked order (lane t reads elements 8t .. 8t+8): one element of padding per
@@ -69,21 +104,29 @@ __global__ __launch_bounds__(CODEC_THREADS) void k_pack_write(EncSrcPairs src, u
     sh.pairs[pad(k)] = i ? src.p[i - 1] : make_uint2(0xFFFFFFFFu, 0u);
   }
   __syncthreads();
-  u64 d[CODEC_ITEMS];
-  u32 nu[CODEC_ITEMS], term[CODEC_ITEMS];
+  // Inside a term the delta of two segment-local coordinates fits 32 bits (<= 3 units); the first posting of a term
+  // carries the 64-bit base and may need up to 5.  d_lo keeps the low 32 bits, heads re-derive the full value.
+  u32 d_lo[CODEC_ITEMS], nu[CODEC_ITEMS], term[CODEC_ITEMS], cy[CODEC_ITEMS];
   bool hd[CODEC_ITEMS];
   u32 s = 0;
   const u32 l0 = threadIdx.x * CODEC_ITEMS;
 #pragma unroll
   for (int j = 0; j < CODEC_ITEMS; j++) {
     u32 li = l0 + j;
-    d[j] = 0; nu[j] = 0; term[j] = 0; hd[j] = false;
+    d_lo[j] = 0; nu[j] = 0; term[j] = 0; cy[j] = 0; hd[j] = false;
     if (li < cnt) {
       uint2 q = sh.pairs[pad(li)], c = sh.pairs[pad(li + 1)];
       hd[j] = (t0 + li == 0) || q.x != c.x;
       term[j] = c.x;
-      d[j] = hd[j] ? src.base + c.y : (u64)c.y - (u64)q.y;
-      nu[j] = seq_nunits(d[j]);
+      cy[j] = c.y;
+      if (hd[j]) {
+        const u64 d = src.base + c.y;
+        d_lo[j] = (u32)d;
+        nu[j] = seq_nunits(d);
+      } else {
+        d_lo[j] = c.y - q.y;
+        nu[j] = seq_nunits32(d_lo[j]);
+      }
       s += nu[j];
     }
   }
@@ -94,7 +137,15 @@ __global__ __launch_bounds__(CODEC_THREADS) void k_pack_write(EncSrcPairs src, u
   for (int j = 0; j < CODEC_ITEMS; j++) {
     if (l0 + j < cnt) {
       if (hd[j]) { src.term_unit_start[term[j]] = gbase + loff; src.term_item_start[term[j]] = t0 + l0 + j; }
-      for (u32 g = 0; g < nu[j]; g++) sh.units[loff + g] = seq_unit(d[j], g, nu[j]);
+      if (hd[j] && nu[j] > 2) {                                   // 64-bit head (rare): the general code
+        const u64 d = src.base + cy[j];
+        for (u32 g = 0; g < nu[j]; g++) sh.units[loff + g] = seq_unit(d, g, nu[j]);
+      } else {                                                    // <= 3 units of a 32-bit value, no loop
+        const u32 d = d_lo[j];
+        sh.units[loff] = (u16)((d & 0x7FFFu) | (nu[j] > 1 ? 0x8000u : 0u));
+        if (nu[j] > 1) sh.units[loff + 1] = (u16)(((d >> 15) & 0x7FFFu) | (nu[j] > 2 ? 0x8000u : 0u));
+        if (nu[j] > 2) sh.units[loff + 2] = (u16)(d >> 30);
+      }
       loff += nu[j];
     }
   }

@@ -87,6 +87,7 @@ __device__ __forceinline__ T block_scan_excl(T v, T* lds, T* total) {
 __device__ __forceinline__ u32 seq_nunits(u64 d) {
   return 1u + (d >= (1ull << 15)) + (d >= (1ull << 30)) + (d >= (1ull << 45)) + (d >= (1ull << 60));
 }
+__device__ __forceinline__ u32 seq_nunits32(u32 d) { return 1u + (d >= (1u << 15)) + (d >= (1u << 30)); }
 // unit #g (0-based, g < n) of delta d occupying n units: low group first, bit 15 = "more follow"
 __device__ __forceinline__ u16 seq_unit(u64 d, u32 g, u32 n) {
   u32 grp = (u32)(d >> (15u * g)) & 0x7FFFu;

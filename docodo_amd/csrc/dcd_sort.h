@@ -9,7 +9,8 @@
 // exclusive scan -> scatter kernel.  Each block owns a contiguous range of items so the count
 // matrix stays tiny (<= 2048 blocks).  The scatter ranks a 2048-item tile with 64-lane ballots
 // (match-any on the digit), re-orders it in LDS and writes each digit run with consecutive lanes
-// -> coalesced HBM stores.  Per pass and item: 8 B read (hist) + 8 B read + 8 B write (scatter).
+// -> coalesced HBM stores; its barriers order LDS only, so stores and the next tile's loads overlap
+// the ranking.  Per pass and item: 8 B read (hist) + 8 B read + 8 B write (scatter).
 #pragma once
 #include "dcd_common.h"
 #include "dcd_prims.h"
@@ -49,6 +50,14 @@ inline RsPlan rs_plan(u64 n) {
 // key transform: optional gather through `remap` (first pass over hash-slot ids)
 __device__ __forceinline__ u32 rs_key(u32 k, const u32* __restrict__ remap) { return remap ? remap[k] : k; }
 
+// Workgroup barrier that orders LDS traffic only: s_waitcnt lgkmcnt(0) + s_barrier.  __syncthreads() also drains
+// vmcnt, i.e. it would wait for every scattered store (and prefetched load) of the tile before the next phase starts.
+__device__ __forceinline__ void lds_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 template <int BITS>
 __global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const uint2* __restrict__ in, const u32* __restrict__ remap, u64 n, u64 ipb,
                                                        u32 nblk, int shift, u32* __restrict__ hist) {
@@ -58,32 +67,33 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const uint2* __restrict_
   __syncthreads();
   const u32 w = threadIdx.x >> 6;
   u64 beg = (u64)blockIdx.x * ipb, end = beg + ipb < n ? beg + ipb : n;
-  // Zipf keys: a plain per-item LDS atomic serialises on the hot digit (13.5 % of all items carry the
-  // top term).  Lanes holding the same digit are found with 64-lane ballots (match-any) and only the
-  // lowest of them adds the group's size.  Four independent loads are issued before the first use so a
-  // wave keeps several HBM requests in flight.
+  // The order of the items inside a block does not matter for the counts: every lane reads TWO tuples per load
+  // (16 B) and keeps four loads in flight, so that enough bytes are outstanding to cover the HBM latency; the counts
+  // go to per-wave LDS histograms with plain LDS atomics (a few-way conflict on a hot digit costs less than finding
+  // the peer lanes with BITS ballots first -- measured).
   constexpr int UN = 4;
   const u64 span = end > beg ? end - beg : 0;
-  for (u64 o = 0; o < span; o += (u64)RS_THREADS * UN) {
-    u32 key[UN];
-    bool valid[UN];
+  if ((reinterpret_cast<uintptr_t>(in) & 15) == 0) {          // beg is a multiple of RS_TILE: pairs stay aligned
+    const uint4* in2 = reinterpret_cast<const uint4*>(in + beg);
+    const u64 pairs = (span + 1) >> 1;
+    for (u64 o = 0; o < pairs; o += (u64)RS_THREADS * UN) {
+      uint4 kv[UN];
+      u64 p[UN];
 #pragma unroll
-    for (int u = 0; u < UN; u++) {
-      u64 i = beg + o + (u64)u * RS_THREADS + threadIdx.x;
-      valid[u] = i < end;
-      key[u] = valid[u] ? in[i].x : 0u;
-    }
-#pragma unroll
-    for (int u = 0; u < UN; u++) {
-      u32 d = valid[u] ? (rs_key(key[u], remap) >> shift) & (NB - 1) : 0u;
-      u64 peers = ballot64(valid[u]);
-#pragma unroll
-      for (int b = 0; b < BITS; b++) {
-        u64 m = ballot64((d >> b) & 1u);
-        peers &= ((d >> b) & 1u) ? m : ~m;
+      for (int u = 0; u < UN; u++) {
+        p[u] = o + (u64)u * RS_THREADS + threadIdx.x;
+        // the second tuple of the last pair may lie past `end` but never past the 16-byte granule of the buffer
+        kv[u] = p[u] < pairs ? in2[p[u]] : make_uint4(0u, 0u, 0u, 0u);
       }
-      if (valid[u] && mbcnt(peers) == 0) atomicAdd(&h[w][d], popc64(peers));
+#pragma unroll
+      for (int u = 0; u < UN; u++) {
+        if (2 * p[u] < span) atomicAdd(&h[w][(rs_key(kv[u].x, remap) >> shift) & (NB - 1)], 1u);
+        if (2 * p[u] + 1 < span) atomicAdd(&h[w][(rs_key(kv[u].z, remap) >> shift) & (NB - 1)], 1u);
+      }
     }
+  } else {
+    for (u64 o = threadIdx.x; o < span; o += RS_THREADS)
+      atomicAdd(&h[w][(rs_key(in[beg + o].x, remap) >> shift) & (NB - 1)], 1u);
   }
   __syncthreads();
   for (int d = threadIdx.x; d < NB; d += RS_THREADS) {
@@ -94,101 +104,118 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const uint2* __restrict_
   }
 }
 
+#ifndef DCD_RS_WPE
+#define DCD_RS_WPE 4
+#endif
 template <int BITS>
-__global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const uint2* __restrict__ in, const u32* __restrict__ remap, u64 n, u64 ipb,
+__global__ __launch_bounds__(RS_THREADS) __attribute__((amdgpu_waves_per_eu(DCD_RS_WPE, DCD_RS_WPE))) void k_rs_scatter(const uint2* __restrict__ in, const u32* __restrict__ remap, u64 n, u64 ipb,
                                                           u32 nblk, int shift, const u32* __restrict__ hist_scanned,
                                                           uint2* __restrict__ out) {
   constexpr int NB = 1 << BITS;
-  __shared__ u32 s_cnt[RS_WAVES][NB];   // per-wave digit counts of the tile -> per-wave exclusive offsets
-  __shared__ u32 s_base[NB];            // running global output position per digit for this block
-  __shared__ u32 s_dstart[NB];          // start of each digit inside the LDS-sorted tile
+  constexpr int Q = (NB + RS_THREADS - 1) / RS_THREADS;   // digits per owner thread: d = threadIdx.x * Q + q (adjacent)
+  __shared__ u32 s_cnt[RS_WAVES][NB];   // ranking: per-wave digit counts; afterwards: position of (wave, digit) in the sorted tile
+  __shared__ u32 s_off[NB];             // output position of the digit's run minus its start in the sorted tile (mod 2^32)
   __shared__ uint2 s_tile[RS_TILE];
-  __shared__ u32 s_scan[RS_WAVES + 1];
+  __shared__ u32 s_wtot[RS_WAVES];
   const u32 lane = lane_id(), w = threadIdx.x >> 6;
 
-  for (int d = threadIdx.x; d < NB; d += RS_THREADS) s_base[d] = hist_scanned[(u64)d * nblk + blockIdx.x];
+  // running output position of the owned digits: registers of the owner thread
+  u32 base[Q];
+#pragma unroll
+  for (int q = 0; q < Q; q++) {
+    const int d = threadIdx.x * Q + q;
+    base[q] = d < NB ? hist_scanned[(u64)d * nblk + blockIdx.x] : 0u;
+  }
   u64 beg = (u64)blockIdx.x * ipb, end = beg + ipb < n ? beg + ipb : n;
 
+  // Four LDS-only barriers per tile; the scattered stores of a tile and the loads of the next one stay in flight
+  // across them (the next tile is fetched into the item registers as soon as the current one sits in LDS).
+  uint2 item[RS_ROWS];
+#pragma unroll
+  for (int r = 0; r < RS_ROWS; r++) {
+    u64 i = beg + (u64)(w * RS_ROWS + r) * 64 + lane;
+    item[r] = i < end ? in[i] : make_uint2(0xFFFFFFFFu, 0u);
+  }
   for (u64 t0 = beg; t0 < end; t0 += RS_TILE) {
-    for (int i = threadIdx.x; i < RS_WAVES * NB; i += RS_THREADS) (&s_cnt[0][0])[i] = 0;
-    __syncthreads();
-    uint2 item[RS_ROWS];
+    // ---- A: rank inside the wave (rows in order, lanes in order: stable); s_cnt[w] is private to the wave here
+    for (int i = lane; i < NB; i += 64) s_cnt[w][i] = 0;
     u32 dig[RS_ROWS], rk[RS_ROWS];
-    // rank inside the wave: rows in order, lanes in order (stable)
+    bool valid[RS_ROWS];
 #pragma unroll
     for (int r = 0; r < RS_ROWS; r++) {
-      u64 i = t0 + (u64)(w * RS_ROWS + r) * 64 + lane;
-      bool valid = i < end;
-      uint2 it = valid ? in[i] : make_uint2(0xFFFFFFFFu, 0u);
-      if (valid) it.x = rs_key(it.x, remap);
-      u32 d = (it.x >> shift) & (NB - 1);
-      u64 peers = ballot64(valid);
+      valid[r] = t0 + (u64)(w * RS_ROWS + r) * 64 + lane < end;
+      if (valid[r]) item[r].x = rs_key(item[r].x, remap);   // independent gathers (first pass only), issued together
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int r = 0; r < RS_ROWS; r++) {
+      u32 d = (item[r].x >> shift) & (NB - 1);
+      u64 peers = ballot64(valid[r]);
 #pragma unroll
       for (int b = 0; b < BITS; b++) {
         u64 m = ballot64((d >> b) & 1u);
         peers &= ((d >> b) & 1u) ? m : ~m;
       }
-      u32 prev = valid ? s_cnt[w][d] : 0u;   // count of this digit in earlier rows of this wave
+      u32 prev = valid[r] ? s_cnt[w][d] : 0u;   // count of this digit in earlier rows of this wave
       u32 below = mbcnt(peers);
-      if (valid && below == 0) s_cnt[w][d] = prev + popc64(peers);  // leader = lowest peer lane
-      item[r] = it;
-      dig[r] = valid ? d : 0xFFFFFFFFu;
+      if (valid[r] && below == 0) s_cnt[w][d] = prev + popc64(peers);  // leader = lowest peer lane
+      dig[r] = valid[r] ? d : 0xFFFFFFFFu;
       rk[r] = prev + below;
     }
-    __syncthreads();
-    // per digit: exclusive offsets across waves, tile totals
-    u32 tot_d[(NB + RS_THREADS - 1) / RS_THREADS];
+    lds_barrier();
+    // ---- B: per digit, exclusive offsets across the waves; exclusive scan of the tile totals over the digits
+    u32 wex[Q][RS_WAVES], tot[Q], mine = 0;
 #pragma unroll
-    for (int q = 0; q < (NB + RS_THREADS - 1) / RS_THREADS; q++) {
-      int d = threadIdx.x + q * RS_THREADS;
+    for (int q = 0; q < Q; q++) {
+      const int d = threadIdx.x * Q + q;
       u32 run = 0;
+#pragma unroll
+      for (int k = 0; k < RS_WAVES; k++) {
+        u32 c = d < NB ? s_cnt[k][d] : 0u;
+        wex[q][k] = run;
+        run += c;
+      }
+      tot[q] = run;
+      mine += run;
+    }
+    const u32 incl = wave_scan_incl(mine);
+    if (lane == 63) s_wtot[w] = incl;
+    lds_barrier();
+    u32 ex = incl - mine;
+#pragma unroll
+    for (int k = 0; k < RS_WAVES; k++) ex += k < (int)w ? s_wtot[k] : 0u;
+#pragma unroll
+    for (int q = 0; q < Q; q++) {
+      const int d = threadIdx.x * Q + q;
       if (d < NB) {
 #pragma unroll
-        for (int k = 0; k < RS_WAVES; k++) { u32 c = s_cnt[k][d]; s_cnt[k][d] = run; run += c; }
+        for (int k = 0; k < RS_WAVES; k++) s_cnt[k][d] = ex + wex[q][k];
+        s_off[d] = base[q] - ex;
       }
-      tot_d[q] = run;
+      base[q] += tot[q];
+      ex += tot[q];
     }
-    // exclusive scan over digits of the tile totals -> s_dstart
-    {
-      u32 mine = 0;
+    lds_barrier();
+    // ---- C: tile -> LDS in sorted order; fetch the next tile
 #pragma unroll
-      for (int q = 0; q < (NB + RS_THREADS - 1) / RS_THREADS; q++) mine += tot_d[q];
-      // thread t owns digits {t, t+256, ...}: scan needs digit order, so do it in q-major passes
-      u32 carry = 0;
-#pragma unroll
-      for (int q = 0; q < (NB + RS_THREADS - 1) / RS_THREADS; q++) {
-        u32 tot;
-        u32 ex = block_scan_excl<u32, RS_WAVES>(tot_d[q], s_scan, &tot);
-        int d = threadIdx.x + q * RS_THREADS;
-        if (d < NB) s_dstart[d] = carry + ex;
-        carry += tot;
-      }
-      (void)mine;
-    }
-    __syncthreads();
-    // local sorted position -> LDS
+    for (int r = 0; r < RS_ROWS; r++)
+      if (dig[r] != 0xFFFFFFFFu) s_tile[s_cnt[w][dig[r]] + rk[r]] = item[r];
 #pragma unroll
     for (int r = 0; r < RS_ROWS; r++) {
-      if (dig[r] != 0xFFFFFFFFu) {
-        u32 pos = s_dstart[dig[r]] + s_cnt[w][dig[r]] + rk[r];
-        s_tile[pos] = item[r];
-      }
+      u64 i = t0 + RS_TILE + (u64)(w * RS_ROWS + r) * 64 + lane;
+      item[r] = i < end ? in[i] : make_uint2(0xFFFFFFFFu, 0u);
     }
-    __syncthreads();
+    lds_barrier();
+    // ---- D: digit runs -> HBM with consecutive lanes
     u32 tile_n = (u32)((end - t0) < (u64)RS_TILE ? (end - t0) : (u64)RS_TILE);
     for (u32 j = threadIdx.x; j < tile_n; j += RS_THREADS) {
       uint2 it = s_tile[j];
       u32 d = (it.x >> shift) & (NB - 1);
-      out[(u64)s_base[d] + (j - s_dstart[d])] = it;
+      out[(u64)(u32)(s_off[d] + j)] = it;
     }
-    __syncthreads();
-    // advance the running bases by this tile's totals
-#pragma unroll
-    for (int q = 0; q < (NB + RS_THREADS - 1) / RS_THREADS; q++) {
-      int d = threadIdx.x + q * RS_THREADS;
-      if (d < NB) s_base[d] += tot_d[q];
-    }
-    __syncthreads();
+    // no barrier here: phase A of the next tile touches only the wave's own s_cnt row, and everything that phase D
+    // reads is rewritten behind the next tile's first barrier at the earliest
   }
 }
 
