@@ -23,10 +23,15 @@ namespace dcd {
 constexpr int RS_THREADS = 256;
 constexpr int RS_WAVES = RS_THREADS / 64;
 #ifndef DCD_RS_ROWS
-#define DCD_RS_ROWS 8
+#define DCD_RS_ROWS 12
 #endif
-constexpr int RS_ROWS = DCD_RS_ROWS;               // 64-item rows per wave and tile
-constexpr int RS_TILE = RS_THREADS * RS_ROWS;       // 2048 items
+constexpr int RS_ROWS = DCD_RS_ROWS;               // 64-item rows per wave and tile (8 waves x 12 rows: 6144-item tiles measured best)
+#ifndef DCD_RSS_THREADS
+#define DCD_RSS_THREADS 512
+#endif
+constexpr int RSS_THREADS = DCD_RSS_THREADS;        // workgroup of the scatter kernel (the histogram kernel keeps RS_THREADS)
+constexpr int RSS_WAVES = RSS_THREADS / 64;
+constexpr int RS_TILE = RSS_THREADS * RS_ROWS;      // items per scatter tile
 #ifndef DCD_RS_MAX_BLOCKS
 #define DCD_RS_MAX_BLOCKS 2048
 #endif
@@ -58,19 +63,26 @@ __device__ __forceinline__ void lds_barrier() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
+#ifndef DCD_RS_HCOPIES
+#define DCD_RS_HCOPIES 8
+#endif
 template <int BITS>
 __global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const uint2* __restrict__ in, const u32* __restrict__ remap, u64 n, u64 ipb,
                                                        u32 nblk, int shift, u32* __restrict__ hist) {
   constexpr int NB = 1 << BITS;
-  __shared__ u32 h[RS_WAVES][NB];
-  for (int i = threadIdx.x; i < RS_WAVES * NB; i += RS_THREADS) (&h[0][0])[i] = 0;
+  // Same-address LDS atomics of one wave instruction are executed one after the other (a Zipf head puts ~9 of 64
+  // lanes on one digit): lane l counts into copy l % HC of the histogram, so that peers mostly hit different
+  // addresses, and the copies are NB + 1 words apart, so that they hit different banks.  The copies are shared by
+  // the four waves of the block.  (Finding the peer lanes with BITS ballots first costs more VALU time than the
+  // remaining conflicts -- measured.)
+  constexpr int HC = DCD_RS_HCOPIES, HS = NB + 1;
+  __shared__ u32 h[HC * HS];
+  for (int i = threadIdx.x; i < HC * HS; i += RS_THREADS) h[i] = 0;
   __syncthreads();
-  const u32 w = threadIdx.x >> 6;
+  u32* hl = h + (threadIdx.x % HC) * HS;
   u64 beg = (u64)blockIdx.x * ipb, end = beg + ipb < n ? beg + ipb : n;
   // The order of the items inside a block does not matter for the counts: every lane reads TWO tuples per load
-  // (16 B) and keeps four loads in flight, so that enough bytes are outstanding to cover the HBM latency; the counts
-  // go to per-wave LDS histograms with plain LDS atomics (a few-way conflict on a hot digit costs less than finding
-  // the peer lanes with BITS ballots first -- measured).
+  // (16 B) and keeps four loads in flight, so that enough bytes are outstanding to cover the HBM latency.
   constexpr int UN = 4;
   const u64 span = end > beg ? end - beg : 0;
   if ((reinterpret_cast<uintptr_t>(in) & 15) == 0) {          // beg is a multiple of RS_TILE: pairs stay aligned
@@ -87,19 +99,19 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const uint2* __restrict_
       }
 #pragma unroll
       for (int u = 0; u < UN; u++) {
-        if (2 * p[u] < span) atomicAdd(&h[w][(rs_key(kv[u].x, remap) >> shift) & (NB - 1)], 1u);
-        if (2 * p[u] + 1 < span) atomicAdd(&h[w][(rs_key(kv[u].z, remap) >> shift) & (NB - 1)], 1u);
+        if (2 * p[u] < span) atomicAdd(&hl[(rs_key(kv[u].x, remap) >> shift) & (NB - 1)], 1u);
+        if (2 * p[u] + 1 < span) atomicAdd(&hl[(rs_key(kv[u].z, remap) >> shift) & (NB - 1)], 1u);
       }
     }
   } else {
     for (u64 o = threadIdx.x; o < span; o += RS_THREADS)
-      atomicAdd(&h[w][(rs_key(in[beg + o].x, remap) >> shift) & (NB - 1)], 1u);
+      atomicAdd(&hl[(rs_key(in[beg + o].x, remap) >> shift) & (NB - 1)], 1u);
   }
   __syncthreads();
   for (int d = threadIdx.x; d < NB; d += RS_THREADS) {
     u32 s = 0;
 #pragma unroll
-    for (int k = 0; k < RS_WAVES; k++) s += h[k][d];
+    for (int k = 0; k < HC; k++) s += h[k * HS + d];
     hist[(u64)d * nblk + blockIdx.x] = s;
   }
 }
@@ -108,15 +120,15 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const uint2* __restrict_
 #define DCD_RS_WPE 4
 #endif
 template <int BITS>
-__global__ __launch_bounds__(RS_THREADS) __attribute__((amdgpu_waves_per_eu(DCD_RS_WPE, DCD_RS_WPE))) void k_rs_scatter(const uint2* __restrict__ in, const u32* __restrict__ remap, u64 n, u64 ipb,
+__global__ __launch_bounds__(RSS_THREADS) __attribute__((amdgpu_waves_per_eu(DCD_RS_WPE, DCD_RS_WPE))) void k_rs_scatter(const uint2* __restrict__ in, const u32* __restrict__ remap, u64 n, u64 ipb,
                                                           u32 nblk, int shift, const u32* __restrict__ hist_scanned,
                                                           uint2* __restrict__ out) {
   constexpr int NB = 1 << BITS;
-  constexpr int Q = (NB + RS_THREADS - 1) / RS_THREADS;   // digits per owner thread: d = threadIdx.x * Q + q (adjacent)
-  __shared__ u32 s_cnt[RS_WAVES][NB];   // ranking: per-wave digit counts; afterwards: position of (wave, digit) in the sorted tile
+  constexpr int Q = (NB + RSS_THREADS - 1) / RSS_THREADS;   // digits per owner thread: d = threadIdx.x * Q + q (adjacent)
+  __shared__ u32 s_cnt[RSS_WAVES][NB];   // ranking: per-wave digit counts; afterwards: position of (wave, digit) in the sorted tile
   __shared__ u32 s_off[NB];             // output position of the digit's run minus its start in the sorted tile (mod 2^32)
   __shared__ uint2 s_tile[RS_TILE];
-  __shared__ u32 s_wtot[RS_WAVES];
+  __shared__ u32 s_wtot[RSS_WAVES];
   const u32 lane = lane_id(), w = threadIdx.x >> 6;
 
   // running output position of the owned digits: registers of the owner thread
@@ -165,13 +177,13 @@ __global__ __launch_bounds__(RS_THREADS) __attribute__((amdgpu_waves_per_eu(DCD_
     }
     lds_barrier();
     // ---- B: per digit, exclusive offsets across the waves; exclusive scan of the tile totals over the digits
-    u32 wex[Q][RS_WAVES], tot[Q], mine = 0;
+    u32 wex[Q][RSS_WAVES], tot[Q], mine = 0;
 #pragma unroll
     for (int q = 0; q < Q; q++) {
       const int d = threadIdx.x * Q + q;
       u32 run = 0;
 #pragma unroll
-      for (int k = 0; k < RS_WAVES; k++) {
+      for (int k = 0; k < RSS_WAVES; k++) {
         u32 c = d < NB ? s_cnt[k][d] : 0u;
         wex[q][k] = run;
         run += c;
@@ -184,13 +196,13 @@ __global__ __launch_bounds__(RS_THREADS) __attribute__((amdgpu_waves_per_eu(DCD_
     lds_barrier();
     u32 ex = incl - mine;
 #pragma unroll
-    for (int k = 0; k < RS_WAVES; k++) ex += k < (int)w ? s_wtot[k] : 0u;
+    for (int k = 0; k < RSS_WAVES; k++) ex += k < (int)w ? s_wtot[k] : 0u;
 #pragma unroll
     for (int q = 0; q < Q; q++) {
       const int d = threadIdx.x * Q + q;
       if (d < NB) {
 #pragma unroll
-        for (int k = 0; k < RS_WAVES; k++) s_cnt[k][d] = ex + wex[q][k];
+        for (int k = 0; k < RSS_WAVES; k++) s_cnt[k][d] = ex + wex[q][k];
         s_off[d] = base[q] - ex;
       }
       base[q] += tot[q];
@@ -209,7 +221,7 @@ __global__ __launch_bounds__(RS_THREADS) __attribute__((amdgpu_waves_per_eu(DCD_
     lds_barrier();
     // ---- D: digit runs -> HBM with consecutive lanes
     u32 tile_n = (u32)((end - t0) < (u64)RS_TILE ? (end - t0) : (u64)RS_TILE);
-    for (u32 j = threadIdx.x; j < tile_n; j += RS_THREADS) {
+    for (u32 j = threadIdx.x; j < tile_n; j += RSS_THREADS) {
       uint2 it = s_tile[j];
       u32 d = (it.x >> shift) & (NB - 1);
       out[(u64)(u32)(s_off[d] + j)] = it;
@@ -241,7 +253,7 @@ inline void rs_pass(const uint2* in, uint2* out, const u32* remap, u64 n, int sh
   u64 ne = (u64)p.nblk << BITS;
   scan_exclusive<u32, u32>(hist, hist, ne, scan_scratch, st);
   pr.rec(st);
-  hipLaunchKernelGGL((k_rs_scatter<BITS>), dim3(p.nblk), dim3(RS_THREADS), 0, st, in, remap, n, p.ipb, p.nblk, shift, hist, out);
+  hipLaunchKernelGGL((k_rs_scatter<BITS>), dim3(p.nblk), dim3(RSS_THREADS), 0, st, in, remap, n, p.ipb, p.nblk, shift, hist, out);
   pr.rec(st);
 }
 
@@ -267,7 +279,9 @@ inline RsSchedule rs_schedule(int total_bits, int max_width = 9) {
   s.npass = (total_bits + max_width - 1) / max_width;
   int rem = total_bits;
   for (int i = 0; i < s.npass; i++) {
-    int wdt = (rem + (s.npass - i) - 1) / (s.npass - i);
+    // narrower digits first: the first pass scatters text-order input (short digit runs, fragmented stores), the
+    // later ones see skewed high digits and long runs (17 bits: 8 + 9 measured faster than 9 + 8)
+    int wdt = i + 1 < s.npass ? rem / (s.npass - i) : rem;
     if (wdt < 6) wdt = 6;
     if (wdt > 10) wdt = 10;
     s.width[i] = wdt;
