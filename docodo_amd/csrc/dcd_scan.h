@@ -26,17 +26,23 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_reduce(const TIn* __restr
   if (threadIdx.x == 0) partial[blockIdx.x] = lds[0] + lds[1] + lds[2] + lds[3];
 }
 
-// one block; partial[0..nb) -> exclusive in place, partial[nb] = grand total
+// one block; partial[0..nb) -> exclusive in place, partial[nb] = grand total.  Thread t owns 8 consecutive elements
+// of every 8192-element round (one block scan and three barriers per round instead of per 1024 elements: the pack
+// stage scans ~67 k tile totals through here).
 template <typename T>
 __global__ __launch_bounds__(1024) void k_scan_partials(T* __restrict__ partial, u64 nb) {
+  constexpr int PER = 8;
   __shared__ T lds[17];
   T carry = 0;
-  for (u64 b0 = 0; b0 < nb; b0 += 1024) {
-    u64 i = b0 + threadIdx.x;
-    T v = i < nb ? partial[i] : (T)0;
+  for (u64 b0 = 0; b0 < nb; b0 += 1024 * PER) {
+    const u64 i0 = b0 + (u64)threadIdx.x * PER;
+    T v[PER], s = 0;
+#pragma unroll
+    for (int j = 0; j < PER; j++) { v[j] = i0 + j < nb ? partial[i0 + j] : (T)0; s += v[j]; }
     T tot;
-    T ex = block_scan_excl<T, 16>(v, lds, &tot);
-    if (i < nb) partial[i] = carry + ex;
+    T ex = carry + block_scan_excl<T, 16>(s, lds, &tot);
+#pragma unroll
+    for (int j = 0; j < PER; j++) { if (i0 + j < nb) partial[i0 + j] = ex; ex += v[j]; }
     carry += tot;
   }
   if (threadIdx.x == 0) partial[nb] = carry;
