@@ -38,7 +38,7 @@ constexpr int TK_HALO = 4;                       // look-ahead chunks after the 
 constexpr int TK_OWN = 64 - TK_PRE - TK_HALO;    // 59 chunks
 constexpr int TK_TILE = TK_OWN * TK_CPT;         // 944 characters per wave tile
 constexpr int TK_SPAN = 64 * TK_CPT;             // 1024 characters staged per wave tile
-constexpr int TK_MAXTOK = TK_TILE / 2 + 1;       // tokens of length 1 separated by one character
+constexpr int TK_MAXTOK = TK_TILE;               // min_word_length 1 and alternating classes ("a1a1..."): every character is a token
 
 // orders a wave's LDS writes before its later LDS reads of other lanes' data (no s_barrier involved)
 __device__ __forceinline__ void wave_sync() {

@@ -241,6 +241,10 @@ class Index:
         if stemmers is not None:
             self.set_stemmers(stemmers)
 
+    def set_limits(self, min_len=3, max_len=32, max_pages=30001, max_docs=500, keep_forms=False):
+        """MIN_WORD_LENGTH / MAX_WORD_LENGTH (Index.cs:97,113), MAX_FOUND_PAGES / MAX_FOUND_DOCS, bKeepForms."""
+        self.L.orc_index_set_limits(self.h, int(min_len), int(max_len), int(max_pages), int(max_docs), 1 if keep_forms else 0)
+
     def __del__(self):
         try:
             self.L.orc_index_free(self.h)

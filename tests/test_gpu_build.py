@@ -161,6 +161,24 @@ def test_word_length_limits_and_empty(oracle_mod):
     assert b.index_image() == bytes(8)
 
 
+def test_min_word_length_one_dense_tokens(oracle_mod):
+    """MIN_WORD_LENGTH = 1 and alternating letter / digit classes: every character is a token of its own (the regex
+    `\\p{L}+|\\p{N}+` splits at a class change without a separator), i.e. the densest token stream a tile can hold."""
+    pages = ["a1" * 3000, "x9y8z7" * 700 + " tail", "b2" * 5, "", "a1b" * 1500]
+    ids = ["1", "2", "3", "4", "5"]
+    docs = [("s", "d", 5)]
+    ix = oracle_mod.Index(stemmers=[])
+    ix.set_limits(min_len=1)
+    ob = oracle_mod.Builder(ix)
+    ob.add_doc("s", "d")
+    for i, t in zip(ids, pages):
+        ob.index_page(i, t)
+    oi, ol = ob.save()
+    (gi, gl), gb, st = _gpu_images(pages, docs=docs, ids=ids, min_word_length=1)
+    assert st.n_postings == ob.total_count
+    assert gi == oi and gl == ol
+
+
 def test_explicit_postings_builder_api(oracle_mod, known):
     """Index.Builder standalone path (BuilderTest, IndexTest.cs:272-313): AddWord(token, offset) for the
     \\b\\w+\\b tokens of TestText1, EndPage("1"); identity codes (no stemmer / vocab)."""
