@@ -364,8 +364,7 @@ int32_t dcd_build_create(const dcd_build_opts* opts, dcd_build** out) {
   h->opts = o;
   h->device = o.device;
   memset(&h->stats, 0, sizeof h->stats);
-  hipError_t e = hipStreamCreateWithFlags(&h->st, hipStreamNonBlocking);
-  if (e != hipSuccess) { delete h; DCD_FAIL(DCD_E_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
+  if (stream_acquire(o.device, &h->st) != DCD_OK) { delete h; return DCD_E_HIP; }
   h->page_off.push_back(0);
   h->coord_cursor = o.coord_base;
   *out = h;
@@ -375,8 +374,11 @@ int32_t dcd_build_create(const dcd_build_opts* opts, dcd_build** out) {
 void dcd_build_free(dcd_build* h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
-  if (h->st) { (void)hipStreamSynchronize(h->st); (void)hipStreamDestroy(h->st); }
-  delete h;
+  hipStream_t st = h->st;
+  if (st) (void)hipStreamSynchronize(st);
+  const int dev = h->device;
+  delete h;                       // (buffers go back to the pool before the stream is parked)
+  stream_release(dev, st);
 }
 
 int32_t dcd_build_add_doc(dcd_build* h, const uint16_t* source, size_t source_len, const uint16_t* name, size_t name_len) {
@@ -660,18 +662,19 @@ struct Probes {
   struct P { int id; hipEvent_t a, b; };
   std::vector<P> v;
   hipStream_t st;
-  explicit Probes(hipStream_t s) : st(s) {}
-  void begin(int id) { P p{id, nullptr, nullptr}; (void)hipEventCreate(&p.a); (void)hipEventCreate(&p.b); (void)hipEventRecord(p.a, st); v.push_back(p); }
-  void end() { (void)hipEventRecord(v.back().b, st); }
+  int dev;
+  explicit Probes(hipStream_t s, int device) : st(s), dev(device) {}
+  void begin(int id) { P p{id, event_acquire(dev), event_acquire(dev)}; if (p.a) (void)hipEventRecord(p.a, st); v.push_back(p); }
+  void end() { if (v.back().b) (void)hipEventRecord(v.back().b, st); }
   void collect(float* ms, u32* n) {   // after the stream was synchronised
     for (auto& p : v) {
       float t = 0;
-      if (hipEventElapsedTime(&t, p.a, p.b) == hipSuccess) { ms[p.id] += t; n[p.id]++; }
-      (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b);
+      if (p.a && p.b && hipEventElapsedTime(&t, p.a, p.b) == hipSuccess) { ms[p.id] += t; n[p.id]++; }
+      event_release(dev, p.a); event_release(dev, p.b);
     }
     v.clear();
   }
-  ~Probes() { for (auto& p : v) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); } }
+  ~Probes() { for (auto& p : v) { event_release(dev, p.a); event_release(dev, p.b); } }
 };
 }  // namespace
 
@@ -687,8 +690,8 @@ static int32_t build_phase1(dcd_build* h, bool codes_mode) {
   HostTrace tr;
   tr.mark("begin");
   EvTimer t_all, t_tok, t_voc;
-  DCD_TRY(t_all.init(st)); DCD_TRY(t_tok.init(st)); DCD_TRY(t_voc.init(st));
-  Probes probes(st);
+  DCD_TRY(t_all.init(st, dev)); DCD_TRY(t_tok.init(st, dev)); DCD_TRY(t_voc.init(st, dev));
+  Probes probes(st, dev);
 
   const u64 n_chars = h->n_chars;
   const bool uniform = h->pages.uniform;
@@ -890,8 +893,8 @@ static int32_t build_phase2(dcd_build* h) {
   HostTrace tr;
   tr.mark("begin2");
   EvTimer t_all, t_sort, t_pack, t_img;
-  DCD_TRY(t_all.init(st)); DCD_TRY(t_sort.init(st)); DCD_TRY(t_pack.init(st)); DCD_TRY(t_img.init(st));
-  Probes probes(st);
+  DCD_TRY(t_all.init(st, dev)); DCD_TRY(t_sort.init(st, dev)); DCD_TRY(t_pack.init(st, dev)); DCD_TRY(t_img.init(st, dev));
+  Probes probes(st, dev);
   DeviceIndex& ix = h->ix;
   ix.device = dev;
 
@@ -1006,7 +1009,7 @@ static int32_t build_phase2(dcd_build* h) {
     }
     int p2 = 0;
     RsProbe rp;
-    rp.ev = &sort_events;
+    rp.ev = &sort_events; rp.device = dev;
     sorted = rs_sort(a, b, remap, N, (int)log2_ceil(V ? V : 1), M.d_hist.p, M.scan_scr32.p, st, &p2, rp);
     passes += p2;
   }
@@ -1112,7 +1115,7 @@ static int32_t build_phase2(dcd_build* h) {
     if (hipEventElapsedTime(&t, sort_events[i], sort_events[i + 1]) == hipSuccess) { s.ms_kernel[DCD_K_RS_HIST] += t; s.n_launch[DCD_K_RS_HIST]++; }
     if (hipEventElapsedTime(&t, sort_events[i + 2], sort_events[i + 3]) == hipSuccess) { s.ms_kernel[DCD_K_RS_SCATTER] += t; s.n_launch[DCD_K_RS_SCATTER]++; }
   }
-  for (auto e : sort_events) (void)hipEventDestroy(e);
+  for (auto e : sort_events) event_release(dev, e);
   tr.mark("mirrors+stats");
   h->mid.reset();
   tr.mark("free");

@@ -112,6 +112,54 @@ void dev_pool_trim(int device) {
   }
 }
 
+// ---- stream / event caches ---------------------------------------------------------------------
+// Creating and destroying a HIP stream costs ~0.1-0.3 ms and an event a few microseconds: per-handle streams and the
+// dozens of timing events of a build are recycled instead (idle streams per device, events per device).
+namespace {
+struct HandlePool {
+  std::mutex mu;
+  std::map<int, std::vector<hipStream_t>> streams;
+  std::map<int, std::vector<hipEvent_t>> events;
+};
+HandlePool& handles() { static HandlePool* h = new HandlePool(); return *h; }   // leaked on purpose (no teardown races)
+}  // namespace
+
+int32_t stream_acquire(int device, hipStream_t* out) {
+  {
+    HandlePool& H = handles();
+    std::lock_guard<std::mutex> g(H.mu);
+    auto& v = H.streams[device];
+    if (!v.empty()) { *out = v.back(); v.pop_back(); return DCD_OK; }
+  }
+  DCD_HIP(hipSetDevice(device));
+  DCD_HIP(hipStreamCreateWithFlags(out, hipStreamNonBlocking));
+  return DCD_OK;
+}
+void stream_release(int device, hipStream_t st) {
+  if (!st) return;
+  if (hipStreamSynchronize(st) != hipSuccess) { (void)hipGetLastError(); (void)hipStreamDestroy(st); return; }   // never recycle a broken stream
+  HandlePool& H = handles();
+  std::lock_guard<std::mutex> g(H.mu);
+  H.streams[device].push_back(st);
+}
+hipEvent_t event_acquire(int device) {
+  {
+    HandlePool& H = handles();
+    std::lock_guard<std::mutex> g(H.mu);
+    auto& v = H.events[device];
+    if (!v.empty()) { hipEvent_t e = v.back(); v.pop_back(); return e; }
+  }
+  hipEvent_t e = nullptr;
+  if (hipEventCreate(&e) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  return e;
+}
+void event_release(int device, hipEvent_t e) {
+  if (!e) return;
+  HandlePool& H = handles();
+  std::lock_guard<std::mutex> g(H.mu);
+  H.events[device].push_back(e);
+}
+
 }  // namespace dcd
 
 extern "C" {

@@ -57,6 +57,12 @@ void dev_release(int device, void* p);   // back to the pool
 void dev_pool_trim(int device);          // hipFree everything cached
 size_t dev_pool_cached_bytes(int device);   // bytes held by the cache (released blocks not yet returned to HIP)
 
+// idle HIP streams (hipStreamNonBlocking) and events are recycled per device instead of created per handle
+int32_t stream_acquire(int device, hipStream_t* out);
+void stream_release(int device, hipStream_t st);     // synchronises the stream, then parks it
+hipEvent_t event_acquire(int device);                // nullptr on failure
+void event_release(int device, hipEvent_t e);        // the event must not be pending
+
 // RAII device buffer bound to the pool
 template <typename T>
 struct DevBuf {
@@ -94,10 +100,13 @@ struct DevBuf {
 struct EvTimer {
   hipEvent_t a = nullptr, b = nullptr;
   hipStream_t s = nullptr;
-  int32_t init(hipStream_t st) {
+  int device = 0;
+  int32_t init(hipStream_t st, int dev = 0) {
     s = st;
-    if (!a) DCD_HIP(hipEventCreate(&a));
-    if (!b) DCD_HIP(hipEventCreate(&b));
+    device = dev;
+    if (!a) a = event_acquire(dev);
+    if (!b) b = event_acquire(dev);
+    if (!a || !b) DCD_FAIL(DCD_E_HIP, "hipEventCreate failed");
     return DCD_OK;
   }
   int32_t start() { DCD_HIP(hipEventRecord(a, s)); return DCD_OK; }
@@ -108,8 +117,8 @@ struct EvTimer {
     return t;
   }
   ~EvTimer() {
-    if (a) (void)hipEventDestroy(a);
-    if (b) (void)hipEventDestroy(b);
+    event_release(device, a);
+    event_release(device, b);
   }
 };
 

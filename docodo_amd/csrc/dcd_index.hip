@@ -198,8 +198,7 @@ int32_t dcd_index_from_build(dcd_build* b, dcd_index** out) {
   DCD_TRY(index_fetch_host(*src));
   dcd_index* h = new dcd_index();
   h->ix = std::move(*src);
-  hipError_t e = hipStreamCreateWithFlags(&h->st, hipStreamNonBlocking);
-  if (e != hipSuccess) { delete h; DCD_FAIL(DCD_E_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
+  if (stream_acquire(h->ix.device, &h->st) != DCD_OK) { delete h; return DCD_E_HIP; }
   *out = h;
   return DCD_OK;
 }
@@ -213,7 +212,7 @@ int32_t dcd_index_from_images(const uint8_t* index_img, size_t n_index, const ui
   DCD_TRY(parse_index_image(index_img, n_index, h->ix, units));
   DCD_TRY(parse_list_image(list_img, n_list, h->ix.pages));
   DCD_TRY(index_from_host(h->ix, units, device));
-  DCD_HIP(hipStreamCreateWithFlags(&h->st, hipStreamNonBlocking));
+  DCD_TRY(stream_acquire(device, &h->st));
   *out = h.release();
   return DCD_OK;
 }
@@ -231,8 +230,11 @@ int32_t dcd_index_open(const char* dir_utf8, int32_t device, dcd_index** out) {
 void dcd_index_free(dcd_index* h) {
   if (!h) return;
   (void)hipSetDevice(h->ix.device);
-  if (h->st) { (void)hipStreamSynchronize(h->st); (void)hipStreamDestroy(h->st); }
+  hipStream_t st = h->st;
+  if (st) (void)hipStreamSynchronize(st);
+  const int dev = h->ix.device;
   delete h;
+  stream_release(dev, st);
 }
 
 int32_t dcd_index_count(dcd_index* h, uint64_t* n) { if (!h || !n) DCD_FAIL(DCD_E_BADARG, "NULL argument"); *n = h->ix.n_terms; return DCD_OK; }

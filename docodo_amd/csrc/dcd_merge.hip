@@ -347,7 +347,7 @@ int32_t dcd_merge_begin(int32_t device, uint32_t n_sources, const uint64_t* term
   std::unique_ptr<dcd_index>& h = mg->h;
   DevBuf<uint2>&pa = mg->pa, &pb = mg->pb;
   DevBuf<u64>&dst_off = mg->dst_off, &src_off = mg->src_off;
-  DCD_HIP(hipStreamCreateWithFlags(&h->st, hipStreamNonBlocking));
+  DCD_TRY(stream_acquire(device, &h->st));
   hipStream_t st = h->st;
   DeviceIndex& ix = h->ix;
   ix.device = device;
@@ -459,7 +459,11 @@ int32_t dcd_merge_finish(dcd_merge* m, const uint16_t* units_dev, dcd_index** ou
   return DCD_OK;
 }
 
-void dcd_merge_free(dcd_merge* m) { delete m; }
+void dcd_merge_free(dcd_merge* m) {
+  if (!m) return;
+  if (m->h && m->h->st) { stream_release(m->h->ix.device, m->h->st); m->h->st = nullptr; }
+  delete m;
+}
 
 int32_t dcd_merge_shards(int32_t device, uint32_t n_sources, const uint64_t* term_count, const uint64_t* key_count,
                          const uint64_t* unit_count, const void* meta_dev, const uint16_t* keys_dev, const uint16_t* units_dev,

@@ -1656,8 +1656,8 @@ static int32_t seq_binop(int opc, const u16* a, size_t na, int32_t Ra, const u16
   dcd_index tmp;
   tmp.ix.device = 0;
   DCD_TRY(ensure_device(0));
-  DCD_HIP(hipStreamCreateWithFlags(&tmp.st, hipStreamNonBlocking));
-  struct Guard { hipStream_t s; ~Guard() { (void)hipStreamDestroy(s); } } g{tmp.st};
+  DCD_TRY(stream_acquire(0, &tmp.st));
+  struct Guard { hipStream_t s; ~Guard() { stream_release(0, s); } } g{tmp.st};
   hipStream_t st = tmp.st;
   const u16* src[2] = {a, b};
   const size_t nu[2] = {na, nb};

@@ -236,10 +236,11 @@ inline u64 rs_hist_elems(u64 n, int bits) { return (u64)rs_plan(n).nblk << bits;
 // optional per-kernel event probes (build stats): pairs of events recorded around the two kernels
 struct RsProbe {
   std::vector<hipEvent_t>* ev = nullptr;  // appended: hist_begin, hist_end, scatter_begin, scatter_end per pass
+  int device = 0;
   void rec(hipStream_t st) const {
     if (!ev) return;
-    hipEvent_t e;
-    if (hipEventCreate(&e) == hipSuccess) { (void)hipEventRecord(e, st); ev->push_back(e); }
+    hipEvent_t e = event_acquire(device);
+    if (e) { (void)hipEventRecord(e, st); ev->push_back(e); }
   }
 };
 
