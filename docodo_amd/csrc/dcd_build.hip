@@ -1010,7 +1010,8 @@ static int32_t build_phase2(dcd_build* h) {
     int p2 = 0;
     RsProbe rp;
     rp.ev = &sort_events; rp.device = dev;
-    sorted = rs_sort(a, b, remap, N, (int)log2_ceil(V ? V : 1), M.d_hist.p, M.scan_scr32.p, st, &p2, rp);
+    sorted = rs_sort(a, b, remap, N, (int)log2_ceil(V ? V : 1), M.d_hist.p, M.scan_scr32.p, st, &p2, rp, 9,
+                     remap != nullptr && rs_cache_ok(1ull << M.cap_log2, V));
     passes += p2;
   }
   DCD_TRY(t_sort.stop());

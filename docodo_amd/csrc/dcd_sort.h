@@ -66,10 +66,32 @@ __device__ __forceinline__ void lds_barrier() {
 #ifndef DCD_RS_HCOPIES
 #define DCD_RS_HCOPIES 8
 #endif
-template <int BITS>
+// remap[key] through a small direct-mapped LDS cache: the keys of the first pass are vocabulary slots with a Zipf
+// distribution, the table is sparse (one useful entry per cache line) and every miss of the CU's L1 is an L2 request.
+// Entry = (key >> RC_BITS) << 20 | value in ONE 32-bit word (no torn reads); usable while values < 2^20 - 1 and
+// keys < 2^(RC_BITS + 12) (the host checks), 0xFFFFFFFF = empty.
+constexpr int RC_BITS = 12;        // histogram kernel: 4096 entries
+constexpr int RCS_BITS = 11;       // scatter kernel: 2048 entries (its LDS is nearly full with the tile)
+template <int CB>
+__device__ __forceinline__ u32 rs_key_cached(u32 k, const u32* __restrict__ remap, u32* cache) {
+  const u32 e = cache[k & ((1u << CB) - 1)];
+  if ((e >> 20) == (k >> CB)) return e & 0xFFFFFu;
+  const u32 v = remap[k];
+  cache[k & ((1u << CB) - 1)] = ((k >> CB) << 20) | v;
+  return v;
+}
+inline bool rs_cache_ok(u64 max_key_excl, u64 max_value_excl) {
+  return max_key_excl <= (1ull << (RCS_BITS + 12)) && max_value_excl < (1ull << 20) - 1;
+}
+
+template <int BITS, bool CACHE>
 __global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const uint2* __restrict__ in, const u32* __restrict__ remap, u64 n, u64 ipb,
                                                        u32 nblk, int shift, u32* __restrict__ hist) {
   constexpr int NB = 1 << BITS;
+  __shared__ u32 s_cache[CACHE ? (1 << RC_BITS) : 1];
+  if (CACHE)
+    for (int i = threadIdx.x; i < (1 << RC_BITS); i += RS_THREADS) s_cache[i] = 0xFFFFFFFFu;
+  auto key_of = [&](u32 k) -> u32 { return CACHE ? rs_key_cached<RC_BITS>(k, remap, s_cache) : rs_key(k, remap); };
   // Same-address LDS atomics of one wave instruction are executed one after the other (a Zipf head puts ~9 of 64
   // lanes on one digit): lane l counts into copy l % HC of the histogram, so that peers mostly hit different
   // addresses, and the copies are NB + 1 words apart, so that they hit different banks.  The copies are shared by
@@ -99,13 +121,13 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const uint2* __restrict_
       }
 #pragma unroll
       for (int u = 0; u < UN; u++) {
-        if (2 * p[u] < span) atomicAdd(&hl[(rs_key(kv[u].x, remap) >> shift) & (NB - 1)], 1u);
-        if (2 * p[u] + 1 < span) atomicAdd(&hl[(rs_key(kv[u].z, remap) >> shift) & (NB - 1)], 1u);
+        if (2 * p[u] < span) atomicAdd(&hl[(key_of(kv[u].x) >> shift) & (NB - 1)], 1u);
+        if (2 * p[u] + 1 < span) atomicAdd(&hl[(key_of(kv[u].z) >> shift) & (NB - 1)], 1u);
       }
     }
   } else {
     for (u64 o = threadIdx.x; o < span; o += RS_THREADS)
-      atomicAdd(&hl[(rs_key(in[beg + o].x, remap) >> shift) & (NB - 1)], 1u);
+      atomicAdd(&hl[(key_of(in[beg + o].x) >> shift) & (NB - 1)], 1u);
   }
   __syncthreads();
   for (int d = threadIdx.x; d < NB; d += RS_THREADS) {
@@ -119,7 +141,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const uint2* __restrict_
 #ifndef DCD_RS_WPE
 #define DCD_RS_WPE 4
 #endif
-template <int BITS>
+template <int BITS, bool CACHE>
 __global__ __launch_bounds__(RSS_THREADS) __attribute__((amdgpu_waves_per_eu(DCD_RS_WPE, DCD_RS_WPE))) void k_rs_scatter(const uint2* __restrict__ in, const u32* __restrict__ remap, u64 n, u64 ipb,
                                                           u32 nblk, int shift, const u32* __restrict__ hist_scanned,
                                                           uint2* __restrict__ out) {
@@ -129,7 +151,12 @@ __global__ __launch_bounds__(RSS_THREADS) __attribute__((amdgpu_waves_per_eu(DCD
   __shared__ u32 s_off[NB];             // output position of the digit's run minus its start in the sorted tile (mod 2^32)
   __shared__ uint2 s_tile[RS_TILE];
   __shared__ u32 s_wtot[RSS_WAVES];
+  __shared__ u32 s_cache[CACHE ? (1 << RCS_BITS) : 1];
   const u32 lane = lane_id(), w = threadIdx.x >> 6;
+  if (CACHE) {
+    for (int i = threadIdx.x; i < (1 << RCS_BITS); i += RSS_THREADS) s_cache[i] = 0xFFFFFFFFu;
+    lds_barrier();
+  }
 
   // running output position of the owned digits: registers of the owner thread
   u32 base[Q];
@@ -156,7 +183,7 @@ __global__ __launch_bounds__(RSS_THREADS) __attribute__((amdgpu_waves_per_eu(DCD
 #pragma unroll
     for (int r = 0; r < RS_ROWS; r++) {
       valid[r] = t0 + (u64)(w * RS_ROWS + r) * 64 + lane < end;
-      if (valid[r]) item[r].x = rs_key(item[r].x, remap);   // independent gathers (first pass only), issued together
+      if (valid[r]) item[r].x = CACHE ? rs_key_cached<RCS_BITS>(item[r].x, remap, s_cache) : rs_key(item[r].x, remap);   // (first pass only)
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -246,26 +273,32 @@ struct RsProbe {
 
 template <int BITS>
 inline void rs_pass(const uint2* in, uint2* out, const u32* remap, u64 n, int shift, u32* hist, u32* scan_scratch,
-                    hipStream_t st, const RsProbe& pr) {
+                    hipStream_t st, const RsProbe& pr, bool remap_cache) {
   RsPlan p = rs_plan(n);
   pr.rec(st);
-  hipLaunchKernelGGL((k_rs_hist<BITS>), dim3(p.nblk), dim3(RS_THREADS), 0, st, in, remap, n, p.ipb, p.nblk, shift, hist);
+  if (remap && remap_cache)
+    hipLaunchKernelGGL((k_rs_hist<BITS, true>), dim3(p.nblk), dim3(RS_THREADS), 0, st, in, remap, n, p.ipb, p.nblk, shift, hist);
+  else
+    hipLaunchKernelGGL((k_rs_hist<BITS, false>), dim3(p.nblk), dim3(RS_THREADS), 0, st, in, remap, n, p.ipb, p.nblk, shift, hist);
   pr.rec(st);
   u64 ne = (u64)p.nblk << BITS;
   scan_exclusive<u32, u32>(hist, hist, ne, scan_scratch, st);
   pr.rec(st);
-  hipLaunchKernelGGL((k_rs_scatter<BITS>), dim3(p.nblk), dim3(RSS_THREADS), 0, st, in, remap, n, p.ipb, p.nblk, shift, hist, out);
+  if (remap && remap_cache)
+    hipLaunchKernelGGL((k_rs_scatter<BITS, true>), dim3(p.nblk), dim3(RSS_THREADS), 0, st, in, remap, n, p.ipb, p.nblk, shift, hist, out);
+  else
+    hipLaunchKernelGGL((k_rs_scatter<BITS, false>), dim3(p.nblk), dim3(RSS_THREADS), 0, st, in, remap, n, p.ipb, p.nblk, shift, hist, out);
   pr.rec(st);
 }
 
 inline void rs_pass_dyn(int bits, const uint2* in, uint2* out, const u32* remap, u64 n, int shift, u32* hist,
-                        u32* scan_scratch, hipStream_t st, const RsProbe& pr) {
+                        u32* scan_scratch, hipStream_t st, const RsProbe& pr, bool remap_cache) {
   switch (bits) {
-    case 6: rs_pass<6>(in, out, remap, n, shift, hist, scan_scratch, st, pr); break;
-    case 7: rs_pass<7>(in, out, remap, n, shift, hist, scan_scratch, st, pr); break;
-    case 8: rs_pass<8>(in, out, remap, n, shift, hist, scan_scratch, st, pr); break;
-    case 9: rs_pass<9>(in, out, remap, n, shift, hist, scan_scratch, st, pr); break;
-    default: rs_pass<10>(in, out, remap, n, shift, hist, scan_scratch, st, pr); break;
+    case 6: rs_pass<6>(in, out, remap, n, shift, hist, scan_scratch, st, pr, remap_cache); break;
+    case 7: rs_pass<7>(in, out, remap, n, shift, hist, scan_scratch, st, pr, remap_cache); break;
+    case 8: rs_pass<8>(in, out, remap, n, shift, hist, scan_scratch, st, pr, remap_cache); break;
+    case 9: rs_pass<9>(in, out, remap, n, shift, hist, scan_scratch, st, pr, remap_cache); break;
+    default: rs_pass<10>(in, out, remap, n, shift, hist, scan_scratch, st, pr, remap_cache); break;
   }
 }
 
@@ -295,14 +328,15 @@ inline RsSchedule rs_schedule(int total_bits, int max_width = 9) {
 // Sorts n pairs by key bits [0, total_bits) (stable).  buf_a holds the input; buf_b is scratch of
 // the same size.  Returns the buffer that holds the result.  After the first pass the keys are the
 // remapped ones (remap applied once).  hist: >= RS_MAX_BLOCKS << 10 u32; scan_scratch: >=
-// scan_scratch_elems(RS_MAX_BLOCKS << 10) u32.
+// scan_scratch_elems(RS_MAX_BLOCKS << 10) u32.  remap_cache: the caller guarantees rs_cache_ok(key range, value range).
 inline uint2* rs_sort(uint2* buf_a, uint2* buf_b, const u32* remap, u64 n, int total_bits, u32* hist, u32* scan_scratch,
-                      hipStream_t st, int* passes_out = nullptr, const RsProbe& pr = RsProbe(), int max_width = 9) {
+                      hipStream_t st, int* passes_out = nullptr, const RsProbe& pr = RsProbe(), int max_width = 9,
+                      bool remap_cache = false) {
   RsSchedule sc = rs_schedule(total_bits, max_width);
   int shift = 0;
   uint2 *in = buf_a, *out = buf_b;
   for (int i = 0; i < sc.npass; i++) {
-    rs_pass_dyn(sc.width[i], in, out, i == 0 ? remap : nullptr, n, shift, hist, scan_scratch, st, pr);
+    rs_pass_dyn(sc.width[i], in, out, i == 0 ? remap : nullptr, n, shift, hist, scan_scratch, st, pr, remap_cache);
     shift += sc.width[i];
     uint2* t = in; in = out; out = t;
   }
