@@ -68,14 +68,14 @@ __device__ __forceinline__ void lds_barrier() {
 #endif
 // remap[key] through a small direct-mapped LDS cache: the keys of the first pass are vocabulary slots with a Zipf
 // distribution, the table is sparse (one useful entry per cache line) and every miss of the CU's L1 is an L2 request.
-// Entry = (key >> RC_BITS) << 20 | value in ONE 32-bit word (no torn reads); usable while values < 2^20 - 1 and
-// keys < 2^(RC_BITS + 12) (the host checks), 0xFFFFFFFF = empty.
+// Entry = (key >> bits) << 20 | value in ONE 32-bit word (no torn reads); usable while values < 2^20 - 1 (so that no
+// valid entry equals the empty word 0xFFFFFFFF) and keys < 2^(bits + 12) (the host checks).
 constexpr int RC_BITS = 12;        // histogram kernel: 4096 entries
 constexpr int RCS_BITS = 11;       // scatter kernel: 2048 entries (its LDS is nearly full with the tile)
 template <int CB>
 __device__ __forceinline__ u32 rs_key_cached(u32 k, const u32* __restrict__ remap, u32* cache) {
   const u32 e = cache[k & ((1u << CB) - 1)];
-  if ((e >> 20) == (k >> CB)) return e & 0xFFFFFu;
+  if ((e >> 20) == (k >> CB) && e != 0xFFFFFFFFu) return e & 0xFFFFFu;   // (an empty entry carries the tag 0xFFF)
   const u32 v = remap[k];
   cache[k & ((1u << CB) - 1)] = ((k >> CB) << 20) | v;
   return v;

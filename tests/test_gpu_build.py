@@ -179,6 +179,28 @@ def test_min_word_length_one_dense_tokens(oracle_mod):
     assert gi == oi and gl == ol
 
 
+@pytest.mark.parametrize("cap_log2", [20, 23, 24, 26])
+def test_vocabulary_capacity_does_not_change_the_index(cap_log2):
+    """The sort's first pass reads slot -> rank through a small LDS cache whose entries pack (slot tag, rank) into one
+    word: table sizes on both sides of the packing limit (2^23 slots: the highest tag equals the empty marker's) and
+    beyond it (no cache) must give the same bytes as the default table."""
+    import docodo_amd
+    from docodo_amd import synth
+    n_docs = 3000
+    text = synth.corpus_host(n_docs)
+    off = np.arange(n_docs + 1, dtype=np.uint64) * synth.DOC_BYTES
+    images = []
+    for cap in (0, cap_log2):
+        b = docodo_amd.Builder(vocab_capacity_log2=cap)
+        b.AddPages(text, off, docs_per_page=True)
+        st = b.Finish()
+        if cap:
+            assert st.vocab_capacity_log2 == cap
+        images.append((b.index_image(), b.list_image()))
+        b.close()
+    assert images[0] == images[1]
+
+
 def test_explicit_postings_builder_api(oracle_mod, known):
     """Index.Builder standalone path (BuilderTest, IndexTest.cs:272-313): AddWord(token, offset) for the
     \\b\\w+\\b tokens of TestText1, EndPage("1"); identity codes (no stemmer / vocab)."""
