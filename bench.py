@@ -52,9 +52,15 @@ def measured_traffic(kernel, T, N, U):
     tr = json.load(open(path))
     if (tr.get("T"), tr.get("N"), tr.get("U")) != (T, N, U):
         return None
-    names = {"k_rs_scatter": "k_rs_scatter<9>", "k_rs_hist": "k_rs_hist<9>", "k_enc_write": "k_pack_write"}
-    k = tr["kernels"].get(names.get(kernel, kernel))
-    return None if k is None else int(k["fetch_bytes_x2"] + k["write_bytes"])
+    # names as rocprofv3 prints them (per-launch maxima, i.e. the full-size tuple passes of the radix kernels)
+    names = {"k_rs_scatter": ("k_rs_scatter<",), "k_rs_hist": ("k_rs_hist<",), "k_enc_write": ("k_pack_write",),
+             "k_enc_reduce": ("k_pack_count",), "k_tok_emit": ("k_tok_emit<",), "k_tok_count": ("k_tok_count<",)}
+    pref = names.get(kernel, (kernel,))
+    hits = [v for n, v in tr["kernels"].items() if n.startswith(pref)]
+    if not hits:
+        return None
+    k = max(hits, key=lambda v: v["fetch_bytes_x2"] + v["write_bytes"])
+    return int(k["fetch_bytes_x2"] + k["write_bytes"])
 
 
 def cpu_baseline(n_docs_sample):
