@@ -42,6 +42,13 @@ def algorithmic_bytes(kernel, T, N, U):
     }.get(kernel, 0)
 
 
+# what actually limits each kernel (PMC runs): the roofline above prices every kernel against HBM, as the
+# contract asks, but the tokeniser kernels are bound by VALU issue, not by bytes
+LIMITER = {"k_tok_emit": "VALU issue (PMC: ~92 % busy; 906 wave-instructions per 944-character wave tile) + L2 / Infinity Cache gathers",
+           "k_tok_count": "VALU issue (PMC: ~100 % busy; 280 wave-instructions per wave tile)",
+           "k_rs_scatter": "hbm (first pass: fragmented stores of short digit runs)", "k_rs_hist": "hbm + L2 gather (first pass)"}
+
+
 def measured_traffic(kernel, T, N, U):
     """HBM bytes per launch from the PMC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes,
     stored in profiles/r01_final_traffic.json; FETCH_SIZE doubled per the gfx950 correction of
@@ -231,7 +238,8 @@ def main():
             "roofline": {"bound": "hbm", "kernel": name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "frac_of_measured_copy": round(achieved / HBM_COPY_GBS, 4),
                          "algorithmic_bytes_per_launch": int(abytes), "avg_launch_ms": round(avg_ms, 4),
-                         "launches_per_step": round(kcnt[dom] / args.steps, 2), "traffic": measured_traffic(name, T, int(N), int(U))},
+                         "launches_per_step": round(kcnt[dom] / args.steps, 2), "traffic": measured_traffic(name, T, int(N), int(U)),
+                         "limiter": LIMITER.get(name, "hbm")},
             "roofline_all": {KERNEL_NAMES[k]: round(algorithmic_bytes(KERNEL_NAMES[k], T, N, U) / 1e9 /
                                                     (max(ksum[k], 1e-9) / max(1.0, kcnt[k]) / 1e3) / HBM_PEAK_GBS, 4) for k in range(7)},
             "device_ms_per_step": {"tokenize": round(stage[0] / args.steps, 3), "vocab": round(stage[1] / args.steps, 3),
