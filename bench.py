@@ -44,7 +44,7 @@ def algorithmic_bytes(kernel, T, N, U):
 
 # what actually limits each kernel (PMC runs): the roofline above prices every kernel against HBM, as the
 # contract asks, but the tokeniser kernels are bound by VALU issue, not by bytes
-LIMITER = {"k_tok_emit": "VALU issue (PMC: ~92 % busy; 906 wave-instructions per 944-character wave tile) + L2 / Infinity Cache gathers",
+LIMITER = {"k_tok_emit": "VALU issue (PMC before the string pool: ~92 % busy, 906 wave-instructions per 944-character wave tile) + L2 / Infinity Cache gathers",
            "k_tok_count": "VALU issue (PMC: ~100 % busy; 280 wave-instructions per wave tile)",
            "k_rs_scatter": "hbm (first pass: fragmented stores of short digit runs)", "k_rs_hist": "hbm + L2 gather (first pass)"}
 

@@ -72,9 +72,17 @@ __global__ __launch_bounds__(TK_THREADS) void k_tok_emit(const CharT* __restrict
     auto word = [txt, i, nbytes](u32 q) -> u32 { return lds_word(txt, i * CS, q) & tail_mask(nbytes, q); };
     HashState hs;
     hs.init(len);
-    for (u32 q = 0; q < nw; q++) hs.add(word(q));
+    constexpr u32 PW = VocPool<CharT>::W;
+    u32 wv[PW];
+#pragma unroll
+    for (u32 q = 0; q < PW; q++) {
+      wv[q] = q < nw ? word(q) : 0u;
+      if (q < nw) hs.add(wv[q]);
+    }
+    for (u32 q = PW; q < nw; q++) hs.add(word(q));
     const u64 gpos = (u64)(org + (int64_t)i);
-    u32 slot = vocab_lookup_insert<CharT>(vt, tv, hs.fin(), len, gpos, word);
+    u32 slot = vt.pool ? vocab_lookup_insert_pooled<CharT>(vt, tv, hs.fin(), len, gpos, wv, word)
+                       : vocab_lookup_insert<CharT>(vt, tv, hs.fin(), len, gpos, word);
     u32 coord = (u32)gpos;
     if (P.n_runs) {
       u32 a = 0, b = P.n_runs;   // last run with run_off <= gpos
@@ -793,6 +801,7 @@ static int32_t build_phase1(dcd_build* h, bool codes_mode) {
   TextView<CharT> tv;
   tv.text = text; tv.n_chars = n_chars; tv.pool = (const CharT*)M.d_pool_raw.p; tv.n_pool = M.n_pool; tv.tab = tab;
   u64 V = 0;
+  DevBuf<u32> voc_pool;                       // first words of every slot's string (vocab_lookup_insert_pooled)
   for (;;) {
     if (cap_log2 > 30) DCD_FAIL(DCD_E_OVERFLOW, "vocabulary does not fit a 2^30-slot table");
     const u64 cap = 1ull << cap_log2;
@@ -801,6 +810,13 @@ static int32_t build_phase1(dcd_build* h, bool codes_mode) {
     DCD_HIP(hipMemsetAsync(M.d_flags.p, 0, 16, st));
     VocabTable vt;
     vt.slots = M.slots.p; vt.mask = (u32)(cap - 1); vt.overflow = M.d_flags.p;
+    vt.pool = nullptr;
+    static const bool no_pool = getenv("DOCODO_VOCAB_POOL") && atoi(getenv("DOCODO_VOCAB_POOL")) == 0;
+    if (!no_pool) {
+      DCD_TRY(voc_pool.alloc(dev, cap * VocPool<CharT>::W));
+      DCD_HIP(hipMemsetAsync(voc_pool.p, 0, cap * VocPool<CharT>::W * 4, st));
+      vt.pool = voc_pool.p;
+    }
     if (n_tiles) {
       probes.begin(DCD_K_TOK_EMIT);
       hipLaunchKernelGGL((k_tok_emit<CharT>), dim3((u32)div_up(n_tiles, TK_WAVES)), dim3(TK_THREADS), 0, st, text, P, tab, tv, vt,

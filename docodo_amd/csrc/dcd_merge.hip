@@ -380,7 +380,7 @@ int32_t dcd_merge_begin(int32_t device, uint32_t n_sources, const uint64_t* term
     DCD_HIP(hipMemsetAsync(slots.p, 0, cap * 8, st));
     DCD_HIP(hipMemsetAsync(flags.p, 0, 16, st));
     VocabTable vt;
-    vt.slots = slots.p; vt.mask = (u32)(cap - 1); vt.overflow = flags.p;
+    vt.slots = slots.p; vt.mask = (u32)(cap - 1); vt.overflow = flags.p; vt.pool = nullptr;
     hipLaunchKernelGGL(k_insert_keys, dim3((u32)div_up(M, 256)), dim3(256), 0, st, meta, key_off.p, M, tv, vt, pa.p);
     scan_exclusive_f<SlotUsed, u32>(SlotUsed{slots.p}, slot_excl.p, cap, sscr32.p, st);
     u32 v32 = 0, fl[4] = {0, 0, 0, 0};

@@ -275,7 +275,10 @@ struct VocabTable {
   u64* slots;
   u32 mask;        // capacity - 1
   u32* overflow;   // set to 1 when a probe sequence gets too long
+  u32* pool;       // optional: VOC_PW<CharT> words per slot, zeroed; the first words of the slot's string (see below)
 };
+// words of a string kept next to its slot: 16 characters' worth
+template <typename CharT> struct VocPool { static constexpr u32 W = 4 * sizeof(CharT); };
 
 // Look up / insert the string whose (masked) words are get(k), k < nw, nbytes long, `len` characters,
 // canonical position `pos`.  Returns the slot index (0xFFFFFFFF on table overflow).
@@ -303,6 +306,62 @@ __device__ __forceinline__ u32 vocab_lookup_insert(const VocabTable& vt, const T
         if (((tv.canon_word(cp, k) ^ get(k)) & tail_mask(nbytes, k)) != 0u) { eq = false; break; }
       }
       if (eq) return idx;
+    }
+    idx = (idx + 1) & vt.mask;
+  }
+  *vt.overflow = 1u;
+  return 0xFFFFFFFFu;
+}
+
+// The same with a STRING POOL beside the table.  Verifying a hit against the canonical occurrence costs, per word, an
+// unaligned two-load fetch from the text, its lower-casing and a re-read of the token's own word from LDS -- half of the
+// instructions of the emit kernel, which is bound by VALU issue.  Here the first W words of every slot's string (lower-cased,
+// zero padded) live in pool[slot * W ...]: a hit is confirmed by one aligned 16-byte load per four words and a few XORs.
+// Soundness does not depend on cache coherence: a pool word is only ever 0 or the word of the slot's string (whoever writes
+// it -- the inserting lane, or a lane that has just verified the string against the text -- writes the same values), token
+// words are never 0, so "all words equal" implies the strings are equal; any other outcome (entry not written yet, stale
+// zeros in this CU's or XCD's cache, a different string, a string longer than the pool entry) falls back to the exact
+// comparison with the text, after which the lane writes the entry itself, healing its own cache hierarchy.
+// wv[0..W): the token's masked words, 0 beyond its length.
+template <typename CharT, typename GetWord>
+__device__ __forceinline__ u32 vocab_lookup_insert_pooled(const VocabTable& vt, const TextView<CharT>& tv, TokHash h, u32 len, u64 pos,
+                                                          const u32 (&wv)[VocPool<CharT>::W], GetWord get) {
+  constexpr u32 W = VocPool<CharT>::W;
+  const u64 mine = voc_word(h.tag, len, pos);
+  const u32 nbytes = len * (u32)sizeof(CharT), nw = (nbytes + 3u) >> 2;
+  u32 idx = h.idx & vt.mask;
+  for (u32 probes = 0; probes < 4096u; probes++) {
+    u64 w = vt.slots[idx];
+    uint4* pe = reinterpret_cast<uint4*>(vt.pool + (u64)idx * W);
+    if (w == 0) {
+      u64 old = atomicCAS((unsigned long long*)&vt.slots[idx], 0ull, (unsigned long long)mine);
+      if (old == 0) {
+#pragma unroll
+        for (u32 q = 0; q < W / 4; q++) pe[q] = make_uint4(wv[4 * q], wv[4 * q + 1], wv[4 * q + 2], wv[4 * q + 3]);
+        return idx;
+      }
+      w = old;
+    }
+    if ((w >> 42) == (mine >> 42)) {  // tag and length agree
+      u32 diff = 0;
+#pragma unroll
+      for (u32 q = 0; q < W / 4; q++) {
+        const uint4 p = pe[q];
+        diff |= (p.x ^ wv[4 * q]) | (p.y ^ wv[4 * q + 1]) | (p.z ^ wv[4 * q + 2]) | (p.w ^ wv[4 * q + 3]);
+      }
+      if (diff == 0 && nw <= W) return idx;
+      const u64 cp = voc_pos(w);
+      bool eq = true;
+      for (u32 k = 0; k < nw; k++) {
+        if (((tv.canon_word(cp, k) ^ get(k)) & tail_mask(nbytes, k)) != 0u) { eq = false; break; }
+      }
+      if (eq) {
+        if (diff != 0) {
+#pragma unroll
+          for (u32 q = 0; q < W / 4; q++) pe[q] = make_uint4(wv[4 * q], wv[4 * q + 1], wv[4 * q + 2], wv[4 * q + 3]);
+        }
+        return idx;
+      }
     }
     idx = (idx + 1) & vt.mask;
   }
