@@ -812,8 +812,9 @@ static int32_t build_phase1(dcd_build* h, bool codes_mode) {
     vt.slots = M.slots.p; vt.mask = (u32)(cap - 1); vt.overflow = M.d_flags.p;
     vt.pool = nullptr;
     static const bool no_pool = getenv("DOCODO_VOCAB_POOL") && atoi(getenv("DOCODO_VOCAB_POOL")) == 0;
-    if (!no_pool) {
-      DCD_TRY(voc_pool.alloc(dev, cap * VocPool<CharT>::W));
+    // the string pool is an accelerator, not a requirement: very large tables (> 2^26 slots: 1-2 GB of pool) or a failed
+    // allocation fall back to verifying every hit against the text
+    if (!no_pool && cap_log2 <= 26 && voc_pool.alloc(dev, cap * VocPool<CharT>::W) == DCD_OK) {
       DCD_HIP(hipMemsetAsync(voc_pool.p, 0, cap * VocPool<CharT>::W * 4, st));
       vt.pool = voc_pool.p;
     }

@@ -179,11 +179,12 @@ def test_min_word_length_one_dense_tokens(oracle_mod):
     assert gi == oi and gl == ol
 
 
-@pytest.mark.parametrize("cap_log2", [20, 23, 24, 26])
+@pytest.mark.parametrize("cap_log2", [20, 23, 24, 26, 27])
 def test_vocabulary_capacity_does_not_change_the_index(cap_log2):
     """The sort's first pass reads slot -> rank through a small LDS cache whose entries pack (slot tag, rank) into one
     word: table sizes on both sides of the packing limit (2^23 slots: the highest tag equals the empty marker's) and
-    beyond it (no cache) must give the same bytes as the default table."""
+    beyond it (no cache) must give the same bytes as the default table.  2^27 slots is also past the size up to which
+    the tokeniser keeps a string pool beside the table (hits are then verified against the text only)."""
     import docodo_amd
     from docodo_amd import synth
     n_docs = 3000
