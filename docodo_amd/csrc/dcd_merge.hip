@@ -93,13 +93,17 @@ __global__ void k_export_meta(const uint2* __restrict__ perm, u64 n_terms, const
   for (u32 i = 0; i < m.key_len; i++) d[i] = s[i];
 }
 
-// segmented copy: dst_off[j] .. dst_off[j+1] <- src[src_start(j) ..].  A workgroup owns a tile of 2048 output units
-// (8 consecutive ones = 16 bytes per thread); the tile's first and last segment are found once per workgroup, every
-// thread then searches only that range; 8 units inside one segment move as one 16-byte store fed by (possibly
-// 2-byte-aligned) dword loads.
+// segmented copy: dst_off[j] .. dst_off[j+1] <- src[src_start(j) ..].  A workgroup owns a tile of 8192 output units,
+// each of its four waves a span of 2048 (4 x 8 consecutive units = 4 x 16 bytes per lane, lane-interleaved so that
+// every store instruction of the wave is contiguous).  The tile's first and last segment are found once per workgroup.
+// A span that lies inside ONE segment (by weight almost all of a Zipf index) takes the segment's bookkeeping once per
+// wave and streams; other spans fall back to one search per 8-unit chunk.  8 units inside one segment move as one
+// 16-byte store fed by (possibly 2-byte-aligned) dword loads.
 constexpr int CP_UPT = 8;
 constexpr int CP_THREADS = 256;
-constexpr int CP_TILE = CP_UPT * CP_THREADS;
+constexpr int CP_CPL = 4;                               // chunks per lane
+constexpr int CP_SPAN = 64 * CP_UPT * CP_CPL;           // units per wave
+constexpr int CP_TILE = CP_SPAN * (CP_THREADS / 64);
 typedef u32 __attribute__((aligned(2))) u32_a2;
 
 // last j in [0, n) with off[j] <= u  (off ascending, off[0] <= u)
@@ -124,17 +128,31 @@ __global__ __launch_bounds__(CP_THREADS) void k_export_units(const uint2* __rest
   __shared__ u64 s_q[2];
   const u64 tile_base = (u64)blockIdx.x * CP_TILE;
   tile_seg_range(dst_off, n_terms, tile_base, total_units, s_q);
-  const u64 u0 = tile_base + (u64)threadIdx.x * CP_UPT;
-  if (u0 >= total_units) return;
-  u64 j = seg_of(dst_off, s_q[0], s_q[1] + 1, u0);
-  u64 next = j + 1 < n_terms ? dst_off[j + 1] : total_units;
-  u64 src = unit_start[perm[j].y] + (u0 - dst_off[j]);
-  if (u0 + CP_UPT <= next && ((reinterpret_cast<uintptr_t>(out + u0) & 15) == 0)) { copy8(units + src, out + u0); return; }
-  for (int k = 0; k < CP_UPT; k++) {
-    u64 u = u0 + k;
-    if (u >= total_units) break;
-    while (u >= next) { j++; next = j + 1 < n_terms ? dst_off[j + 1] : total_units; src = unit_start[perm[j].y]; }
-    out[u] = units[src++];
+  const u32 lane = threadIdx.x & 63;
+  const u64 span = tile_base + (u64)(threadIdx.x >> 6) * CP_SPAN;
+  if (span >= total_units) return;
+  const bool aligned = (reinterpret_cast<uintptr_t>(out) & 15) == 0;
+  const u64 j0 = seg_of(dst_off, s_q[0], s_q[1] + 1, span);                 // wave-uniform
+  const u64 next0 = j0 + 1 < n_terms ? dst_off[j0 + 1] : total_units;
+  if (aligned && span + CP_SPAN <= next0) {                                 // the whole span inside one segment
+    const u16* src = units + unit_start[perm[j0].y] + (span - dst_off[j0]);
+#pragma unroll
+    for (int c = 0; c < CP_CPL; c++) copy8(src + (c * 64 + lane) * CP_UPT, out + span + (c * 64 + lane) * CP_UPT);
+    return;
+  }
+  for (int c = 0; c < CP_CPL; c++) {
+    const u64 u0 = span + (u64)(c * 64 + lane) * CP_UPT;
+    if (u0 >= total_units) break;
+    u64 j = seg_of(dst_off, j0, s_q[1] + 1, u0);
+    u64 next = j + 1 < n_terms ? dst_off[j + 1] : total_units;
+    u64 src = unit_start[perm[j].y] + (u0 - dst_off[j]);
+    if (aligned && u0 + CP_UPT <= next) { copy8(units + src, out + u0); continue; }
+    for (int k = 0; k < CP_UPT; k++) {
+      u64 u = u0 + k;
+      if (u >= total_units) break;
+      while (u >= next) { j++; next = j + 1 < n_terms ? dst_off[j + 1] : total_units; src = unit_start[perm[j].y]; }
+      out[u] = units[src++];
+    }
   }
 }
 
@@ -189,28 +207,50 @@ __global__ __launch_bounds__(CP_THREADS) void k_merge_copy(SegPlan p, u64 n_seg,
   __shared__ u64 s_q[2];
   const u64 tile_base = (u64)blockIdx.x * CP_TILE;
   tile_seg_range(dst_off, n_seg, tile_base, total_units, s_q);
-  const u64 u0 = tile_base + (u64)threadIdx.x * CP_UPT;
-  if (u0 >= total_units) return;
-  u64 q = seg_of(dst_off, s_q[0], s_q[1] + 1, u0);
+  const u32 lane = threadIdx.x & 63;
+  const u64 span = tile_base + (u64)(threadIdx.x >> 6) * CP_SPAN;
+  if (span >= total_units) return;
+  const bool aligned = (reinterpret_cast<uintptr_t>(out) & 15) == 0;
+  const u64 q0 = seg_of(dst_off, s_q[0], s_q[1] + 1, span);                 // wave-uniform
   {
-    // 8 units of one segment, all behind its (re-coded) head: plain copy
-    const u64 next = q + 1 < n_seg ? dst_off[q + 1] : total_units;
-    if (u0 + CP_UPT <= next) {
-      const dcd_term_meta& m = p.meta[p.sorted[q].y];
-      const u32 newlen = seq_nunits(p.new_delta(q)), oldlen = seq_nunits(m.first);
-      const u64 r = u0 - dst_off[q];
-      if (r >= newlen) { copy8(units + src_off[p.sorted[q].y] + oldlen + (r - newlen), out + u0); return; }
+    // the whole span inside one segment and behind its (re-coded) head: the segment's bookkeeping once per wave
+    const u64 next0 = q0 + 1 < n_seg ? dst_off[q0 + 1] : total_units;
+    if (aligned && span + CP_SPAN <= next0) {
+      const u32 sg = p.sorted[q0].y;
+      const u32 newlen = seq_nunits(p.new_delta(q0)), oldlen = seq_nunits(p.meta[sg].first);
+      const u64 r = span - dst_off[q0];
+      if (r >= newlen) {
+        const u16* src = units + src_off[sg] + oldlen + (r - newlen);
+#pragma unroll
+        for (int c = 0; c < CP_CPL; c++) copy8(src + (c * 64 + lane) * CP_UPT, out + span + (c * 64 + lane) * CP_UPT);
+        return;
+      }
     }
   }
-  for (int k = 0; k < CP_UPT; k++) {
-    u64 u = u0 + k;
-    if (u >= total_units) break;
-    while (q + 1 < n_seg && u >= dst_off[q + 1]) q++;
-    const dcd_term_meta& m = p.meta[p.sorted[q].y];
-    u64 nd = p.new_delta(q);
-    u32 newlen = seq_nunits(nd), oldlen = seq_nunits(m.first);
-    u64 r = u - dst_off[q];
-    out[u] = r < newlen ? seq_unit(nd, (u32)r, newlen) : units[src_off[p.sorted[q].y] + oldlen + (r - newlen)];
+  for (int c = 0; c < CP_CPL; c++) {
+    const u64 u0 = span + (u64)(c * 64 + lane) * CP_UPT;
+    if (u0 >= total_units) break;
+    u64 q = seg_of(dst_off, q0, s_q[1] + 1, u0);
+    {
+      // 8 units of one segment, all behind its (re-coded) head: plain copy
+      const u64 next = q + 1 < n_seg ? dst_off[q + 1] : total_units;
+      if (aligned && u0 + CP_UPT <= next) {
+        const dcd_term_meta& m = p.meta[p.sorted[q].y];
+        const u32 newlen = seq_nunits(p.new_delta(q)), oldlen = seq_nunits(m.first);
+        const u64 r = u0 - dst_off[q];
+        if (r >= newlen) { copy8(units + src_off[p.sorted[q].y] + oldlen + (r - newlen), out + u0); continue; }
+      }
+    }
+    for (int k = 0; k < CP_UPT; k++) {
+      u64 u = u0 + k;
+      if (u >= total_units) break;
+      while (q + 1 < n_seg && u >= dst_off[q + 1]) q++;
+      const dcd_term_meta& m = p.meta[p.sorted[q].y];
+      u64 nd = p.new_delta(q);
+      u32 newlen = seq_nunits(nd), oldlen = seq_nunits(m.first);
+      u64 r = u - dst_off[q];
+      out[u] = r < newlen ? seq_unit(nd, (u32)r, newlen) : units[src_off[p.sorted[q].y] + oldlen + (r - newlen)];
+    }
   }
 }
 
