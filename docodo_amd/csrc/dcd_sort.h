@@ -190,12 +190,19 @@ __global__ __launch_bounds__(RSS_THREADS) __attribute__((amdgpu_waves_per_eu(DCD
 #pragma unroll
     for (int r = 0; r < RS_ROWS; r++) {
       u32 d = (item[r].x >> shift) & (NB - 1);
-      u64 peers = ballot64(valid[r]);
+      // match-any on the digit: per bit, the lanes that agree with this lane are m (bit set) or ~m, i.e. m ^ (bit - 1);
+      // kept in 32-bit halves so that each step is one three-input bit operation per half
+      const u64 vm = ballot64(valid[r]);
+      u32 plo = (u32)vm, phi = (u32)(vm >> 32);
 #pragma unroll
       for (int b = 0; b < BITS; b++) {
-        u64 m = ballot64((d >> b) & 1u);
-        peers &= ((d >> b) & 1u) ? m : ~m;
+        const u32 bit = (d >> b) & 1u;
+        const u64 m = ballot64(bit != 0u);
+        const u32 t = bit - 1u;
+        plo &= (u32)m ^ t;
+        phi &= (u32)(m >> 32) ^ t;
       }
+      const u64 peers = ((u64)phi << 32) | plo;
       u32 prev = valid[r] ? s_cnt[w][d] : 0u;   // count of this digit in earlier rows of this wave
       u32 below = mbcnt(peers);
       if (valid[r] && below == 0) s_cnt[w][d] = prev + popc64(peers);  // leader = lowest peer lane
