@@ -70,7 +70,10 @@ __device__ __forceinline__ void lds_barrier() {
 // distribution, the table is sparse (one useful entry per cache line) and every miss of the CU's L1 is an L2 request.
 // Entry = (key >> bits) << 20 | value in ONE 32-bit word (no torn reads); usable while values < 2^20 - 1 (so that no
 // valid entry equals the empty word 0xFFFFFFFF) and keys < 2^(bits + 12) (the host checks).
-constexpr int RC_BITS = 12;        // histogram kernel: 4096 entries
+#ifndef DCD_RC_BITS
+#define DCD_RC_BITS 12
+#endif
+constexpr int RC_BITS = DCD_RC_BITS;        // histogram kernel: 4096 entries
 constexpr int RCS_BITS = 11;       // scatter kernel: 2048 entries (its LDS is nearly full with the tile)
 template <int CB>
 __device__ __forceinline__ u32 rs_key_cached(u32 k, const u32* __restrict__ remap, u32* cache) {
