@@ -41,7 +41,9 @@ __global__ __launch_bounds__(TK_THREADS) void k_tok_count(const CharT* __restric
 template <typename CharT>
 __global__ __launch_bounds__(TK_THREADS) void k_tok_emit(const CharT* __restrict__ text, TokParams P, CharTables16 tab,
                                                         TextView<CharT> tv, VocabTable vt, const u64* __restrict__ tile_off,
-                                                        uint2* __restrict__ tuples, u64 n_tiles) {
+                                                        uint2* __restrict__ tuples, u64 n_tiles, u32 stride, u32* __restrict__ tile_cnt) {
+  // stride != 0: no counting pass ran; the tile's tuples go to tuples[tile * stride ...] and their number to tile_cnt
+  // (the first sort pass compacts, RsStrided in dcd_sort.h).  stride == 0: dense output at tile_off[tile].
   __shared__ TokLds<CharT, true> SW[TK_WAVES];
   const u64 tile = (u64)blockIdx.x * TK_WAVES + (threadIdx.x >> 6);
   if (tile >= n_tiles) return;
@@ -62,7 +64,8 @@ __global__ __launch_bounds__(TK_THREADS) void k_tok_emit(const CharT* __restrict
   }
   wave_sync();
   const int64_t org = tile_origin(tile);
-  const u64 obase = tile_off[tile];
+  const u64 obase = stride ? tile * stride : tile_off[tile];
+  if (stride && lane == 0) tile_cnt[tile] = total;
   constexpr u32 CS = sizeof(CharT);
   for (u32 k = lane; k < total; k += 64) {
     const u32 t = S.tok[k];
@@ -112,6 +115,14 @@ __global__ void k_explicit(const u32* __restrict__ xoff, const u32* __restrict__
 }
 
 __global__ void k_set_u64(u64* p, u64 v) { *p = v; }
+// coordinate of the last tuple of a tile-strided buffer (the last non-empty tile is almost always the last one)
+__global__ void k_last_strided_coord(const uint2* __restrict__ tuples, const u32* __restrict__ cnt, u64 n_tiles, u32 stride, u32* out) {
+  for (u64 t = n_tiles; t-- > 0;) {
+    const u32 c = cnt[t];
+    if (c) { *out = tuples[t * stride + c - 1].y; return; }
+  }
+  *out = 0;
+}
 __global__ void k_term_first_last(const uint2* __restrict__ sorted, const u64* __restrict__ item_start, u64 n_terms, u64 base,
                                   u64* __restrict__ first, u64* __restrict__ last) {
   u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -631,6 +642,12 @@ struct BuildMid {
   u64 N = 0, n_text_tok = 0, n_xdev = 0, V = 0;
   u32 cap_log2 = 0, last_text_coord = 0;
   DevBuf<uint2> tupA, tupB;
+  // tile-strided tuples (no counting pass): tupA holds tile t at [t * stride, t * stride + tile_cnt[t])
+  bool strided = false;
+  u32 stride = 0;
+  u64 n_tiles = 0;
+  DevBuf<u32> tile_cnt;
+  DevBuf<u64> tile_off;
   DevBuf<u8> d_pool_raw;            // explicit strings on the device (CharT units)
   u64 n_pool = 0;
   DevBuf<u64> slots;
@@ -766,34 +783,49 @@ static int32_t build_phase1(dcd_build* h, bool codes_mode) {
     DCD_HIP(hipStreamSynchronize(st));
     P.run_off = d_run_off.p; P.run_delta = d_run_delta.p; P.n_runs = (u32)h->run_off.size();
   }
-  DevBuf<u32> tile_count;
-  DevBuf<u64> tile_off, scan_scr64;
+  // Plain text builds (no explicit postings, no word codes) skip the counting pass: the emit kernel writes every tile's
+  // tuples at a fixed stride and the first sort pass compacts them (RsStrided, dcd_sort.h).  A tile of TK_TILE
+  // characters holds at most TK_TILE / min_word_length + 1 kept tokens; the compacting kernel reads up to
+  // 64 * RS_STRIDE_ROUNDS per tile.  DOCODO_TOK_TWO_PASS=1 forces the counting pass.
+  static const bool env_two_pass = getenv("DOCODO_TOK_TWO_PASS") && atoi(getenv("DOCODO_TOK_TWO_PASS")) != 0;
+  const u32 stride_need = (u32)(TK_TILE / (P.min_len ? P.min_len : 1u)) + 2u;
+  const bool strided = !env_two_pass && !codes_mode && n_x == 0 && n_tiles != 0 && stride_need <= 64u * RS_STRIDE_ROUNDS &&
+                       n_tiles * (u64)stride_need < (1ull << 32);
+  M.strided = strided; M.stride = strided ? stride_need : 0u; M.n_tiles = n_tiles;
+  DevBuf<u64> scan_scr64;
   u64 n_text_tok = 0;
   if (n_tiles) {
-    DCD_TRY(tile_count.alloc(dev, n_tiles));
-    DCD_TRY(tile_off.alloc(dev, n_tiles));
+    DCD_TRY(M.tile_cnt.alloc(dev, n_tiles));
+    DCD_TRY(M.tile_off.alloc(dev, n_tiles));
     DCD_TRY(scan_scr64.alloc(dev, scan_scratch_elems(n_tiles)));
+  }
+  if (n_tiles && !strided) {
     probes.begin(DCD_K_TOK_COUNT);
-    hipLaunchKernelGGL((k_tok_count<CharT>), dim3((u32)div_up(n_tiles, TK_WAVES)), dim3(TK_THREADS), 0, st, text, P, tab, tile_count.p,
+    hipLaunchKernelGGL((k_tok_count<CharT>), dim3((u32)div_up(n_tiles, TK_WAVES)), dim3(TK_THREADS), 0, st, text, P, tab, M.tile_cnt.p,
                        n_tiles);
     probes.end();
-    scan_exclusive<u32, u64>(tile_count.p, tile_off.p, n_tiles, scan_scr64.p, st);
+    scan_exclusive<u32, u64>(M.tile_cnt.p, M.tile_off.p, n_tiles, scan_scr64.p, st);
     DCD_HIP(hipMemcpyAsync(&n_text_tok, scan_scr64.p + scan_nblocks(n_tiles), 8, hipMemcpyDeviceToHost, st));
     DCD_HIP(hipStreamSynchronize(st));
   }
   tr.mark("count");
-  const u64 N = n_text_tok + n_x;
+  u64 N = n_text_tok + n_x;
   if (N >= (1ull << 32)) DCD_FAIL(DCD_E_OVERFLOW, "more than 2^32 postings in one build segment");
-  M.N = N; M.n_text_tok = n_text_tok;
 
   // ---- 2. vocabulary table + emit ---------------------------------------------------------------
-  DCD_TRY(M.tupA.alloc(dev, N ? N : 1));
-  DCD_TRY(M.tupB.alloc(dev, N ? N : 1));
+  if (strided) {
+    DCD_TRY(M.tupA.alloc(dev, n_tiles * (u64)M.stride));
+  } else {
+    DCD_TRY(M.tupA.alloc(dev, N ? N : 1));
+    DCD_TRY(M.tupB.alloc(dev, N ? N : 1));
+  }
   u32 cap_log2 = h->opts.vocab_capacity_log2;
   if (cap_log2 == 0) {
     // first guess: one slot per 64 postings -- small enough to stay close to the caches (every probe of a
-    // tail term is a random access); grown x4 and the emit re-run if the load exceeds 1/2
-    cap_log2 = log2_ceil((N ? N : 1) / DCD_CAPDIV + 1);
+    // tail term is a random access); grown x4 and the emit re-run if the load exceeds 1/2.  Without a counting pass
+    // the postings are estimated as one per 7 characters.
+    const u64 n_est = strided ? n_chars / 7 : N;
+    cap_log2 = log2_ceil((n_est ? n_est : 1) / DCD_CAPDIV + 1);
     if (cap_log2 < 12) cap_log2 = 12;
     if (cap_log2 > 24) cap_log2 = 24;
   }
@@ -821,8 +853,13 @@ static int32_t build_phase1(dcd_build* h, bool codes_mode) {
     if (n_tiles) {
       probes.begin(DCD_K_TOK_EMIT);
       hipLaunchKernelGGL((k_tok_emit<CharT>), dim3((u32)div_up(n_tiles, TK_WAVES)), dim3(TK_THREADS), 0, st, text, P, tab, tv, vt,
-                         tile_off.p, M.tupA.p, n_tiles);
+                         M.tile_off.p, M.tupA.p, n_tiles, M.stride, M.tile_cnt.p);
       probes.end();
+      if (strided) {
+        // the tiles' dense offsets and the number of postings, now that the emit kernel has counted
+        scan_exclusive<u32, u64>(M.tile_cnt.p, M.tile_off.p, n_tiles, scan_scr64.p, st);
+        DCD_HIP(hipMemcpyAsync(&n_text_tok, scan_scr64.p + scan_nblocks(n_tiles), 8, hipMemcpyDeviceToHost, st));
+      }
     }
     if (n_x)
       hipLaunchKernelGGL((k_explicit<CharT>), dim3((u32)div_up(n_x, 256)), dim3(256), 0, st, d_xoff.p, d_xlen.p, d_xcoord.p,
@@ -840,12 +877,25 @@ static int32_t build_phase1(dcd_build* h, bool codes_mode) {
     if (flags[0] || V * 2 > cap) { cap_log2 += 2; continue; }  // overflow or load > 0.5: rebuild larger
     break;
   }
+  if (strided) {
+    N = n_text_tok;
+    if (N >= (1ull << 32)) DCD_FAIL(DCD_E_OVERFLOW, "more than 2^32 postings in one build segment");
+    DCD_TRY(M.tupB.alloc(dev, N ? N : 1));
+  }
+  M.N = N; M.n_text_tok = n_text_tok;
   tr.mark("emit");
   const u64 cap = 1ull << cap_log2;
   M.cap_log2 = cap_log2; M.V = V;
   DCD_TRY(t_tok.stop());
   // maxCoord = coordinate of the last posting added (Build.cs:326)
-  if (n_text_tok) DCD_HIP(hipMemcpyAsync(&M.last_text_coord, &M.tupA.p[n_text_tok - 1].y, 4, hipMemcpyDeviceToHost, st));
+  if (n_text_tok) {
+    if (strided) {
+      hipLaunchKernelGGL(k_last_strided_coord, dim3(1), dim3(1), 0, st, M.tupA.p, M.tile_cnt.p, n_tiles, M.stride, M.d_flags.p + 2);
+      DCD_HIP(hipMemcpyAsync(&M.last_text_coord, M.d_flags.p + 2, 4, hipMemcpyDeviceToHost, st));
+    } else {
+      DCD_HIP(hipMemcpyAsync(&M.last_text_coord, &M.tupA.p[n_text_tok - 1].y, 4, hipMemcpyDeviceToHost, st));
+    }
+  }
 
   // ---- 3. vocabulary: compact, sort the word strings ordinally, materialise them -------------------
   DCD_TRY(t_voc.start());
@@ -1027,8 +1077,11 @@ static int32_t build_phase2(dcd_build* h) {
     int p2 = 0;
     RsProbe rp;
     rp.ev = &sort_events; rp.device = dev;
+    RsStrided sd;
+    sd.cnt = M.tile_cnt.p; sd.tile_off = M.tile_off.p; sd.stride = M.stride; sd.n_tiles = M.n_tiles;
+    const bool strided = M.strided && a == M.tupA.p && remap != nullptr;     // (codes mode sorts its own expanded tuples)
     sorted = rs_sort(a, b, remap, N, (int)log2_ceil(V ? V : 1), M.d_hist.p, M.scan_scr32.p, st, &p2, rp, 9,
-                     remap != nullptr && rs_cache_ok(1ull << M.cap_log2, V));
+                     remap != nullptr && rs_cache_ok(1ull << M.cap_log2, V), strided ? &sd : nullptr);
     passes += p2;
   }
   DCD_TRY(t_sort.stop());

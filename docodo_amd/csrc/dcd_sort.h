@@ -141,6 +141,88 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const uint2* __restrict_
   }
 }
 
+// ---- first pass over a TILE-STRIDED input ------------------------------------------------------------
+// The tokeniser can write tile t's tuples at in[t * stride + 0 .. cnt[t]) without knowing where the tile lands in the
+// dense array (no counting pass over the text).  The first histogram kernel then reads the strided tuples -- it has to
+// read every tuple anyway -- counts them per dense block and writes the DENSE copy (key already remapped), which the
+// scatter kernel of the pass consumes.  tile_off = exclusive scan of cnt.
+struct RsStrided {
+  const u32* cnt;        // [n_tiles]
+  const u64* tile_off;   // [n_tiles] dense index of the tile's first tuple
+  u32 stride;            // tuples reserved per tile (>= any cnt)
+  u64 n_tiles;
+};
+constexpr int RS_STRIDE_ROUNDS = 5;      // a tile holds at most 64 * RS_STRIDE_ROUNDS tuples (the host checks the stride)
+
+template <int BITS, bool CACHE>
+__global__ __launch_bounds__(RS_THREADS) void k_rs_hist_compact(const uint2* __restrict__ in, RsStrided sd, const u32* __restrict__ remap,
+                                                               u64 n, u64 ipb, u32 nblk, int shift, u32* __restrict__ hist,
+                                                               uint2* __restrict__ dense) {
+  constexpr int NB = 1 << BITS;
+  __shared__ u32 s_cache[CACHE ? (1 << RC_BITS) : 1];
+  __shared__ u64 s_first;
+  if (CACHE)
+    for (int i = threadIdx.x; i < (1 << RC_BITS); i += RS_THREADS) s_cache[i] = 0xFFFFFFFFu;
+  auto key_of = [&](u32 k) -> u32 { return CACHE ? rs_key_cached<RC_BITS>(k, remap, s_cache) : rs_key(k, remap); };
+  constexpr int HC = DCD_RS_HCOPIES, HS = NB + 1;
+  __shared__ u32 h[HC * HS];
+  for (int i = threadIdx.x; i < HC * HS; i += RS_THREADS) h[i] = 0;
+  const u64 beg = (u64)blockIdx.x * ipb, end = beg + ipb < n ? beg + ipb : n;
+  if (threadIdx.x == 0) {
+    // last tile whose first tuple is at or before `beg` (tile_off ascending, tile_off[0] = 0): it holds dense index beg
+    u64 lo = 0, hi = sd.n_tiles;
+    while (lo + 1 < hi) { const u64 m = (lo + hi) >> 1; if (sd.tile_off[m] <= beg) lo = m; else hi = m; }
+    s_first = lo;
+  }
+  __syncthreads();
+  u32* hl = h + (threadIdx.x % HC) * HS;
+  const u32 lane = lane_id(), w = threadIdx.x >> 6;
+  // every wave takes TU tiles at a time (tile bookkeeping and all tuple loads of the group issued together)
+  constexpr int TU = 2;
+  for (u64 t0 = s_first + (u64)w * TU; t0 < sd.n_tiles; t0 += (u64)RS_WAVES * TU) {
+    u64 off[TU];
+    u32 c[TU];
+#pragma unroll
+    for (int u = 0; u < TU; u++) {
+      const u64 t = t0 + u;
+      const bool live = t < sd.n_tiles;
+      off[u] = live ? sd.tile_off[t] : ~0ull;
+      c[u] = live ? sd.cnt[t] : 0u;
+    }
+    if (off[0] >= end) break;                                  // (wave-uniform; later tiles start even further right)
+    uint2 tup[TU][RS_STRIDE_ROUNDS];
+    bool ok[TU][RS_STRIDE_ROUNDS];
+#pragma unroll
+    for (int u = 0; u < TU; u++) {
+#pragma unroll
+      for (int k = 0; k < RS_STRIDE_ROUNDS; k++) {
+        const u32 j = lane + 64u * k;
+        const u64 di = off[u] + j;
+        ok[u][k] = j < c[u] && di >= beg && di < end;
+        tup[u][k] = ok[u][k] ? in[(t0 + u) * sd.stride + j] : make_uint2(0u, 0u);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < TU; u++) {
+#pragma unroll
+      for (int k = 0; k < RS_STRIDE_ROUNDS; k++) {
+        if (ok[u][k]) {
+          const u32 key = key_of(tup[u][k].x);
+          atomicAdd(&hl[(key >> shift) & (NB - 1)], 1u);
+          dense[off[u] + lane + 64u * k] = make_uint2(key, tup[u][k].y);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  for (int d = threadIdx.x; d < NB; d += RS_THREADS) {
+    u32 s = 0;
+#pragma unroll
+    for (int k = 0; k < HC; k++) s += h[k * HS + d];
+    hist[(u64)d * nblk + blockIdx.x] = s;
+  }
+}
+
 #ifndef DCD_RS_WPE
 #define DCD_RS_WPE 4
 #endif
@@ -283,9 +365,24 @@ struct RsProbe {
 
 template <int BITS>
 inline void rs_pass(const uint2* in, uint2* out, const u32* remap, u64 n, int shift, u32* hist, u32* scan_scratch,
-                    hipStream_t st, const RsProbe& pr, bool remap_cache) {
+                    hipStream_t st, const RsProbe& pr, bool remap_cache, const RsStrided* sd = nullptr, uint2* mid = nullptr) {
   RsPlan p = rs_plan(n);
   pr.rec(st);
+  if (sd) {
+    // strided input: the histogram kernel also writes the dense, remapped copy to `mid`; the scatter reads that
+    if (remap && remap_cache)
+      hipLaunchKernelGGL((k_rs_hist_compact<BITS, true>), dim3(p.nblk), dim3(RS_THREADS), 0, st, in, *sd, remap, n, p.ipb, p.nblk, shift, hist, mid);
+    else
+      hipLaunchKernelGGL((k_rs_hist_compact<BITS, false>), dim3(p.nblk), dim3(RS_THREADS), 0, st, in, *sd, remap, n, p.ipb, p.nblk, shift, hist, mid);
+    pr.rec(st);
+    u64 ne = (u64)p.nblk << BITS;
+    scan_exclusive<u32, u32>(hist, hist, ne, scan_scratch, st);
+    pr.rec(st);
+    hipLaunchKernelGGL((k_rs_scatter<BITS, false>), dim3(p.nblk), dim3(RSS_THREADS), 0, st, (const uint2*)mid, (const u32*)nullptr, n, p.ipb, p.nblk,
+                       shift, hist, out);
+    pr.rec(st);
+    return;
+  }
   if (remap && remap_cache)
     hipLaunchKernelGGL((k_rs_hist<BITS, true>), dim3(p.nblk), dim3(RS_THREADS), 0, st, in, remap, n, p.ipb, p.nblk, shift, hist);
   else
@@ -302,13 +399,14 @@ inline void rs_pass(const uint2* in, uint2* out, const u32* remap, u64 n, int sh
 }
 
 inline void rs_pass_dyn(int bits, const uint2* in, uint2* out, const u32* remap, u64 n, int shift, u32* hist,
-                        u32* scan_scratch, hipStream_t st, const RsProbe& pr, bool remap_cache) {
+                        u32* scan_scratch, hipStream_t st, const RsProbe& pr, bool remap_cache, const RsStrided* sd = nullptr,
+                        uint2* mid = nullptr) {
   switch (bits) {
-    case 6: rs_pass<6>(in, out, remap, n, shift, hist, scan_scratch, st, pr, remap_cache); break;
-    case 7: rs_pass<7>(in, out, remap, n, shift, hist, scan_scratch, st, pr, remap_cache); break;
-    case 8: rs_pass<8>(in, out, remap, n, shift, hist, scan_scratch, st, pr, remap_cache); break;
-    case 9: rs_pass<9>(in, out, remap, n, shift, hist, scan_scratch, st, pr, remap_cache); break;
-    default: rs_pass<10>(in, out, remap, n, shift, hist, scan_scratch, st, pr, remap_cache); break;
+    case 6: rs_pass<6>(in, out, remap, n, shift, hist, scan_scratch, st, pr, remap_cache, sd, mid); break;
+    case 7: rs_pass<7>(in, out, remap, n, shift, hist, scan_scratch, st, pr, remap_cache, sd, mid); break;
+    case 8: rs_pass<8>(in, out, remap, n, shift, hist, scan_scratch, st, pr, remap_cache, sd, mid); break;
+    case 9: rs_pass<9>(in, out, remap, n, shift, hist, scan_scratch, st, pr, remap_cache, sd, mid); break;
+    default: rs_pass<10>(in, out, remap, n, shift, hist, scan_scratch, st, pr, remap_cache, sd, mid); break;
   }
 }
 
@@ -339,13 +437,21 @@ inline RsSchedule rs_schedule(int total_bits, int max_width = 9) {
 // the same size.  Returns the buffer that holds the result.  After the first pass the keys are the
 // remapped ones (remap applied once).  hist: >= RS_MAX_BLOCKS << 10 u32; scan_scratch: >=
 // scan_scratch_elems(RS_MAX_BLOCKS << 10) u32.  remap_cache: the caller guarantees rs_cache_ok(key range, value range).
+// strided: buf_a is tile-strided (RsStrided) instead of dense; it must hold at least n tuples.
 inline uint2* rs_sort(uint2* buf_a, uint2* buf_b, const u32* remap, u64 n, int total_bits, u32* hist, u32* scan_scratch,
                       hipStream_t st, int* passes_out = nullptr, const RsProbe& pr = RsProbe(), int max_width = 9,
-                      bool remap_cache = false) {
+                      bool remap_cache = false, const RsStrided* strided = nullptr) {
   RsSchedule sc = rs_schedule(total_bits, max_width);
   int shift = 0;
   uint2 *in = buf_a, *out = buf_b;
   for (int i = 0; i < sc.npass; i++) {
+    if (i == 0 && strided) {
+      // buf_a holds the tile-strided input (and is large enough for n dense tuples): strided A -> dense B -> sorted A
+      rs_pass_dyn(sc.width[i], buf_a, buf_a, remap, n, shift, hist, scan_scratch, st, pr, remap_cache, strided, buf_b);
+      shift += sc.width[i];
+      in = buf_a; out = buf_b;
+      continue;
+    }
     rs_pass_dyn(sc.width[i], in, out, i == 0 ? remap : nullptr, n, shift, hist, scan_scratch, st, pr, remap_cache);
     shift += sc.width[i];
     uint2* t = in; in = out; out = t;
