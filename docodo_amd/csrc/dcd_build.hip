@@ -784,13 +784,13 @@ static int32_t build_phase1(dcd_build* h, bool codes_mode) {
     P.run_off = d_run_off.p; P.run_delta = d_run_delta.p; P.n_runs = (u32)h->run_off.size();
   }
   // Plain text builds (no explicit postings, no word codes) skip the counting pass: the emit kernel writes every tile's
-  // tuples at a fixed stride and the first sort pass compacts them (RsStrided, dcd_sort.h).  A tile of TK_TILE
-  // characters holds at most TK_TILE / min_word_length + 1 kept tokens; the compacting kernel reads up to
-  // 64 * RS_STRIDE_ROUNDS per tile.  DOCODO_TOK_TWO_PASS=1 forces the counting pass.
+  // tuples at a fixed stride and the first sort pass reads that layout in place (RsStrided, dcd_sort.h).  A tile of
+  // TK_TILE characters holds at most TK_TILE / min_word_length + 1 kept tokens.  DOCODO_TOK_TWO_PASS=1 forces the
+  // counting pass.
   static const bool env_two_pass = getenv("DOCODO_TOK_TWO_PASS") && atoi(getenv("DOCODO_TOK_TWO_PASS")) != 0;
-  const u32 stride_need = (u32)(TK_TILE / (P.min_len ? P.min_len : 1u)) + 2u;
-  const bool strided = !env_two_pass && !codes_mode && n_x == 0 && n_tiles != 0 && stride_need <= 64u * RS_STRIDE_ROUNDS &&
-                       n_tiles * (u64)stride_need < (1ull << 32);
+  const u32 stride_need = ((u32)(TK_TILE / (P.min_len ? P.min_len : 1u)) + 2u + 1u) & ~1u;     // even: tiles start 16-byte aligned
+  const bool strided = !env_two_pass && !codes_mode && n_x == 0 && n_tiles != 0 && stride_need <= (u32)RS_STRIDE_MAX &&
+                       rs_tile_plan(n_tiles).tpb <= (u32)RS_TPB_MAX;
   M.strided = strided; M.stride = strided ? stride_need : 0u; M.n_tiles = n_tiles;
   DevBuf<u64> scan_scr64;
   u64 n_text_tok = 0;
@@ -1078,7 +1078,7 @@ static int32_t build_phase2(dcd_build* h) {
     RsProbe rp;
     rp.ev = &sort_events; rp.device = dev;
     RsStrided sd;
-    sd.cnt = M.tile_cnt.p; sd.tile_off = M.tile_off.p; sd.stride = M.stride; sd.n_tiles = M.n_tiles;
+    sd.cnt = M.tile_cnt.p; sd.stride = M.stride; sd.n_tiles = M.n_tiles;
     const bool strided = M.strided && a == M.tupA.p && remap != nullptr;     // (codes mode sorts its own expanded tuples)
     sorted = rs_sort(a, b, remap, N, (int)log2_ceil(V ? V : 1), M.d_hist.p, M.scan_scr32.p, st, &p2, rp, 9,
                      remap != nullptr && rs_cache_ok(1ull << M.cap_log2, V), strided ? &sd : nullptr);

@@ -142,75 +142,64 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const uint2* __restrict_
 }
 
 // ---- first pass over a TILE-STRIDED input ------------------------------------------------------------
-// The tokeniser can write tile t's tuples at in[t * stride + 0 .. cnt[t]) without knowing where the tile lands in the
-// dense array (no counting pass over the text).  The first histogram kernel then reads the strided tuples -- it has to
-// read every tuple anyway -- counts them per dense block and writes the DENSE copy (key already remapped), which the
-// scatter kernel of the pass consumes.  tile_off = exclusive scan of cnt.
+// The tokeniser can write tile t's tuples at in[t * stride + 0 .. cnt[t]) without knowing where the tile lands in a dense
+// array (no counting pass over the text).  The first radix pass reads that layout directly: a block owns a fixed number
+// of TILES (tpb) instead of a fixed number of tuples, its tuples in order are the tiles' tuples in order, 64 per "row"
+// (the last row of a tile is partly empty).  Everything behind the ranking is the same as for dense input.
 struct RsStrided {
   const u32* cnt;        // [n_tiles]
-  const u64* tile_off;   // [n_tiles] dense index of the tile's first tuple
-  u32 stride;            // tuples reserved per tile (>= any cnt)
+  u32 stride;            // tuples reserved per tile (>= any cnt), even
   u64 n_tiles;
 };
-constexpr int RS_STRIDE_ROUNDS = 5;      // a tile holds at most 64 * RS_STRIDE_ROUNDS tuples (the host checks the stride)
+constexpr int RS_STRIDE_MAX = 320;       // largest tile population handled (the host checks its stride against it)
+constexpr int RS_TPB_MAX = 2304;         // tiles per block (LDS slice of the tile table in the scatter kernel)
+struct RsTilePlan { u32 nblk, tpb; };
+inline RsTilePlan rs_tile_plan(u64 n_tiles) {
+  RsTilePlan p;
+  u64 nb = n_tiles < (u64)RS_MAX_BLOCKS ? (n_tiles ? n_tiles : 1) : (u64)RS_MAX_BLOCKS;
+  p.tpb = (u32)div_up(n_tiles ? n_tiles : 1, nb);
+  p.nblk = (u32)div_up(n_tiles ? n_tiles : 1, p.tpb);
+  return p;
+}
 
 template <int BITS, bool CACHE>
-__global__ __launch_bounds__(RS_THREADS) void k_rs_hist_compact(const uint2* __restrict__ in, RsStrided sd, const u32* __restrict__ remap,
-                                                               u64 n, u64 ipb, u32 nblk, int shift, u32* __restrict__ hist,
-                                                               uint2* __restrict__ dense) {
+__global__ __launch_bounds__(RS_THREADS) void k_rs_hist_strided(const uint2* __restrict__ in, RsStrided sd, const u32* __restrict__ remap,
+                                                               u32 tpb, u32 nblk, int shift, u32* __restrict__ hist) {
   constexpr int NB = 1 << BITS;
   __shared__ u32 s_cache[CACHE ? (1 << RC_BITS) : 1];
-  __shared__ u64 s_first;
   if (CACHE)
     for (int i = threadIdx.x; i < (1 << RC_BITS); i += RS_THREADS) s_cache[i] = 0xFFFFFFFFu;
   auto key_of = [&](u32 k) -> u32 { return CACHE ? rs_key_cached<RC_BITS>(k, remap, s_cache) : rs_key(k, remap); };
   constexpr int HC = DCD_RS_HCOPIES, HS = NB + 1;
   __shared__ u32 h[HC * HS];
   for (int i = threadIdx.x; i < HC * HS; i += RS_THREADS) h[i] = 0;
-  const u64 beg = (u64)blockIdx.x * ipb, end = beg + ipb < n ? beg + ipb : n;
-  if (threadIdx.x == 0) {
-    // last tile whose first tuple is at or before `beg` (tile_off ascending, tile_off[0] = 0): it holds dense index beg
-    u64 lo = 0, hi = sd.n_tiles;
-    while (lo + 1 < hi) { const u64 m = (lo + hi) >> 1; if (sd.tile_off[m] <= beg) lo = m; else hi = m; }
-    s_first = lo;
-  }
   __syncthreads();
   u32* hl = h + (threadIdx.x % HC) * HS;
   const u32 lane = lane_id(), w = threadIdx.x >> 6;
-  // every wave takes TU tiles at a time (tile bookkeeping and all tuple loads of the group issued together)
-  constexpr int TU = 2;
-  for (u64 t0 = s_first + (u64)w * TU; t0 < sd.n_tiles; t0 += (u64)RS_WAVES * TU) {
-    u64 off[TU];
+  const u64 ta = (u64)blockIdx.x * tpb, tb = ta + tpb < sd.n_tiles ? ta + tpb : sd.n_tiles;
+  // a wave takes two tiles at a time; a lane reads tuple pairs (16 B; the stride is even, so tiles start 16-byte aligned)
+  constexpr int TU = 2, PR = (RS_STRIDE_MAX / 2 + 63) / 64;     // pair rounds per tile
+  for (u64 t0 = ta + (u64)w * TU; t0 < tb; t0 += (u64)RS_WAVES * TU) {
     u32 c[TU];
+    uint4 kv[TU][PR];
+#pragma unroll
+    for (int u = 0; u < TU; u++) c[u] = t0 + u < tb ? sd.cnt[t0 + u] : 0u;
 #pragma unroll
     for (int u = 0; u < TU; u++) {
-      const u64 t = t0 + u;
-      const bool live = t < sd.n_tiles;
-      off[u] = live ? sd.tile_off[t] : ~0ull;
-      c[u] = live ? sd.cnt[t] : 0u;
-    }
-    if (off[0] >= end) break;                                  // (wave-uniform; later tiles start even further right)
-    uint2 tup[TU][RS_STRIDE_ROUNDS];
-    bool ok[TU][RS_STRIDE_ROUNDS];
+      const uint4* tp = reinterpret_cast<const uint4*>(in + (t0 + u) * sd.stride);
 #pragma unroll
-    for (int u = 0; u < TU; u++) {
-#pragma unroll
-      for (int k = 0; k < RS_STRIDE_ROUNDS; k++) {
-        const u32 j = lane + 64u * k;
-        const u64 di = off[u] + j;
-        ok[u][k] = j < c[u] && di >= beg && di < end;
-        tup[u][k] = ok[u][k] ? in[(t0 + u) * sd.stride + j] : make_uint2(0u, 0u);
+      for (int k = 0; k < PR; k++) {
+        const u32 pi = lane + 64u * k;
+        kv[u][k] = 2 * pi < c[u] ? tp[pi] : make_uint4(0u, 0u, 0u, 0u);     // (the second tuple of the last pair may be unused)
       }
     }
 #pragma unroll
     for (int u = 0; u < TU; u++) {
 #pragma unroll
-      for (int k = 0; k < RS_STRIDE_ROUNDS; k++) {
-        if (ok[u][k]) {
-          const u32 key = key_of(tup[u][k].x);
-          atomicAdd(&hl[(key >> shift) & (NB - 1)], 1u);
-          dense[off[u] + lane + 64u * k] = make_uint2(key, tup[u][k].y);
-        }
+      for (int k = 0; k < PR; k++) {
+        const u32 pi = lane + 64u * k;
+        if (2 * pi < c[u]) atomicAdd(&hl[(key_of(kv[u][k].x) >> shift) & (NB - 1)], 1u);
+        if (2 * pi + 1 < c[u]) atomicAdd(&hl[(key_of(kv[u][k].z) >> shift) & (NB - 1)], 1u);
       }
     }
   }
@@ -226,10 +215,10 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_hist_compact(const uint2* __r
 #ifndef DCD_RS_WPE
 #define DCD_RS_WPE 4
 #endif
-template <int BITS, bool CACHE>
+template <int BITS, bool CACHE, bool STRIDED>
 __global__ __launch_bounds__(RSS_THREADS) __attribute__((amdgpu_waves_per_eu(DCD_RS_WPE, DCD_RS_WPE))) void k_rs_scatter(const uint2* __restrict__ in, const u32* __restrict__ remap, u64 n, u64 ipb,
                                                           u32 nblk, int shift, const u32* __restrict__ hist_scanned,
-                                                          uint2* __restrict__ out) {
+                                                          uint2* __restrict__ out, RsStrided sd, u32 tpb) {
   constexpr int NB = 1 << BITS;
   constexpr int Q = (NB + RSS_THREADS - 1) / RSS_THREADS;   // digits per owner thread: d = threadIdx.x * Q + q (adjacent)
   __shared__ u32 s_cnt[RSS_WAVES][NB];   // ranking: per-wave digit counts; afterwards: position of (wave, digit) in the sorted tile
@@ -250,24 +239,95 @@ __global__ __launch_bounds__(RSS_THREADS) __attribute__((amdgpu_waves_per_eu(DCD
     const int d = threadIdx.x * Q + q;
     base[q] = d < NB ? hist_scanned[(u64)d * nblk + blockIdx.x] : 0u;
   }
+  // dense input: the block owns tuples [beg, end).  Strided input: it owns tiles [ta, ta + nt); its tuples in order are
+  // the tiles' tuples, 64 per row, every tile starting a new row (its last row is partly empty: ~20 % more rows than a
+  // dense layout, but a row is one contiguous load; rows packed across tile borders cost more than they save --
+  // measured).  s_rowpre[t] = number of rows before tile t (block-local), rows_b = all of them.
   u64 beg = (u64)blockIdx.x * ipb, end = beg + ipb < n ? beg + ipb : n;
+  __shared__ u16 s_tcnt[STRIDED ? RS_TPB_MAX : 1];
+  __shared__ u16 s_rowpre[STRIDED ? RS_TPB_MAX + 1 : 1];
+  const u64 ta = (u64)blockIdx.x * tpb;
+  u32 nt = 0, rows_b = 0;
+  if (STRIDED) {
+    nt = (u32)(ta + tpb < sd.n_tiles ? tpb : sd.n_tiles - ta);
+    constexpr int K = (RS_TPB_MAX + RSS_THREADS - 1) / RSS_THREADS;
+    u32 loc[K], sum = 0;
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+      const u32 i = threadIdx.x * K + k;
+      const u32 c = i < nt ? sd.cnt[ta + i] : 0u;
+      if (i < nt) s_tcnt[i] = (u16)c;
+      loc[k] = sum;
+      sum += (c + 63u) >> 6;
+    }
+    const u32 incl = wave_scan_incl(sum);
+    if (lane == 63) s_wtot[w] = incl;
+    lds_barrier();
+    u32 ex = incl - sum;
+#pragma unroll
+    for (int k = 0; k < RSS_WAVES; k++) ex += k < (int)w ? s_wtot[k] : 0u;
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+      const u32 i = threadIdx.x * K + k;
+      if (i < nt) s_rowpre[i] = (u16)(ex + loc[k]);
+    }
+    if (threadIdx.x == RSS_THREADS - 1) s_rowpre[nt] = (u16)(ex + sum);
+    lds_barrier();
+    rows_b = s_rowpre[nt];
+  }
+  // rows q .. q + RS_ROWS of the block (strided input) -> item[], vrow[] (number of tuples in the row; wave-uniform)
+  u32 vrow[RS_ROWS];
+  uint2 item[RS_ROWS];
+  auto load_rows = [&](u32 q) {
+    u32 t = nt, c = 0, ct = 0;                 // (rows behind the block's last one: no tile, nothing to advance to)
+    if (q < rows_b) {
+      u32 lo = 0, hi = nt;                     // last tile with s_rowpre <= q: the non-empty one among equal prefixes
+      while (lo + 1 < hi) { const u32 m = (lo + hi) >> 1; if (s_rowpre[m] <= q) lo = m; else hi = m; }
+      t = lo; c = q - s_rowpre[lo]; ct = s_tcnt[lo];
+    }
+    t = __builtin_amdgcn_readfirstlane(t); c = __builtin_amdgcn_readfirstlane(c); ct = __builtin_amdgcn_readfirstlane(ct);
+#pragma unroll
+    for (int r = 0; r < RS_ROWS; r++) {
+      const u32 j0 = c * 64u;
+      const u32 left = ct > j0 ? ct - j0 : 0u;
+      vrow[r] = left < 64u ? left : 64u;
+      item[r] = lane < vrow[r] ? in[(ta + t) * sd.stride + j0 + lane] : make_uint2(0xFFFFFFFFu, 0u);
+      // next row: the next 64 tuples of this tile, else the first ones of the next non-empty tile
+      if (left > 64u) {
+        c++;
+      } else {
+        c = 0; ct = 0;
+        u32 t2 = t + 1;
+        while (t2 < nt && s_tcnt[t2] == 0) t2++;
+        if (t2 < nt) ct = s_tcnt[t2];
+        t = __builtin_amdgcn_readfirstlane(t2); ct = __builtin_amdgcn_readfirstlane(ct);
+      }
+    }
+  };
 
   // Four LDS-only barriers per tile; the scattered stores of a tile and the loads of the next one stay in flight
   // across them (the next tile is fetched into the item registers as soon as the current one sits in LDS).
-  uint2 item[RS_ROWS];
+  if (STRIDED) {
+    load_rows(w * RS_ROWS);
+  } else {
 #pragma unroll
-  for (int r = 0; r < RS_ROWS; r++) {
-    u64 i = beg + (u64)(w * RS_ROWS + r) * 64 + lane;
-    item[r] = i < end ? in[i] : make_uint2(0xFFFFFFFFu, 0u);
+    for (int r = 0; r < RS_ROWS; r++) {
+      u64 i = beg + (u64)(w * RS_ROWS + r) * 64 + lane;
+      item[r] = i < end ? in[i] : make_uint2(0xFFFFFFFFu, 0u);
+    }
   }
-  for (u64 t0 = beg; t0 < end; t0 += RS_TILE) {
+  const u64 n_steps = STRIDED ? ((u64)rows_b + RS_ROWS * RSS_WAVES - 1) / (RS_ROWS * RSS_WAVES)
+                              : (end > beg ? (end - beg + RS_TILE - 1) / RS_TILE : 0);
+  for (u64 step = 0; step < n_steps; step++) {
+    const u64 t0 = beg + step * RS_TILE;                          // (dense input)
+    const u32 q0 = (u32)step * RS_ROWS * RSS_WAVES;               // (strided input)
     // ---- A: rank inside the wave (rows in order, lanes in order: stable); s_cnt[w] is private to the wave here
     for (int i = lane; i < NB; i += 64) s_cnt[w][i] = 0;
     u32 dig[RS_ROWS], rk[RS_ROWS];
     bool valid[RS_ROWS];
 #pragma unroll
     for (int r = 0; r < RS_ROWS; r++) {
-      valid[r] = t0 + (u64)(w * RS_ROWS + r) * 64 + lane < end;
+      valid[r] = STRIDED ? lane < vrow[r] : t0 + (u64)(w * RS_ROWS + r) * 64 + lane < end;
       if (valid[r]) item[r].x = CACHE ? rs_key_cached<RCS_BITS>(item[r].x, remap, s_cache) : rs_key(item[r].x, remap);   // (first pass only)
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -332,14 +392,25 @@ __global__ __launch_bounds__(RSS_THREADS) __attribute__((amdgpu_waves_per_eu(DCD
 #pragma unroll
     for (int r = 0; r < RS_ROWS; r++)
       if (dig[r] != 0xFFFFFFFFu) s_tile[s_cnt[w][dig[r]] + rk[r]] = item[r];
+    if (STRIDED) {
+      load_rows(q0 + RS_ROWS * RSS_WAVES + w * RS_ROWS);
+    } else {
 #pragma unroll
-    for (int r = 0; r < RS_ROWS; r++) {
-      u64 i = t0 + RS_TILE + (u64)(w * RS_ROWS + r) * 64 + lane;
-      item[r] = i < end ? in[i] : make_uint2(0xFFFFFFFFu, 0u);
+      for (int r = 0; r < RS_ROWS; r++) {
+        u64 i = t0 + RS_TILE + (u64)(w * RS_ROWS + r) * 64 + lane;
+        item[r] = i < end ? in[i] : make_uint2(0xFFFFFFFFu, 0u);
+      }
     }
     lds_barrier();
     // ---- D: digit runs -> HBM with consecutive lanes
-    u32 tile_n = (u32)((end - t0) < (u64)RS_TILE ? (end - t0) : (u64)RS_TILE);
+    u32 tile_n;
+    if (STRIDED) {
+      tile_n = 0;
+#pragma unroll
+      for (int k = 0; k < RSS_WAVES; k++) tile_n += s_wtot[k];    // tuples of this step = sum of the waves' digit totals
+    } else {
+      tile_n = (u32)((end - t0) < (u64)RS_TILE ? (end - t0) : (u64)RS_TILE);
+    }
     for (u32 j = threadIdx.x; j < tile_n; j += RSS_THREADS) {
       uint2 it = s_tile[j];
       u32 d = (it.x >> shift) & (NB - 1);
@@ -365,21 +436,26 @@ struct RsProbe {
 
 template <int BITS>
 inline void rs_pass(const uint2* in, uint2* out, const u32* remap, u64 n, int shift, u32* hist, u32* scan_scratch,
-                    hipStream_t st, const RsProbe& pr, bool remap_cache, const RsStrided* sd = nullptr, uint2* mid = nullptr) {
+                    hipStream_t st, const RsProbe& pr, bool remap_cache, const RsStrided* sd = nullptr) {
   RsPlan p = rs_plan(n);
   pr.rec(st);
   if (sd) {
-    // strided input: the histogram kernel also writes the dense, remapped copy to `mid`; the scatter reads that
+    // tile-strided input: blocks own tiles, not tuples
+    const RsTilePlan tp = rs_tile_plan(sd->n_tiles);
     if (remap && remap_cache)
-      hipLaunchKernelGGL((k_rs_hist_compact<BITS, true>), dim3(p.nblk), dim3(RS_THREADS), 0, st, in, *sd, remap, n, p.ipb, p.nblk, shift, hist, mid);
+      hipLaunchKernelGGL((k_rs_hist_strided<BITS, true>), dim3(tp.nblk), dim3(RS_THREADS), 0, st, in, *sd, remap, tp.tpb, tp.nblk, shift, hist);
     else
-      hipLaunchKernelGGL((k_rs_hist_compact<BITS, false>), dim3(p.nblk), dim3(RS_THREADS), 0, st, in, *sd, remap, n, p.ipb, p.nblk, shift, hist, mid);
+      hipLaunchKernelGGL((k_rs_hist_strided<BITS, false>), dim3(tp.nblk), dim3(RS_THREADS), 0, st, in, *sd, remap, tp.tpb, tp.nblk, shift, hist);
     pr.rec(st);
-    u64 ne = (u64)p.nblk << BITS;
+    u64 ne = (u64)tp.nblk << BITS;
     scan_exclusive<u32, u32>(hist, hist, ne, scan_scratch, st);
     pr.rec(st);
-    hipLaunchKernelGGL((k_rs_scatter<BITS, false>), dim3(p.nblk), dim3(RSS_THREADS), 0, st, (const uint2*)mid, (const u32*)nullptr, n, p.ipb, p.nblk,
-                       shift, hist, out);
+    if (remap && remap_cache)
+      hipLaunchKernelGGL((k_rs_scatter<BITS, true, true>), dim3(tp.nblk), dim3(RSS_THREADS), 0, st, in, remap, n, (u64)0, tp.nblk, shift, hist, out, *sd,
+                         tp.tpb);
+    else
+      hipLaunchKernelGGL((k_rs_scatter<BITS, false, true>), dim3(tp.nblk), dim3(RSS_THREADS), 0, st, in, remap, n, (u64)0, tp.nblk, shift, hist, out, *sd,
+                         tp.tpb);
     pr.rec(st);
     return;
   }
@@ -392,21 +468,22 @@ inline void rs_pass(const uint2* in, uint2* out, const u32* remap, u64 n, int sh
   scan_exclusive<u32, u32>(hist, hist, ne, scan_scratch, st);
   pr.rec(st);
   if (remap && remap_cache)
-    hipLaunchKernelGGL((k_rs_scatter<BITS, true>), dim3(p.nblk), dim3(RSS_THREADS), 0, st, in, remap, n, p.ipb, p.nblk, shift, hist, out);
+    hipLaunchKernelGGL((k_rs_scatter<BITS, true, false>), dim3(p.nblk), dim3(RSS_THREADS), 0, st, in, remap, n, p.ipb, p.nblk, shift, hist, out,
+                       RsStrided{nullptr, 0, 0}, 0u);
   else
-    hipLaunchKernelGGL((k_rs_scatter<BITS, false>), dim3(p.nblk), dim3(RSS_THREADS), 0, st, in, remap, n, p.ipb, p.nblk, shift, hist, out);
+    hipLaunchKernelGGL((k_rs_scatter<BITS, false, false>), dim3(p.nblk), dim3(RSS_THREADS), 0, st, in, remap, n, p.ipb, p.nblk, shift, hist, out,
+                       RsStrided{nullptr, 0, 0}, 0u);
   pr.rec(st);
 }
 
 inline void rs_pass_dyn(int bits, const uint2* in, uint2* out, const u32* remap, u64 n, int shift, u32* hist,
-                        u32* scan_scratch, hipStream_t st, const RsProbe& pr, bool remap_cache, const RsStrided* sd = nullptr,
-                        uint2* mid = nullptr) {
+                        u32* scan_scratch, hipStream_t st, const RsProbe& pr, bool remap_cache, const RsStrided* sd = nullptr) {
   switch (bits) {
-    case 6: rs_pass<6>(in, out, remap, n, shift, hist, scan_scratch, st, pr, remap_cache, sd, mid); break;
-    case 7: rs_pass<7>(in, out, remap, n, shift, hist, scan_scratch, st, pr, remap_cache, sd, mid); break;
-    case 8: rs_pass<8>(in, out, remap, n, shift, hist, scan_scratch, st, pr, remap_cache, sd, mid); break;
-    case 9: rs_pass<9>(in, out, remap, n, shift, hist, scan_scratch, st, pr, remap_cache, sd, mid); break;
-    default: rs_pass<10>(in, out, remap, n, shift, hist, scan_scratch, st, pr, remap_cache, sd, mid); break;
+    case 6: rs_pass<6>(in, out, remap, n, shift, hist, scan_scratch, st, pr, remap_cache, sd); break;
+    case 7: rs_pass<7>(in, out, remap, n, shift, hist, scan_scratch, st, pr, remap_cache, sd); break;
+    case 8: rs_pass<8>(in, out, remap, n, shift, hist, scan_scratch, st, pr, remap_cache, sd); break;
+    case 9: rs_pass<9>(in, out, remap, n, shift, hist, scan_scratch, st, pr, remap_cache, sd); break;
+    default: rs_pass<10>(in, out, remap, n, shift, hist, scan_scratch, st, pr, remap_cache, sd); break;
   }
 }
 
@@ -437,7 +514,8 @@ inline RsSchedule rs_schedule(int total_bits, int max_width = 9) {
 // the same size.  Returns the buffer that holds the result.  After the first pass the keys are the
 // remapped ones (remap applied once).  hist: >= RS_MAX_BLOCKS << 10 u32; scan_scratch: >=
 // scan_scratch_elems(RS_MAX_BLOCKS << 10) u32.  remap_cache: the caller guarantees rs_cache_ok(key range, value range).
-// strided: buf_a is tile-strided (RsStrided) instead of dense; it must hold at least n tuples.
+// strided: buf_a is tile-strided (RsStrided) instead of dense (the first pass reads it in place); it must also hold n
+// dense tuples, because later passes ping-pong between buf_b and buf_a.
 inline uint2* rs_sort(uint2* buf_a, uint2* buf_b, const u32* remap, u64 n, int total_bits, u32* hist, u32* scan_scratch,
                       hipStream_t st, int* passes_out = nullptr, const RsProbe& pr = RsProbe(), int max_width = 9,
                       bool remap_cache = false, const RsStrided* strided = nullptr) {
@@ -445,14 +523,8 @@ inline uint2* rs_sort(uint2* buf_a, uint2* buf_b, const u32* remap, u64 n, int t
   int shift = 0;
   uint2 *in = buf_a, *out = buf_b;
   for (int i = 0; i < sc.npass; i++) {
-    if (i == 0 && strided) {
-      // buf_a holds the tile-strided input (and is large enough for n dense tuples): strided A -> dense B -> sorted A
-      rs_pass_dyn(sc.width[i], buf_a, buf_a, remap, n, shift, hist, scan_scratch, st, pr, remap_cache, strided, buf_b);
-      shift += sc.width[i];
-      in = buf_a; out = buf_b;
-      continue;
-    }
-    rs_pass_dyn(sc.width[i], in, out, i == 0 ? remap : nullptr, n, shift, hist, scan_scratch, st, pr, remap_cache);
+    rs_pass_dyn(sc.width[i], in, out, i == 0 ? remap : nullptr, n, shift, hist, scan_scratch, st, pr, remap_cache,
+                i == 0 ? strided : nullptr);
     shift += sc.width[i];
     uint2* t = in; in = out; out = t;
   }
