@@ -1091,7 +1091,7 @@ static int32_t build_phase2(dcd_build* h) {
   DCD_TRY(t_pack.start());
   DCD_TRY(ix.term_unit_start.alloc(dev, V + 1));
   DCD_TRY(ix.term_item_start.alloc(dev, V + 1));
-  DevBuf<u64> enc_part;
+  DevBuf<u64> enc_part, enc_scr;
   u64 enb = encode_nblocks(N);
   DCD_TRY(enc_part.alloc(dev, enb + 1));
   u64 U = 0;
@@ -1104,8 +1104,10 @@ static int32_t build_phase2(dcd_build* h) {
     else
       hipLaunchKernelGGL((k_enc_reduce<EncSrcPairs>), dim3((u32)enb), dim3(CODEC_THREADS), 0, st, src, N, enc_part.p);
     probes.end();
-    hipLaunchKernelGGL((k_scan_partials<u64>), dim3(1), dim3(1024), 0, st, enc_part.p, enb);
-    DCD_HIP(hipMemcpyAsync(&U, enc_part.p + enb, 8, hipMemcpyDeviceToHost, st));
+    // ~67 k tile totals at C2 size: the multi-block scan (in place) instead of the single-block one
+    DCD_TRY(enc_scr.alloc(dev, scan_scratch_elems(enb)));
+    scan_exclusive<u64, u64>(enc_part.p, enc_part.p, enb, enc_scr.p, st);
+    DCD_HIP(hipMemcpyAsync(&U, enc_scr.p + scan_nblocks(enb), 8, hipMemcpyDeviceToHost, st));
     DCD_HIP(hipStreamSynchronize(st));
   }
   tr.mark("enc-reduce");
