@@ -162,8 +162,14 @@ inline int32_t vocab_rank(int dev, hipStream_t st, const u64* slots, u64 cap, co
   DCD_HIP(hipStreamSynchronize(st));
   const u32 bits = std::max<u32>(1, log2_ceil((u64)n_sym + 1));     // ranks 0 .. n_sym
   // measured on MI355X (V = 1e5): 8-bit passes over 32-bit chunks 0.35 ms, 9 over 27: 0.35, 10 over 30: 0.56; before (8 or 16 bits per character): 0.40
+  // characters per chunk: the choice that needs the fewest radix passes for this vocabulary (every pass is three small
+  // launches and the stage is launch-bound): chunks of cpc characters, each sorted with ceil(cpc * bits / VOC_WIDTH) passes
   constexpr int VOC_WIDTH = 8, VOC_CHUNK = 32;
-  const u32 cpc = std::max<u32>(1, VOC_CHUNK / bits);                 // characters per chunk
+  u32 cpc = 1, best = ~0u;
+  for (u32 c = 1; c * bits <= (u32)VOC_CHUNK; c++) {
+    const u32 passes = ((maxlen + c - 1) / c) * ((c * bits + VOC_WIDTH - 1) / VOC_WIDTH);
+    if (passes <= best) { best = passes; cpc = c; }       // ties: fewer, larger chunks (fewer key kernels)
+  }
   const u32 nchunks = (maxlen + cpc - 1) / cpc;
   uint2* cur = permA.p;
   uint2* other = permB.p;
