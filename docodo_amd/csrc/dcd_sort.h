@@ -162,6 +162,9 @@ inline RsTilePlan rs_tile_plan(u64 n_tiles) {
   return p;
 }
 
+#ifndef DCD_RS_TU
+#define DCD_RS_TU 4
+#endif
 template <int BITS, bool CACHE>
 __global__ __launch_bounds__(RS_THREADS) void k_rs_hist_strided(const uint2* __restrict__ in, RsStrided sd, const u32* __restrict__ remap,
                                                                u32 tpb, u32 nblk, int shift, u32* __restrict__ hist) {
@@ -177,8 +180,8 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_hist_strided(const uint2* __r
   u32* hl = h + (threadIdx.x % HC) * HS;
   const u32 lane = lane_id(), w = threadIdx.x >> 6;
   const u64 ta = (u64)blockIdx.x * tpb, tb = ta + tpb < sd.n_tiles ? ta + tpb : sd.n_tiles;
-  // a wave takes two tiles at a time; a lane reads tuple pairs (16 B; the stride is even, so tiles start 16-byte aligned)
-  constexpr int TU = 2, PR = (RS_STRIDE_MAX / 2 + 63) / 64;     // pair rounds per tile
+  // a wave takes DCD_RS_TU tiles at a time; a lane reads tuple pairs (16 B; the stride is even, so tiles start 16-byte aligned)
+  constexpr int TU = DCD_RS_TU, PR = (RS_STRIDE_MAX / 2 + 63) / 64;     // pair rounds per tile
   for (u64 t0 = ta + (u64)w * TU; t0 < tb; t0 += (u64)RS_WAVES * TU) {
     u32 c[TU];
     uint4 kv[TU][PR];
