@@ -63,6 +63,9 @@ __device__ __forceinline__ void lds_barrier() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
+#ifndef DCD_RS_UN
+#define DCD_RS_UN 4
+#endif
 #ifndef DCD_RS_HCOPIES
 #define DCD_RS_HCOPIES 8
 #endif
@@ -108,7 +111,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const uint2* __restrict_
   u64 beg = (u64)blockIdx.x * ipb, end = beg + ipb < n ? beg + ipb : n;
   // The order of the items inside a block does not matter for the counts: every lane reads TWO tuples per load
   // (16 B) and keeps four loads in flight, so that enough bytes are outstanding to cover the HBM latency.
-  constexpr int UN = 4;
+  constexpr int UN = DCD_RS_UN;
   const u64 span = end > beg ? end - beg : 0;
   if ((reinterpret_cast<uintptr_t>(in) & 15) == 0) {          // beg is a multiple of RS_TILE: pairs stay aligned
     const uint4* in2 = reinterpret_cast<const uint4*>(in + beg);
