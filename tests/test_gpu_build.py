@@ -202,6 +202,22 @@ def test_vocabulary_capacity_does_not_change_the_index(cap_log2):
     assert images[0] == images[1]
 
 
+def test_tile_population_extremes(oracle_mod):
+    """Plain text builds write tile-strided tuples (no counting pass) that the first sort pass reads in place: tiles at
+    the population limit (3-character tokens back to back, a class change and no separator between them: 314 per
+    944-character tile), empty tiles (long runs of blanks / punctuation), tiles of one token, and a mix."""
+    dense = "abc123" * 4000                                  # 24 000 characters, one token per 3 characters
+    blanks = " " * 5000 + "." * 3000
+    sparse = ("x" * 31 + " " * 900) * 8                      # one long token per tile or so
+    pages = [dense, blanks, "word " * 10, blanks + "tail", sparse, dense[:1000] + blanks[:2000] + dense[:1001], "", "end"]
+    ids = [str(i + 1) for i in range(len(pages))]
+    docs = [("s", "d", len(pages))]
+    (gi, gl), gb, st = _gpu_images(pages, docs=docs, ids=ids)
+    (oi, ol), ob = _oracle_images(oracle_mod, pages, docs=docs, ids=ids)
+    assert st.n_postings == ob.total_count
+    assert gi == oi and gl == ol
+
+
 def test_explicit_postings_builder_api(oracle_mod, known):
     """Index.Builder standalone path (BuilderTest, IndexTest.cs:272-313): AddWord(token, offset) for the
     \\b\\w+\\b tokens of TestText1, EndPage("1"); identity codes (no stemmer / vocab)."""
