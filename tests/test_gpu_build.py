@@ -218,6 +218,31 @@ def test_tile_population_extremes(oracle_mod):
     assert gi == oi and gl == ol
 
 
+@pytest.mark.parametrize("env", [{"DOCODO_TOK_TWO_PASS": "1"}, {"DOCODO_VOCAB_POOL": "0"},
+                                 {"DOCODO_TOK_TWO_PASS": "1", "DOCODO_VOCAB_POOL": "0"}])
+def test_alternative_build_paths_give_the_same_bytes(env):
+    """The default build tokenises once (tile-strided tuples, string pool beside the vocabulary table); the counting-pass
+    form and the text-only verification stay available behind environment switches and must produce the same files."""
+    import hashlib
+    import os
+    import subprocess
+    import sys
+    import docodo_amd
+    from docodo_amd import synth
+    n_docs = 20000
+    text = synth.corpus_host(n_docs)
+    b = docodo_amd.Builder()
+    b.AddPages(text, np.arange(n_docs + 1, dtype=np.uint64) * synth.DOC_BYTES, docs_per_page=True)
+    b.Finish()
+    h = hashlib.sha256(b.index_image())
+    h.update(b.list_image())
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "helpers", "build_digest_worker.py"), str(n_docs)],
+                       env=dict(os.environ, **env), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "digest " + h.hexdigest() in r.stdout
+
+
 def test_explicit_postings_builder_api(oracle_mod, known):
     """Index.Builder standalone path (BuilderTest, IndexTest.cs:272-313): AddWord(token, offset) for the
     \\b\\w+\\b tokens of TestText1, EndPage("1"); identity codes (no stemmer / vocab)."""
