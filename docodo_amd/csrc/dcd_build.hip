@@ -193,15 +193,24 @@ __global__ void k_img_headers(const u16* __restrict__ chars, const u32* __restri
   pay_off[r] = o;
 }
 
-// units -> image payloads.  A workgroup owns a tile of 2048 units (8 = 16 bytes per thread) and finds the tile's
-// first / last term once; 8 units of one term move as four dword stores at the payload's (arbitrary) byte alignment.
-constexpr int IMG_UPT = 8;  // units per thread
+// units -> image payloads.  A workgroup owns a tile of 8192 units, each of its four waves a span of 2048 (4 x 8 units = 4 x
+// 16 bytes per lane, lane-interleaved) and the tile's first / last term are found once; a span inside ONE term (by weight
+// almost all of a Zipf index) looks its term up once per wave and streams; 8 units of one term move as one 16-byte store
+// at the payload's (arbitrary) byte alignment.
+constexpr int IMG_UPT = 8;  // units per chunk
 constexpr int IMG_THREADS = 256;
-constexpr int IMG_TILE = IMG_UPT * IMG_THREADS;
+constexpr int IMG_CPL = 4;  // chunks per lane
+constexpr int IMG_SPAN = 64 * IMG_UPT * IMG_CPL;
+constexpr int IMG_TILE = IMG_SPAN * (IMG_THREADS / 64);
 typedef u32 __attribute__((aligned(1))) u32_a1;
 __device__ __forceinline__ u64 img_term_of(const u64* __restrict__ unit_start, u64 lo, u64 hi, u64 u) {   // last t in [lo, hi) with unit_start[t] <= u
   while (lo + 1 < hi) { u64 m = (lo + hi) >> 1; if (unit_start[m] <= u) lo = m; else hi = m; }
   return lo;
+}
+__device__ __forceinline__ void img_copy8(const u16* __restrict__ units, u64 u0, u8* __restrict__ img, u64 dst) {
+  const uint4 v = *reinterpret_cast<const uint4*>(units + u0);     // units is 16-byte aligned at u0 (a multiple of 8)
+  u32_a1* d = reinterpret_cast<u32_a1*>(img + dst);
+  d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
 }
 __global__ __launch_bounds__(IMG_THREADS) void k_img_units(const u16* __restrict__ units, u64 n_units, const u64* __restrict__ unit_start,
                                                           u64 n_terms, const u64* __restrict__ pay_off, u8* __restrict__ img) {
@@ -210,25 +219,32 @@ __global__ __launch_bounds__(IMG_THREADS) void k_img_units(const u16* __restrict
   if (threadIdx.x == 0) s_t[0] = img_term_of(unit_start, 0, n_terms, tile_base);
   if (threadIdx.x == 64) { u64 e = tile_base + IMG_TILE; s_t[1] = img_term_of(unit_start, 0, n_terms, (e < n_units ? e : n_units) - 1); }
   __syncthreads();
-  const u64 u0 = tile_base + (u64)threadIdx.x * IMG_UPT;
-  if (u0 >= n_units) return;
-  u64 t = img_term_of(unit_start, s_t[0], s_t[1] + 1, u0);
-  u64 next = unit_start[t + 1];
-  u64 dst = pay_off[t] + 2 * (u0 - unit_start[t]);
-  if (u0 + IMG_UPT <= next) {                      // units is 16-byte aligned at u0 (u0 is a multiple of 8)
-    const uint4 v = *reinterpret_cast<const uint4*>(units + u0);
-    u32_a1* d = reinterpret_cast<u32_a1*>(img + dst);
-    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+  const u32 lane = threadIdx.x & 63;
+  const u64 span = tile_base + (u64)(threadIdx.x >> 6) * IMG_SPAN;
+  if (span >= n_units) return;
+  const u64 t0 = img_term_of(unit_start, s_t[0], s_t[1] + 1, span);          // wave-uniform
+  if (span + IMG_SPAN <= unit_start[t0 + 1]) {                               // the whole span inside one term
+    const u64 dst0 = pay_off[t0] + 2 * (span - unit_start[t0]);
+#pragma unroll
+    for (int c = 0; c < IMG_CPL; c++) img_copy8(units, span + (u64)(c * 64 + lane) * IMG_UPT, img, dst0 + (u64)(c * 64 + lane) * IMG_UPT * 2);
     return;
   }
-  for (int k = 0; k < IMG_UPT; k++) {
-    u64 u = u0 + k;
-    if (u >= n_units) break;
-    while (u >= next) { t++; next = unit_start[t + 1]; dst = pay_off[t]; }
-    u16 v = units[u];
-    img[dst] = (u8)v;
-    img[dst + 1] = (u8)(v >> 8);
-    dst += 2;
+  for (int c = 0; c < IMG_CPL; c++) {
+    const u64 u0 = span + (u64)(c * 64 + lane) * IMG_UPT;
+    if (u0 >= n_units) break;
+    u64 t = img_term_of(unit_start, t0, s_t[1] + 1, u0);
+    u64 next = unit_start[t + 1];
+    u64 dst = pay_off[t] + 2 * (u0 - unit_start[t]);
+    if (u0 + IMG_UPT <= next) { img_copy8(units, u0, img, dst); continue; }
+    for (int k = 0; k < IMG_UPT; k++) {
+      u64 u = u0 + k;
+      if (u >= n_units) break;
+      while (u >= next) { t++; next = unit_start[t + 1]; dst = pay_off[t]; }
+      u16 v = units[u];
+      img[dst] = (u8)v;
+      img[dst + 1] = (u8)(v >> 8);
+      dst += 2;
+    }
   }
 }
 
