@@ -9,7 +9,10 @@
 namespace dcd {
 
 constexpr int CODEC_THREADS = 256;
-constexpr int CODEC_ITEMS = 8;
+#ifndef DCD_CODEC_ITEMS
+#define DCD_CODEC_ITEMS 8
+#endif
+constexpr int CODEC_ITEMS = DCD_CODEC_ITEMS;
 constexpr int CODEC_TILE = CODEC_THREADS * CODEC_ITEMS;
 
 // ---- delta sources for the encoder -----------------------------------------------------------
