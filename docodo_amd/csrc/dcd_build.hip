@@ -1130,7 +1130,7 @@ static int32_t build_phase2(dcd_build* h) {
   DCD_TRY(ix.units.alloc(dev, U ? U : 1));
   if (N) {
     probes.begin(DCD_K_ENC_WRITE);
-    hipLaunchKernelGGL(k_pack_write, dim3((u32)enb), dim3(CODEC_THREADS), 0, st, src, N, enc_part.p, ix.units.p);
+    hipLaunchKernelGGL(k_pack_write, dim3((u32)div_up(enb, PACK_TPB)), dim3(CODEC_THREADS), 0, st, src, N, enc_part.p, ix.units.p);
     probes.end();
   }
   hipLaunchKernelGGL(k_set_u64, dim3(1), dim3(1), 0, st, ix.term_unit_start.p + V, U);

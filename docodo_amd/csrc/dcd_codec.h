@@ -14,6 +14,10 @@ constexpr int CODEC_THREADS = 256;
 #endif
 constexpr int CODEC_ITEMS = DCD_CODEC_ITEMS;
 constexpr int CODEC_TILE = CODEC_THREADS * CODEC_ITEMS;
+#ifndef DCD_PACK_TPB
+#define DCD_PACK_TPB 4
+#endif
+constexpr int PACK_TPB = DCD_PACK_TPB;               // tiles per workgroup of k_pack_write
 
 // ---- delta sources for the encoder -----------------------------------------------------------
 // Src::delta(i) -> u64 delta of item i; Src::on_item(i, unit_offset, delta) -> side outputs.

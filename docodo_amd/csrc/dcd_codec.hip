@@ -90,74 +90,101 @@ __global__ __launch_bounds__(CODEC_THREADS) void k_pack_count(EncSrcPairs src, u
   if (threadIdx.x == 0) partial[blockIdx.x] = (u64)lds[0] + lds[1] + lds[2] + lds[3];
 }
 
+// A workgroup writes PACK_TPB consecutive tiles.  The barriers order LDS only and the pairs of the next tile are fetched
+// into registers while the current one is encoded, so that loads and stores stay in flight across tiles.
 __global__ __launch_bounds__(CODEC_THREADS) void k_pack_write(EncSrcPairs src, u64 n, const u64* __restrict__ partial, u16* __restrict__ out) {
-  __shared__ u32 lds[5];
+  __shared__ u32 lds[CODEC_THREADS / 64];
   // pairs are read back in blocked order (lane t reads elements 8t .. 8t+8): one element of padding per
   // 8 keeps those 64-bit LDS reads conflict-free (stride 72 B instead of 64 B)
   __shared__ union { uint2 pairs[(CODEC_TILE + 1) + (CODEC_TILE + 1) / 8 + 1]; u16 units[CODEC_TILE * 5]; } sh;
   auto pad = [](u32 k) -> u32 { return k + (k >> 3); };
-  const u64 t0 = (u64)blockIdx.x * CODEC_TILE;
-  const u32 cnt = (u32)min((u64)CODEC_TILE, n - t0);
-  // pairs[0] = item before the tile
-  for (u32 k = threadIdx.x; k < cnt + 1; k += CODEC_THREADS) {
-    u64 i = t0 + k;   // pairs[k] = p[i - 1]
-    sh.pairs[pad(k)] = i ? src.p[i - 1] : make_uint2(0xFFFFFFFFu, 0u);
-  }
-  __syncthreads();
-  // Inside a term the delta of two segment-local coordinates fits 32 bits (<= 3 units); the first posting of a term
-  // carries the 64-bit base and may need up to 5.  d_lo keeps the low 32 bits, heads re-derive the full value.
-  u32 d_lo[CODEC_ITEMS], nu[CODEC_ITEMS], term[CODEC_ITEMS], cy[CODEC_ITEMS];
-  bool hd[CODEC_ITEMS];
-  u32 s = 0;
-  const u32 l0 = threadIdx.x * CODEC_ITEMS;
+  constexpr int NLD = (CODEC_TILE + 1 + CODEC_THREADS - 1) / CODEC_THREADS;       // loads per thread and tile (incl. the pair before it)
+  const u64 n_tiles = (n + CODEC_TILE - 1) / CODEC_TILE;
+  const u64 tile_a = (u64)blockIdx.x * PACK_TPB, tile_b = tile_a + PACK_TPB < n_tiles ? tile_a + PACK_TPB : n_tiles;
+  const u32 lane = lane_id(), w = threadIdx.x >> 6;
+  uint2 pf[NLD];
+  auto fetch = [&](u64 tile) {
+    const u64 t0 = tile * CODEC_TILE;
+    const u32 cnt = (u32)min((u64)CODEC_TILE, n - t0);
 #pragma unroll
-  for (int j = 0; j < CODEC_ITEMS; j++) {
-    u32 li = l0 + j;
-    d_lo[j] = 0; nu[j] = 0; term[j] = 0; cy[j] = 0; hd[j] = false;
-    if (li < cnt) {
-      uint2 q = sh.pairs[pad(li)], c = sh.pairs[pad(li + 1)];
-      hd[j] = (t0 + li == 0) || q.x != c.x;
-      term[j] = c.x;
-      cy[j] = c.y;
-      if (hd[j]) {
-        const u64 d = src.base + c.y;
-        d_lo[j] = (u32)d;
-        nu[j] = seq_nunits(d);
-      } else {
-        d_lo[j] = c.y - q.y;
-        nu[j] = seq_nunits32(d_lo[j]);
-      }
-      s += nu[j];
+    for (int i = 0; i < NLD; i++) {
+      const u32 k = threadIdx.x + i * CODEC_THREADS;                   // pairs[k] = p[t0 + k - 1]
+      const u64 g = t0 + k;
+      pf[i] = (k < cnt + 1 && g) ? src.p[g - 1] : make_uint2(0xFFFFFFFFu, 0u);
     }
-  }
-  u32 tot;
-  u32 loff = block_scan_excl<u32, 4>(s, lds, &tot);   // (contains barriers: all pair reads are done)
-  const u64 gbase = partial[blockIdx.x];
+  };
+  if (tile_a < tile_b) fetch(tile_a);
+  for (u64 tile = tile_a; tile < tile_b; tile++) {
+    const u64 t0 = tile * CODEC_TILE;
+    const u32 cnt = (u32)min((u64)CODEC_TILE, n - t0);
+    const u64 gbase = partial[tile];
 #pragma unroll
-  for (int j = 0; j < CODEC_ITEMS; j++) {
-    if (l0 + j < cnt) {
-      if (hd[j]) { src.term_unit_start[term[j]] = gbase + loff; src.term_item_start[term[j]] = t0 + l0 + j; }
-      if (hd[j] && nu[j] > 2) {                                   // 64-bit head (rare): the general code
-        const u64 d = src.base + cy[j];
-        for (u32 g = 0; g < nu[j]; g++) sh.units[loff + g] = seq_unit(d, g, nu[j]);
-      } else {                                                    // <= 3 units of a 32-bit value, no loop
-        const u32 d = d_lo[j];
-        sh.units[loff] = (u16)((d & 0x7FFFu) | (nu[j] > 1 ? 0x8000u : 0u));
-        if (nu[j] > 1) sh.units[loff + 1] = (u16)(((d >> 15) & 0x7FFFu) | (nu[j] > 2 ? 0x8000u : 0u));
-        if (nu[j] > 2) sh.units[loff + 2] = (u16)(d >> 30);
-      }
-      loff += nu[j];
+    for (int i = 0; i < NLD; i++) {
+      const u32 k = threadIdx.x + i * CODEC_THREADS;
+      if (k < cnt + 1) sh.pairs[pad(k)] = pf[i];
     }
+    lds_barrier();
+    // Inside a term the delta of two segment-local coordinates fits 32 bits (<= 3 units); the first posting of a term
+    // carries the 64-bit base and may need up to 5.  d_lo keeps the low 32 bits, heads re-derive the full value.
+    u32 d_lo[CODEC_ITEMS], nu[CODEC_ITEMS], term[CODEC_ITEMS], cy[CODEC_ITEMS];
+    bool hd[CODEC_ITEMS];
+    u32 s = 0;
+    const u32 l0 = threadIdx.x * CODEC_ITEMS;
+#pragma unroll
+    for (int j = 0; j < CODEC_ITEMS; j++) {
+      u32 li = l0 + j;
+      d_lo[j] = 0; nu[j] = 0; term[j] = 0; cy[j] = 0; hd[j] = false;
+      if (li < cnt) {
+        uint2 q = sh.pairs[pad(li)], c = sh.pairs[pad(li + 1)];
+        hd[j] = (t0 + li == 0) || q.x != c.x;
+        term[j] = c.x;
+        cy[j] = c.y;
+        if (hd[j]) {
+          const u64 d = src.base + c.y;
+          d_lo[j] = (u32)d;
+          nu[j] = seq_nunits(d);
+        } else {
+          d_lo[j] = c.y - q.y;
+          nu[j] = seq_nunits32(d_lo[j]);
+        }
+        s += nu[j];
+      }
+    }
+    if (tile + 1 < tile_b) fetch(tile + 1);                            // in flight while this tile is encoded and stored
+    // block scan of the unit counts (LDS-only barriers)
+    const u32 incl = wave_scan_incl(s);
+    if (lane == 63) lds[w] = incl;
+    lds_barrier();                                                     // (also: every pair read of the tile is done)
+    u32 loff = incl - s, tot = 0;
+#pragma unroll
+    for (int k = 0; k < CODEC_THREADS / 64; k++) { const u32 v = lds[k]; tot += v; loff += k < (int)w ? v : 0u; }
+#pragma unroll
+    for (int j = 0; j < CODEC_ITEMS; j++) {
+      if (l0 + j < cnt) {
+        if (hd[j]) { src.term_unit_start[term[j]] = gbase + loff; src.term_item_start[term[j]] = t0 + l0 + j; }
+        if (hd[j] && nu[j] > 2) {                                   // 64-bit head (rare): the general code
+          const u64 d = src.base + cy[j];
+          for (u32 g = 0; g < nu[j]; g++) sh.units[loff + g] = seq_unit(d, g, nu[j]);
+        } else {                                                    // <= 3 units of a 32-bit value, no loop
+          const u32 d = d_lo[j];
+          sh.units[loff] = (u16)((d & 0x7FFFu) | (nu[j] > 1 ? 0x8000u : 0u));
+          if (nu[j] > 1) sh.units[loff + 1] = (u16)(((d >> 15) & 0x7FFFu) | (nu[j] > 2 ? 0x8000u : 0u));
+          if (nu[j] > 2) sh.units[loff + 2] = (u16)(d >> 30);
+        }
+        loff += nu[j];
+      }
+    }
+    lds_barrier();
+    u16* dst = out + gbase;
+    u32 head = (u32)(((uintptr_t)dst >> 1) & 1u) & (tot ? 1u : 0u);
+    if (threadIdx.x == 0 && head) dst[0] = sh.units[0];
+    u32 npair = (tot - head) >> 1;
+    u32* dst32 = reinterpret_cast<u32*>(dst + head);
+    for (u32 k = threadIdx.x; k < npair; k += CODEC_THREADS)
+      dst32[k] = (u32)sh.units[head + 2 * k] | ((u32)sh.units[head + 2 * k + 1] << 16);
+    if (threadIdx.x == 0 && ((tot - head) & 1u)) dst[tot - 1] = sh.units[tot - 1];
+    lds_barrier();                                                     // the units are out of LDS: the next tile's pairs may come in
   }
-  __syncthreads();
-  u16* dst = out + gbase;
-  u32 head = (u32)(((uintptr_t)dst >> 1) & 1u) & (tot ? 1u : 0u);
-  if (threadIdx.x == 0 && head) dst[0] = sh.units[0];
-  u32 npair = (tot - head) >> 1;
-  u32* dst32 = reinterpret_cast<u32*>(dst + head);
-  for (u32 k = threadIdx.x; k < npair; k += CODEC_THREADS)
-    dst32[k] = (u32)sh.units[head + 2 * k] | ((u32)sh.units[head + 2 * k + 1] << 16);
-  if (threadIdx.x == 0 && ((tot - head) & 1u)) dst[tot - 1] = sh.units[tot - 1];
 }
 
 void decode_count_launch(const u16* units, u64 n, u64* partial, hipStream_t st) {

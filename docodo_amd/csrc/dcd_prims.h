@@ -61,6 +61,14 @@ __device__ __forceinline__ u32 wave_max(u32 v) {
   return v;
 }
 
+// Workgroup barrier that orders LDS traffic only: s_waitcnt lgkmcnt(0) + s_barrier.  __syncthreads() also drains
+// vmcnt, i.e. it would wait for every scattered store (and prefetched load) of the tile before the next phase starts.
+__device__ __forceinline__ void lds_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 // Block-wide exclusive scan of one value per thread.  NW = waves per block.  `lds` needs NW+1
 // entries of T.  Returns the exclusive prefix; *total receives the block sum (all threads).
 template <typename T, int NW>

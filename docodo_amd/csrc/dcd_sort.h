@@ -55,14 +55,6 @@ inline RsPlan rs_plan(u64 n) {
 // key transform: optional gather through `remap` (first pass over hash-slot ids)
 __device__ __forceinline__ u32 rs_key(u32 k, const u32* __restrict__ remap) { return remap ? remap[k] : k; }
 
-// Workgroup barrier that orders LDS traffic only: s_waitcnt lgkmcnt(0) + s_barrier.  __syncthreads() also drains
-// vmcnt, i.e. it would wait for every scattered store (and prefetched load) of the tile before the next phase starts.
-__device__ __forceinline__ void lds_barrier() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-  __builtin_amdgcn_s_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-}
-
 #ifndef DCD_RS_UN
 #define DCD_RS_UN 4
 #endif
