@@ -61,6 +61,8 @@ SIGNATURES = {
     "dcd_version": (_i32, []),
     "dcd_last_error": (_i32, [C.c_char_p, _sz]),
     "dcd_device_count": (_i32, [_pi32]),
+    "dcd_pool_trim": (_i32, [_i32]),
+    "dcd_pool_cached_bytes": (_i32, [_i32, _pu64]),
     "dcd_seq_encode": (_i32, [_vp, _sz, _vp, _sz, _pz]),
     "dcd_seq_decode": (_i32, [_vp, _sz, _vp, _sz, _pz]),
     "dcd_seq_count": (_i32, [_vp, _sz, _pz]),
@@ -157,6 +159,18 @@ def last_error():
     buf = C.create_string_buffer(2048)
     lib().dcd_last_error(buf, len(buf))
     return buf.value.decode("utf-8", "replace")
+
+
+def pool_trim(device=0):
+    """Returns the library's cached device blocks to HIP (dcd_pool_trim): call it when another allocator in the process
+    (torch) needs the memory, or after the last handle of a large build / index was closed."""
+    check(lib().dcd_pool_trim(device))
+
+
+def pool_cached_bytes(device=0):
+    n = C.c_uint64(0)
+    check(lib().dcd_pool_cached_bytes(device, C.byref(n)))
+    return int(n.value)
 
 
 def check(code):

@@ -308,6 +308,7 @@ hipStream_t build_stream(dcd_build* b) { return b->st; }
 int32_t index_make_image(const DeviceIndex& ix, hipStream_t st, DevBuf<u8>& image, u64* image_bytes) {
   const int dev = ix.device;
   DCD_TRY(ensure_device(dev));
+  StreamScope ss_(st);
   const u64 V = ix.n_terms, U = ix.n_units;
   DevBuf<u64> rec_off, pay_off, scr64b;
   DCD_TRY(rec_off.alloc(dev, V + 1));
@@ -410,6 +411,7 @@ void dcd_build_free(dcd_build* h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
   hipStream_t st = h->st;
+  StreamScope ss_(st);
   if (st) (void)hipStreamSynchronize(st);
   const int dev = h->device;
   delete h;                       // (buffers go back to the pool before the stream is parked)
@@ -480,6 +482,7 @@ static int32_t add_pages_impl(dcd_build* h, const void* text, u64 n_chars, const
                               const uint16_t* page_ids, const uint64_t* ids_off, int32_t docs_per_page, uint64_t first_doc,
                               const uint16_t* source, size_t source_len, bool device_text) {
   if (h->mid) DCD_FAIL(DCD_E_STATE, "pages cannot be added after dcd_build_words");
+  StreamScope ss_(h->st);
   if (docs_per_page) {
     if (!h->pages.docs.empty() || (h->pages.n_pages() && !h->pages.doc_per_page))
       DCD_FAIL(DCD_E_STATE, "cannot mix docs_per_page with explicit documents");
@@ -724,6 +727,7 @@ template <typename CharT>
 static int32_t build_phase1(dcd_build* h, bool codes_mode) {
   const int dev = h->device;
   hipStream_t st = h->st;
+  StreamScope ss_(st);
   DCD_TRY(ensure_device(dev));
   h->mid.reset(new BuildMid());
   BuildMid& M = *h->mid;
@@ -971,6 +975,7 @@ template <typename CharT>
 static int32_t build_phase2(dcd_build* h) {
   const int dev = h->device;
   hipStream_t st = h->st;
+  StreamScope ss_(st);
   DCD_TRY(ensure_device(dev));
   BuildMid& M = *h->mid;
   HostTrace tr;

@@ -227,6 +227,7 @@ int32_t dcd_seq_encode(const uint64_t* values, size_t n, uint16_t* out, size_t c
   if (n == 0) { *n_units = 0; return DCD_OK; }
   SeqCtx* c;
   DCD_TRY(seq_ctx(&c));
+  StreamScope ss_(c->st);
   DevBuf<u64> dv, part;
   DevBuf<u16> du;
   u64 nb = encode_nblocks(n);
@@ -253,6 +254,7 @@ static int32_t seq_decode_impl(const uint16_t* units, size_t n_units, uint64_t* 
   if (n_units == 0) { *n = 0; return DCD_OK; }
   SeqCtx* c;
   DCD_TRY(seq_ctx(&c));
+  StreamScope ss_(c->st);
   DevBuf<u16> du;
   DevBuf<u64> part;
   u64 nb = div_up(n_units, CODEC_TILE);

@@ -1,6 +1,7 @@
 // dcd_common.cpp -- error state, device check and the caching device allocator.
 #include "dcd_common.h"
 
+#include <cstdlib>
 #include <map>
 #include <mutex>
 
@@ -31,11 +32,41 @@ int32_t ensure_device(int device) {
   return DCD_OK;
 }
 
+// ---- stream-ordered caching allocator ------------------------------------------------------------
+// Every handle of the library works on its own hipStreamNonBlocking stream, and the error unwinds
+// (DCD_TRY / DCD_HIP early returns) destroy DevBufs whose kernels or copies may still be in flight.
+// A released block therefore carries the stream it was last used on plus an event recorded there at
+// release time; it is handed out again at once to the same stream (stream order covers it), and to
+// any other stream only after the event has completed (or behind a hipStreamWaitEvent).
+static thread_local hipStream_t t_cur_stream = nullptr;
+static thread_local bool t_have_stream = false;
+
+StreamScope::StreamScope(hipStream_t s) : prev(t_cur_stream), prev_have(t_have_stream) {
+  t_cur_stream = s;
+  t_have_stream = true;
+}
+StreamScope::~StreamScope() {
+  t_cur_stream = prev;
+  t_have_stream = prev_have;
+}
+
 namespace {
+struct FreeBlock {
+  void* p;
+  hipStream_t stream;   // stream the release was ordered on (meaningful only with ev)
+  hipEvent_t ev;        // recorded on `stream` at release; nullptr = nothing pending
+};
+struct LiveBlock {
+  size_t size;
+  hipStream_t stream;
+  bool tagged;          // allocated inside a StreamScope
+};
 struct Pool {
   std::mutex mu;
-  std::multimap<size_t, void*> free_;   // rounded size -> block
-  std::map<void*, size_t> live;         // block -> rounded size
+  std::multimap<size_t, FreeBlock> free_;   // rounded size -> block
+  std::map<void*, LiveBlock> live;          // block -> rounded size + owner stream
+  size_t cached = 0;                        // bytes in free_
+  size_t cap = 0;                           // 0 = not initialised yet
 };
 Pool& pool(int device) {
   static Pool pools[64];
@@ -46,18 +77,54 @@ size_t round_size(size_t b) {
   size_t g = b >= (1ull << 20) ? big : small;
   return (b + g - 1) / g * g;
 }
+// Upper bound of the bytes the cache may hold on to (released blocks beyond it go back to HIP at once, so that a
+// process that shares the GPU with another allocator -- torch in bench.py / dist.py -- is not starved):
+// DOCODO_POOL_MAX_CACHED bytes, default half of the device memory.
+size_t pool_cap(int device) {
+  if (const char* e = getenv("DOCODO_POOL_MAX_CACHED")) {
+    char* end = nullptr;
+    unsigned long long v = strtoull(e, &end, 10);
+    if (end != e) return (size_t)v;
+  }
+  size_t fr = 0, tot = 0;
+  (void)hipSetDevice(device);
+  if (hipMemGetInfo(&fr, &tot) != hipSuccess) { (void)hipGetLastError(); return (size_t)64 << 30; }
+  return tot / 2;
+}
+// true when the block may be used by `want` right now (possibly after queueing a wait on `want`)
+bool make_usable(int device, FreeBlock& b, hipStream_t want, bool have_want) {
+  if (!b.ev) return true;
+  bool ok = false;
+  if (have_want && want == b.stream) ok = true;
+  else {
+    hipError_t q = hipEventQuery(b.ev);
+    if (q == hipSuccess) ok = true;
+    else {
+      (void)hipGetLastError();
+      if (q == hipErrorNotReady) {
+        hipError_t w = have_want && want ? hipStreamWaitEvent(want, b.ev, 0) : hipEventSynchronize(b.ev);
+        if (w == hipSuccess) ok = true; else (void)hipGetLastError();
+      }
+    }
+  }
+  if (ok) { event_release(device, b.ev); b.ev = nullptr; }
+  return ok;
+}
 }  // namespace
 
 int32_t dev_alloc(int device, size_t bytes, void** out) {
   Pool& P = pool(device);
   size_t r = round_size(bytes);
+  const hipStream_t want = t_cur_stream;
+  const bool have_want = t_have_stream;
   {
     std::lock_guard<std::mutex> g(P.mu);
-    auto it = P.free_.lower_bound(r);
     // accept a cached block up to 25 % larger than needed
-    if (it != P.free_.end() && it->first <= r + r / 4) {
-      *out = it->second;
-      P.live[it->second] = it->first;
+    for (auto it = P.free_.lower_bound(r); it != P.free_.end() && it->first <= r + r / 4; ++it) {
+      if (!make_usable(device, it->second, want, have_want)) continue;
+      *out = it->second.p;
+      P.live[it->second.p] = LiveBlock{it->first, want, have_want};
+      P.cached -= it->first;
       P.free_.erase(it);
       return DCD_OK;
     }
@@ -75,7 +142,7 @@ int32_t dev_alloc(int device, size_t bytes, void** out) {
     }
   }
   std::lock_guard<std::mutex> g(P.mu);
-  P.live[p] = r;
+  P.live[p] = LiveBlock{r, want, have_want};
   *out = p;
   return DCD_OK;
 }
@@ -83,32 +150,70 @@ int32_t dev_alloc(int device, size_t bytes, void** out) {
 void dev_release(int device, void* p) {
   if (!p) return;
   Pool& P = pool(device);
-  std::lock_guard<std::mutex> g(P.mu);
-  auto it = P.live.find(p);
-  if (it == P.live.end()) return;  // double release: ignore (error, not UB)
-  P.free_.emplace(it->second, p);
-  P.live.erase(it);
+  LiveBlock lb;
+  {
+    std::lock_guard<std::mutex> g(P.mu);
+    auto it = P.live.find(p);
+    if (it == P.live.end()) return;  // double release: ignore (error, not UB)
+    lb = it->second;
+    P.live.erase(it);
+    if (!P.cap) P.cap = pool_cap(device);
+  }
+  // order the release: on the releasing thread's stream when it has one (that is the stream the block was last used
+  // on), and behind the allocating stream too when that is a different one
+  FreeBlock fb{p, nullptr, nullptr};
+  const bool have_cur = t_have_stream;
+  const hipStream_t cur = have_cur ? t_cur_stream : lb.stream;
+  if (have_cur || lb.tagged) {
+    hipEvent_t ev = event_acquire(device);
+    bool ok = ev != nullptr;
+    if (ok && have_cur && lb.tagged && lb.stream != cur) {
+      ok = hipEventRecord(ev, lb.stream) == hipSuccess && hipStreamWaitEvent(cur, ev, 0) == hipSuccess;
+    }
+    if (ok) ok = hipEventRecord(ev, cur) == hipSuccess;
+    if (ok) { fb.stream = cur; fb.ev = ev; }
+    else {
+      (void)hipGetLastError();
+      if (ev) event_release(device, ev);
+      (void)hipStreamSynchronize(cur);                       // cannot tag: wait here instead
+      if (lb.tagged && lb.stream != cur) (void)hipStreamSynchronize(lb.stream);
+      (void)hipGetLastError();
+    }
+  }
+  bool drop = false;
+  {
+    std::lock_guard<std::mutex> g(P.mu);
+    if (P.cached + lb.size > P.cap) drop = true;
+    else { P.free_.emplace(lb.size, fb); P.cached += lb.size; }
+  }
+  if (drop) {   // over the cap: back to HIP (hipFree waits for the device, so pending work is safe)
+    if (fb.ev) event_release(device, fb.ev);
+    (void)hipSetDevice(device);
+    (void)hipFree(p);
+  }
 }
 
 size_t dev_pool_cached_bytes(int device) {
   Pool& P = pool(device);
   std::lock_guard<std::mutex> g(P.mu);
-  size_t t = 0;
-  for (auto& kv : P.free_) t += kv.first;
-  return t;
+  return P.cached;
 }
 
 void dev_pool_trim(int device) {
   Pool& P = pool(device);
-  std::vector<void*> v;
+  std::vector<FreeBlock> v;
   {
     std::lock_guard<std::mutex> g(P.mu);
     for (auto& kv : P.free_) v.push_back(kv.second);
     P.free_.clear();
+    P.cached = 0;
   }
   if (!v.empty()) {
     (void)hipSetDevice(device);
-    for (void* p : v) (void)hipFree(p);
+    for (FreeBlock& b : v) {
+      if (b.ev) event_release(device, b.ev);
+      (void)hipFree(b.p);   // implicit device synchronisation: in-flight users of the block have finished
+    }
   }
 }
 
@@ -172,6 +277,19 @@ int32_t dcd_last_error(char* buf, size_t cap) {
     buf[n] = 0;
   }
   return (int32_t)e.size();
+}
+int32_t dcd_pool_trim(int32_t device) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); n = 0; }
+  if (device < 0 || device >= n) DCD_FAIL(DCD_E_BADARG, "dcd_pool_trim: device %d out of range (have %d)", device, n);
+  dcd::dev_pool_trim(device);
+  return DCD_OK;
+}
+int32_t dcd_pool_cached_bytes(int32_t device, uint64_t* bytes) {
+  if (!bytes) DCD_FAIL(DCD_E_BADARG, "bytes is NULL");
+  if (device < 0 || device >= 64) DCD_FAIL(DCD_E_BADARG, "dcd_pool_cached_bytes: device %d out of range", device);
+  *bytes = dcd::dev_pool_cached_bytes(device);
+  return DCD_OK;
 }
 int32_t dcd_device_count(int32_t* n) {
   if (!n) DCD_FAIL(DCD_E_BADARG, "n is NULL");

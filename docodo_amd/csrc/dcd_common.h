@@ -52,6 +52,17 @@ struct Status {
 // ---- caching device allocator ---------------------------------------------------------------
 // Blocks are rounded up to 2 MiB (>= 1 MiB requests) or 64 KiB and kept in a per-device free list
 // when released, so that repeated builds / query batches of the same shape do not call hipMalloc.
+// The allocator is stream-ordered: an entry point declares the stream its work runs on with a StreamScope; blocks
+// allocated or released inside the scope are tagged with that stream, a released block carries an event recorded on
+// it, and another stream gets the block only once that event has completed (see dcd_common.cpp).
+struct StreamScope {
+  hipStream_t prev;
+  bool prev_have;
+  explicit StreamScope(hipStream_t s);
+  ~StreamScope();
+  StreamScope(const StreamScope&) = delete;
+  StreamScope& operator=(const StreamScope&) = delete;
+};
 int32_t dev_alloc(int device, size_t bytes, void** out);
 void dev_release(int device, void* p);   // back to the pool
 void dev_pool_trim(int device);          // hipFree everything cached

@@ -9,6 +9,7 @@
 
 namespace dcd {
 DeviceIndex* build_take_index(dcd_build* b);
+DeviceIndex* build_peek_index(dcd_build* b);
 int build_device(dcd_build* b);
 }  // namespace dcd
 
@@ -64,12 +65,16 @@ static int32_t parse_index_image(const u8* p, size_t n, DeviceIndex& ix, std::ve
     int sh = 0;
     for (;;) {
       if (i >= n) DCD_FAIL(DCD_E_IO, "truncated key length in .index");
+      // BinaryReader.Read7BitEncodedInt: at most 5 length bytes, FormatException on a 6th (Index.Load then fails,
+      // Index.cs:373-376)
+      if (sh > 28) DCD_FAIL(DCD_E_IO, "malformed key length in .index (more than 5 length bytes)");
       u8 c = p[i++];
       len |= (u32)(c & 0x7F) << sh;
       sh += 7;
       if (!(c & 0x80)) break;
     }
-    if (i + len + 4 > n) DCD_FAIL(DCD_E_IO, "truncated record in .index");
+    if ((int32_t)len < 0) DCD_FAIL(DCD_E_IO, "negative key length in .index");
+    if (i + (size_t)len + 4 > n) DCD_FAIL(DCD_E_IO, "truncated record in .index");
     ustr key;
     utf8_to_utf16(p + i, len, key);
     i += len;
@@ -105,17 +110,19 @@ static int32_t parse_list_image(const u8* p, size_t n, PageTable& pt) {
     int sh = 0;
     bool ok = true;
     for (;;) {
-      if (i >= n) { ok = false; break; }
+      if (i >= n || sh > 28) { ok = false; break; }   // EndOfStream / FormatException after 5 length bytes
       u8 c = p[i++];
       len |= (u32)(c & 0x7F) << sh;
       sh += 7;
       if (!(c & 0x80)) break;
     }
-    if (!ok || i + len > n) break;  // EndOfStream: the reference stops silently
+    // IndexPageList.Load swallows every exception and keeps what it has read so far (Build.cs:119-148)
+    if (!ok || (int32_t)len < 0 || i + (size_t)len > n) break;
     ustr s;
     utf8_to_utf16(p + i, len, s);
     i += len;
-    if (s.empty() || s[0] != u':') {
+    if (s.empty()) break;   // s[0] throws in the reference (Build.cs:131): the load ends at this record
+    if (s[0] != u':') {
       DocMeta d;
       d.name = s;
       d.first_page = pt.end.size();
@@ -193,12 +200,16 @@ extern "C" {
 
 int32_t dcd_index_from_build(dcd_build* b, dcd_index** out) {
   if (!b || !out) DCD_FAIL(DCD_E_BADARG, "dcd_index_from_build: NULL argument");
+  // everything that can fail happens while the build still owns its index: a failed call leaves the builder usable
+  DeviceIndex* peek = build_peek_index(b);
+  if (!peek) DCD_FAIL(DCD_E_STATE, "build is not finished or its index was already adopted");
+  DCD_TRY(index_fetch_host(*peek));
+  hipStream_t st = nullptr;
+  DCD_TRY(stream_acquire(peek->device, &st));
   DeviceIndex* src = build_take_index(b);
-  if (!src) DCD_FAIL(DCD_E_STATE, "build is not finished or its index was already adopted");
-  DCD_TRY(index_fetch_host(*src));
   dcd_index* h = new dcd_index();
   h->ix = std::move(*src);
-  if (stream_acquire(h->ix.device, &h->st) != DCD_OK) { delete h; return DCD_E_HIP; }
+  h->st = st;
   *out = h;
   return DCD_OK;
 }
@@ -206,11 +217,11 @@ int32_t dcd_index_from_build(dcd_build* b, dcd_index** out) {
 int32_t dcd_index_from_images(const uint8_t* index_img, size_t n_index, const uint8_t* list_img, size_t n_list, int32_t device,
                               dcd_index** out) {
   if (!index_img || !out || (!list_img && n_list)) DCD_FAIL(DCD_E_BADARG, "dcd_index_from_images: NULL argument");
-  DCD_TRY(ensure_device(device));
   std::unique_ptr<dcd_index> h(new dcd_index());
   std::vector<u16> units;
-  DCD_TRY(parse_index_image(index_img, n_index, h->ix, units));
+  DCD_TRY(parse_index_image(index_img, n_index, h->ix, units));   // host-side format checks first: DCD_E_IO needs no device
   DCD_TRY(parse_list_image(list_img, n_list, h->ix.pages));
+  DCD_TRY(ensure_device(device));
   DCD_TRY(index_from_host(h->ix, units, device));
   DCD_TRY(stream_acquire(device, &h->st));
   *out = h.release();
@@ -231,6 +242,7 @@ void dcd_index_free(dcd_index* h) {
   if (!h) return;
   (void)hipSetDevice(h->ix.device);
   hipStream_t st = h->st;
+  StreamScope ss_(st);
   if (st) (void)hipStreamSynchronize(st);
   const int dev = h->ix.device;
   delete h;
@@ -391,6 +403,7 @@ int32_t dcd_index_close_words(dcd_index* h, const uint16_t* word, size_t len, ui
   const int dev = ix.device;
   DCD_TRY(ensure_device(dev));
   hipStream_t st = h->st;
+  StreamScope ss_(st);
   LevWord w;
   memset(&w, 0, sizeof w);
   for (size_t i = 0; i < len; i++) w.c[i] = word[i];

@@ -277,6 +277,7 @@ static int32_t export_plan_impl(const void* h, DeviceIndex* ix, hipStream_t st, 
   if (ix->n_terms && (!ix->term_first.p || !ix->term_last.p)) DCD_FAIL(DCD_E_STATE, "this index carries no first/last coordinates per term (loaded from files)");
   const int dev = ix->device;
   DCD_TRY(ensure_device(dev));
+  StreamScope ss_(st);
   const u64 V = ix->n_terms;
   std::unique_ptr<ExportPlan> ep(new ExportPlan());
   ep->n_owners = n_owners;
@@ -326,6 +327,7 @@ static int32_t export_fill_impl(const void* h, DeviceIndex* ix, hipStream_t st, 
   const u64 V = ep->n_terms;
   if (V && (!meta_dev || (!keys_dev && ep->total_keys) || (!units_dev && ep->total_units))) DCD_FAIL(DCD_E_BADARG, "export fill: NULL buffer");
   DCD_TRY(ensure_device(ix->device));
+  StreamScope ss_(st);
   if (V) {
     hipLaunchKernelGGL(k_export_meta, dim3((u32)div_up(V, 256)), dim3(256), 0, st, ep->perm.p, V, ix->term_unit_start.p, ix->term_item_start.p,
                        ix->term_str_off.p, ix->term_chars.p, ix->term_first.p, ix->term_last.p, ep->key_dst.p, (dcd_term_meta*)meta_dev, keys_dev);
@@ -389,6 +391,7 @@ int32_t dcd_merge_begin(int32_t device, uint32_t n_sources, const uint64_t* term
   DevBuf<u64>&dst_off = mg->dst_off, &src_off = mg->src_off;
   DCD_TRY(stream_acquire(device, &h->st));
   hipStream_t st = h->st;
+  StreamScope ss_(st);
   DeviceIndex& ix = h->ix;
   ix.device = device;
   ix.max_coord = max_coord;
@@ -489,6 +492,7 @@ int32_t dcd_merge_finish(dcd_merge* m, const uint16_t* units_dev, dcd_index** ou
   if (!units_dev && mg->U) DCD_FAIL(DCD_E_BADARG, "dcd_merge_finish: NULL units buffer");
   dcd_index* h = mg->h.get();
   DCD_HIP(hipSetDevice(h->ix.device));
+  StreamScope ss_(h->st);
   if (mg->Uout) {
     hipLaunchKernelGGL(k_merge_copy, dim3((u32)div_up(mg->Uout, CP_TILE)), dim3(CP_THREADS), 0, h->st, mg->sp, mg->M, mg->dst_off.p, mg->Uout,
                        mg->src_off.p, units_dev, h->ix.units.p);
@@ -501,8 +505,14 @@ int32_t dcd_merge_finish(dcd_merge* m, const uint16_t* units_dev, dcd_index** ou
 
 void dcd_merge_free(dcd_merge* m) {
   if (!m) return;
-  if (m->h && m->h->st) { stream_release(m->h->ix.device, m->h->st); m->h->st = nullptr; }
-  delete m;
+  hipStream_t st = m->h ? m->h->st : nullptr;
+  const int dev = m->h ? m->h->ix.device : 0;
+  {
+    StreamScope ss_(st);   // the buffers go back to the pool ordered behind whatever is still queued on the stream
+    if (m->h) m->h->st = nullptr;
+    delete m;
+  }
+  if (st) stream_release(dev, st);
 }
 
 int32_t dcd_merge_shards(int32_t device, uint32_t n_sources, const uint64_t* term_count, const uint64_t* key_count,

@@ -1120,6 +1120,7 @@ static int32_t ensure_values(dcd_index* h) {
   DeviceIndex& ix = h->ix;
   const int dev = ix.device;
   hipStream_t st = h->st;
+  StreamScope ss_(st);
   const u64 U = ix.n_units, N = ix.n_postings, V = ix.n_terms;
   DCD_TRY(h->values.alloc(dev, N ? N : 1));
   if (N) {
@@ -1238,6 +1239,7 @@ static int32_t run_batch(dcd_index* h, const int32_t* prog, const u64* prog_off,
   DeviceIndex& ix = h->ix;
   const int dev = ix.device;
   hipStream_t st = h->st;
+  StreamScope ss_(st);
   DCD_TRY(ensure_device(dev));
   if (!ext_values) DCD_TRY(ensure_values(h));
   const u64* idx_values = ext_values ? ext_values : h->values.p;
@@ -1469,6 +1471,9 @@ static int32_t run_batch(dcd_index* h, const int32_t* prog, const u64* prog_off,
       const u64* src = (s.kind == 0 ? idx_values : pool.p) + s.off;
       size_t base = R->seq_units.size();
       if (n) {
+        // tests: fail AFTER the result arrays were filled (the caller must not keep anything of this attempt)
+        if (const char* inj = getenv("DOCODO_QUERY_TEST_NOMEM_LATE"))
+          if (nq > (size_t)atoll(inj)) DCD_FAIL(DCD_E_NOMEM, "injected late out-of-memory (DOCODO_QUERY_TEST_NOMEM_LATE)");
         DevBuf<u64> part;
         DevBuf<u16> du;
         u64 nb = encode_nblocks(n);
@@ -1604,9 +1609,11 @@ int32_t dcd_query_batch(dcd_index* h, const int32_t* prog, const uint64_t* prog_
       st = DCD_E_NOMEM;
     } else
     if (q0 == 0 && q1 == n_queries) {                      // the common case: one sub-batch, no copies
-      R.reset(new dcd_results());
-      st = run_batch(h, prog, prog_off, n_queries, o, R.get(), nullptr, nullptr);
-      if (st == DCD_OK) break;
+      // a failed attempt may already have filled its result arrays (run_batch can run out of memory after the
+      // download, in the want_sequences loop): it works on an object of its own that is adopted only on success
+      std::unique_ptr<dcd_results> one(new dcd_results());
+      st = run_batch(h, prog, prog_off, n_queries, o, one.get(), nullptr, nullptr);
+      if (st == DCD_OK) { R = std::move(one); break; }
     } else {
       single = false;
       std::vector<u64> off(q1 - q0 + 1);
@@ -1618,6 +1625,7 @@ int32_t dcd_query_batch(dcd_index* h, const int32_t* prog, const uint64_t* prog_
     if (st != DCD_E_NOMEM || q1 - q0 <= 1) return st;
     dev_pool_trim(h->ix.device);                           // out of memory: release the cache, halve the sub-batch, try again
     budget = std::max<u64>(1, std::min(budget, acc) / 2);
+    if (single) R.reset(new dcd_results());                // nothing of a failed single attempt survives
     single = false;
   }
   *out = R.release();
@@ -1659,6 +1667,7 @@ static int32_t seq_binop(int opc, const u16* a, size_t na, int32_t Ra, const u16
   DCD_TRY(stream_acquire(0, &tmp.st));
   struct Guard { hipStream_t s; ~Guard() { stream_release(0, s); } } g{tmp.st};
   hipStream_t st = tmp.st;
+  StreamScope ss_(st);
   const u16* src[2] = {a, b};
   const size_t nu[2] = {na, nb};
   u64 nv[2] = {0, 0};

@@ -119,6 +119,7 @@ int32_t dcd_synth_corpus_dev(void* out_dev, uint64_t first_doc, uint64_t n_docs,
                              double zipf_s, uint64_t seed, int32_t device) {
   if (!out_dev || vocab == 0 || doc_bytes == 0) DCD_FAIL(DCD_E_BADARG, "dcd_synth_corpus_dev: bad argument");
   DCD_TRY(ensure_device(device));
+  StreamScope ss_(nullptr);   // the generator runs on the null stream
   auto cdf = zipf_cdf(vocab, zipf_s);
   DevBuf<double> dc;
   DCD_TRY(dc.alloc(device, vocab));

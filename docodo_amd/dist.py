@@ -79,7 +79,7 @@ def merge_received(term_count, key_count, unit_count, meta, keys, units, max_coo
     check(lib().dcd_merge_shards(device_index, tc.size, tc.ctypes.data, kc.ctypes.data, uc.ctypes.data,
                                  meta.data_ptr() if meta.numel() else None, keys.data_ptr() if keys.numel() else None,
                                  units.data_ptr() if units.numel() else None, int(max_coord), C.byref(h)))
-    return Index(h)
+    return Index(h, device_index)
 
 
 class PendingMerge:
@@ -91,6 +91,7 @@ class PendingMerge:
         kc = np.ascontiguousarray(key_count, np.uint64)
         uc = np.ascontiguousarray(unit_count, np.uint64)
         self._keep = (meta, keys)            # the segment table is read again by finish
+        self.device_index = device_index
         self.h = C.c_void_p()
         check(lib().dcd_merge_begin(device_index, tc.size, tc.ctypes.data, kc.ctypes.data, uc.ctypes.data,
                                     meta.data_ptr() if meta.numel() else None, keys.data_ptr() if keys.numel() else None,
@@ -101,7 +102,7 @@ class PendingMerge:
         out = C.c_void_p()
         check(lib().dcd_merge_finish(h, units.data_ptr() if units.numel() else None, C.byref(out)))
         self._keep = None
-        return Index(out)
+        return Index(out, self.device_index)
 
     def __del__(self):
         if getattr(self, "h", None):

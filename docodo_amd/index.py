@@ -37,6 +37,7 @@ class Builder:
         o.min_word_length, o.max_word_length = min_word_length, max_word_length
         o.vocab_capacity_log2 = vocab_capacity_log2
         self.encoding = encoding
+        self.device = device
         self.h = C.c_void_p()
         check(lib().dcd_build_create(C.byref(o), C.byref(self.h)))
         self._keep = []
@@ -206,20 +207,21 @@ class QueryBatchResult:
 class Index:
     """Docodo.Index as far as the hot path goes: Load, Count, MaxCoord, this[key], batched Search."""
 
-    def __init__(self, handle):
+    def __init__(self, handle, device=0):
         self.h = handle
+        self.device = device
 
     @classmethod
     def from_build(cls, builder):
         h = C.c_void_p()
         check(lib().dcd_index_from_build(builder.h, C.byref(h)))
-        return cls(h)
+        return cls(h, getattr(builder, "device", 0))
 
     @classmethod
     def Load(cls, dirpath, device=0):  # Index.cs:312
         h = C.c_void_p()
         check(lib().dcd_index_open(dirpath.encode("utf-8"), device, C.byref(h)))
-        return cls(h)
+        return cls(h, device)
 
     @classmethod
     def from_images(cls, index_bytes, list_bytes, device=0):
@@ -227,7 +229,7 @@ class Index:
         lb = np.frombuffer(list_bytes, np.uint8)
         h = C.c_void_p()
         check(lib().dcd_index_from_images(ib.ctypes.data, ib.size, lb.ctypes.data if lb.size else None, lb.size, device, C.byref(h)))
-        return cls(h)
+        return cls(h, device)
 
     def close(self):
         if self.h:
@@ -251,7 +253,12 @@ class Index:
         return bool(self.h)
 
     def Dispose(self):            # Index.cs:247-251
+        """Releases the handle and hands the library's cached device blocks back to HIP (dcd_pool_trim): after Dispose
+        the memory is available to every other allocator of the process."""
+        dev = getattr(self, "device", 0)
         self.close()
+        from ._lib import pool_trim
+        pool_trim(dev)
 
     def Search(self, req, opt=None, get_word_codes=None):   # Index.Search(string, SearchOptions), Search.cs:437
         from .search import Search

@@ -51,6 +51,13 @@ int32_t dcd_version(void);
 /* copies the calling thread's last error message (UTF-8, NUL-terminated); returns its length */
 int32_t dcd_last_error(char* buf, size_t cap);
 int32_t dcd_device_count(int32_t* n);
+/* The library keeps released device blocks in a per-device cache (stream-ordered: a block is reused by another
+ * stream only after the work queued on it at release time has completed).  dcd_pool_trim returns the cached blocks
+ * to HIP -- call it when another allocator in the process (the host's own, torch, ...) needs the memory, e.g. from
+ * Index.Dispose(); the cache never holds more than DOCODO_POOL_MAX_CACHED bytes (default: half of the device memory).
+ * No reference counterpart: the C# reference leaves this to the garbage collector. */
+int32_t dcd_pool_trim(int32_t device);
+int32_t dcd_pool_cached_bytes(int32_t device, uint64_t* bytes);
 
 /* ------------------------------------------------------------------------------------------
  * IndexSequence codec and algebra on host buffers (IndexSequence.cs).  These are the per-object

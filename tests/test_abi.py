@@ -111,3 +111,52 @@ def test_abi_demo_runs_from_plain_c(tmp_path):
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.strip().endswith("ok")
     assert os.path.exists(tmp_path / ".index") and os.path.exists(tmp_path / ".index.list")
+
+
+def _rec(key, units):
+    k = key.encode("utf-8")
+    assert len(k) < 128
+    return bytes([len(k)]) + k + len(units).to_bytes(4, "little") + b"".join(int(u).to_bytes(2, "little") for u in units)
+
+
+@pytest.mark.parametrize("name,img", [
+    ("short header", b"\x01\x02\x03"),
+    # BinaryReader.Read7BitEncodedInt throws FormatException on a 6th length byte (Index.Load fails, Index.cs:373-376)
+    ("six length bytes", (5).to_bytes(8, "little") + b"\x81\x80\x80\x80\x80\x00" + b"a" + (0).to_bytes(4, "little")),
+    ("length runs off the image", (5).to_bytes(8, "little") + b"\x7f" + b"abc"),
+    ("negative length", (5).to_bytes(8, "little") + b"\xff\xff\xff\xff\x0f" + b"abc"),
+    ("truncated postings", (5).to_bytes(8, "little") + b"\x03abc" + (4).to_bytes(4, "little") + b"\x01\x00"),
+    ("keys not ascending", (5).to_bytes(8, "little") + _rec("b", [1]) + _rec("a", [2])),
+])
+def test_malformed_index_images_are_io_errors(name, img):
+    """The format checks of dcd_index_from_images are host-side and run before anything touches a device: a corrupt
+    .index is DCD_E_IO with or without a GPU (the reference's Index.Load prints "Can't load" and returns false)."""
+    import docodo_amd
+    from docodo_amd import _lib
+    with pytest.raises(docodo_amd.DocodoError) as e:
+        docodo_amd.Index.from_images(img, b"")
+    assert e.value.code == _lib.DCD_E_IO, name
+
+
+@pytest.mark.gpu
+def test_malformed_list_images_end_the_load_like_the_reference():
+    """IndexPageList.Load swallows every exception and keeps the pages read so far (Build.cs:119-148): an empty string
+    (s[0] throws), more than 5 length bytes (FormatException) and a truncated record all END the load at that record."""
+    import docodo_amd
+    idx = (10).to_bytes(8, "little") + _rec("abc", [3]) + _rec("abd", [7])
+
+    def s(x):
+        b = x.encode("utf-8")
+        return bytes([len(b)]) + b
+
+    good = (100).to_bytes(8, "little") + s("src:doc") + (100).to_bytes(8, "little") + s(":1") + (200).to_bytes(8, "little") + s(":2")
+    more = (300).to_bytes(8, "little") + s(":3")
+    for bad in ((250).to_bytes(8, "little") + b"\x00",                               # empty string
+                (250).to_bytes(8, "little") + b"\x81\x80\x80\x80\x80\x00" + b"x",    # six length bytes
+                (250).to_bytes(8, "little") + b"\x05:9"):                            # string runs off the image
+        ix = docodo_amd.Index.from_images(idx, good + bad + (more if bad[-1:] != b"9" else b""))
+        assert ix.n_pages == 2 and ix.n_docs == 1
+        ix.close()
+    ix = docodo_amd.Index.from_images(idx, good + more)
+    assert ix.n_pages == 3
+    ix.close()

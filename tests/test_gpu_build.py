@@ -285,3 +285,42 @@ def test_vocabulary_table_growth(oracle_mod):
     assert st.n_terms == ob.n_terms and st.n_terms > 100_000
     assert st.vocab_capacity_log2 >= 18
     assert gi == oi and gl == ol
+
+
+@pytest.mark.gpu
+def test_device_cache_is_stream_ordered_and_can_be_trimmed():
+    """Released blocks stay in the library's per-device cache (no hipMalloc in repeated builds) and go back to HIP with
+    dcd_pool_trim; two builders working from different threads (= different streams, Index.cs:464-465) that recycle each
+    other's blocks still produce the images of a build that ran alone."""
+    import threading
+    import docodo_amd
+    from docodo_amd import synth
+    n_docs = 3000
+    text = synth.corpus_host(n_docs)
+    off = np.arange(n_docs + 1, dtype=np.uint64) * synth.DOC_BYTES
+
+    def build(first, count):
+        b = docodo_amd.Builder(coord_base=first * synth.DOC_BYTES)
+        b.AddPages(text[first * synth.DOC_BYTES:(first + count) * synth.DOC_BYTES], off[:count + 1], docs_per_page=True, first_doc=first)
+        b.Finish()
+        img = (b.index_image(), b.list_image())
+        b.close()
+        return img
+
+    want = [build(0, 1500), build(1500, 1500)]
+    docodo_amd.pool_trim(0)
+    assert docodo_amd.pool_cached_bytes(0) == 0
+    got = [[], []]
+
+    def worker(k):
+        for _ in range(6):
+            got[k].append(build(1500 * k, 1500))
+
+    ts = [threading.Thread(target=worker, args=(k,)) for k in range(2)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    for k in range(2):
+        assert all(g == want[k] for g in got[k])
+    assert docodo_amd.pool_cached_bytes(0) > 0
+    docodo_amd.pool_trim(0)
+    assert docodo_amd.pool_cached_bytes(0) == 0

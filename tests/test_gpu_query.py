@@ -230,6 +230,33 @@ def test_out_of_memory_sub_batches_are_retried_smaller(synth_index, monkeypatch)
         assert np.array_equal(getattr(a, name), getattr(b, name)), name
 
 
+def test_late_out_of_memory_of_the_single_attempt_leaves_no_stale_results(synth_index, monkeypatch):
+    """The one-shot attempt can fail AFTER it filled its result arrays (the want_sequences re-encode allocates per
+    query; injected here for batches of more than 9 queries).  The retry in sub-batches must start from an empty
+    result: same arrays as the undisturbed evaluation, n_queries unchanged."""
+    import docodo_amd
+    from docodo_amd import synth
+    ix, oix, _, _ = synth_index
+    prog, off = [], [0]
+    for row in synth.query_ranks(60, 2, lo_rank=5):
+        ts = [ix.find(synth.term(int(k))) for k in row]
+        if any(t is None for t in ts):
+            continue
+        for k, t in enumerate(ts):
+            prog += [docodo_amd.DCD_OP_TERM, t, 255 + len(synth.term(int(row[k])))]
+            if k:
+                prog.append(docodo_amd.DCD_OP_AND)
+        off.append(len(prog))
+    monkeypatch.delenv("DOCODO_QUERY_TEST_NOMEM_LATE", raising=False)
+    a = ix.query_batch(prog, off, want_sequences=True)
+    monkeypatch.setenv("DOCODO_QUERY_TEST_NOMEM_LATE", "9")
+    b = ix.query_batch(prog, off, want_sequences=True)
+    assert len(b.status) == len(off) - 1
+    for name in ("status", "page_off", "page_index", "page_rank", "pos_off", "pos", "doc_off", "doc_index", "doc_rank",
+                 "doc_n_pages", "seq_off", "seq_units", "seq_R"):
+        assert np.array_equal(getattr(a, name), getattr(b, name)), name
+
+
 def test_concurrent_batches_on_one_index(synth_index):
     """The reference issues Search from many pool threads (server.cs:16-30) under one lock (Search.cs:448);
     dcd_query_batch on one handle is serialised internally: concurrent callers get the single-threaded answers."""
