@@ -41,11 +41,13 @@ __global__ __launch_bounds__(TK_THREADS) void k_tok_count(const CharT* __restric
 template <typename CharT>
 __global__ __launch_bounds__(TK_THREADS) void k_tok_emit(const CharT* __restrict__ text, TokParams P, CharTables16 tab,
                                                         TextView<CharT> tv, VocabTable vt, const u64* __restrict__ tile_off,
-                                                        uint2* __restrict__ tuples, u64 n_tiles, u32 stride, u32* __restrict__ tile_cnt) {
+                                                        uint2* __restrict__ tuples, u64 n_tiles, u32 stride, u32* __restrict__ tile_cnt,
+                                                        u64 tile0) {
   // stride != 0: no counting pass ran; the tile's tuples go to tuples[tile * stride ...] and their number to tile_cnt
   // (the first sort pass compacts, RsStrided in dcd_sort.h).  stride == 0: dense output at tile_off[tile].
+  // The launch covers the tiles [tile0, n_tiles) (see the seed launch in build_phase1).
   __shared__ TokLds<CharT, true> SW[TK_WAVES];
-  const u64 tile = (u64)blockIdx.x * TK_WAVES + (threadIdx.x >> 6);
+  const u64 tile = tile0 + (u64)blockIdx.x * TK_WAVES + (threadIdx.x >> 6);
   if (tile >= n_tiles) return;
   TokLds<CharT, true>& S = SW[threadIdx.x >> 6];
   const u32 lane = lane_id();
@@ -67,15 +69,24 @@ __global__ __launch_bounds__(TK_THREADS) void k_tok_emit(const CharT* __restrict
   const u64 obase = stride ? tile * stride : tile_off[tile];
   if (stride && lane == 0) tile_cnt[tile] = total;
   constexpr u32 CS = sizeof(CharT);
+  constexpr u32 PW = VocPool<CharT>::W;
+  const u32* txt = S.txt;
+  auto coord_of = [&](u64 gpos) -> u32 {
+    u32 coord = (u32)gpos;
+    if (P.n_runs) {
+      u32 a = 0, b = P.n_runs;   // last run with run_off <= gpos
+      while (a + 1 < b) { u32 m = (a + b) >> 1; if (P.run_off[m] <= (u32)gpos) a = m; else b = m; }
+      coord += P.run_delta[a];
+    }
+    return coord;
+  };
   for (u32 k = lane; k < total; k += 64) {
     const u32 t = S.tok[k];
     const u32 i = t & 0xFFFFu, len = t >> 16;
     const u32 nbytes = len * CS, nw = (nbytes + 3u) >> 2;
-    const u32* txt = S.txt;
     auto word = [txt, i, nbytes](u32 q) -> u32 { return lds_word(txt, i * CS, q) & tail_mask(nbytes, q); };
     HashState hs;
     hs.init(len);
-    constexpr u32 PW = VocPool<CharT>::W;
     u32 wv[PW];
 #pragma unroll
     for (u32 q = 0; q < PW; q++) {
@@ -84,15 +95,31 @@ __global__ __launch_bounds__(TK_THREADS) void k_tok_emit(const CharT* __restrict
     }
     for (u32 q = PW; q < nw; q++) hs.add(word(q));
     const u64 gpos = (u64)(org + (int64_t)i);
+#if defined(DCD_DIAG_TOK)   // timing-only builds (scripts/diag_tok.py): the outputs are wrong on purpose
+    u32 slot;
+    {
+      const TokHash hh = hs.fin();
+      if (DCD_DIAG_TOK == 1) {          // slot word only: a tag + length match counts as a hit (no string compare)
+        slot = hh.idx & vt.mask;
+        const u64 sw = vt.slots[slot];
+        if ((sw >> 42) != (voc_word(hh.tag, len, gpos) >> 42)) slot ^= 1u;
+      } else if (DCD_DIAG_TOK == 2) {   // no table access at all
+        slot = hh.idx & vt.mask;
+      } else if (DCD_DIAG_TOK == 3) {   // every fourth token looks itself up (an ideal 75 % LDS cache, its own cost excluded)
+        slot = (hh.tag & 3u) ? (hh.idx & vt.mask) : vocab_lookup_insert_pooled<CharT>(vt, tv, hh, len, gpos, wv, word);
+      } else if (DCD_DIAG_TOK >= 6) {   // production lookup (6: the launch is repeated on the populated table)
+        slot = vocab_lookup_insert_pooled<CharT>(vt, tv, hh, len, gpos, wv, word);
+      } else {                          // 4: pool entry and slot word in ONE gather (pool only), first probe only
+        slot = hh.idx & vt.mask;
+        const uint4 pq = *reinterpret_cast<const uint4*>(vt.pool + (u64)slot * PW);
+        if (((pq.x ^ wv[0]) | (pq.y ^ wv[1]) | (pq.z ^ wv[2]) | (pq.w ^ wv[3])) != 0u) slot ^= 1u;
+      }
+    }
+#else
     u32 slot = vt.pool ? vocab_lookup_insert_pooled<CharT>(vt, tv, hs.fin(), len, gpos, wv, word)
                        : vocab_lookup_insert<CharT>(vt, tv, hs.fin(), len, gpos, word);
-    u32 coord = (u32)gpos;
-    if (P.n_runs) {
-      u32 a = 0, b = P.n_runs;   // last run with run_off <= gpos
-      while (a + 1 < b) { u32 m = (a + b) >> 1; if (P.run_off[m] <= (u32)gpos) a = m; else b = m; }
-      coord += P.run_delta[a];
-    }
-    tuples[obase + k] = make_uint2(slot, coord);
+#endif
+    tuples[obase + k] = make_uint2(slot, coord_of(gpos));
   }
 }
 
@@ -871,10 +898,41 @@ static int32_t build_phase1(dcd_build* h, bool codes_mode) {
       vt.pool = voc_pool.p;
     }
     if (n_tiles) {
+      // A small SEED launch first: on an empty table every resident wave (7000+) finds the slots of the most frequent
+      // terms empty and tries to insert them -- tens of thousands of compare-and-swaps on a handful of addresses that
+      // execute one after the other (measured: the launch on an empty table takes 0.15 ms longer than on a populated
+      // one).  256 tiles (~33 k tokens) insert the head of the distribution with 1/28 of the contention; the main launch
+      // then finds those slots populated (a kernel boundary makes them visible to every XCD).
+      static const u64 seed_tiles = getenv("DOCODO_TOK_SEED_TILES") ? strtoull(getenv("DOCODO_TOK_SEED_TILES"), nullptr, 10) : 256;
+      const u64 n_seed = n_tiles > 2 * seed_tiles ? seed_tiles : 0;   // small builds: one launch
+      if (n_seed) {   // (not a DCD_K_TOK_EMIT probe: per-launch averages are quoted for the main launch)
+        hipLaunchKernelGGL((k_tok_emit<CharT>), dim3((u32)div_up(n_seed, TK_WAVES)), dim3(TK_THREADS), 0, st, text, P, tab, tv, vt,
+                           M.tile_off.p, M.tupA.p, n_seed, M.stride, M.tile_cnt.p, (u64)0);
+      }
       probes.begin(DCD_K_TOK_EMIT);
-      hipLaunchKernelGGL((k_tok_emit<CharT>), dim3((u32)div_up(n_tiles, TK_WAVES)), dim3(TK_THREADS), 0, st, text, P, tab, tv, vt,
-                         M.tile_off.p, M.tupA.p, n_tiles, M.stride, M.tile_cnt.p);
+      if (n_tiles > n_seed)
+        hipLaunchKernelGGL((k_tok_emit<CharT>), dim3((u32)div_up(n_tiles - n_seed, TK_WAVES)), dim3(TK_THREADS), 0, st, text, P, tab, tv, vt,
+                           M.tile_off.p, M.tupA.p, n_tiles, M.stride, M.tile_cnt.p, n_seed);
       probes.end();
+#if defined(DCD_DIAG_TOK)
+      if (DCD_DIAG_TOK == 6) {          // second launch: every term is in the table, no CAS, no insert storm
+        DCD_HIP(hipStreamSynchronize(st));
+        float msa[8] = {0}; u32 nla[8] = {0};
+        probes.collect(msa, nla);
+        fprintf(stderr, "DIAG_TOK mode 6: first launch %.3f ms\n", msa[DCD_K_TOK_EMIT]);
+        probes.begin(DCD_K_TOK_EMIT);
+        hipLaunchKernelGGL((k_tok_emit<CharT>), dim3((u32)div_up(n_tiles, TK_WAVES)), dim3(TK_THREADS), 0, st, text, P, tab, tv, vt,
+                           M.tile_off.p, M.tupA.p, n_tiles, M.stride, M.tile_cnt.p, (u64)0);
+        probes.end();
+      }
+      {
+        DCD_HIP(hipStreamSynchronize(st));
+        float ms8[8] = {0}; u32 nl8[8] = {0};
+        probes.collect(ms8, nl8);
+        fprintf(stderr, "DIAG_TOK mode %d: k_tok_emit %.3f ms\n", (int)DCD_DIAG_TOK, ms8[DCD_K_TOK_EMIT]);
+        DCD_FAIL(DCD_E_STATE, "diagnostic build (DCD_DIAG_TOK): timing only");
+      }
+#endif
       if (strided) {
         // the tiles' dense offsets and the number of postings, now that the emit kernel has counted
         scan_exclusive<u32, u64>(M.tile_cnt.p, M.tile_off.p, n_tiles, scan_scr64.p, st);

@@ -35,9 +35,9 @@ int32_t ensure_device(int device) {
 // ---- stream-ordered caching allocator ------------------------------------------------------------
 // Every handle of the library works on its own hipStreamNonBlocking stream, and the error unwinds
 // (DCD_TRY / DCD_HIP early returns) destroy DevBufs whose kernels or copies may still be in flight.
-// A released block therefore carries the stream it was last used on plus an event recorded there at
-// release time; it is handed out again at once to the same stream (stream order covers it), and to
-// any other stream only after the event has completed (or behind a hipStreamWaitEvent).
+// A released block therefore carries the stream it was last used on plus its position in that stream's
+// release order; it is handed out again at once to the same stream (stream order covers it), and to any
+// other stream only behind an event recorded on the releasing stream (hipStreamWaitEvent; see below).
 static thread_local hipStream_t t_cur_stream = nullptr;
 static thread_local bool t_have_stream = false;
 
@@ -53,18 +53,28 @@ StreamScope::~StreamScope() {
 namespace {
 struct FreeBlock {
   void* p;
-  hipStream_t stream;   // stream the release was ordered on (meaningful only with ev)
-  hipEvent_t ev;        // recorded on `stream` at release; nullptr = nothing pending
+  hipStream_t stream;   // stream the release was ordered on
+  u64 ticket;           // position of the release in that stream's release order; 0 = nothing pending
 };
 struct LiveBlock {
   size_t size;
   hipStream_t stream;
   bool tagged;          // allocated inside a StreamScope
 };
+// Release order per stream.  A release costs no HIP call: the block only takes the next ticket of its stream.  The
+// event is recorded LAZILY, by the first other stream that wants such a block (an event recorded later on the stream
+// covers everything queued before, in particular whatever was in flight when the block was released).
+struct StreamState {
+  u64 issued = 0;         // tickets handed out
+  u64 completed = 0;      // every release with ticket <= completed has finished on the device
+  hipEvent_t ev = nullptr;
+  u64 ev_ticket = 0;      // ev covers the releases up to this ticket
+};
 struct Pool {
   std::mutex mu;
   std::multimap<size_t, FreeBlock> free_;   // rounded size -> block
   std::map<void*, LiveBlock> live;          // block -> rounded size + owner stream
+  std::map<hipStream_t, StreamState> streams;
   size_t cached = 0;                        // bytes in free_
   size_t cap = 0;                           // 0 = not initialised yet
 };
@@ -91,24 +101,36 @@ size_t pool_cap(int device) {
   if (hipMemGetInfo(&fr, &tot) != hipSuccess) { (void)hipGetLastError(); return (size_t)64 << 30; }
   return tot / 2;
 }
-// true when the block may be used by `want` right now (possibly after queueing a wait on `want`)
-bool make_usable(int device, FreeBlock& b, hipStream_t want, bool have_want) {
-  if (!b.ev) return true;
-  bool ok = false;
-  if (have_want && want == b.stream) ok = true;
-  else {
-    hipError_t q = hipEventQuery(b.ev);
-    if (q == hipSuccess) ok = true;
-    else {
-      (void)hipGetLastError();
-      if (q == hipErrorNotReady) {
-        hipError_t w = have_want && want ? hipStreamWaitEvent(want, b.ev, 0) : hipEventSynchronize(b.ev);
-        if (w == hipSuccess) ok = true; else (void)hipGetLastError();
-      }
-    }
+// Makes the block usable by `want` (queues a wait on `want`, or blocks the host when the caller declared no stream).
+// Called with P.mu held.
+bool make_usable(int device, Pool& P, const FreeBlock& b, hipStream_t want, bool have_want) {
+  if (!b.ticket) return true;
+  if (have_want && want == b.stream) return true;               // stream order covers it
+  StreamState& S = P.streams[b.stream];
+  if (S.completed >= b.ticket) return true;
+  if (S.ev && hipEventQuery(S.ev) == hipSuccess) {
+    S.completed = S.ev_ticket;
+    event_release(device, S.ev);
+    S.ev = nullptr;
+    if (S.completed >= b.ticket) return true;
   }
-  if (ok) { event_release(device, b.ev); b.ev = nullptr; }
-  return ok;
+  (void)hipGetLastError();
+  if (!S.ev || S.ev_ticket < b.ticket) {                         // need an event that covers this release
+    hipEvent_t ev = event_acquire(device);
+    if (!ev || hipEventRecord(ev, b.stream) != hipSuccess) {     // (a destroyed stream: wait for the device instead)
+      (void)hipGetLastError();
+      if (ev) event_release(device, ev);
+      if (hipDeviceSynchronize() != hipSuccess) { (void)hipGetLastError(); return false; }
+      S.completed = S.issued;
+      return true;
+    }
+    if (S.ev) event_release(device, S.ev);                       // superseded: the newer event covers it
+    S.ev = ev;
+    S.ev_ticket = S.issued;
+  }
+  hipError_t w = (have_want && want) ? hipStreamWaitEvent(want, S.ev, 0) : hipEventSynchronize(S.ev);
+  if (w != hipSuccess) { (void)hipGetLastError(); return false; }
+  return true;
 }
 }  // namespace
 
@@ -121,7 +143,7 @@ int32_t dev_alloc(int device, size_t bytes, void** out) {
     std::lock_guard<std::mutex> g(P.mu);
     // accept a cached block up to 25 % larger than needed
     for (auto it = P.free_.lower_bound(r); it != P.free_.end() && it->first <= r + r / 4; ++it) {
-      if (!make_usable(device, it->second, want, have_want)) continue;
+      if (!make_usable(device, P, it->second, want, have_want)) continue;
       *out = it->second.p;
       P.live[it->second.p] = LiveBlock{it->first, want, have_want};
       P.cached -= it->first;
@@ -150,44 +172,36 @@ int32_t dev_alloc(int device, size_t bytes, void** out) {
 void dev_release(int device, void* p) {
   if (!p) return;
   Pool& P = pool(device);
-  LiveBlock lb;
+  size_t size = 0;
+  bool drop = false;
   {
     std::lock_guard<std::mutex> g(P.mu);
     auto it = P.live.find(p);
     if (it == P.live.end()) return;  // double release: ignore (error, not UB)
-    lb = it->second;
+    const LiveBlock lb = it->second;
     P.live.erase(it);
+    size = lb.size;
     if (!P.cap) P.cap = pool_cap(device);
-  }
-  // order the release: on the releasing thread's stream when it has one (that is the stream the block was last used
-  // on), and behind the allocating stream too when that is a different one
-  FreeBlock fb{p, nullptr, nullptr};
-  const bool have_cur = t_have_stream;
-  const hipStream_t cur = have_cur ? t_cur_stream : lb.stream;
-  if (have_cur || lb.tagged) {
-    hipEvent_t ev = event_acquire(device);
-    bool ok = ev != nullptr;
-    if (ok && have_cur && lb.tagged && lb.stream != cur) {
-      ok = hipEventRecord(ev, lb.stream) == hipSuccess && hipStreamWaitEvent(cur, ev, 0) == hipSuccess;
-    }
-    if (ok) ok = hipEventRecord(ev, cur) == hipSuccess;
-    if (ok) { fb.stream = cur; fb.ev = ev; }
+    if (P.cached + size > P.cap) drop = true;
     else {
-      (void)hipGetLastError();
-      if (ev) event_release(device, ev);
-      (void)hipStreamSynchronize(cur);                       // cannot tag: wait here instead
-      if (lb.tagged && lb.stream != cur) (void)hipStreamSynchronize(lb.stream);
-      (void)hipGetLastError();
+      // The release is ordered on the releasing thread's stream when it declared one (that is the stream the block was
+      // last used on), else on the stream it was allocated for.  A block that changed streams inside the library (a
+      // build's index adopted by an index handle, ...) is ordered behind both.
+      FreeBlock fb{p, nullptr, 0};
+      const bool have_cur = t_have_stream;
+      if (have_cur || lb.tagged) {
+        fb.stream = have_cur ? t_cur_stream : lb.stream;
+        if (have_cur && lb.tagged && lb.stream != fb.stream) {
+          FreeBlock other{p, lb.stream, ++P.streams[lb.stream].issued};
+          if (!make_usable(device, P, other, fb.stream, true)) (void)hipStreamSynchronize(lb.stream);
+        }
+        fb.ticket = ++P.streams[fb.stream].issued;
+      }
+      P.free_.emplace(size, fb);
+      P.cached += size;
     }
-  }
-  bool drop = false;
-  {
-    std::lock_guard<std::mutex> g(P.mu);
-    if (P.cached + lb.size > P.cap) drop = true;
-    else { P.free_.emplace(lb.size, fb); P.cached += lb.size; }
   }
   if (drop) {   // over the cap: back to HIP (hipFree waits for the device, so pending work is safe)
-    if (fb.ev) event_release(device, fb.ev);
     (void)hipSetDevice(device);
     (void)hipFree(p);
   }
@@ -201,19 +215,16 @@ size_t dev_pool_cached_bytes(int device) {
 
 void dev_pool_trim(int device) {
   Pool& P = pool(device);
-  std::vector<FreeBlock> v;
+  std::vector<void*> v;
   {
     std::lock_guard<std::mutex> g(P.mu);
-    for (auto& kv : P.free_) v.push_back(kv.second);
+    for (auto& kv : P.free_) v.push_back(kv.second.p);
     P.free_.clear();
     P.cached = 0;
   }
   if (!v.empty()) {
     (void)hipSetDevice(device);
-    for (FreeBlock& b : v) {
-      if (b.ev) event_release(device, b.ev);
-      (void)hipFree(b.p);   // implicit device synchronisation: in-flight users of the block have finished
-    }
+    for (void* p : v) (void)hipFree(p);   // implicit device synchronisation: in-flight users of the block have finished
   }
 }
 
