@@ -29,16 +29,20 @@ HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 
 HBM_COPY_GBS = 6290.0
 
 
-def algorithmic_bytes(kernel, T, N, U):
-    """Algorithmic HBM bytes of ONE launch ("Kernels and their rooflines")."""
+def algorithmic_bytes(kernel, T, N, U, n_launch=1, n_hot=0, id_keys=False):
+    """Algorithmic HBM bytes of ONE launch, averaged over the kernel's launches of a step.
+    With the hot / cold split the radix kernels run once over all N tuples and (n_launch - 1) times over the N - n_hot
+    cold ones; an id-keyed build's k_img_units also writes the units in term order (one read, two writes)."""
+    n_launch = max(1, int(round(n_launch)))
+    tuples = (N + (n_launch - 1) * (N - n_hot)) / n_launch if n_hot else N
     return {
         "k_tok_count": T,                 # reads the text once
         "k_tok_emit": T + 8 * N,          # reads the text, writes one (term, coord) tuple per posting
-        "k_rs_hist": 4 * N,               # reads the keys
-        "k_rs_scatter": 16 * N,           # reads and writes every 8-byte tuple
+        "k_rs_hist": 4 * tuples,          # reads the keys
+        "k_rs_scatter": 16 * tuples,      # reads and writes every 8-byte tuple
         "k_enc_reduce": 8 * N,            # reads the sorted tuples
         "k_enc_write": 8 * N + 2 * U,     # reads the tuples, writes the ushort units
-        "k_img_units": 4 * U,             # copies the units into the .index image
+        "k_img_units": (6 if id_keys else 4) * U,   # copies the units into the .index image (+ into term order)
     }.get(kernel, 0)
 
 
@@ -207,7 +211,7 @@ def main():
         ksum += np.array(list(st.ms_kernel))
         kcnt += np.array(list(st.n_launch))
         stage += np.array([st.ms_tokenize, st.ms_vocab, st.ms_sort, st.ms_pack, st.ms_image, st.ms_total])
-        last = (st.n_postings, st.n_terms, st.n_units, st.index_bytes, st.sort_passes)
+        last = (st.n_postings, st.n_terms, st.n_units, st.index_bytes, st.sort_passes, st.id_keys, st.n_hot_terms, st.n_hot_postings)
         b.close()
     fence()
     dt = time.perf_counter() - t0
@@ -217,7 +221,11 @@ def main():
         dt = float(tt.item())
 
     if rank == 0:
-        N, V, U, img_bytes, passes = last
+        N, V, U, img_bytes, passes, id_keys, hot_terms, hot_post = last
+        lps = kcnt / args.steps            # launches per step of every kernel
+
+        def abytes_of(k):
+            return algorithmic_bytes(KERNEL_NAMES[k], T, N, U, lps[k], hot_post, bool(id_keys))
         ms_step = dt / args.steps * 1e3
         value = world * T / 1e9 / (dt / args.steps)
         # dominant kernel = largest total device time per step (HIP events on the build stream)
@@ -225,7 +233,7 @@ def main():
         dom = int(np.argmax(per_step[:7]))
         name = KERNEL_NAMES[dom]
         avg_ms = ksum[dom] / max(1.0, kcnt[dom])
-        abytes = algorithmic_bytes(name, T, N, U)
+        abytes = abytes_of(dom)
         achieved = abytes / 1e9 / (avg_ms / 1e3)
         out = {
             "metric": "text_indexed_GB_per_s", "value": round(value, 3), "unit": "GB/s",
@@ -234,15 +242,18 @@ def main():
             "config": {"workload": "configs[1]: %d synthetic 1 KiB docs per GPU, Zipf-1.1 over 100k terms (SURVEY App. F); "
                                    "full index build, text resident in HBM -> .index image resident in HBM" % D,
                        "docs_per_gpu": D, "text_bytes_per_gpu": T, "postings": int(N), "terms": int(V), "units": int(U),
-                       "index_bytes": int(img_bytes), "sort_passes": int(passes), "sharding": "doc-range, global coordinates"},
+                       "index_bytes": int(img_bytes), "sort_passes": int(passes), "sort": (
+                           "by dense vocabulary id, ordinal vocabulary sort on a second stream; %d hot terms (%.1f %% of the postings) final "
+                           "after the first radix pass" % (hot_terms, 100.0 * hot_post / max(1, N))) if id_keys else "by ordinal rank",
+                       "sharding": "doc-range, global coordinates"},
             "roofline": {"bound": "hbm", "kernel": name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "frac_of_measured_copy": round(achieved / HBM_COPY_GBS, 4),
                          "algorithmic_bytes_per_launch": int(abytes), "avg_launch_ms": round(avg_ms, 4),
                          "launches_per_step": round(kcnt[dom] / args.steps, 2), "traffic": measured_traffic(name, T, int(N), int(U)),
                          "limiter": LIMITER.get(name, "hbm")},
             # (k_tok_count does not run in plain text builds: the tokeniser writes tile-strided tuples without a counting pass)
-            "roofline_all": {KERNEL_NAMES[k]: round(algorithmic_bytes(KERNEL_NAMES[k], T, N, U) / 1e9 /
-                                                    (ksum[k] / kcnt[k] / 1e3) / HBM_PEAK_GBS, 4) for k in range(7) if kcnt[k] > 0},
+            "roofline_all": {KERNEL_NAMES[k]: round(abytes_of(k) / 1e9 / (ksum[k] / kcnt[k] / 1e3) / HBM_PEAK_GBS, 4)
+                             for k in range(7) if kcnt[k] > 0},
             "device_ms_per_step": {"tokenize": round(stage[0] / args.steps, 3), "vocab": round(stage[1] / args.steps, 3),
                                    "sort": round(stage[2] / args.steps, 3), "pack": round(stage[3] / args.steps, 3),
                                    "image": round(stage[4] / args.steps, 3), "total": round(stage[5] / args.steps, 3)},

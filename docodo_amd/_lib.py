@@ -33,7 +33,8 @@ class BuildStats(C.Structure):
                 ("n_terms", C.c_uint64), ("n_units", C.c_uint64), ("max_coord", C.c_uint64), ("index_bytes", C.c_uint64),
                 ("list_bytes", C.c_uint64), ("ms_tokenize", C.c_float), ("ms_vocab", C.c_float), ("ms_sort", C.c_float),
                 ("ms_pack", C.c_float), ("ms_image", C.c_float), ("ms_total", C.c_float), ("sort_passes", C.c_uint32),
-                ("vocab_capacity_log2", C.c_uint32), ("ms_kernel", C.c_float * 8), ("n_launch", C.c_uint32 * 8)]
+                ("vocab_capacity_log2", C.c_uint32), ("ms_kernel", C.c_float * 8), ("n_launch", C.c_uint32 * 8),
+                ("id_keys", C.c_uint32), ("n_hot_terms", C.c_uint32), ("n_hot_postings", C.c_uint64)]
 
 
 KERNEL_NAMES = ["k_tok_count", "k_tok_emit", "k_rs_hist", "k_rs_scatter", "k_enc_reduce", "k_enc_write", "k_img_units",

@@ -16,10 +16,13 @@
 
 namespace dcd {
 
-constexpr u32 MAX_CODE_LEN = 63;
+constexpr u32 MAX_CODE_LEN = 63;   // explicit index codes (Builder.Add); text tokens are <= 32
 #ifndef DCD_CAPDIV
-#define DCD_CAPDIV 64
-#endif  // explicit index codes (Builder.Add); text tokens are <= 32
+#define DCD_CAPDIV 256             // first guess of the vocabulary table: one slot per DCD_CAPDIV postings
+#endif
+#ifndef DCD_HOT_SAMPLE_TILES
+#define DCD_HOT_SAMPLE_TILES 1024
+#endif
 
 // ================================================================================================
 // kernels
@@ -42,13 +45,16 @@ template <typename CharT>
 __global__ __launch_bounds__(TK_THREADS) void k_tok_emit(const CharT* __restrict__ text, TokParams P, CharTables16 tab,
                                                         TextView<CharT> tv, VocabTable vt, const u64* __restrict__ tile_off,
                                                         uint2* __restrict__ tuples, u64 n_tiles, u32 stride, u32* __restrict__ tile_cnt,
-                                                        u64 tile0) {
+                                                        u64 tile0, u32* __restrict__ sample_cnt, u32 sample_mask) {
   // stride != 0: no counting pass ran; the tile's tuples go to tuples[tile * stride ...] and their number to tile_cnt
   // (the first sort pass compacts, RsStrided in dcd_sort.h).  stride == 0: dense output at tile_off[tile].
   // The launch covers the tiles [tile0, n_tiles) (see the seed launch in build_phase1).
   __shared__ TokLds<CharT, true> SW[TK_WAVES];
   const u64 tile = tile0 + (u64)blockIdx.x * TK_WAVES + (threadIdx.x >> 6);
   if (tile >= n_tiles) return;
+  // every (sample_mask + 1)-th tile counts its tokens per vocabulary slot: the frequency sample behind the hot / cold
+  // split of the tuple sort (build_phase2)
+  const bool sampled = sample_cnt != nullptr && ((u32)tile & sample_mask) == 0u;
   TokLds<CharT, true>& S = SW[threadIdx.x >> 6];
   const u32 lane = lane_id();
   u32 keep;
@@ -120,6 +126,7 @@ __global__ __launch_bounds__(TK_THREADS) void k_tok_emit(const CharT* __restrict
                        : vocab_lookup_insert<CharT>(vt, tv, hs.fin(), len, gpos, word);
 #endif
     tuples[obase + k] = make_uint2(slot, coord_of(gpos));
+    if (sampled && slot != 0xFFFFFFFFu) atomicAdd(&sample_cnt[slot], 1u);
   }
 }
 
@@ -156,6 +163,85 @@ __global__ void k_term_first_last(const uint2* __restrict__ sorted, const u64* _
   if (t >= n_terms) return;
   first[t] = base + sorted[item_start[t]].y;
   last[t] = base + sorted[item_start[t + 1] - 1].y;
+}
+// ---- hot / cold split of the vocabulary ---------------------------------------------------------------------------
+// The H slots with the largest sample counts are "hot" (Zipf: a few hundred terms hold most postings).  Dense ids: hot
+// terms 0 .. n_hot-1 (in slot order), the others n_hot + (rank among the used cold slots).  The first radix pass gives
+// every hot term a bucket of its own -- their tuples are final after ONE pass -- and only the cold tuples are sorted further.
+constexpr int HOT_BINS = 4096;
+__global__ __launch_bounds__(256) void k_hot_hist(const u32* __restrict__ cnt, u64 cap, u32* __restrict__ hist) {
+  __shared__ u32 s_h[HOT_BINS];
+  for (u32 i = threadIdx.x; i < HOT_BINS; i += 256) s_h[i] = 0;
+  __syncthreads();
+  for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < cap; i += (u64)gridDim.x * 256) {
+    const u32 c = cnt[i];
+    if (c) atomicAdd(&s_h[c < HOT_BINS ? c : HOT_BINS - 1], 1u);
+  }
+  __syncthreads();
+  for (u32 i = threadIdx.x; i < HOT_BINS; i += 256) { const u32 v = s_h[i]; if (v) atomicAdd(&hist[i], v); }
+}
+// one workgroup: theta = the smallest sample count such that at most H slots reach it (0xFFFFFFFF: nothing is hot)
+__global__ __launch_bounds__(1024) void k_hot_pick(const u32* __restrict__ hist, u32 H, u32* __restrict__ theta) {
+  __shared__ u32 lds[17];
+  __shared__ u32 s_best;
+  constexpr int PER = HOT_BINS / 1024;
+  const u32 t = threadIdx.x;
+  u32 v[PER], s = 0;
+#pragma unroll
+  for (int k = 0; k < PER; k++) { v[k] = t * PER + k ? hist[t * PER + k] : 0u; s += v[k]; }   // (bin 0 = never sampled)
+  if (t == 0) s_best = 0xFFFFFFFFu;
+  u32 tot;
+  u32 before = block_scan_excl<u32, 16>(s, lds, &tot);          // slots in lower bins
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < PER; k++) {
+    const u32 b = t * PER + k;
+    if (b >= 1 && tot - before <= H) atomicMin(&s_best, b);      // tot - before = slots with count >= b
+    before += v[k];
+  }
+  __syncthreads();
+  if (t == 0) *theta = s_best;
+}
+struct HotUsedF {   // low word: the slot is used; high word: it holds a hot term
+  const u64* slots;
+  const u32* cnt;
+  const u32* theta;
+  __device__ __forceinline__ u64 operator()(u64 i) const {
+    if (!slots[i]) return 0ull;
+    return 1ull | ((u64)(cnt[i] >= *theta ? 1u : 0u) << 32);
+  }
+};
+__global__ void k_dense_table(const u64* __restrict__ slots, const u32* __restrict__ cnt, const u32* __restrict__ theta,
+                              const u64* __restrict__ excl, const u64* __restrict__ total, u64 cap, u32* __restrict__ dense) {
+  u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= cap) return;
+  u32 d = 0;
+  if (slots[i]) {
+    const u64 e = excl[i];
+    const u32 n_hot = (u32)(*total >> 32), hot_before = (u32)(e >> 32), used_before = (u32)e;
+    d = cnt[i] >= *theta ? hot_before : n_hot + (used_before - hot_before);
+  }
+  dense[i] = d;
+}
+
+// id-keyed builds (tuples sorted by dense id d, terms delivered in ordinal rank order r; d = dense_of_rank[r])
+__global__ void k_term_first_last_perm(const uint2* __restrict__ sorted, const u64* __restrict__ item_start_id, const u32* __restrict__ dense_of_rank,
+                                       u64 n_terms, u64 base, u64* __restrict__ first, u64* __restrict__ last) {
+  u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n_terms) return;
+  const u32 d = dense_of_rank[r];
+  first[r] = base + sorted[item_start_id[d]].y;
+  last[r] = base + sorted[item_start_id[d + 1] - 1].y;
+}
+__global__ void k_copy_u64(u64* dst, const u64* src) { *dst = *src; }
+struct PermLenF {   // length of the term with rank r in an array of starts indexed by dense id
+  const u32* dense_of_rank;
+  const u64* start_id;
+  __device__ __forceinline__ u64 operator()(u64 r) const { const u32 d = dense_of_rank[r]; return start_id[d + 1] - start_id[d]; }
+};
+__global__ void k_perm_src_start(const u32* __restrict__ dense_of_rank, const u64* __restrict__ start_id, u64 n, u64* __restrict__ out) {
+  u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < n) out[r] = start_id[dense_of_rank[r]];
 }
 __global__ void k_uniform_page_end(u64* out, u64 n, u64 base, u64 chars) {
   u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -239,8 +325,22 @@ __device__ __forceinline__ void img_copy8(const u16* __restrict__ units, u64 u0,
   u32_a1* d = reinterpret_cast<u32_a1*>(img + dst);
   d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
 }
+// PERM: the source holds the terms in another order (src_start[t] = first unit of term t in `units`); the units also go,
+// in term order, to units_out (the index's posting array): one read, two writes.  The source run of a term starts at an
+// arbitrary 2-byte boundary (dword loads at that alignment), units_out[u0] is 16-byte aligned.
+__device__ __forceinline__ void img_copy8_perm(const u16* __restrict__ units, u64 s0, u8* __restrict__ img, u64 dst, u16* __restrict__ units_out,
+                                               u64 u0) {
+  const u32_a1* s = reinterpret_cast<const u32_a1*>(units + s0);
+  uint4 v;
+  v.x = s[0]; v.y = s[1]; v.z = s[2]; v.w = s[3];
+  u32_a1* d = reinterpret_cast<u32_a1*>(img + dst);
+  d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+  *reinterpret_cast<uint4*>(units_out + u0) = v;
+}
+template <bool PERM>
 __global__ __launch_bounds__(IMG_THREADS) void k_img_units(const u16* __restrict__ units, u64 n_units, const u64* __restrict__ unit_start,
-                                                          u64 n_terms, const u64* __restrict__ pay_off, u8* __restrict__ img) {
+                                                          u64 n_terms, const u64* __restrict__ pay_off, u8* __restrict__ img,
+                                                          const u64* __restrict__ src_start, u16* __restrict__ units_out) {
   __shared__ u64 s_t[2];
   const u64 tile_base = (u64)blockIdx.x * IMG_TILE;
   if (threadIdx.x == 0) s_t[0] = img_term_of(unit_start, 0, n_terms, tile_base);
@@ -252,6 +352,15 @@ __global__ __launch_bounds__(IMG_THREADS) void k_img_units(const u16* __restrict
   const u64 t0 = img_term_of(unit_start, s_t[0], s_t[1] + 1, span);          // wave-uniform
   if (span + IMG_SPAN <= unit_start[t0 + 1]) {                               // the whole span inside one term
     const u64 dst0 = pay_off[t0] + 2 * (span - unit_start[t0]);
+    if (PERM) {
+      const u64 s0 = src_start[t0] + (span - unit_start[t0]);
+#pragma unroll
+      for (int c = 0; c < IMG_CPL; c++) {
+        const u64 o = (u64)(c * 64 + lane) * IMG_UPT;
+        img_copy8_perm(units, s0 + o, img, dst0 + o * 2, units_out, span + o);
+      }
+      return;
+    }
 #pragma unroll
     for (int c = 0; c < IMG_CPL; c++) img_copy8(units, span + (u64)(c * 64 + lane) * IMG_UPT, img, dst0 + (u64)(c * 64 + lane) * IMG_UPT * 2);
     return;
@@ -262,12 +371,17 @@ __global__ __launch_bounds__(IMG_THREADS) void k_img_units(const u16* __restrict
     u64 t = img_term_of(unit_start, t0, s_t[1] + 1, u0);
     u64 next = unit_start[t + 1];
     u64 dst = pay_off[t] + 2 * (u0 - unit_start[t]);
-    if (u0 + IMG_UPT <= next) { img_copy8(units, u0, img, dst); continue; }
+    u64 sp = PERM ? src_start[t] + (u0 - unit_start[t]) : u0;       // source position of unit u0
+    if (u0 + IMG_UPT <= next) {
+      if (PERM) img_copy8_perm(units, sp, img, dst, units_out, u0); else img_copy8(units, u0, img, dst);
+      continue;
+    }
     for (int k = 0; k < IMG_UPT; k++) {
       u64 u = u0 + k;
       if (u >= n_units) break;
-      while (u >= next) { t++; next = unit_start[t + 1]; dst = pay_off[t]; }
-      u16 v = units[u];
+      while (u >= next) { t++; next = unit_start[t + 1]; dst = pay_off[t]; if (PERM) sp = src_start[t]; }
+      u16 v = units[PERM ? sp : u];
+      if (PERM) { units_out[u] = v; sp++; }
       img[dst] = (u8)v;
       img[dst + 1] = (u8)(v >> 8);
       dst += 2;
@@ -353,8 +467,8 @@ int32_t index_make_image(const DeviceIndex& ix, hipStream_t st, DevBuf<u8>& imag
   if (V) {
     hipLaunchKernelGGL(k_img_headers, dim3((u32)div_up(V, 256)), dim3(256), 0, st, ix.term_chars.p, ix.term_str_off.p, ix.term_unit_start.p,
                        rec_off.p, V, (u64)8, image.p, pay_off.p);
-    if (U) hipLaunchKernelGGL(k_img_units, dim3((u32)div_up(U, IMG_TILE)), dim3(IMG_THREADS), 0, st, ix.units.p, U, ix.term_unit_start.p, V,
-                              pay_off.p, image.p);
+    if (U) hipLaunchKernelGGL(k_img_units<false>, dim3((u32)div_up(U, IMG_TILE)), dim3(IMG_THREADS), 0, st, ix.units.p, U, ix.term_unit_start.p, V,
+                              pay_off.p, image.p, (const u64*)nullptr, (u16*)nullptr);
   }
   DCD_HIP(hipStreamSynchronize(st));
   DCD_HIP(hipGetLastError());
@@ -692,6 +806,10 @@ struct BuildMid {
   bool strided = false;
   u32 stride = 0;
   u64 n_tiles = 0;
+  // plain text builds: the tuples are sorted by DENSE id (position among the used table slots) and the vocabulary's
+  // ordinal sort runs on a second stream beside the tuple sort; term order is restored when the units are copied out
+  bool id_keys = false;
+  u32 n_hot = 0;                    // hot / cold split: dense ids 0 .. n_hot-1 are the hot terms (0 = no split)
   DevBuf<u32> tile_cnt;
   DevBuf<u64> tile_off;
   DevBuf<u8> d_pool_raw;            // explicit strings on the device (CharT units)
@@ -748,6 +866,29 @@ struct Probes {
   ~Probes() { for (auto& p : v) { event_release(dev, p.a); event_release(dev, p.b); } }
 };
 }  // namespace
+
+// Vocabulary: compact, sort the word strings ordinally, materialise them (ordinal order).  Runs on stream `vs` (the build's
+// own stream, or a second one beside the tuple sort) and returns with `vs` drained.
+template <typename CharT>
+static int32_t build_vocab(dcd_build* h, BuildMid& M, hipStream_t vs, const TextView<CharT>& tv, u32* d_hist, u32* scan_scr32) {
+  const int dev = h->device;
+  const u64 cap = 1ull << M.cap_log2, V = M.V;
+  DCD_TRY(vocab_rank<CharT>(dev, vs, M.slots.p, cap, M.slot_excl.p, V, tv, d_hist, scan_scr32, M.d_flags.p + 1, &M.vr));
+  DCD_TRY(M.word_str_off.alloc(dev, V + 1));
+  u32 total_chars = 0;
+  if (V) {
+    scan_exclusive_f<TermLenF, u32>(TermLenF{M.vr.rk_word.p}, M.word_str_off.p, V, scan_scr32, vs);
+    DCD_HIP(hipMemcpyAsync(&total_chars, scan_scr32 + scan_nblocks(V), 4, hipMemcpyDeviceToHost, vs));
+    DCD_HIP(hipStreamSynchronize(vs));
+  }
+  DCD_HIP(hipMemcpyAsync(M.word_str_off.p + V, &total_chars, 4, hipMemcpyHostToDevice, vs));
+  DCD_TRY(M.word_chars.alloc(dev, total_chars ? total_chars : 1));
+  if (V) hipLaunchKernelGGL((k_term_strings<CharT>), dim3((u32)div_up(V, 256)), dim3(256), 0, vs, M.vr.rk_word.p, V, M.word_str_off.p, tv,
+                            M.word_chars.p);
+  M.total_chars = total_chars;
+  DCD_HIP(hipStreamSynchronize(vs));
+  return DCD_OK;
+}
 
 // ---- phase 1: tokenise -> exact vocabulary -> distinct words in ordinal order ----------------------------------
 template <typename CharT>
@@ -868,8 +1009,9 @@ static int32_t build_phase1(dcd_build* h, bool codes_mode) {
   }
   u32 cap_log2 = h->opts.vocab_capacity_log2;
   if (cap_log2 == 0) {
-    // first guess: one slot per 64 postings -- small enough to stay close to the caches (every probe of a
-    // tail term is a random access); grown x4 and the emit re-run if the load exceeds 1/2.  Without a counting pass
+    // first guess: one slot per 256 postings -- small enough to stay close to the caches (every probe of a
+    // tail term is a random access, and the table is scanned a few times); grown x4 and the emit re-run if the load exceeds 1/2
+    // (measured at C2 size: 2^20 slots against 2^22: tokenise the same, everything behind it ~0.07 ms faster).  Without a counting pass
     // the postings are estimated as one per 7 characters.
     const u64 n_est = strided ? n_chars / 7 : N;
     cap_log2 = log2_ceil((n_est ? n_est : 1) / DCD_CAPDIV + 1);
@@ -881,6 +1023,18 @@ static int32_t build_phase1(dcd_build* h, bool codes_mode) {
   tv.text = text; tv.n_chars = n_chars; tv.pool = (const CharT*)M.d_pool_raw.p; tv.n_pool = M.n_pool; tv.tab = tab;
   u64 V = 0;
   DevBuf<u32> voc_pool;                       // first words of every slot's string (vocab_lookup_insert_pooled)
+  // hot / cold split (plain text builds): sample counts per slot from every (mask + 1)-th tile, ~1000-2000 tiles in all
+  // (~200 k tokens: the 255th term of a Zipf-1.1 vocabulary still shows up ~60 times; every count is an atomic, and those
+  // of the top terms hit ONE address each -- 4096 sampled tiles slowed the emit kernel by 6 %)
+  static const int env_hot = getenv("DOCODO_BUILD_HOT") ? atoi(getenv("DOCODO_BUILD_HOT")) : 255;   // hot terms at most; 0 = off
+  static const bool env_rank_keys0 = getenv("DOCODO_BUILD_RANK_KEYS") && atoi(getenv("DOCODO_BUILD_RANK_KEYS")) != 0;
+  const bool hot_try = strided && !env_rank_keys0 && env_hot > 0;
+  const bool fast_end = strided && !env_rank_keys0;
+  u32 sample_mask = 0;
+  while (((u64)sample_mask + 1) * DCD_HOT_SAMPLE_TILES < n_tiles) sample_mask = sample_mask * 2 + 1;
+  DevBuf<u32> sample_cnt, hot_hist;           // [cap] / [HOT_BINS + 1] (theta behind the bins)
+  DevBuf<u64> hot_excl, hot_scr;
+  u32 n_hot = 0;
   for (;;) {
     if (cap_log2 > 30) DCD_FAIL(DCD_E_OVERFLOW, "vocabulary does not fit a 2^30-slot table");
     const u64 cap = 1ull << cap_log2;
@@ -897,6 +1051,12 @@ static int32_t build_phase1(dcd_build* h, bool codes_mode) {
       DCD_HIP(hipMemsetAsync(voc_pool.p, 0, cap * VocPool<CharT>::W * 4, st));
       vt.pool = voc_pool.p;
     }
+    if (hot_try) {
+      DCD_TRY(sample_cnt.alloc(dev, cap));
+      DCD_TRY(hot_hist.alloc(dev, HOT_BINS + 1));
+      DCD_HIP(hipMemsetAsync(sample_cnt.p, 0, cap * 4, st));
+      DCD_HIP(hipMemsetAsync(hot_hist.p, 0, (HOT_BINS + 1) * 4, st));
+    }
     if (n_tiles) {
       // A small SEED launch first: on an empty table every resident wave (7000+) finds the slots of the most frequent
       // terms empty and tries to insert them -- tens of thousands of compare-and-swaps on a handful of addresses that
@@ -907,12 +1067,12 @@ static int32_t build_phase1(dcd_build* h, bool codes_mode) {
       const u64 n_seed = n_tiles > 2 * seed_tiles ? seed_tiles : 0;   // small builds: one launch
       if (n_seed) {   // (not a DCD_K_TOK_EMIT probe: per-launch averages are quoted for the main launch)
         hipLaunchKernelGGL((k_tok_emit<CharT>), dim3((u32)div_up(n_seed, TK_WAVES)), dim3(TK_THREADS), 0, st, text, P, tab, tv, vt,
-                           M.tile_off.p, M.tupA.p, n_seed, M.stride, M.tile_cnt.p, (u64)0);
+                           M.tile_off.p, M.tupA.p, n_seed, M.stride, M.tile_cnt.p, (u64)0, sample_cnt.p, sample_mask);
       }
       probes.begin(DCD_K_TOK_EMIT);
       if (n_tiles > n_seed)
         hipLaunchKernelGGL((k_tok_emit<CharT>), dim3((u32)div_up(n_tiles - n_seed, TK_WAVES)), dim3(TK_THREADS), 0, st, text, P, tab, tv, vt,
-                           M.tile_off.p, M.tupA.p, n_tiles, M.stride, M.tile_cnt.p, n_seed);
+                           M.tile_off.p, M.tupA.p, n_tiles, M.stride, M.tile_cnt.p, n_seed, sample_cnt.p, sample_mask);
       probes.end();
 #if defined(DCD_DIAG_TOK)
       if (DCD_DIAG_TOK == 6) {          // second launch: every term is in the table, no CAS, no insert storm
@@ -922,7 +1082,7 @@ static int32_t build_phase1(dcd_build* h, bool codes_mode) {
         fprintf(stderr, "DIAG_TOK mode 6: first launch %.3f ms\n", msa[DCD_K_TOK_EMIT]);
         probes.begin(DCD_K_TOK_EMIT);
         hipLaunchKernelGGL((k_tok_emit<CharT>), dim3((u32)div_up(n_tiles, TK_WAVES)), dim3(TK_THREADS), 0, st, text, P, tab, tv, vt,
-                           M.tile_off.p, M.tupA.p, n_tiles, M.stride, M.tile_cnt.p, (u64)0);
+                           M.tile_off.p, M.tupA.p, n_tiles, M.stride, M.tile_cnt.p, (u64)0, sample_cnt.p, sample_mask);
         probes.end();
       }
       {
@@ -945,12 +1105,44 @@ static int32_t build_phase1(dcd_build* h, bool codes_mode) {
     // compaction: dense ids for the used slots
     DCD_TRY(M.slot_excl.alloc(dev, cap));
     DCD_TRY(M.scan_scr32.alloc(dev, std::max<u64>(scan_scratch_elems(cap), scan_scratch_elems((u64)RS_MAX_BLOCKS << 10))));
-    scan_exclusive_f<SlotUsed, u32>(SlotUsed{M.slots.p}, M.slot_excl.p, cap, M.scan_scr32.p, st);
     u32 flags[4] = {0, 0, 0, 0};
     u32 v32 = 0;
-    DCD_HIP(hipMemcpyAsync(flags, M.d_flags.p, 16, hipMemcpyDeviceToHost, st));
-    DCD_HIP(hipMemcpyAsync(&v32, M.scan_scr32.p + scan_nblocks(cap), 4, hipMemcpyDeviceToHost, st));
-    DCD_HIP(hipStreamSynchronize(st));
+    if (strided) {
+      // maxCoord = coordinate of the last posting added (Build.cs:326): fetched with the counters below, ONE host round trip
+      hipLaunchKernelGGL(k_last_strided_coord, dim3(1), dim3(1), 0, st, M.tupA.p, M.tile_cnt.p, n_tiles, M.stride, M.d_flags.p + 2);
+      DCD_HIP(hipMemcpyAsync(&M.last_text_coord, M.d_flags.p + 2, 4, hipMemcpyDeviceToHost, st));
+    }
+    const bool last_round = fast_end;      // id-keyed builds: phase 1 ends with this round trip (the stage timers stop here)
+    auto stop_timers = [&]() -> int32_t {
+      DCD_TRY(t_tok.stop()); DCD_TRY(t_voc.start()); DCD_TRY(t_voc.stop()); DCD_TRY(t_all.stop());
+      return DCD_OK;
+    };
+    if (hot_try) {
+      // hot terms first: theta from the histogram of the sample counts, ONE 64-bit scan counts used and hot slots, the
+      // dense-id table (hot terms 0 .. n_hot-1, then the others in slot order) takes the place of the plain "used" scan
+      u32* theta = hot_hist.p + HOT_BINS;
+      DCD_TRY(hot_excl.alloc(dev, cap));
+      DCD_TRY(hot_scr.alloc(dev, scan_scratch_elems(cap)));
+      hipLaunchKernelGGL(k_hot_hist, dim3(512), dim3(256), 0, st, (const u32*)sample_cnt.p, cap, hot_hist.p);
+      hipLaunchKernelGGL(k_hot_pick, dim3(1), dim3(1024), 0, st, (const u32*)hot_hist.p, (u32)env_hot, theta);
+      scan_exclusive_f<HotUsedF, u64>(HotUsedF{M.slots.p, sample_cnt.p, theta}, hot_excl.p, cap, hot_scr.p, st);
+      const u64* total = hot_scr.p + scan_nblocks(cap);
+      hipLaunchKernelGGL(k_dense_table, dim3((u32)div_up(cap, 256)), dim3(256), 0, st, (const u64*)M.slots.p, (const u32*)sample_cnt.p,
+                         (const u32*)theta, (const u64*)hot_excl.p, total, cap, M.slot_excl.p);
+      if (last_round) DCD_TRY(stop_timers());
+      u64 tot64 = 0;
+      DCD_HIP(hipMemcpyAsync(flags, M.d_flags.p, 16, hipMemcpyDeviceToHost, st));
+      DCD_HIP(hipMemcpyAsync(&tot64, total, 8, hipMemcpyDeviceToHost, st));
+      DCD_HIP(hipStreamSynchronize(st));
+      v32 = (u32)tot64;
+      n_hot = (u32)(tot64 >> 32);
+    } else {
+      scan_exclusive_f<SlotUsed, u32>(SlotUsed{M.slots.p}, M.slot_excl.p, cap, M.scan_scr32.p, st);
+      if (last_round) DCD_TRY(stop_timers());
+      DCD_HIP(hipMemcpyAsync(flags, M.d_flags.p, 16, hipMemcpyDeviceToHost, st));
+      DCD_HIP(hipMemcpyAsync(&v32, M.scan_scr32.p + scan_nblocks(cap), 4, hipMemcpyDeviceToHost, st));
+      DCD_HIP(hipStreamSynchronize(st));
+    }
     V = v32;
     if (flags[0] || V * 2 > cap) { cap_log2 += 2; continue; }  // overflow or load > 0.5: rebuild larger
     break;
@@ -962,40 +1154,32 @@ static int32_t build_phase1(dcd_build* h, bool codes_mode) {
   }
   M.N = N; M.n_text_tok = n_text_tok;
   tr.mark("emit");
-  const u64 cap = 1ull << cap_log2;
   M.cap_log2 = cap_log2; M.V = V;
-  DCD_TRY(t_tok.stop());
-  // maxCoord = coordinate of the last posting added (Build.cs:326)
-  if (n_text_tok) {
-    if (strided) {
-      hipLaunchKernelGGL(k_last_strided_coord, dim3(1), dim3(1), 0, st, M.tupA.p, M.tile_cnt.p, n_tiles, M.stride, M.d_flags.p + 2);
-      DCD_HIP(hipMemcpyAsync(&M.last_text_coord, M.d_flags.p + 2, 4, hipMemcpyDeviceToHost, st));
-    } else {
-      DCD_HIP(hipMemcpyAsync(&M.last_text_coord, &M.tupA.p[n_text_tok - 1].y, 4, hipMemcpyDeviceToHost, st));
-    }
-  }
+  if (!fast_end) DCD_TRY(t_tok.stop());
+  // maxCoord = coordinate of the last posting added (Build.cs:326); strided builds fetched it above
+  if (n_text_tok && !strided) DCD_HIP(hipMemcpyAsync(&M.last_text_coord, &M.tupA.p[n_text_tok - 1].y, 4, hipMemcpyDeviceToHost, st));
 
   // ---- 3. vocabulary: compact, sort the word strings ordinally, materialise them -------------------
-  DCD_TRY(t_voc.start());
+  // Plain text builds defer it: phase 2 sorts the tuples by dense id and runs the vocabulary beside that sort.
+  // DOCODO_BUILD_RANK_KEYS=1 keeps the ordinal rank as the sort key (vocabulary first, as explicit postings / word codes need).
+  static const bool env_rank_keys = getenv("DOCODO_BUILD_RANK_KEYS") && atoi(getenv("DOCODO_BUILD_RANK_KEYS")) != 0;
+  M.id_keys = strided && !env_rank_keys && V != 0;
+  // the split pays when the cold vocabulary is much larger than the hot set (and fits the 2^20 remap-cache values)
+  // (without the split the table is still a bijection slot -> [0, V): any such ids sort the tuples by term)
+  M.n_hot = (M.id_keys && n_hot && V > 4ull * n_hot) ? n_hot : 0;
   DCD_TRY(M.d_hist.alloc(dev, (u64)RS_MAX_BLOCKS << 10));
-  probes.begin(DCD_K_VOCAB_SORT);
-  DCD_TRY(vocab_rank<CharT>(dev, st, M.slots.p, cap, M.slot_excl.p, V, tv, M.d_hist.p, M.scan_scr32.p, M.d_flags.p + 1, &M.vr));
-  DCD_TRY(M.word_str_off.alloc(dev, V + 1));
-  u32 total_chars = 0;
-  if (V) {
-    scan_exclusive_f<TermLenF, u32>(TermLenF{M.vr.rk_word.p}, M.word_str_off.p, V, M.scan_scr32.p, st);
-    DCD_HIP(hipMemcpyAsync(&total_chars, M.scan_scr32.p + scan_nblocks(V), 4, hipMemcpyDeviceToHost, st));
+  if (!M.id_keys) {
+    if (fast_end) DCD_TRY(t_tok.start());     // (V == 0: the timers were stopped in the loop; nothing left to measure)
+    if (fast_end) DCD_TRY(t_tok.stop());
+    DCD_TRY(t_voc.start());
+    probes.begin(DCD_K_VOCAB_SORT);
+    DCD_TRY(build_vocab<CharT>(h, M, st, tv, M.d_hist.p, M.scan_scr32.p));
+    probes.end();
+    DCD_TRY(t_voc.stop());
+    DCD_TRY(t_all.stop());
     DCD_HIP(hipStreamSynchronize(st));
   }
-  DCD_HIP(hipMemcpyAsync(M.word_str_off.p + V, &total_chars, 4, hipMemcpyHostToDevice, st));
-  DCD_TRY(M.word_chars.alloc(dev, total_chars ? total_chars : 1));
-  if (V) hipLaunchKernelGGL((k_term_strings<CharT>), dim3((u32)div_up(V, 256)), dim3(256), 0, st, M.vr.rk_word.p, V, M.word_str_off.p, tv,
-                            M.word_chars.p);
-  probes.end();
-  M.total_chars = total_chars;
-  DCD_TRY(t_voc.stop());
-  DCD_TRY(t_all.stop());
-  DCD_HIP(hipStreamSynchronize(st));
+  const u32 total_chars = M.total_chars;
   DCD_HIP(hipGetLastError());
   tr.mark("vocab");
   M.ms_tok = t_tok.ms(); M.ms_voc = t_voc.ms(); M.ms_total = t_all.ms();
@@ -1047,7 +1231,10 @@ static int32_t build_phase2(dcd_build* h) {
   u64 N = M.N, V = M.V;
   uint2* a = M.tupA.p;
   uint2* b = M.tupB.p;
-  const u32* remap = M.vr.rank_of_slot.p;     // tuple.x = hash slot -> key id = rank of the word
+  // tuple.x = hash slot -> sort key: the ordinal rank of the word, or (id-keyed plain text builds) its dense id = the number of
+  // used slots before it, which the scan behind the emit kernel left in slot_excl -- no vocabulary sort needed to start
+  const bool idk = M.id_keys;
+  const u32* remap = idk ? M.slot_excl.p : M.vr.rank_of_slot.p;
   bool coord_sort = M.n_xdev != 0;            // mixed input is not in coordinate order
   DevBuf<uint2> expA, expB;
   u64 n_text_postings = M.n_text_tok;          // postings that came from the text (they precede the explicit ones)
@@ -1137,6 +1324,8 @@ static int32_t build_phase2(dcd_build* h) {
   // ---- 4. sort the tuples by key (stable; explicit postings first need coordinate order) ----
   uint2* sorted = a;
   int passes = 0;
+  u32 hot_n = 0, hot_s = 0;
+  u64 n_hot_postings = 0;
   std::vector<hipEvent_t> sort_events;
   if (N) {
     if (coord_sort) {
@@ -1159,23 +1348,64 @@ static int32_t build_phase2(dcd_build* h) {
     RsStrided sd;
     sd.cnt = M.tile_cnt.p; sd.stride = M.stride; sd.n_tiles = M.n_tiles;
     const bool strided = M.strided && a == M.tupA.p && remap != nullptr;     // (codes mode sorts its own expanded tuples)
-    sorted = rs_sort(a, b, remap, N, (int)log2_ceil(V ? V : 1), M.d_hist.p, M.scan_scr32.p, st, &p2, rp, 9,
-                     remap != nullptr && rs_cache_ok(1ull << M.cap_log2, V), strided ? &sd : nullptr);
-    passes += p2;
+    const bool cache_ok = remap != nullptr && rs_cache_ok(1ull << M.cap_log2, V);
+    hot_n = (idk && strided && M.n_hot && V > M.n_hot) ? M.n_hot : 0;
+    if (hot_n) {
+      // Hot / cold split.  Pass A scatters by the digit (key >> hot_s): every hot term gets a bucket of its own, all cold
+      // tuples share the bucket hot_n.  A hot term is then complete -- contiguous, in coordinate order -- after ONE pass,
+      // and only the cold region (a third of the tuples of a Zipf corpus) is sorted further, by the low hot_s bits.
+      hot_s = std::max<u32>(1, log2_ceil(V - hot_n));
+      int bits_a = (int)log2_ceil((u64)hot_n + 1);
+      if (bits_a < 6) bits_a = 6;
+      sd.hot_n = hot_n; sd.hot_s = hot_s;
+      rs_pass_dyn(bits_a, a, b, remap, N, (int)hot_s, M.d_hist.p, M.scan_scr32.p, st, rp, cache_ok, &sd);
+      passes++;
+      const RsTilePlan tp = rs_tile_plan(M.n_tiles);
+      u32 n_hot_tuples = 0;                  // tuples in front of the cold bucket = scanned count of (digit hot_n, block 0)
+      DCD_HIP(hipMemcpyAsync(&n_hot_tuples, M.d_hist.p + (u64)hot_n * tp.nblk, 4, hipMemcpyDeviceToHost, st));
+      DCD_HIP(hipStreamSynchronize(st));
+      const u64 Nh = n_hot_tuples, Nc = N - Nh;
+      n_hot_postings = Nh;
+      if (Nc) {
+        int pc = 0;
+        uint2* r = rs_sort(b + Nh, a + Nh, nullptr, Nc, (int)hot_s, M.d_hist.p, M.scan_scr32.p, st, &pc, rp, 9);
+        passes += pc;
+        if (r != b + Nh) DCD_HIP(hipMemcpyAsync(b + Nh, r, Nc * sizeof(uint2), hipMemcpyDeviceToDevice, st));   // (odd number of cold passes)
+      }
+      sorted = b;
+    } else {
+      sorted = rs_sort(a, b, remap, N, (int)log2_ceil(V ? V : 1), M.d_hist.p, M.scan_scr32.p, st, &p2, rp, 9, cache_ok, strided ? &sd : nullptr);
+      passes += p2;
+    }
   }
   DCD_TRY(t_sort.stop());
   tr.mark("sort-enqueue");
 
   // ---- 5. pack: deltas -> var-ushort units (IndexSequence.Builder.Add) -----------------------
+  // id-keyed: the units come out in dense-id order into a scratch array sized for the worst case (a delta inside a term is
+  // < 2^32: <= 3 units; the first posting of a term <= 5), so that no host round trip sits between the sort and the pack;
+  // step 6 copies them into ordinal term order.
   DCD_TRY(t_pack.start());
   DCD_TRY(ix.term_unit_start.alloc(dev, V + 1));
   DCD_TRY(ix.term_item_start.alloc(dev, V + 1));
+  DevBuf<u64> us_id, is_id;            // id-keyed: unit / item starts per dense id
+  DevBuf<u16> units_id;
+  if (idk) {
+    DCD_TRY(us_id.alloc(dev, V + 1));
+    DCD_TRY(is_id.alloc(dev, V + 1));
+    DCD_TRY(units_id.alloc(dev, 3 * N + 2 * V + 8));
+  }
   DevBuf<u64> enc_part, enc_scr;
   u64 enb = encode_nblocks(N);
   DCD_TRY(enc_part.alloc(dev, enb + 1));
+  DCD_TRY(enc_scr.alloc(dev, scan_scratch_elems(enb) + 1));
   u64 U = 0;
   EncSrcPairs src;
-  src.p = sorted; src.base = h->opts.coord_base; src.term_unit_start = ix.term_unit_start.p; src.term_item_start = ix.term_item_start.p;
+  src.p = sorted; src.base = h->opts.coord_base;
+  src.term_unit_start = idk ? us_id.p : ix.term_unit_start.p;
+  src.term_item_start = idk ? is_id.p : ix.term_item_start.p;
+  src.hot_n = hot_n; src.hot_s = hot_s;
+  u64* d_U = enc_scr.p + scan_nblocks(enb);        // the scan leaves the number of units here
   if (N) {
     probes.begin(DCD_K_ENC_REDUCE);
     if ((reinterpret_cast<uintptr_t>(sorted) & 15) == 0)
@@ -1184,25 +1414,64 @@ static int32_t build_phase2(dcd_build* h) {
       hipLaunchKernelGGL((k_enc_reduce<EncSrcPairs>), dim3((u32)enb), dim3(CODEC_THREADS), 0, st, src, N, enc_part.p);
     probes.end();
     // ~67 k tile totals at C2 size: the multi-block scan (in place) instead of the single-block one
-    DCD_TRY(enc_scr.alloc(dev, scan_scratch_elems(enb)));
     scan_exclusive<u64, u64>(enc_part.p, enc_part.p, enb, enc_scr.p, st);
-    DCD_HIP(hipMemcpyAsync(&U, enc_scr.p + scan_nblocks(enb), 8, hipMemcpyDeviceToHost, st));
-    DCD_HIP(hipStreamSynchronize(st));
+    if (!idk) {
+      DCD_HIP(hipMemcpyAsync(&U, d_U, 8, hipMemcpyDeviceToHost, st));
+      DCD_HIP(hipStreamSynchronize(st));
+    }
+  } else {
+    DCD_HIP(hipMemsetAsync(d_U, 0, 8, st));
   }
   tr.mark("enc-reduce");
-  DCD_TRY(ix.units.alloc(dev, U ? U : 1));
+  if (!idk) DCD_TRY(ix.units.alloc(dev, U ? U : 1));
   if (N) {
     probes.begin(DCD_K_ENC_WRITE);
-    hipLaunchKernelGGL(k_pack_write, dim3((u32)div_up(enb, PACK_TPB)), dim3(CODEC_THREADS), 0, st, src, N, enc_part.p, ix.units.p);
+    hipLaunchKernelGGL(k_pack_write, dim3((u32)div_up(enb, PACK_TPB)), dim3(CODEC_THREADS), 0, st, src, N, enc_part.p, idk ? units_id.p : ix.units.p);
     probes.end();
   }
-  hipLaunchKernelGGL(k_set_u64, dim3(1), dim3(1), 0, st, ix.term_unit_start.p + V, U);
-  hipLaunchKernelGGL(k_set_u64, dim3(1), dim3(1), 0, st, ix.term_item_start.p + V, N);
   DCD_TRY(ix.term_first.alloc(dev, V ? V : 1));
   DCD_TRY(ix.term_last.alloc(dev, V ? V : 1));
-  if (V) hipLaunchKernelGGL(k_term_first_last, dim3((u32)div_up(V, 256)), dim3(256), 0, st, sorted, ix.term_item_start.p, V,
-                            h->opts.coord_base, ix.term_first.p, ix.term_last.p);
+  if (!idk) {
+    hipLaunchKernelGGL(k_set_u64, dim3(1), dim3(1), 0, st, ix.term_unit_start.p + V, U);
+    hipLaunchKernelGGL(k_set_u64, dim3(1), dim3(1), 0, st, ix.term_item_start.p + V, N);
+    if (V) hipLaunchKernelGGL(k_term_first_last, dim3((u32)div_up(V, 256)), dim3(256), 0, st, sorted, ix.term_item_start.p, V,
+                              h->opts.coord_base, ix.term_first.p, ix.term_last.p);
+  } else {
+    hipLaunchKernelGGL(k_copy_u64, dim3(1), dim3(1), 0, st, us_id.p + V, (const u64*)d_U);
+    hipLaunchKernelGGL(k_set_u64, dim3(1), dim3(1), 0, st, is_id.p + V, N);
+  }
   DCD_TRY(t_pack.stop());
+
+  // ---- 5b. id-keyed: the vocabulary, on a second stream, while the main stream works through sort + pack ----------
+  DevBuf<u64> src_start;               // [V] first unit (in units_id) of the term with rank r
+  DevBuf<u32> side_hist, side_scr;
+  hipStream_t vs = nullptr;
+  struct SideGuard {                   // the side stream goes back to the cache (drained) however this function is left
+    int dev; hipStream_t* s;
+    ~SideGuard() { if (*s) { stream_release(dev, *s); *s = nullptr; } }
+  } side_guard{dev, &vs};
+  float ms_voc_side = 0.f;
+  if (idk) {
+    DCD_TRY(stream_acquire(dev, &vs));
+    {
+      StreamScope ss_v(vs);            // allocations below belong to the side stream
+      TextView<CharT> tv;
+      tv.text = (const CharT*)h->text_dev; tv.n_chars = h->n_chars; tv.pool = (const CharT*)M.d_pool_raw.p; tv.n_pool = M.n_pool;
+      tv.tab = CharTables16{nullptr, nullptr};
+      if (sizeof(CharT) == 2) DCD_TRY(get_char_tables16(dev, &tv.tab));
+      DCD_TRY(side_hist.alloc(dev, (u64)RS_MAX_BLOCKS << 10));     // (the tuple sort is using M.d_hist / M.scan_scr32 right now)
+      DCD_TRY(side_scr.alloc(dev, scan_scratch_elems((u64)RS_MAX_BLOCKS << 10) + scan_scratch_elems(V) + 8));
+      EvTimer t_vs;
+      DCD_TRY(t_vs.init(vs, dev));
+      DCD_TRY(t_vs.start());
+      DCD_TRY(build_vocab<CharT>(h, M, vs, tv, side_hist.p, side_scr.p));
+      DCD_TRY(t_vs.stop());
+      DCD_HIP(hipStreamSynchronize(vs));
+      ms_voc_side = t_vs.ms();
+    }
+    // build_vocab returned with the side stream drained: its results are visible to the main stream from here on
+    tr.mark("vocab-side");
+  }
 
   // ---- 6. keys + ".index" image -----------------------------------------------------------------
   DCD_TRY(t_img.start());
@@ -1212,6 +1481,20 @@ static int32_t build_phase2(dcd_build* h) {
   DCD_TRY(rec_off.alloc(dev, V + 1));
   DCD_TRY(pay_off.alloc(dev, V + 1));
   DCD_TRY(scr64b.alloc(dev, scan_scratch_elems(V ? V : 1)));
+  if (idk) {
+    // term order: unit / item starts by ordinal rank = scans of the id-ordered lengths through dense_of_rank
+    const u32* dor = M.vr.dense_of_rank.p;
+    u64* tot = scr64b.p + scan_nblocks(V);
+    scan_exclusive_f<PermLenF, u64>(PermLenF{dor, us_id.p}, ix.term_unit_start.p, V, scr64b.p, st);
+    hipLaunchKernelGGL(k_copy_u64, dim3(1), dim3(1), 0, st, ix.term_unit_start.p + V, (const u64*)tot);
+    scan_exclusive_f<PermLenF, u64>(PermLenF{dor, is_id.p}, ix.term_item_start.p, V, scr64b.p, st);
+    hipLaunchKernelGGL(k_copy_u64, dim3(1), dim3(1), 0, st, ix.term_item_start.p + V, (const u64*)tot);
+    DCD_TRY(src_start.alloc(dev, V));
+    hipLaunchKernelGGL(k_perm_src_start, dim3((u32)div_up(V, 256)), dim3(256), 0, st, dor, (const u64*)us_id.p, V, src_start.p);
+    hipLaunchKernelGGL(k_term_first_last_perm, dim3((u32)div_up(V, 256)), dim3(256), 0, st, sorted, (const u64*)is_id.p, dor, V,
+                       h->opts.coord_base, ix.term_first.p, ix.term_last.p);
+    DCD_HIP(hipMemcpyAsync(&U, d_U, 8, hipMemcpyDeviceToHost, st));
+  }
   u64 rec_total = 0;
   if (V) {
     scan_exclusive_f<RecSizeF, u64>(RecSizeF{ix.term_chars.p, ix.term_str_off.p, ix.term_unit_start.p}, rec_off.p, V, scr64b.p, st);
@@ -1219,6 +1502,7 @@ static int32_t build_phase2(dcd_build* h) {
   }
   DCD_HIP(hipStreamSynchronize(st));
   tr.mark("pack");
+  if (idk) DCD_TRY(ix.units.alloc(dev, U ? U : 1));
   u64 max_coord = 0;
   {
     // coordinate of the last Add call: the later of (last explicit posting, last text token)
@@ -1236,8 +1520,12 @@ static int32_t build_phase2(dcd_build* h) {
                        ix.term_unit_start.p, rec_off.p, V, (u64)8, h->image.p, pay_off.p);
     if (U) {
       probes.begin(DCD_K_IMG_UNITS);
-      hipLaunchKernelGGL(k_img_units, dim3((u32)div_up(U, IMG_TILE)), dim3(IMG_THREADS), 0, st, ix.units.p, U, ix.term_unit_start.p, V,
-                         pay_off.p, h->image.p);
+      if (idk)
+        hipLaunchKernelGGL(k_img_units<true>, dim3((u32)div_up(U, IMG_TILE)), dim3(IMG_THREADS), 0, st, (const u16*)units_id.p, U,
+                           (const u64*)ix.term_unit_start.p, V, (const u64*)pay_off.p, h->image.p, (const u64*)src_start.p, ix.units.p);
+      else
+        hipLaunchKernelGGL(k_img_units<false>, dim3((u32)div_up(U, IMG_TILE)), dim3(IMG_THREADS), 0, st, (const u16*)ix.units.p, U,
+                           (const u64*)ix.term_unit_start.p, V, (const u64*)pay_off.p, h->image.p, (const u64*)nullptr, (u16*)nullptr);
       probes.end();
     }
   }
@@ -1257,9 +1545,11 @@ static int32_t build_phase2(dcd_build* h) {
   s.n_chars = h->n_chars; s.n_pages = h->pages.n_pages(); s.n_docs = h->pages.n_docs();
   s.n_postings = N; s.n_terms = V; s.n_units = U; s.max_coord = max_coord;
   s.index_bytes = h->image_bytes; s.list_bytes = 0;  // the list image is generated on demand
+  if (idk) { M.ms_voc = ms_voc_side; M.ms_kernel[DCD_K_VOCAB_SORT] += ms_voc_side; M.n_launch[DCD_K_VOCAB_SORT]++; }   // (overlapped with the sort)
   s.ms_tokenize = M.ms_tok; s.ms_vocab = M.ms_voc; s.ms_sort = t_sort.ms(); s.ms_pack = t_pack.ms(); s.ms_image = t_img.ms();
   s.ms_total = M.ms_total + t_all.ms();
   s.sort_passes = (u32)passes; s.vocab_capacity_log2 = M.cap_log2;
+  s.id_keys = idk ? 1u : 0u; s.n_hot_terms = hot_n; s.n_hot_postings = n_hot_postings;
   for (int k = 0; k < 8; k++) { s.ms_kernel[k] = M.ms_kernel[k]; s.n_launch[k] = M.n_launch[k]; }
   probes.collect(s.ms_kernel, s.n_launch);
   for (size_t i = 0; i + 3 < sort_events.size(); i += 4) {

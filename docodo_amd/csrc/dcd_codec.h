@@ -34,6 +34,13 @@ struct EncSrcPairs {
   u64 base;            // global coordinate of local 0
   u64* term_unit_start;  // [n_terms+1]
   u64* term_item_start;  // [n_terms+1]
+  // hot / cold split keys (RsStrided::hot_n / hot_s, dcd_sort.h): x is the transformed key, the directory is indexed by the dense id
+  u32 hot_n = 0, hot_s = 0;
+  __device__ __forceinline__ u32 id_of(u32 x) const {
+    if (!hot_s) return x;
+    const u32 hi = x >> hot_s;
+    return hi < hot_n ? hi : hot_n + (x - (hot_n << hot_s));
+  }
   __device__ __forceinline__ bool head(u64 i) const { return i == 0 || p[i].x != p[i - 1].x; }
   __device__ __forceinline__ u64 delta(u64 i) const {
     uint2 c = p[i];
@@ -42,7 +49,7 @@ struct EncSrcPairs {
     return q.x != c.x ? base + c.y : (u64)c.y - (u64)q.y;
   }
   __device__ __forceinline__ void on_item(u64 i, u64 off, u64) const {
-    if (head(i)) { term_unit_start[p[i].x] = off; term_item_start[p[i].x] = i; }
+    if (head(i)) { const u32 t = id_of(p[i].x); term_unit_start[t] = off; term_item_start[t] = i; }
   }
 };
 

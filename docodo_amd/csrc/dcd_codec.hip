@@ -161,7 +161,7 @@ __global__ __launch_bounds__(CODEC_THREADS) void k_pack_write(EncSrcPairs src, u
 #pragma unroll
     for (int j = 0; j < CODEC_ITEMS; j++) {
       if (l0 + j < cnt) {
-        if (hd[j]) { src.term_unit_start[term[j]] = gbase + loff; src.term_item_start[term[j]] = t0 + l0 + j; }
+        if (hd[j]) { const u32 t = src.id_of(term[j]); src.term_unit_start[t] = gbase + loff; src.term_item_start[t] = t0 + l0 + j; }
         if (hd[j] && nu[j] > 2) {                                   // 64-bit head (rare): the general code
           const u64 d = src.base + cy[j];
           for (u32 g = 0; g < nu[j]; g++) sh.units[loff + g] = seq_unit(d, g, nu[j]);

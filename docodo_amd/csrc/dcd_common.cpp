@@ -37,7 +37,7 @@ int32_t ensure_device(int device) {
 // (DCD_TRY / DCD_HIP early returns) destroy DevBufs whose kernels or copies may still be in flight.
 // A released block therefore carries the stream it was last used on plus its position in that stream's
 // release order; it is handed out again at once to the same stream (stream order covers it), and to any
-// other stream only behind an event recorded on the releasing stream (hipStreamWaitEvent; see below).
+// other stream only once the releasing stream has passed that point (see make_usable below).
 static thread_local hipStream_t t_cur_stream = nullptr;
 static thread_local bool t_have_stream = false;
 
@@ -61,9 +61,9 @@ struct LiveBlock {
   hipStream_t stream;
   bool tagged;          // allocated inside a StreamScope
 };
-// Release order per stream.  A release costs no HIP call: the block only takes the next ticket of its stream.  The
-// event is recorded LAZILY, by the first other stream that wants such a block (an event recorded later on the stream
-// covers everything queued before, in particular whatever was in flight when the block was released).
+// Release order per stream.  A release costs no HIP call: the block only takes the next ticket of its stream.  Another
+// stream gets the block once the releasing stream is known to have passed that ticket (it was seen idle, or an event
+// recorded behind the ticket has completed); until then the block is passed over (see make_usable).
 struct StreamState {
   u64 issued = 0;         // tickets handed out
   u64 completed = 0;      // every release with ticket <= completed has finished on the device
@@ -101,20 +101,30 @@ size_t pool_cap(int device) {
   if (hipMemGetInfo(&fr, &tot) != hipSuccess) { (void)hipGetLastError(); return (size_t)64 << 30; }
   return tot / 2;
 }
-// Makes the block usable by `want` (queues a wait on `want`, or blocks the host when the caller declared no stream).
-// Called with P.mu held.
-bool make_usable(int device, Pool& P, const FreeBlock& b, hipStream_t want, bool have_want) {
+// Is the block usable by `want` right now?  allow_wait = false (allocation): never makes `want` wait for another stream --
+// an event recorded NOW on the releasing stream would also cover everything that was queued there after the release (a
+// build's side stream would wait for the whole tuple sort of the main stream); a block whose releasing stream is still
+// busy is simply passed over.  allow_wait = true (release of a block that changed streams): orders `want` behind the
+// other stream with an event.  Called with P.mu held.
+bool make_usable(int device, Pool& P, const FreeBlock& b, hipStream_t want, bool have_want, bool allow_wait) {
   if (!b.ticket) return true;
   if (have_want && want == b.stream) return true;               // stream order covers it
   StreamState& S = P.streams[b.stream];
   if (S.completed >= b.ticket) return true;
-  if (S.ev && hipEventQuery(S.ev) == hipSuccess) {
-    S.completed = S.ev_ticket;
-    event_release(device, S.ev);
-    S.ev = nullptr;
-    if (S.completed >= b.ticket) return true;
+  if (S.ev) {
+    if (hipEventQuery(S.ev) == hipSuccess) {
+      S.completed = S.ev_ticket;
+      event_release(device, S.ev);
+      S.ev = nullptr;
+      if (S.completed >= b.ticket) return true;
+    } else (void)hipGetLastError();
   }
-  (void)hipGetLastError();
+  {
+    const u64 issued = S.issued;                                 // an idle stream has finished everything released on it so far
+    if (hipStreamQuery(b.stream) == hipSuccess) { S.completed = issued; return true; }
+    (void)hipGetLastError();
+  }
+  if (!allow_wait) return false;
   if (!S.ev || S.ev_ticket < b.ticket) {                         // need an event that covers this release
     hipEvent_t ev = event_acquire(device);
     if (!ev || hipEventRecord(ev, b.stream) != hipSuccess) {     // (a destroyed stream: wait for the device instead)
@@ -143,7 +153,7 @@ int32_t dev_alloc(int device, size_t bytes, void** out) {
     std::lock_guard<std::mutex> g(P.mu);
     // accept a cached block up to 25 % larger than needed
     for (auto it = P.free_.lower_bound(r); it != P.free_.end() && it->first <= r + r / 4; ++it) {
-      if (!make_usable(device, P, it->second, want, have_want)) continue;
+      if (!make_usable(device, P, it->second, want, have_want, false)) continue;
       *out = it->second.p;
       P.live[it->second.p] = LiveBlock{it->first, want, have_want};
       P.cached -= it->first;
@@ -193,7 +203,7 @@ void dev_release(int device, void* p) {
         fb.stream = have_cur ? t_cur_stream : lb.stream;
         if (have_cur && lb.tagged && lb.stream != fb.stream) {
           FreeBlock other{p, lb.stream, ++P.streams[lb.stream].issued};
-          if (!make_usable(device, P, other, fb.stream, true)) (void)hipStreamSynchronize(lb.stream);
+          if (!make_usable(device, P, other, fb.stream, true, true)) (void)hipStreamSynchronize(lb.stream);
         }
         fb.ticket = ++P.streams[fb.stream].issued;
       }

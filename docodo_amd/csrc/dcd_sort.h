@@ -145,7 +145,12 @@ struct RsStrided {
   const u32* cnt;        // [n_tiles]
   u32 stride;            // tuples reserved per tile (>= any cnt), even
   u64 n_tiles;
+  // hot / cold split (hot_s != 0): the remapped key is a dense id d whose first hot_n values are the hot terms; the sort
+  // key becomes d << hot_s for a hot term and (hot_n << hot_s) + (d - hot_n) for a cold one (d - hot_n < 2^hot_s), so that
+  // the digit (key >> hot_s) gives every hot term a bucket of its own and all cold terms the bucket hot_n
+  u32 hot_n = 0, hot_s = 0;
 };
+__device__ __forceinline__ u32 rs_hot_key(u32 d, u32 hot_n, u32 hot_s) { return d < hot_n ? d << hot_s : (hot_n << hot_s) + (d - hot_n); }
 constexpr int RS_STRIDE_MAX = 320;       // largest tile population handled (the host checks its stride against it)
 constexpr int RS_TPB_MAX = 2304;         // tiles per block (LDS slice of the tile table in the scatter kernel)
 struct RsTilePlan { u32 nblk, tpb; };
@@ -167,7 +172,10 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_hist_strided(const uint2* __r
   __shared__ u32 s_cache[CACHE ? (1 << RC_BITS) : 1];
   if (CACHE)
     for (int i = threadIdx.x; i < (1 << RC_BITS); i += RS_THREADS) s_cache[i] = 0xFFFFFFFFu;
-  auto key_of = [&](u32 k) -> u32 { return CACHE ? rs_key_cached<RC_BITS>(k, remap, s_cache) : rs_key(k, remap); };
+  auto key_of = [&](u32 k) -> u32 {
+    const u32 d = CACHE ? rs_key_cached<RC_BITS>(k, remap, s_cache) : rs_key(k, remap);
+    return sd.hot_s ? rs_hot_key(d, sd.hot_n, sd.hot_s) : d;
+  };
   constexpr int HC = DCD_RS_HCOPIES, HS = NB + 1;
   __shared__ u32 h[HC * HS];
   for (int i = threadIdx.x; i < HC * HS; i += RS_THREADS) h[i] = 0;
@@ -326,7 +334,10 @@ __global__ __launch_bounds__(RSS_THREADS) __attribute__((amdgpu_waves_per_eu(DCD
 #pragma unroll
     for (int r = 0; r < RS_ROWS; r++) {
       valid[r] = STRIDED ? lane < vrow[r] : t0 + (u64)(w * RS_ROWS + r) * 64 + lane < end;
-      if (valid[r]) item[r].x = CACHE ? rs_key_cached<RCS_BITS>(item[r].x, remap, s_cache) : rs_key(item[r].x, remap);   // (first pass only)
+      if (valid[r]) {
+        item[r].x = CACHE ? rs_key_cached<RCS_BITS>(item[r].x, remap, s_cache) : rs_key(item[r].x, remap);   // (first pass only)
+        if (STRIDED && sd.hot_s) item[r].x = rs_hot_key(item[r].x, sd.hot_n, sd.hot_s);
+      }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();

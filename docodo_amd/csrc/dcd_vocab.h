@@ -98,12 +98,13 @@ __global__ void k_term_keys(uint2* __restrict__ perm, u64 n, const u64* __restri
 }
 
 static __global__ void k_assign_rank(const uint2* __restrict__ perm, u64 n, const u32* __restrict__ term_slot, const u64* __restrict__ term_word,
-                              u32* __restrict__ rank_of_slot, u64* __restrict__ rk_word) {
+                              u32* __restrict__ rank_of_slot, u64* __restrict__ rk_word, u32* __restrict__ dense_of_rank) {
   u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= n) return;
   u32 d = perm[r].y;
   rank_of_slot[term_slot[d]] = (u32)r;
   rk_word[r] = term_word[d];
+  dense_of_rank[r] = d;
 }
 
 struct TermLenF {
@@ -129,6 +130,7 @@ struct VocabRanks {
   u64 V = 0;
   DevBuf<u32> rank_of_slot;   // [capacity] valid at used slots
   DevBuf<u64> rk_word;        // [V] slot word {tag,len,pos} of the term with rank r
+  DevBuf<u32> dense_of_rank;  // [V] dense id (position among the used slots) of the term with rank r
 };
 
 // slots[0..cap) is a filled table, slot_excl its exclusive "used" scan (dense ids), V the number of
@@ -144,6 +146,7 @@ inline int32_t vocab_rank(int dev, hipStream_t st, const u64* slots, u64 cap, co
   DCD_TRY(out->rk_word.alloc(dev, V ? V : 1));
   DCD_TRY(term_slot.alloc(dev, V ? V : 1));
   DCD_TRY(out->rank_of_slot.alloc(dev, cap));
+  DCD_TRY(out->dense_of_rank.alloc(dev, V ? V : 1));
   DCD_TRY(permA.alloc(dev, V ? V : 1));
   DCD_TRY(permB.alloc(dev, V ? V : 1));
   if (!V) return DCD_OK;
@@ -180,7 +183,7 @@ inline int32_t vocab_rank(int dev, hipStream_t st, const u64* slots, u64 cap, co
     if (res != cur) { other = cur; cur = res; }
   }
   hipLaunchKernelGGL(k_assign_rank, dim3((u32)div_up(V, 256)), dim3(256), 0, st, cur, V, term_slot.p, term_word.p, out->rank_of_slot.p,
-                     out->rk_word.p);
+                     out->rk_word.p, out->dense_of_rank.p);
   DCD_HIP(hipStreamSynchronize(st));   // the temporaries above are released when this function returns
   return DCD_OK;
 }

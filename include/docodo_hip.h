@@ -166,6 +166,12 @@ typedef struct dcd_build_stats {
    * [4] k_enc_reduce  [5] k_enc_write  [6] k_img_units  [7] vocabulary string sort (all kernels) */
   float ms_kernel[8];
   uint32_t n_launch[8];
+  /* how the tuples were sorted: id_keys = 1: by dense vocabulary id, the ordinal vocabulary sort ran beside the tuple sort
+   * ([7] is then overlapped time) and k_img_units also copies the units into term order; n_hot_terms > 0: the first radix
+   * pass gave that many frequent terms a bucket of their own (n_hot_postings tuples, final after one pass) and only the
+   * other n_postings - n_hot_postings tuples took the remaining sort_passes - 1 passes */
+  uint32_t id_keys, n_hot_terms;
+  uint64_t n_hot_postings;
 } dcd_build_stats;
 #define DCD_K_TOK_COUNT 0
 #define DCD_K_TOK_EMIT 1

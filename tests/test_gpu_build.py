@@ -1,10 +1,13 @@
 """GPU parity of the build path: the .index / .index.list byte images produced by the HIP pipeline
 must equal the CPU oracle's (bit-exact), on the synthetic Appendix-F corpora and on adversarial
 Latin-1 / UTF-16 texts (page boundaries inside words, tile-boundary tokens, over-long words, case)."""
+import os
+
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _oracle_images(o, pages_text, ids=None, docs=None, latin1=True):
@@ -324,3 +327,45 @@ def test_device_cache_is_stream_ordered_and_can_be_trimmed():
     assert docodo_amd.pool_cached_bytes(0) > 0
     docodo_amd.pool_trim(0)
     assert docodo_amd.pool_cached_bytes(0) == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_docs", [3, 5000, 60000])
+def test_id_keyed_and_rank_keyed_builds_agree(n_docs, tmp_path):
+    """Plain text builds sort the tuples by dense vocabulary id and run the ordinal vocabulary sort on a second stream
+    (term order is restored when the units are copied out); DOCODO_BUILD_RANK_KEYS=1 keeps the ordinal rank as the sort
+    key.  Same images, same index arrays (units, starts, first / last coordinate per term through the shard export)."""
+    import subprocess
+    import sys
+    code = r'''
+import sys, hashlib, numpy as np
+sys.path.insert(0, %r)
+import docodo_amd
+from docodo_amd import synth, dist
+n = %d
+text = synth.corpus_host(n)
+off = np.arange(n + 1, dtype=np.uint64) * synth.DOC_BYTES
+b = docodo_amd.Builder(coord_base=7 * 1024)
+b.AddPages(text, off, docs_per_page=True)
+st = b.Finish()
+h = hashlib.sha256()
+h.update(b.index_image()); h.update(b.list_image())
+e = dist.export_shard(b, 3)
+for t in (e.meta, e.keys, e.units):
+    h.update(t.cpu().numpy().tobytes())
+h.update(np.concatenate([e.term_count, e.key_count, e.unit_count]).tobytes())
+ix = b.Build()
+for w in ("aaaaaaa", synth.term(17), synth.term(4000)):
+    t = ix.find(w)
+    if t is not None:
+        h.update(ix[w].units.tobytes()); h.update(str(ix.term_count(t)).encode())
+print("DIGEST", h.hexdigest(), st.n_postings, st.n_terms, st.n_units)
+''' % (ROOT, n_docs)
+    outs = []
+    # ordinal-rank keys; dense-id keys without the hot / cold split; with a split of at most 5 / 511 (default) hot terms
+    for extra in ({"DOCODO_BUILD_RANK_KEYS": "1"}, {"DOCODO_BUILD_HOT": "0"}, {"DOCODO_BUILD_HOT": "5"}, {}):
+        env = dict(os.environ, **extra)
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+        assert r.returncode == 0, r.stdout + r.stderr
+        outs.append([l for l in r.stdout.splitlines() if l.startswith("DIGEST")][0])
+    assert len(set(outs)) == 1, outs
