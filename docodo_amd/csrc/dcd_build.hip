@@ -7,6 +7,8 @@
 #include <chrono>
 #include <memory>
 
+#include <functional>
+
 #include "dcd_build_int.h"
 #include "dcd_codec.h"
 #include "dcd_scan.h"
@@ -234,6 +236,7 @@ __global__ void k_term_first_last_perm(const uint2* __restrict__ sorted, const u
   last[r] = base + sorted[item_start_id[d + 1] - 1].y;
 }
 __global__ void k_copy_u64(u64* dst, const u64* src) { *dst = *src; }
+__global__ void k_copy_u32(u32* dst, const u32* src) { *dst = *src; }
 struct PermLenF {   // length of the term with rank r in an array of starts indexed by dense id
   const u32* dense_of_rank;
   const u64* start_id;
@@ -873,20 +876,25 @@ template <typename CharT>
 static int32_t build_vocab(dcd_build* h, BuildMid& M, hipStream_t vs, const TextView<CharT>& tv, u32* d_hist, u32* scan_scr32) {
   const int dev = h->device;
   const u64 cap = 1ull << M.cap_log2, V = M.V;
-  DCD_TRY(vocab_rank<CharT>(dev, vs, M.slots.p, cap, M.slot_excl.p, V, tv, d_hist, scan_scr32, M.d_flags.p + 1, &M.vr));
+  // ONE host round trip inside (the longest key and the alphabet size decide the radix passes); the key pool is sized for
+  // V keys of the longest length, so that the total needs no round trip of its own
+  u32 maxlen = 0;
+  DCD_TRY(vocab_rank<CharT>(dev, vs, M.slots.p, cap, M.slot_excl.p, V, tv, d_hist, scan_scr32, M.d_flags.p + 1, &M.vr, &maxlen));
   DCD_TRY(M.word_str_off.alloc(dev, V + 1));
+  DCD_TRY(M.word_chars.alloc(dev, V * (u64)maxlen + 1));
   u32 total_chars = 0;
   if (V) {
+    u32* tot = scan_scr32 + scan_nblocks(V);
     scan_exclusive_f<TermLenF, u32>(TermLenF{M.vr.rk_word.p}, M.word_str_off.p, V, scan_scr32, vs);
-    DCD_HIP(hipMemcpyAsync(&total_chars, scan_scr32 + scan_nblocks(V), 4, hipMemcpyDeviceToHost, vs));
-    DCD_HIP(hipStreamSynchronize(vs));
+    hipLaunchKernelGGL(k_copy_u32, dim3(1), dim3(1), 0, vs, M.word_str_off.p + V, (const u32*)tot);
+    hipLaunchKernelGGL((k_term_strings<CharT>), dim3((u32)div_up(V, 256)), dim3(256), 0, vs, M.vr.rk_word.p, V, M.word_str_off.p, tv,
+                       M.word_chars.p);
+    DCD_HIP(hipMemcpyAsync(&total_chars, tot, 4, hipMemcpyDeviceToHost, vs));
+  } else {
+    DCD_HIP(hipMemsetAsync(M.word_str_off.p, 0, 4, vs));
   }
-  DCD_HIP(hipMemcpyAsync(M.word_str_off.p + V, &total_chars, 4, hipMemcpyHostToDevice, vs));
-  DCD_TRY(M.word_chars.alloc(dev, total_chars ? total_chars : 1));
-  if (V) hipLaunchKernelGGL((k_term_strings<CharT>), dim3((u32)div_up(V, 256)), dim3(256), 0, vs, M.vr.rk_word.p, V, M.word_str_off.p, tv,
-                            M.word_chars.p);
-  M.total_chars = total_chars;
   DCD_HIP(hipStreamSynchronize(vs));
+  M.total_chars = total_chars;
   return DCD_OK;
 }
 
@@ -1321,6 +1329,40 @@ static int32_t build_phase2(dcd_build* h) {
     DCD_TRY(t_sort.start());
   }
 
+  // ---- id-keyed builds: the vocabulary on a second (high-priority) stream, beside the tuple sort ------------------
+  // The host blocks in here (the chain has host round trips of its own), so it is called once the main stream has
+  // been given enough work: behind the first radix pass of a hot / cold build (the pass takes longer than the chain, and
+  // the host needs the size of the cold region before it can queue the rest), else behind the whole sort + pack.
+  DevBuf<u32> side_hist, side_scr;
+  hipStream_t vs = nullptr;
+  struct SideGuard {                   // the side stream goes back to the cache (drained) however this function is left
+    int dev; hipStream_t* s;
+    ~SideGuard() { if (*s) { stream_release_high(dev, *s); *s = nullptr; } }
+  } side_guard{dev, &vs};
+  float ms_voc_side = 0.f;
+  bool vocab_done = false;
+  auto run_vocab_side = [&]() -> int32_t {
+    vocab_done = true;
+    DCD_TRY(stream_acquire_high(dev, &vs));
+    StreamScope ss_v(vs);              // allocations below belong to the side stream
+    TextView<CharT> tv;
+    tv.text = (const CharT*)h->text_dev; tv.n_chars = h->n_chars; tv.pool = (const CharT*)M.d_pool_raw.p; tv.n_pool = M.n_pool;
+    tv.tab = CharTables16{nullptr, nullptr};
+    if (sizeof(CharT) == 2) DCD_TRY(get_char_tables16(dev, &tv.tab));
+    DCD_TRY(side_hist.alloc(dev, (u64)RS_MAX_BLOCKS << 10));     // (the tuple sort is using M.d_hist / M.scan_scr32 right now)
+    DCD_TRY(side_scr.alloc(dev, scan_scratch_elems((u64)RS_MAX_BLOCKS << 10) + scan_scratch_elems(V) + 8));
+    EvTimer t_vs;
+    DCD_TRY(t_vs.init(vs, dev));
+    DCD_TRY(t_vs.start());
+    DCD_TRY(build_vocab<CharT>(h, M, vs, tv, side_hist.p, side_scr.p));
+    DCD_TRY(t_vs.stop());
+    DCD_HIP(hipStreamSynchronize(vs));
+    ms_voc_side = t_vs.ms();
+    // build_vocab returned with the side stream drained: its results are visible to the main stream from here on
+    tr.mark("vocab-side");
+    return DCD_OK;
+  };
+
   // ---- 4. sort the tuples by key (stable; explicit postings first need coordinate order) ----
   uint2* sorted = a;
   int passes = 0;
@@ -1358,13 +1400,34 @@ static int32_t build_phase2(dcd_build* h) {
       int bits_a = (int)log2_ceil((u64)hot_n + 1);
       if (bits_a < 6) bits_a = 6;
       sd.hot_n = hot_n; sd.hot_s = hot_s;
-      rs_pass_dyn(bits_a, a, b, remap, N, (int)hot_s, M.d_hist.p, M.scan_scr32.p, st, rp, cache_ok, &sd);
-      passes++;
+      // the size of the hot region = scanned count of (digit hot_n, block 0): read back between the scan and the scatter
+      // kernel of pass A, so that the host has it long before that kernel ends and queues the cold passes behind it
+      struct NhRead { const u32* src; u32* dst; hipEvent_t ev; int32_t status; std::function<int32_t()>* side; int32_t side_status; } nh;
       const RsTilePlan tp = rs_tile_plan(M.n_tiles);
-      u32 n_hot_tuples = 0;                  // tuples in front of the cold bucket = scanned count of (digit hot_n, block 0)
-      DCD_HIP(hipMemcpyAsync(&n_hot_tuples, M.d_hist.p + (u64)hot_n * tp.nblk, 4, hipMemcpyDeviceToHost, st));
-      DCD_HIP(hipStreamSynchronize(st));
-      const u64 Nh = n_hot_tuples, Nc = N - Nh;
+      u64* pin = pinned_words();
+      if (!pin) DCD_FAIL(DCD_E_NOMEM, "hipHostMalloc failed");
+      nh.src = M.d_hist.p + (u64)hot_n * tp.nblk; nh.dst = (u32*)pin; nh.ev = event_acquire(dev); nh.status = DCD_OK;
+      if (!nh.ev) DCD_FAIL(DCD_E_HIP, "hipEventCreate failed");
+      // ... and the vocabulary chain runs right there, beside the histogram kernel: the scatter kernel of pass A fills the
+      // LDS of every CU for a millisecond, and small kernels that need LDS would wait behind it (measured: the chain then
+      // takes 1.1-1.5 ms instead of 0.5 and slows the scatter kernel by 0.1 ms)
+      std::function<int32_t()> side_fn = run_vocab_side;
+      nh.side = &side_fn; nh.side_status = DCD_OK;
+      RsProbe rpa = rp;
+      rpa.after_scan_arg = &nh;
+      rpa.after_scan = [](void* arg, hipStream_t s) {
+        NhRead* r = (NhRead*)arg;
+        if (hipMemcpyAsync(r->dst, r->src, 4, hipMemcpyDeviceToHost, s) != hipSuccess || hipEventRecord(r->ev, s) != hipSuccess) r->status = DCD_E_HIP;
+        r->side_status = (*r->side)();
+      };
+      rs_pass_dyn(bits_a, a, b, remap, N, (int)hot_s, M.d_hist.p, M.scan_scr32.p, st, rpa, cache_ok, &sd);
+      passes++;
+      int32_t vst = nh.side_status;
+      if (vst == DCD_OK && nh.status == DCD_OK && hipEventSynchronize(nh.ev) != hipSuccess) nh.status = DCD_E_HIP;
+      event_release(dev, nh.ev);
+      DCD_TRY(vst);
+      if (nh.status != DCD_OK) { (void)hipGetLastError(); DCD_FAIL(DCD_E_HIP, "reading the hot / cold boundary failed"); }
+      const u64 Nh = *nh.dst, Nc = N - Nh;
       n_hot_postings = Nh;
       if (Nc) {
         int pc = 0;
@@ -1442,36 +1505,9 @@ static int32_t build_phase2(dcd_build* h) {
   }
   DCD_TRY(t_pack.stop());
 
-  // ---- 5b. id-keyed: the vocabulary, on a second stream, while the main stream works through sort + pack ----------
+  // ---- 5b. id-keyed without the hot / cold split: the vocabulary now, while the main stream works through sort + pack
+  if (idk && !vocab_done) DCD_TRY(run_vocab_side());
   DevBuf<u64> src_start;               // [V] first unit (in units_id) of the term with rank r
-  DevBuf<u32> side_hist, side_scr;
-  hipStream_t vs = nullptr;
-  struct SideGuard {                   // the side stream goes back to the cache (drained) however this function is left
-    int dev; hipStream_t* s;
-    ~SideGuard() { if (*s) { stream_release(dev, *s); *s = nullptr; } }
-  } side_guard{dev, &vs};
-  float ms_voc_side = 0.f;
-  if (idk) {
-    DCD_TRY(stream_acquire(dev, &vs));
-    {
-      StreamScope ss_v(vs);            // allocations below belong to the side stream
-      TextView<CharT> tv;
-      tv.text = (const CharT*)h->text_dev; tv.n_chars = h->n_chars; tv.pool = (const CharT*)M.d_pool_raw.p; tv.n_pool = M.n_pool;
-      tv.tab = CharTables16{nullptr, nullptr};
-      if (sizeof(CharT) == 2) DCD_TRY(get_char_tables16(dev, &tv.tab));
-      DCD_TRY(side_hist.alloc(dev, (u64)RS_MAX_BLOCKS << 10));     // (the tuple sort is using M.d_hist / M.scan_scr32 right now)
-      DCD_TRY(side_scr.alloc(dev, scan_scratch_elems((u64)RS_MAX_BLOCKS << 10) + scan_scratch_elems(V) + 8));
-      EvTimer t_vs;
-      DCD_TRY(t_vs.init(vs, dev));
-      DCD_TRY(t_vs.start());
-      DCD_TRY(build_vocab<CharT>(h, M, vs, tv, side_hist.p, side_scr.p));
-      DCD_TRY(t_vs.stop());
-      DCD_HIP(hipStreamSynchronize(vs));
-      ms_voc_side = t_vs.ms();
-    }
-    // build_vocab returned with the side stream drained: its results are visible to the main stream from here on
-    tr.mark("vocab-side");
-  }
 
   // ---- 6. keys + ".index" image -----------------------------------------------------------------
   DCD_TRY(t_img.start());
@@ -1481,26 +1517,46 @@ static int32_t build_phase2(dcd_build* h) {
   DCD_TRY(rec_off.alloc(dev, V + 1));
   DCD_TRY(pay_off.alloc(dev, V + 1));
   DCD_TRY(scr64b.alloc(dev, scan_scratch_elems(V ? V : 1)));
+  u64 rec_total_pin = 0;
   if (idk) {
     // term order: unit / item starts by ordinal rank = scans of the id-ordered lengths through dense_of_rank
+    // What the host is waiting for (the number of units and the size of the image) is queued first and read back into
+    // pinned memory behind an event; the rest of the directory (item starts, source positions, first / last coordinate)
+    // runs while the host takes that round trip.
     const u32* dor = M.vr.dense_of_rank.p;
     u64* tot = scr64b.p + scan_nblocks(V);
+    u64* pin = pinned_words();
+    hipEvent_t ev = event_acquire(dev);
+    if (!pin || !ev) { if (ev) event_release(dev, ev); DCD_FAIL(DCD_E_NOMEM, "pinned read-back buffer / event"); }
     scan_exclusive_f<PermLenF, u64>(PermLenF{dor, us_id.p}, ix.term_unit_start.p, V, scr64b.p, st);
     hipLaunchKernelGGL(k_copy_u64, dim3(1), dim3(1), 0, st, ix.term_unit_start.p + V, (const u64*)tot);
-    scan_exclusive_f<PermLenF, u64>(PermLenF{dor, is_id.p}, ix.term_item_start.p, V, scr64b.p, st);
-    hipLaunchKernelGGL(k_copy_u64, dim3(1), dim3(1), 0, st, ix.term_item_start.p + V, (const u64*)tot);
+    scan_exclusive_f<RecSizeF, u64>(RecSizeF{ix.term_chars.p, ix.term_str_off.p, ix.term_unit_start.p}, rec_off.p, V, scr64b.p, st);
+    hipError_t e1 = hipMemcpyAsync(pin + 8, tot, 8, hipMemcpyDeviceToHost, st);
+    hipError_t e2 = hipMemcpyAsync(pin + 9, d_U, 8, hipMemcpyDeviceToHost, st);
+    hipError_t e3 = hipEventRecord(ev, st);
     DCD_TRY(src_start.alloc(dev, V));
-    hipLaunchKernelGGL(k_perm_src_start, dim3((u32)div_up(V, 256)), dim3(256), 0, st, dor, (const u64*)us_id.p, V, src_start.p);
-    hipLaunchKernelGGL(k_term_first_last_perm, dim3((u32)div_up(V, 256)), dim3(256), 0, st, sorted, (const u64*)is_id.p, dor, V,
-                       h->opts.coord_base, ix.term_first.p, ix.term_last.p);
-    DCD_HIP(hipMemcpyAsync(&U, d_U, 8, hipMemcpyDeviceToHost, st));
+    DevBuf<u64> scr_items;
+    int32_t a1 = scr_items.alloc(dev, scan_scratch_elems(V));
+    if (a1 == DCD_OK) {
+      scan_exclusive_f<PermLenF, u64>(PermLenF{dor, is_id.p}, ix.term_item_start.p, V, scr_items.p, st);
+      hipLaunchKernelGGL(k_copy_u64, dim3(1), dim3(1), 0, st, ix.term_item_start.p + V, (const u64*)(scr_items.p + scan_nblocks(V)));
+      hipLaunchKernelGGL(k_perm_src_start, dim3((u32)div_up(V, 256)), dim3(256), 0, st, dor, (const u64*)us_id.p, V, src_start.p);
+      hipLaunchKernelGGL(k_term_first_last_perm, dim3((u32)div_up(V, 256)), dim3(256), 0, st, sorted, (const u64*)is_id.p, dor, V,
+                         h->opts.coord_base, ix.term_first.p, ix.term_last.p);
+    }
+    hipError_t e4 = (e1 == hipSuccess && e2 == hipSuccess && e3 == hipSuccess) ? hipEventSynchronize(ev) : hipErrorUnknown;
+    event_release(dev, ev);
+    DCD_TRY(a1);
+    if (e4 != hipSuccess) { (void)hipGetLastError(); DCD_FAIL(DCD_E_HIP, "reading back the image size failed"); }
+    rec_total_pin = pin[8];
+    U = pin[9];
   }
-  u64 rec_total = 0;
-  if (V) {
+  u64 rec_total = rec_total_pin;
+  if (V && !idk) {
     scan_exclusive_f<RecSizeF, u64>(RecSizeF{ix.term_chars.p, ix.term_str_off.p, ix.term_unit_start.p}, rec_off.p, V, scr64b.p, st);
     DCD_HIP(hipMemcpyAsync(&rec_total, scr64b.p + scan_nblocks(V), 8, hipMemcpyDeviceToHost, st));
   }
-  DCD_HIP(hipStreamSynchronize(st));
+  if (!idk) DCD_HIP(hipStreamSynchronize(st));
   tr.mark("pack");
   if (idk) DCD_TRY(ix.units.alloc(dev, U ? U : 1));
   u64 max_coord = 0;

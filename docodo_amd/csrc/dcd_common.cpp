@@ -245,6 +245,7 @@ namespace {
 struct HandlePool {
   std::mutex mu;
   std::map<int, std::vector<hipStream_t>> streams;
+  std::map<int, std::vector<hipStream_t>> streams_high;    // highest-priority streams (side chains of small kernels)
   std::map<int, std::vector<hipEvent_t>> events;
 };
 HandlePool& handles() { static HandlePool* h = new HandlePool(); return *h; }   // leaked on purpose (no teardown races)
@@ -267,6 +268,38 @@ void stream_release(int device, hipStream_t st) {
   HandlePool& H = handles();
   std::lock_guard<std::mutex> g(H.mu);
   H.streams[device].push_back(st);
+}
+// A few pinned host words per thread: read-backs into pinned memory are truly asynchronous (a D2H copy into pageable memory
+// holds the calling thread until the data has arrived, i.e. until everything queued before it has run).
+u64* pinned_words() {
+  static thread_local u64* p = nullptr;
+  if (!p) {
+    void* q = nullptr;
+    if (hipHostMalloc(&q, 64 * sizeof(u64), hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    p = (u64*)q;   // (kept for the life of the process)
+  }
+  return p;
+}
+int32_t stream_acquire_high(int device, hipStream_t* out) {
+  {
+    HandlePool& H = handles();
+    std::lock_guard<std::mutex> g(H.mu);
+    auto& v = H.streams_high[device];
+    if (!v.empty()) { *out = v.back(); v.pop_back(); return DCD_OK; }
+  }
+  DCD_HIP(hipSetDevice(device));
+  int least = 0, greatest = 0;
+  if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { (void)hipGetLastError(); least = greatest = 0; }
+  if (const char* e = getenv("DOCODO_SIDE_PRIO")) if (atoi(e) == 0) greatest = 0;       // A/B: normal priority
+  DCD_HIP(hipStreamCreateWithPriority(out, hipStreamNonBlocking, greatest));
+  return DCD_OK;
+}
+void stream_release_high(int device, hipStream_t st) {
+  if (!st) return;
+  if (hipStreamSynchronize(st) != hipSuccess) { (void)hipGetLastError(); (void)hipStreamDestroy(st); return; }
+  HandlePool& H = handles();
+  std::lock_guard<std::mutex> g(H.mu);
+  H.streams_high[device].push_back(st);
 }
 hipEvent_t event_acquire(int device) {
   {

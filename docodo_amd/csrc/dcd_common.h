@@ -71,6 +71,11 @@ size_t dev_pool_cached_bytes(int device);   // bytes held by the cache (released
 // idle HIP streams (hipStreamNonBlocking) and events are recycled per device instead of created per handle
 int32_t stream_acquire(int device, hipStream_t* out);
 void stream_release(int device, hipStream_t st);     // synchronises the stream, then parks it
+// the same for streams of the highest priority: a chain of small kernels that runs beside the big kernels of another
+// stream (the vocabulary sort beside the tuple sort) and must not queue behind them
+u64* pinned_words();     // 64 pinned host words of the calling thread (nullptr on failure): targets of asynchronous read-backs
+int32_t stream_acquire_high(int device, hipStream_t* out);
+void stream_release_high(int device, hipStream_t st);
 hipEvent_t event_acquire(int device);                // nullptr on failure
 void event_release(int device, hipEvent_t e);        // the event must not be pending
 

@@ -436,6 +436,10 @@ inline u64 rs_hist_elems(u64 n, int bits) { return (u64)rs_plan(n).nblk << bits;
 struct RsProbe {
   std::vector<hipEvent_t>* ev = nullptr;  // appended: hist_begin, hist_end, scatter_begin, scatter_end per pass
   int device = 0;
+  // optional: called between the scan of the histogram and the scatter kernel of a pass (the scanned counts are final
+  // there: a caller can queue a read-back of bucket boundaries that completes while the scatter kernel still runs)
+  void (*after_scan)(void* arg, hipStream_t st) = nullptr;
+  void* after_scan_arg = nullptr;
   void rec(hipStream_t st) const {
     if (!ev) return;
     hipEvent_t e = event_acquire(device);
@@ -458,6 +462,7 @@ inline void rs_pass(const uint2* in, uint2* out, const u32* remap, u64 n, int sh
     pr.rec(st);
     u64 ne = (u64)tp.nblk << BITS;
     scan_exclusive<u32, u32>(hist, hist, ne, scan_scratch, st);
+    if (pr.after_scan) pr.after_scan(pr.after_scan_arg, st);
     pr.rec(st);
     if (remap && remap_cache)
       hipLaunchKernelGGL((k_rs_scatter<BITS, true, true>), dim3(tp.nblk), dim3(RSS_THREADS), 0, st, in, remap, n, (u64)0, tp.nblk, shift, hist, out, *sd,

@@ -137,7 +137,7 @@ struct VocabRanks {
 // used slots.  d_hist / scan_scr32 as rs_sort needs them; d_maxlen: one zeroed u32 on the device.
 template <typename CharT>
 inline int32_t vocab_rank(int dev, hipStream_t st, const u64* slots, u64 cap, const u32* slot_excl, u64 V, const TextView<CharT>& tv,
-                          u32* d_hist, u32* scan_scr32, u32* d_maxlen, VocabRanks* out) {
+                          u32* d_hist, u32* scan_scr32, u32* d_maxlen, VocabRanks* out, u32* maxlen_out = nullptr) {
   out->V = V;
   DevBuf<u64> term_word;
   DevBuf<u32> term_slot;
@@ -163,6 +163,7 @@ inline int32_t vocab_rank(int dev, hipStream_t st, const u64* slots, u64 cap, co
   DCD_HIP(hipMemcpyAsync(&maxlen, d_maxlen, 4, hipMemcpyDeviceToHost, st));
   DCD_HIP(hipMemcpyAsync(&n_sym, cbits.p + 2048, 4, hipMemcpyDeviceToHost, st));
   DCD_HIP(hipStreamSynchronize(st));
+  if (maxlen_out) *maxlen_out = maxlen;
   const u32 bits = std::max<u32>(1, log2_ceil((u64)n_sym + 1));     // ranks 0 .. n_sym
   // measured on MI355X (V = 1e5): 8-bit passes over 32-bit chunks 0.35 ms, 9 over 27: 0.35, 10 over 30: 0.56; before (8 or 16 bits per character): 0.40
   // characters per chunk: the choice that needs the fewest radix passes for this vocabulary (every pass is three small
@@ -184,7 +185,8 @@ inline int32_t vocab_rank(int dev, hipStream_t st, const u64* slots, u64 cap, co
   }
   hipLaunchKernelGGL(k_assign_rank, dim3((u32)div_up(V, 256)), dim3(256), 0, st, cur, V, term_slot.p, term_word.p, out->rank_of_slot.p,
                      out->rk_word.p, out->dense_of_rank.p);
-  DCD_HIP(hipStreamSynchronize(st));   // the temporaries above are released when this function returns
+  // (no synchronisation: the temporaries above go back to the stream-ordered device cache, which hands them to another
+  // stream only once this one has passed this point)
   return DCD_OK;
 }
 
