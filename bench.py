@@ -92,6 +92,35 @@ def cpu_baseline(n_docs_sample):
                       % (n_docs_sample, text.size / 1e6, dt)}
 
 
+def inflight_bench(n_threads, steps, text, D, device, T):
+    """EXTRA figure, never `value`: the reference runs MaxDegreeOfParallelism (default 2) index tasks at once, each with a
+    Builder of its own (Index.cs:127, 464-465, Build.cs:452).  Here: n_threads host threads, each building the resident
+    text `steps` times through its own handle (own HIP streams); the VALU-bound tokeniser of one build overlaps the
+    memory-bound sort / pack of the other.  Aggregate text bytes / wall time."""
+    import threading
+    import docodo_amd
+    from docodo_amd import synth
+
+    def worker():
+        for _ in range(steps):
+            b = docodo_amd.Builder(device=device)
+            b.AddUniformPagesDev(text.data_ptr(), D, synth.DOC_BYTES)
+            b.Finish()
+            b.close()
+
+    worker()                                    # warm-up: the second handle's buffers
+    torch.cuda.synchronize()
+    ts = [threading.Thread(target=worker) for _ in range(n_threads)]
+    t0 = time.perf_counter()
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"builders": n_threads, "builds": n_threads * steps, "GB_per_s": round(n_threads * steps * T / 1e9 / dt, 2),
+            "ms_per_build": round(dt / (n_threads * steps) * 1e3, 3),
+            "note": "extra: independent build handles driven from %d host threads (the reference's MaxDegreeOfParallelism); `value` is the one-builder figure" % n_threads}
+
+
 def query_bench(ix, n_single, n_and3, cpu_sample, img=None, lst=None, seed_offset=0):
     """configs[1] query leg (10 k single-term queries over ranks 101..100k, Appendix F) plus a batch of
     3-term AND queries (opt == null -> Dist = 255).  Device time of dcd_query_batch (HIP events), results
@@ -143,6 +172,8 @@ def main():
     ap.add_argument("--cpu-docs", type=int, default=500_000, help="documents in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--queries", type=int, default=10_000, help="single-term queries of configs[1] (0 = skip the query leg)")
     ap.add_argument("--and3", type=int, default=20_000, help="3-term AND queries in the extra query batch")
+    ap.add_argument("--inflight", type=int, default=2, help="extra (untimed for `value`) leg: this many builders at once, as the "
+                    "reference's MaxDegreeOfParallelism index tasks (Index.cs:127, 464-465); 0/1 = skip")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -263,6 +294,8 @@ def main():
         if world > 1:
             out["exchange_merge_ms_per_step_rank0"] = round(float(np.mean(merge_ms[args.warmup:])), 3)
             out["config"]["exchange"] = "RCCL all-to-all of per-term segments (meta, keys, units) to owner = hash(key) % world; dcd_merge_begin overlaps the unit exchange, then dcd_merge_finish"
+        if world == 1 and args.inflight > 1:
+            out["builders_in_flight"] = inflight_bench(args.inflight, args.steps, text, D, local_rank, T)
         if world == 1 and args.cpu_docs > 0:
             out["cpu_baseline"] = cpu_baseline(min(args.cpu_docs, D))
         if world == 1 and args.queries > 0:

@@ -24,6 +24,9 @@ namespace Docodo
         [DllImport(Lib)] public static extern int dcd_last_error(byte* buf, UIntPtr cap);
         [DllImport(Lib)] public static extern int dcd_version();
         [DllImport(Lib)] public static extern int dcd_device_count(out int n);
+        // device-memory cache of the library: Index.Dispose() trims it so that the memory goes back to the driver
+        [DllImport(Lib)] public static extern int dcd_pool_trim(int device);
+        [DllImport(Lib)] public static extern int dcd_pool_cached_bytes(int device, out ulong bytes);
 
         // IndexSequence.cs
         [DllImport(Lib)] public static extern int dcd_seq_encode(ulong* values, UIntPtr n, ushort* outp, UIntPtr cap, out UIntPtr nUnits);

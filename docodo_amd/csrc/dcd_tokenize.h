@@ -207,6 +207,7 @@ __device__ __forceinline__ u32 fmix32(u32 h) {
   return h;
 }
 struct TokHash { u32 idx, tag; };
+#ifdef DCD_HASH2   // the two-lane hash of round 1 (A/B builds)
 struct HashState {
   u32 h1, h2;
   __device__ __forceinline__ void init(u32 len) { h1 = 0x811C9DC5u ^ (len * 0x9E3779B1u); h2 = 0x85EBCA6Bu + len; }
@@ -223,6 +224,27 @@ struct HashState {
     return r;
   }
 };
+#else
+// One 32-bit lane: multiply-xorshift per word, murmur3 finaliser for the slot index; the 16-bit tag is a second
+// multiplicative scramble of the same 32 bits.  The emit kernel is bound by VALU issue and the hash is a quarter of a
+// token's instructions; the table is EXACT whatever the hash (a tag match is always confirmed against the string), so the
+// hash only decides probe lengths and how often the 16-byte compare runs in vain (index and tag share the 32 bits:
+// ~2^-12 of the probes at 2^20 slots instead of 2^-16).
+struct HashState {
+  u32 h;
+  __device__ __forceinline__ void init(u32 len) { h = 0x811C9DC5u ^ (len * 0x9E3779B1u); }
+  __device__ __forceinline__ void add(u32 w) {
+    h = (h ^ w) * 0xCC9E2D51u;
+    h ^= h >> 15;
+  }
+  __device__ __forceinline__ TokHash fin() const {
+    TokHash r;
+    r.idx = fmix32(h);
+    r.tag = (r.idx * 0x9E3779B1u) >> 16;
+    return r;
+  }
+};
+#endif
 
 // word k of the byte string starting at byte offset `off` of a 4-byte aligned array
 __device__ __forceinline__ u32 str_word(const u32* __restrict__ base, u64 off, u32 k, u64 n_bytes) {
