@@ -22,6 +22,14 @@ constexpr u32 MAX_CODE_LEN = 63;   // explicit index codes (Builder.Add); text t
 #ifndef DCD_CAPDIV
 #define DCD_CAPDIV 256             // first guess of the vocabulary table: one slot per DCD_CAPDIV postings
 #endif
+#ifndef DCD_TK_TPW
+#define DCD_TK_TPW 1               // tiles per wave of k_tok_emit (measured: 2 / 4 / 8 tiles with the next tile's characters
+                                   // prefetched take 1.67 / 1.88 / 1.73 ms against 1.58 -- one tile per wave and many waves win)
+#endif
+constexpr u32 TK_TPW = DCD_TK_TPW;
+#ifndef DCD_TK_WPE
+#define DCD_TK_WPE 8               // waves per SIMD the emit kernel is compiled for (register budget)
+#endif
 #ifndef DCD_HOT_SAMPLE_TILES
 #define DCD_HOT_SAMPLE_TILES 1024
 #endif
@@ -44,24 +52,35 @@ __global__ __launch_bounds__(TK_THREADS) void k_tok_count(const CharT* __restric
 }
 
 template <typename CharT>
-__global__ __launch_bounds__(TK_THREADS) void k_tok_emit(const CharT* __restrict__ text, TokParams P, CharTables16 tab,
+__global__ __launch_bounds__(TK_THREADS, DCD_TK_WPE) void k_tok_emit(const CharT* __restrict__ text, TokParams P, CharTables16 tab,
                                                         TextView<CharT> tv, VocabTable vt, const u64* __restrict__ tile_off,
                                                         uint2* __restrict__ tuples, u64 n_tiles, u32 stride, u32* __restrict__ tile_cnt,
                                                         u64 tile0, u32* __restrict__ sample_cnt, u32 sample_mask) {
   // stride != 0: no counting pass ran; the tile's tuples go to tuples[tile * stride ...] and their number to tile_cnt
   // (the first sort pass compacts, RsStrided in dcd_sort.h).  stride == 0: dense output at tile_off[tile].
   // The launch covers the tiles [tile0, n_tiles) (see the seed launch in build_phase1).
+  // A wave owns TK_TPW consecutive tiles (1 by default); with more than one it fetches the next tile's characters before it
+  // works on the current one.  That did NOT pay (see DCD_TK_TPW): the register cost of the loop takes more occupancy
+  // than the prefetch hides latency.
   __shared__ TokLds<CharT, true> SW[TK_WAVES];
-  const u64 tile = tile0 + (u64)blockIdx.x * TK_WAVES + (threadIdx.x >> 6);
-  if (tile >= n_tiles) return;
+  const u64 tile_first = tile0 + ((u64)blockIdx.x * TK_WAVES + (threadIdx.x >> 6)) * TK_TPW;
+  if (tile_first >= n_tiles) return;
+  TokLds<CharT, true>& S = SW[threadIdx.x >> 6];
+  const u32 lane = lane_id();
+  Chunk<CharT> nxt;
+  nxt.fetch(text, tile_lane_g0(tile_first), P.n_chars, tile_inside(tile_first, P.n_chars));
+#pragma unroll 1
+  for (u32 tw = 0; tw < TK_TPW; tw++) {
+  const u64 tile = tile_first + tw;
+  if (tile >= n_tiles) break;
+  Chunk<CharT> cur = nxt;
+  if (tw + 1 < TK_TPW && tile + 1 < n_tiles) nxt.fetch(text, tile_lane_g0(tile + 1), P.n_chars, tile_inside(tile + 1, P.n_chars));
   // every (sample_mask + 1)-th tile counts its tokens per vocabulary slot: the frequency sample behind the hot / cold
   // split of the tuple sort (build_phase2)
   const bool sampled = sample_cnt != nullptr && ((u32)tile & sample_mask) == 0u;
-  TokLds<CharT, true>& S = SW[threadIdx.x >> 6];
-  const u32 lane = lane_id();
   u32 keep;
   u64 bnd;
-  tokenize_chunk<CharT, true>(text, P, tab, tile, S, &keep, &bnd);
+  tokenize_chunk<CharT, true>(text, P, tab, tile, S, &keep, &bnd, &cur);
   const u32 mine = (u32)__builtin_popcount(keep);
   const u32 incl = wave_scan_incl(mine);
   const u32 total = __shfl(incl, 63, 64);
@@ -129,6 +148,8 @@ __global__ __launch_bounds__(TK_THREADS) void k_tok_emit(const CharT* __restrict
 #endif
     tuples[obase + k] = make_uint2(slot, coord_of(gpos));
     if (sampled && slot != 0xFFFFFFFFu) atomicAdd(&sample_cnt[slot], 1u);
+  }
+  wave_sync();                        // the next tile overwrites the wave's LDS slice
   }
 }
 
@@ -1074,12 +1095,12 @@ static int32_t build_phase1(dcd_build* h, bool codes_mode) {
       static const u64 seed_tiles = getenv("DOCODO_TOK_SEED_TILES") ? strtoull(getenv("DOCODO_TOK_SEED_TILES"), nullptr, 10) : 256;
       const u64 n_seed = n_tiles > 2 * seed_tiles ? seed_tiles : 0;   // small builds: one launch
       if (n_seed) {   // (not a DCD_K_TOK_EMIT probe: per-launch averages are quoted for the main launch)
-        hipLaunchKernelGGL((k_tok_emit<CharT>), dim3((u32)div_up(n_seed, TK_WAVES)), dim3(TK_THREADS), 0, st, text, P, tab, tv, vt,
+        hipLaunchKernelGGL((k_tok_emit<CharT>), dim3((u32)div_up(n_seed, TK_WAVES * TK_TPW)), dim3(TK_THREADS), 0, st, text, P, tab, tv, vt,
                            M.tile_off.p, M.tupA.p, n_seed, M.stride, M.tile_cnt.p, (u64)0, sample_cnt.p, sample_mask);
       }
       probes.begin(DCD_K_TOK_EMIT);
       if (n_tiles > n_seed)
-        hipLaunchKernelGGL((k_tok_emit<CharT>), dim3((u32)div_up(n_tiles - n_seed, TK_WAVES)), dim3(TK_THREADS), 0, st, text, P, tab, tv, vt,
+        hipLaunchKernelGGL((k_tok_emit<CharT>), dim3((u32)div_up(n_tiles - n_seed, TK_WAVES * TK_TPW)), dim3(TK_THREADS), 0, st, text, P, tab, tv, vt,
                            M.tile_off.p, M.tupA.p, n_tiles, M.stride, M.tile_cnt.p, n_seed, sample_cnt.p, sample_mask);
       probes.end();
 #if defined(DCD_DIAG_TOK)
@@ -1089,7 +1110,7 @@ static int32_t build_phase1(dcd_build* h, bool codes_mode) {
         probes.collect(msa, nla);
         fprintf(stderr, "DIAG_TOK mode 6: first launch %.3f ms\n", msa[DCD_K_TOK_EMIT]);
         probes.begin(DCD_K_TOK_EMIT);
-        hipLaunchKernelGGL((k_tok_emit<CharT>), dim3((u32)div_up(n_tiles, TK_WAVES)), dim3(TK_THREADS), 0, st, text, P, tab, tv, vt,
+        hipLaunchKernelGGL((k_tok_emit<CharT>), dim3((u32)div_up(n_tiles, TK_WAVES * TK_TPW)), dim3(TK_THREADS), 0, st, text, P, tab, tv, vt,
                            M.tile_off.p, M.tupA.p, n_tiles, M.stride, M.tile_cnt.p, (u64)0, sample_cnt.p, sample_mask);
         probes.end();
       }

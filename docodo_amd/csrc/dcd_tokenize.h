@@ -109,7 +109,13 @@ struct Chunk<u8> {
   u32 w[NW];
   u32 L, D;
   // `inside`: the whole staged span of the tile lies inside the text (workgroup-uniform) -> no guards
-  __device__ __forceinline__ void load(const u8* __restrict__ text, int64_t g0, u64 n_chars, const CharTables16&, bool inside) {
+  __device__ __forceinline__ void load(const u8* __restrict__ text, int64_t g0, u64 n_chars, const CharTables16& tab, bool inside) {
+    fetch(text, g0, n_chars, inside);
+    classify(tab);
+  }
+  // fetch: the raw characters (a kernel that walks several tiles issues the next tile's fetch before it works on the
+  // current one); classify: lower-casing + class masks
+  __device__ __forceinline__ void fetch(const u8* __restrict__ text, int64_t g0, u64 n_chars, bool inside) {
     if (inside || (g0 >= 0 && (u64)g0 + TK_CPT <= n_chars)) {
       uint4 v = *reinterpret_cast<const uint4*>(text + g0);
       w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
@@ -125,6 +131,8 @@ struct Chunk<u8> {
         w[k] = x;
       }
     }
+  }
+  __device__ __forceinline__ void classify(const CharTables16&) {
     L = D = 0;
     // pure-ASCII waves (the common case) skip the Latin-1 ranges with ONE wave-uniform branch
     if (__any(((w[0] | w[1] | w[2] | w[3]) & 0x80808080u) != 0u)) {
@@ -155,6 +163,10 @@ struct Chunk<u16> {
   u32 w[NW];
   u32 L, D;
   __device__ __forceinline__ void load(const u16* __restrict__ text, int64_t g0, u64 n_chars, const CharTables16& tab, bool inside) {
+    fetch(text, g0, n_chars, inside);
+    classify(tab);
+  }
+  __device__ __forceinline__ void fetch(const u16* __restrict__ text, int64_t g0, u64 n_chars, bool inside) {
     if (inside || (g0 >= 0 && (u64)g0 + TK_CPT <= n_chars)) {
       const uint4* q = reinterpret_cast<const uint4*>(text + g0);
       uint4 a = q[0], b = q[1];
@@ -171,6 +183,8 @@ struct Chunk<u16> {
         w[k] = x;
       }
     }
+  }
+  __device__ __forceinline__ void classify(const CharTables16& tab) {
     L = D = 0;
     // pure-ASCII waves (English text in a C# string) are classified arithmetically, two characters per 32-bit operation,
     // with ONE wave-uniform branch; anything else goes through the Unicode tables (two gathers per character)
@@ -418,9 +432,16 @@ __device__ __forceinline__ int64_t tile_origin(u64 tile) { return (int64_t)(tile
 // After this call: `keep` = 16-bit mask of kept token starts in this lane's chunk (0 for the lanes that
 // only hold context), `bnd` = 64-bit boundary window whose bit 0 is the first character of the chunk.
 // Wave-synchronous: no workgroup barrier.
+// pre: the tile's characters already fetched by the caller (Chunk::fetch at tile_lane_g0), or nullptr.
+__device__ __forceinline__ int64_t tile_lane_g0(u64 tile) { return tile_origin(tile) + (int64_t)lane_id() * TK_CPT; }
+__device__ __forceinline__ bool tile_inside(u64 tile, u64 n_chars) {
+  const int64_t org = tile_origin(tile);
+  return org >= 0 && (u64)org + TK_SPAN <= n_chars;
+}
 template <typename CharT, bool STAGE_TEXT>
 __device__ __forceinline__ void tokenize_chunk(const CharT* __restrict__ text, const TokParams& P, const CharTables16& tab, u64 tile,
-                                               TokLds<CharT, STAGE_TEXT>& S, u32* keep_out, u64* bnd_out) {
+                                               TokLds<CharT, STAGE_TEXT>& S, u32* keep_out, u64* bnd_out,
+                                               Chunk<CharT>* pre = nullptr) {
   const u32 lane = lane_id();
   const int64_t org = tile_origin(tile);
   const bool inside = org >= 0 && (u64)org + TK_SPAN <= P.n_chars;   // wave-uniform
@@ -453,7 +474,8 @@ __device__ __forceinline__ void tokenize_chunk(const CharT* __restrict__ text, c
   u32 Lc, Dc;
   {
     Chunk<CharT> c;
-    c.load(text, g0, P.n_chars, tab, inside);
+    if (pre) c = *pre; else c.fetch(text, g0, P.n_chars, inside);
+    c.classify(tab);
     Lc = c.L; Dc = c.D;
     if (STAGE_TEXT) {
 #pragma unroll
