@@ -15,8 +15,8 @@ constexpr int CODEC_THREADS = 256;
 constexpr int CODEC_ITEMS = DCD_CODEC_ITEMS;
 constexpr int CODEC_TILE = CODEC_THREADS * CODEC_ITEMS;
 #ifndef DCD_PACK_TPB
-#define DCD_PACK_TPB 4
-#endif
+#define DCD_PACK_TPB 1             // measured (round 2): one tile per workgroup compiled for 8 waves / SIMD 0.32 ms; four tiles
+#endif                             // with the next tile prefetched (163 VGPRs, 3 waves / SIMD) 0.42 ms
 constexpr int PACK_TPB = DCD_PACK_TPB;               // tiles per workgroup of k_pack_write
 
 // ---- delta sources for the encoder -----------------------------------------------------------
@@ -117,7 +117,10 @@ __global__ __launch_bounds__(CODEC_THREADS) void k_enc_write(Src src, u64 n, con
 // Same arithmetic as k_enc_write<EncSrcPairs>, but the tile's pairs are first loaded with coalesced
 // 8-byte-per-lane reads into LDS (plus the item before the tile) and the units share that LDS
 // afterwards; every HBM access of the kernel is then a full-width wave access.
-__global__ __launch_bounds__(CODEC_THREADS) void k_pack_write(EncSrcPairs src, u64 n, const u64* __restrict__ partial, u16* __restrict__ out);
+#ifndef DCD_PACK_WPE
+#define DCD_PACK_WPE 8
+#endif
+__global__ __launch_bounds__(CODEC_THREADS, DCD_PACK_WPE) void k_pack_write(EncSrcPairs src, u64 n, const u64* __restrict__ partial, u16* __restrict__ out);
 __global__ __launch_bounds__(CODEC_THREADS) void k_pack_count(EncSrcPairs src, u64 n, u64* __restrict__ partial);   // == k_enc_reduce<EncSrcPairs>
 
 // Encodes n items.  partial: >= div_up(n, CODEC_TILE) + 1 u64 (grand total of units left in

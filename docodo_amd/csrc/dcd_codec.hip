@@ -92,7 +92,7 @@ __global__ __launch_bounds__(CODEC_THREADS) void k_pack_count(EncSrcPairs src, u
 
 // A workgroup writes PACK_TPB consecutive tiles.  The barriers order LDS only and the pairs of the next tile are fetched
 // into registers while the current one is encoded, so that loads and stores stay in flight across tiles.
-__global__ __launch_bounds__(CODEC_THREADS) void k_pack_write(EncSrcPairs src, u64 n, const u64* __restrict__ partial, u16* __restrict__ out) {
+__global__ __launch_bounds__(CODEC_THREADS, DCD_PACK_WPE) void k_pack_write(EncSrcPairs src, u64 n, const u64* __restrict__ partial, u16* __restrict__ out) {
   __shared__ u32 lds[CODEC_THREADS / 64];
   // pairs are read back in blocked order (lane t reads elements 8t .. 8t+8): one element of padding per
   // 8 keeps those 64-bit LDS reads conflict-free (stride 72 B instead of 64 B)
