@@ -8,6 +8,7 @@
 #include <memory>
 
 #include <functional>
+#include <thread>
 
 #include "dcd_build_int.h"
 #include "dcd_codec.h"
@@ -841,6 +842,9 @@ struct BuildMid {
   DevBuf<u64> slots;
   DevBuf<u32> d_flags, slot_excl, scan_scr32, d_hist;
   VocabRanks vr;
+  VocabPrep vprep;                  // id-keyed builds: first half of the vocabulary finalisation, run at the end of phase 1
+  bool vprep_done = false;
+  u32 voc_maxlen = 0, voc_nsym = 0;
   DevBuf<u64> d_page_end;
   DevBuf<u16> word_chars;           // the distinct words in ordinal order
   DevBuf<u32> word_str_off;
@@ -892,15 +896,20 @@ struct Probes {
 }  // namespace
 
 // Vocabulary: compact, sort the word strings ordinally, materialise them (ordinal order).  Runs on stream `vs` (the build's
-// own stream, or a second one beside the tuple sort) and returns with `vs` drained.
+// own stream, or a second one beside the tuple sort) and returns with `vs` drained -- or, for id-keyed builds, with the work
+// queued (see below).
 template <typename CharT>
 static int32_t build_vocab(dcd_build* h, BuildMid& M, hipStream_t vs, const TextView<CharT>& tv, u32* d_hist, u32* scan_scr32) {
   const int dev = h->device;
   const u64 cap = 1ull << M.cap_log2, V = M.V;
   // ONE host round trip inside (the longest key and the alphabet size decide the radix passes); the key pool is sized for
   // V keys of the longest length, so that the total needs no round trip of its own
-  u32 maxlen = 0;
-  DCD_TRY(vocab_rank<CharT>(dev, vs, M.slots.p, cap, M.slot_excl.p, V, tv, d_hist, scan_scr32, M.d_flags.p + 1, &M.vr, &maxlen));
+  // (id-keyed builds ran the first half and fetched both parameters at the end of phase 1: nothing in here blocks then,
+  // and the function returns with the work queued, not done)
+  u32 maxlen = M.voc_maxlen;
+  const bool queued_only = M.vprep_done;
+  if (queued_only) DCD_TRY(vocab_sort<CharT>(dev, vs, cap, V, tv, M.vprep, M.voc_maxlen, M.voc_nsym, d_hist, scan_scr32, &M.vr));
+  else DCD_TRY(vocab_rank<CharT>(dev, vs, M.slots.p, cap, M.slot_excl.p, V, tv, d_hist, scan_scr32, M.d_flags.p + 1, &M.vr, &maxlen));
   DCD_TRY(M.word_str_off.alloc(dev, V + 1));
   DCD_TRY(M.word_chars.alloc(dev, V * (u64)maxlen + 1));
   u32 total_chars = 0;
@@ -910,12 +919,14 @@ static int32_t build_vocab(dcd_build* h, BuildMid& M, hipStream_t vs, const Text
     hipLaunchKernelGGL(k_copy_u32, dim3(1), dim3(1), 0, vs, M.word_str_off.p + V, (const u32*)tot);
     hipLaunchKernelGGL((k_term_strings<CharT>), dim3((u32)div_up(V, 256)), dim3(256), 0, vs, M.vr.rk_word.p, V, M.word_str_off.p, tv,
                        M.word_chars.p);
-    DCD_HIP(hipMemcpyAsync(&total_chars, tot, 4, hipMemcpyDeviceToHost, vs));
+    if (!queued_only) DCD_HIP(hipMemcpyAsync(&total_chars, tot, 4, hipMemcpyDeviceToHost, vs));
   } else {
     DCD_HIP(hipMemsetAsync(M.word_str_off.p, 0, 4, vs));
   }
-  DCD_HIP(hipStreamSynchronize(vs));
-  M.total_chars = total_chars;
+  if (!queued_only) {
+    DCD_HIP(hipStreamSynchronize(vs));
+    M.total_chars = total_chars;
+  }
   return DCD_OK;
 }
 
@@ -1158,19 +1169,34 @@ static int32_t build_phase1(dcd_build* h, bool codes_mode) {
       const u64* total = hot_scr.p + scan_nblocks(cap);
       hipLaunchKernelGGL(k_dense_table, dim3((u32)div_up(cap, 256)), dim3(256), 0, st, (const u64*)M.slots.p, (const u32*)sample_cnt.p,
                          (const u32*)theta, (const u64*)hot_excl.p, total, cap, M.slot_excl.p);
-      if (last_round) DCD_TRY(stop_timers());
+      if (last_round) {
+        // first half of the vocabulary finalisation here, so that its two parameters come back with this round trip and
+        // phase 2 can queue the ordinal sort without ever blocking (V itself is still on the device: bound = cap / 2 + 1)
+        DCD_TRY(vocab_prepare<CharT>(dev, st, M.slots.p, cap, M.slot_excl.p, cap / 2 + 1, tv, M.d_flags.p + 1, &M.vprep, (const u32*)total));
+        DCD_HIP(hipMemcpyAsync(&M.voc_nsym, M.vprep.d_nsym, 4, hipMemcpyDeviceToHost, st));
+        M.vprep_done = true;
+        DCD_TRY(stop_timers());
+      }
       u64 tot64 = 0;
       DCD_HIP(hipMemcpyAsync(flags, M.d_flags.p, 16, hipMemcpyDeviceToHost, st));
       DCD_HIP(hipMemcpyAsync(&tot64, total, 8, hipMemcpyDeviceToHost, st));
       DCD_HIP(hipStreamSynchronize(st));
+      M.voc_maxlen = flags[1];
       v32 = (u32)tot64;
       n_hot = (u32)(tot64 >> 32);
     } else {
       scan_exclusive_f<SlotUsed, u32>(SlotUsed{M.slots.p}, M.slot_excl.p, cap, M.scan_scr32.p, st);
-      if (last_round) DCD_TRY(stop_timers());
+      if (last_round) {
+        DCD_TRY(vocab_prepare<CharT>(dev, st, M.slots.p, cap, M.slot_excl.p, cap / 2 + 1, tv, M.d_flags.p + 1, &M.vprep,
+                                     (const u32*)(M.scan_scr32.p + scan_nblocks(cap))));
+        DCD_HIP(hipMemcpyAsync(&M.voc_nsym, M.vprep.d_nsym, 4, hipMemcpyDeviceToHost, st));
+        M.vprep_done = true;
+        DCD_TRY(stop_timers());
+      }
       DCD_HIP(hipMemcpyAsync(flags, M.d_flags.p, 16, hipMemcpyDeviceToHost, st));
       DCD_HIP(hipMemcpyAsync(&v32, M.scan_scr32.p + scan_nblocks(cap), 4, hipMemcpyDeviceToHost, st));
       DCD_HIP(hipStreamSynchronize(st));
+      M.voc_maxlen = flags[1];
     }
     V = v32;
     if (flags[0] || V * 2 > cap) { cap_log2 += 2; continue; }  // overflow or load > 0.5: rebuild larger
@@ -1198,6 +1224,7 @@ static int32_t build_phase1(dcd_build* h, bool codes_mode) {
   M.n_hot = (M.id_keys && n_hot && V > 4ull * n_hot) ? n_hot : 0;
   DCD_TRY(M.d_hist.alloc(dev, (u64)RS_MAX_BLOCKS << 10));
   if (!M.id_keys) {
+    if (M.vprep_done) { M.vprep_done = false; DCD_HIP(hipMemsetAsync(M.d_flags.p + 1, 0, 4, st)); }   // (V == 0: redone below)
     if (fast_end) DCD_TRY(t_tok.start());     // (V == 0: the timers were stopped in the loop; nothing left to measure)
     if (fast_end) DCD_TRY(t_tok.stop());
     DCD_TRY(t_voc.start());
@@ -1351,38 +1378,49 @@ static int32_t build_phase2(dcd_build* h) {
   }
 
   // ---- id-keyed builds: the vocabulary on a second (high-priority) stream, beside the tuple sort ------------------
-  // The host blocks in here (the chain has host round trips of its own), so it is called once the main stream has
-  // been given enough work: behind the first radix pass of a hot / cold build (the pass takes longer than the chain, and
-  // the host needs the size of the cold region before it can queue the rest), else behind the whole sort + pack.
+  // Phase 1 ran the first half and fetched the two host-side parameters, so the whole chain (~30 small kernels) is queued
+  // here without blocking; `ev_side` marks its end.  The main stream waits for that event in front of the scatter kernel of
+  // pass A (hot / cold builds): the chain runs beside the histogram kernel, but the scatter kernel fills the LDS of every CU
+  // for a millisecond and small kernels that need LDS would wait behind it (measured: the chain then takes 1.1-1.5 ms
+  // instead of 0.5 and slows the scatter kernel by 0.1 ms).  Without the split the wait sits in front of the unit copy.
   DevBuf<u32> side_hist, side_scr;
   hipStream_t vs = nullptr;
-  struct SideGuard {                   // the side stream goes back to the cache (drained) however this function is left
-    int dev; hipStream_t* s;
-    ~SideGuard() { if (*s) { stream_release_high(dev, *s); *s = nullptr; } }
-  } side_guard{dev, &vs};
-  float ms_voc_side = 0.f;
-  bool vocab_done = false;
-  auto run_vocab_side = [&]() -> int32_t {
-    vocab_done = true;
+  hipEvent_t ev_side = nullptr;
+  EvTimer t_vs;
+  struct SideGuard {                   // stream and event go back to their caches (drained) however this function is left
+    int dev; hipStream_t* s; hipEvent_t* e;
+    ~SideGuard() {
+      if (*s) { stream_release_high(dev, *s); *s = nullptr; }
+      if (*e) { event_release(dev, *e); *e = nullptr; }
+    }
+  } side_guard{dev, &vs, &ev_side};
+  bool side_waited = false;
+  auto queue_vocab_side = [&]() -> int32_t {
     DCD_TRY(stream_acquire_high(dev, &vs));
+    ev_side = event_acquire(dev);
+    if (!ev_side) DCD_FAIL(DCD_E_HIP, "hipEventCreate failed");
     StreamScope ss_v(vs);              // allocations below belong to the side stream
     TextView<CharT> tv;
     tv.text = (const CharT*)h->text_dev; tv.n_chars = h->n_chars; tv.pool = (const CharT*)M.d_pool_raw.p; tv.n_pool = M.n_pool;
     tv.tab = CharTables16{nullptr, nullptr};
     if (sizeof(CharT) == 2) DCD_TRY(get_char_tables16(dev, &tv.tab));
-    DCD_TRY(side_hist.alloc(dev, (u64)RS_MAX_BLOCKS << 10));     // (the tuple sort is using M.d_hist / M.scan_scr32 right now)
+    DCD_TRY(side_hist.alloc(dev, (u64)RS_MAX_BLOCKS << 10));     // (the tuple sort is using M.d_hist / M.scan_scr32)
     DCD_TRY(side_scr.alloc(dev, scan_scratch_elems((u64)RS_MAX_BLOCKS << 10) + scan_scratch_elems(V) + 8));
-    EvTimer t_vs;
     DCD_TRY(t_vs.init(vs, dev));
     DCD_TRY(t_vs.start());
     DCD_TRY(build_vocab<CharT>(h, M, vs, tv, side_hist.p, side_scr.p));
     DCD_TRY(t_vs.stop());
-    DCD_HIP(hipStreamSynchronize(vs));
-    ms_voc_side = t_vs.ms();
-    // build_vocab returned with the side stream drained: its results are visible to the main stream from here on
-    tr.mark("vocab-side");
+    DCD_HIP(hipEventRecord(ev_side, vs));
     return DCD_OK;
   };
+  auto wait_vocab_side = [&]() -> int32_t {   // queues the chain (if that has not happened yet) and orders the main stream
+    if (side_waited) return DCD_OK;           // behind it; no host blocking
+    side_waited = true;
+    if (!ev_side) DCD_TRY(queue_vocab_side());
+    DCD_HIP(hipStreamWaitEvent(st, ev_side, 0));
+    return DCD_OK;
+  };
+  if (idk && !M.vprep_done) DCD_FAIL(DCD_E_STATE, "id-keyed build without the prepared vocabulary");
 
   // ---- 4. sort the tuples by key (stable; explicit postings first need coordinate order) ----
   uint2* sorted = a;
@@ -1429,10 +1467,9 @@ static int32_t build_phase2(dcd_build* h) {
       if (!pin) DCD_FAIL(DCD_E_NOMEM, "hipHostMalloc failed");
       nh.src = M.d_hist.p + (u64)hot_n * tp.nblk; nh.dst = (u32*)pin; nh.ev = event_acquire(dev); nh.status = DCD_OK;
       if (!nh.ev) DCD_FAIL(DCD_E_HIP, "hipEventCreate failed");
-      // ... and the vocabulary chain runs right there, beside the histogram kernel: the scatter kernel of pass A fills the
-      // LDS of every CU for a millisecond, and small kernels that need LDS would wait behind it (measured: the chain then
-      // takes 1.1-1.5 ms instead of 0.5 and slows the scatter kernel by 0.1 ms)
-      std::function<int32_t()> side_fn = run_vocab_side;
+      // ... and the vocabulary chain is queued right there, behind the histogram kernel it is to run beside, and the main
+      // stream ordered behind it (see queue_vocab_side)
+      std::function<int32_t()> side_fn = wait_vocab_side;
       nh.side = &side_fn; nh.side_status = DCD_OK;
       RsProbe rpa = rp;
       rpa.after_scan_arg = &nh;
@@ -1527,7 +1564,7 @@ static int32_t build_phase2(dcd_build* h) {
   DCD_TRY(t_pack.stop());
 
   // ---- 5b. id-keyed without the hot / cold split: the vocabulary now, while the main stream works through sort + pack
-  if (idk && !vocab_done) DCD_TRY(run_vocab_side());
+  if (idk) DCD_TRY(wait_vocab_side());
   DevBuf<u64> src_start;               // [V] first unit (in units_id) of the term with rank r
 
   // ---- 6. keys + ".index" image -----------------------------------------------------------------
@@ -1622,7 +1659,10 @@ static int32_t build_phase2(dcd_build* h) {
   s.n_chars = h->n_chars; s.n_pages = h->pages.n_pages(); s.n_docs = h->pages.n_docs();
   s.n_postings = N; s.n_terms = V; s.n_units = U; s.max_coord = max_coord;
   s.index_bytes = h->image_bytes; s.list_bytes = 0;  // the list image is generated on demand
-  if (idk) { M.ms_voc = ms_voc_side; M.ms_kernel[DCD_K_VOCAB_SORT] += ms_voc_side; M.n_launch[DCD_K_VOCAB_SORT]++; }   // (overlapped with the sort)
+  if (idk) {   // (side-stream time, overlapped with the sort; the final synchronisation of the main stream covered its end)
+    const float ms_voc_side = t_vs.ms();
+    M.ms_voc = ms_voc_side; M.ms_kernel[DCD_K_VOCAB_SORT] += ms_voc_side; M.n_launch[DCD_K_VOCAB_SORT]++;
+  }
   s.ms_tokenize = M.ms_tok; s.ms_vocab = M.ms_voc; s.ms_sort = t_sort.ms(); s.ms_pack = t_pack.ms(); s.ms_image = t_img.ms();
   s.ms_total = M.ms_total + t_all.ms();
   s.sort_passes = (u32)passes; s.vocab_capacity_log2 = M.cap_log2;

@@ -165,8 +165,11 @@ inline RsTilePlan rs_tile_plan(u64 n_tiles) {
 #ifndef DCD_RS_TU
 #define DCD_RS_TU 4
 #endif
+#ifndef DCD_RSH_WPE
+#define DCD_RSH_WPE 1
+#endif
 template <int BITS, bool CACHE>
-__global__ __launch_bounds__(RS_THREADS) void k_rs_hist_strided(const uint2* __restrict__ in, RsStrided sd, const u32* __restrict__ remap,
+__global__ __launch_bounds__(RS_THREADS, DCD_RSH_WPE) void k_rs_hist_strided(const uint2* __restrict__ in, RsStrided sd, const u32* __restrict__ remap,
                                                                u32 tpb, u32 nblk, int shift, u32* __restrict__ hist) {
   constexpr int NB = 1 << BITS;
   __shared__ u32 s_cache[CACHE ? (1 << RC_BITS) : 1];

@@ -14,21 +14,27 @@ struct SlotUsed {
   __device__ __forceinline__ u32 operator()(u64 i) const { return slots[i] != 0 ? 1u : 0u; }
 };
 
+// (n_out: size of the output arrays -- a caller that runs this before it knows V passes a bound; ids beyond it belong to a
+// table that is about to be discarded for being too full)
 static __global__ void k_vocab_compact(const u64* __restrict__ slots, u64 cap, const u32* __restrict__ excl, u64* __restrict__ term_word,
-                                u32* __restrict__ term_slot) {
+                                u32* __restrict__ term_slot, u64 n_out) {
   u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= cap) return;
   u64 w = slots[i];
   if (w) {
     u32 d = excl[i];
-    term_word[d] = w;
-    term_slot[d] = (u32)i;
+    if (d < n_out) {
+      term_word[d] = w;
+      term_slot[d] = (u32)i;
+    }
   }
 }
 // longest key: one atomic per workgroup over the V compacted terms (never one per term: a single
 // address takes ~88 atomics/us on this chip)
-static __global__ __launch_bounds__(256) void k_max_len(const u64* __restrict__ term_word, u64 n, u32* __restrict__ maxlen) {
+// (n_dev != nullptr: the number of terms is still on the device -- the grid covers an upper bound)
+static __global__ __launch_bounds__(256) void k_max_len(const u64* __restrict__ term_word, u64 n, u32* __restrict__ maxlen, const u32* __restrict__ n_dev) {
   __shared__ u32 s[4];
+  if (n_dev) n = *n_dev < n ? *n_dev : n;
   u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   u32 l = i < n ? voc_len(term_word[i]) : 0u;
   l = wave_max(l);
@@ -43,8 +49,10 @@ static __global__ __launch_bounds__(256) void k_max_len(const u64* __restrict__ 
 // preserving, 0 = "past the end"), so a character costs ceil(log2(#distinct + 1)) bits instead of 8 / 16:
 // 6 bits for lower-case ASCII + digits -> five characters per 32-bit chunk.
 template <typename CharT>
-__global__ __launch_bounds__(256) void k_char_used(const u64* __restrict__ term_word, u64 n, TextView<CharT> tv, u32* __restrict__ bitmap) {
+__global__ __launch_bounds__(256) void k_char_used(const u64* __restrict__ term_word, u64 n, TextView<CharT> tv, u32* __restrict__ bitmap,
+                                                   const u32* __restrict__ n_dev) {
   __shared__ u32 s_bits[2048];      // per-workgroup bitmap in LDS; only its non-zero words reach the global one
+  if (n_dev) n = *n_dev < n ? *n_dev : n;
   for (u32 x = threadIdx.x; x < 2048; x += 256) s_bits[x] = 0;
   __syncthreads();
   u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -133,37 +141,49 @@ struct VocabRanks {
   DevBuf<u32> dense_of_rank;  // [V] dense id (position among the used slots) of the term with rank r
 };
 
-// slots[0..cap) is a filled table, slot_excl its exclusive "used" scan (dense ids), V the number of
-// used slots.  d_hist / scan_scr32 as rs_sort needs them; d_maxlen: one zeroed u32 on the device.
+// Vocabulary finalisation in two halves, so that a caller can fetch the two host-side parameters (longest key, alphabet
+// size) with a read-back it makes anyway and then queue the whole sort without blocking:
+//   vocab_prepare: dense arrays of the used slots, longest key, ranked alphabet       (4 small kernels)
+//   vocab_sort:    LSD radix passes over the ranked characters, ranks, dense_of_rank   (no host round trip)
+struct VocabPrep {
+  DevBuf<u64> term_word;      // [V] slot word of the term with dense id d
+  DevBuf<u32> term_slot;      // [V] its slot
+  DevBuf<u32> cbits;          // [2048] used-character bitmap, [2048] = number of used characters
+  DevBuf<u16> crank;          // [65536] character -> rank (0 = unused)
+  const u32* d_maxlen = nullptr;
+  const u32* d_nsym = nullptr;
+};
+// slots[0..cap) is a filled table, slot_excl a bijection used slot -> [0, V) (dense ids), V the number of used slots.
+// d_maxlen: one zeroed u32 on the device.
 template <typename CharT>
-inline int32_t vocab_rank(int dev, hipStream_t st, const u64* slots, u64 cap, const u32* slot_excl, u64 V, const TextView<CharT>& tv,
-                          u32* d_hist, u32* scan_scr32, u32* d_maxlen, VocabRanks* out, u32* maxlen_out = nullptr) {
+// V_dev != nullptr: V is only an upper bound, the true count is read from the device (the caller has not fetched it yet).
+inline int32_t vocab_prepare(int dev, hipStream_t st, const u64* slots, u64 cap, const u32* slot_excl, u64 V, const TextView<CharT>& tv,
+                             u32* d_maxlen, VocabPrep* P, const u32* V_dev = nullptr) {
+  DCD_TRY(P->term_word.alloc(dev, V ? V : 1));
+  DCD_TRY(P->term_slot.alloc(dev, V ? V : 1));
+  DCD_TRY(P->cbits.alloc(dev, 2049));
+  DCD_TRY(P->crank.alloc(dev, 65536));
+  P->d_maxlen = d_maxlen; P->d_nsym = P->cbits.p + 2048;
+  DCD_HIP(hipMemsetAsync(P->cbits.p, 0, 2049 * 4, st));
+  if (!V) return DCD_OK;
+  hipLaunchKernelGGL(k_vocab_compact, dim3((u32)div_up(cap, 256)), dim3(256), 0, st, slots, cap, slot_excl, P->term_word.p, P->term_slot.p, V);
+  hipLaunchKernelGGL(k_max_len, dim3((u32)div_up(V, 256)), dim3(256), 0, st, P->term_word.p, V, d_maxlen, V_dev);
+  hipLaunchKernelGGL((k_char_used<CharT>), dim3((u32)div_up(V, 256)), dim3(256), 0, st, P->term_word.p, V, tv, P->cbits.p, V_dev);
+  hipLaunchKernelGGL(k_char_rank, dim3(1), dim3(1024), 0, st, P->cbits.p, P->crank.p, P->cbits.p + 2048);
+  return DCD_OK;
+}
+// d_hist / scan_scr32 as rs_sort needs them.  Nothing in here blocks the host.
+template <typename CharT>
+inline int32_t vocab_sort(int dev, hipStream_t st, u64 cap, u64 V, const TextView<CharT>& tv, const VocabPrep& P, u32 maxlen, u32 n_sym,
+                          u32* d_hist, u32* scan_scr32, VocabRanks* out) {
   out->V = V;
-  DevBuf<u64> term_word;
-  DevBuf<u32> term_slot;
   DevBuf<uint2> permA, permB;
-  DCD_TRY(term_word.alloc(dev, V ? V : 1));
   DCD_TRY(out->rk_word.alloc(dev, V ? V : 1));
-  DCD_TRY(term_slot.alloc(dev, V ? V : 1));
   DCD_TRY(out->rank_of_slot.alloc(dev, cap));
   DCD_TRY(out->dense_of_rank.alloc(dev, V ? V : 1));
   DCD_TRY(permA.alloc(dev, V ? V : 1));
   DCD_TRY(permB.alloc(dev, V ? V : 1));
   if (!V) return DCD_OK;
-  u32 maxlen = 0, n_sym = 0;
-  DevBuf<u32> cbits;     // [2048] used-character bitmap, [2048] = number of used characters
-  DevBuf<u16> crank;     // [65536]
-  DCD_TRY(cbits.alloc(dev, 2049));
-  DCD_TRY(crank.alloc(dev, 65536));
-  DCD_HIP(hipMemsetAsync(cbits.p, 0, 2049 * 4, st));
-  hipLaunchKernelGGL(k_vocab_compact, dim3((u32)div_up(cap, 256)), dim3(256), 0, st, slots, cap, slot_excl, term_word.p, term_slot.p);
-  hipLaunchKernelGGL(k_max_len, dim3((u32)div_up(V, 256)), dim3(256), 0, st, term_word.p, V, d_maxlen);
-  hipLaunchKernelGGL((k_char_used<CharT>), dim3((u32)div_up(V, 256)), dim3(256), 0, st, term_word.p, V, tv, cbits.p);
-  hipLaunchKernelGGL(k_char_rank, dim3(1), dim3(1024), 0, st, cbits.p, crank.p, cbits.p + 2048);
-  DCD_HIP(hipMemcpyAsync(&maxlen, d_maxlen, 4, hipMemcpyDeviceToHost, st));
-  DCD_HIP(hipMemcpyAsync(&n_sym, cbits.p + 2048, 4, hipMemcpyDeviceToHost, st));
-  DCD_HIP(hipStreamSynchronize(st));
-  if (maxlen_out) *maxlen_out = maxlen;
   const u32 bits = std::max<u32>(1, log2_ceil((u64)n_sym + 1));     // ranks 0 .. n_sym
   // measured on MI355X (V = 1e5): 8-bit passes over 32-bit chunks 0.35 ms, 9 over 27: 0.35, 10 over 30: 0.56; before (8 or 16 bits per character): 0.40
   // characters per chunk: the choice that needs the fewest radix passes for this vocabulary (every pass is three small
@@ -178,16 +198,31 @@ inline int32_t vocab_rank(int dev, hipStream_t st, const u64* slots, u64 cap, co
   uint2* cur = permA.p;
   uint2* other = permB.p;
   for (int c = (int)nchunks - 1; c >= 0; c--) {
-    hipLaunchKernelGGL((k_term_keys<CharT>), dim3((u32)div_up(V, 256)), dim3(256), 0, st, cur, V, term_word.p, tv, (u32)c,
-                       c == (int)nchunks - 1, crank.p, cpc, bits);
+    hipLaunchKernelGGL((k_term_keys<CharT>), dim3((u32)div_up(V, 256)), dim3(256), 0, st, cur, V, P.term_word.p, tv, (u32)c,
+                       c == (int)nchunks - 1, P.crank.p, cpc, bits);
     uint2* res = rs_sort(cur, other, nullptr, V, (int)(cpc * bits), d_hist, scan_scr32, st, nullptr, RsProbe(), VOC_WIDTH);
     if (res != cur) { other = cur; cur = res; }
   }
-  hipLaunchKernelGGL(k_assign_rank, dim3((u32)div_up(V, 256)), dim3(256), 0, st, cur, V, term_slot.p, term_word.p, out->rank_of_slot.p,
+  hipLaunchKernelGGL(k_assign_rank, dim3((u32)div_up(V, 256)), dim3(256), 0, st, cur, V, P.term_slot.p, P.term_word.p, out->rank_of_slot.p,
                      out->rk_word.p, out->dense_of_rank.p);
   // (no synchronisation: the temporaries above go back to the stream-ordered device cache, which hands them to another
   // stream only once this one has passed this point)
   return DCD_OK;
+}
+// both halves with the host round trip in between
+template <typename CharT>
+inline int32_t vocab_rank(int dev, hipStream_t st, const u64* slots, u64 cap, const u32* slot_excl, u64 V, const TextView<CharT>& tv,
+                          u32* d_hist, u32* scan_scr32, u32* d_maxlen, VocabRanks* out, u32* maxlen_out = nullptr) {
+  VocabPrep P;
+  DCD_TRY(vocab_prepare<CharT>(dev, st, slots, cap, slot_excl, V, tv, d_maxlen, &P));
+  u32 maxlen = 0, n_sym = 0;
+  if (V) {
+    DCD_HIP(hipMemcpyAsync(&maxlen, P.d_maxlen, 4, hipMemcpyDeviceToHost, st));
+    DCD_HIP(hipMemcpyAsync(&n_sym, P.d_nsym, 4, hipMemcpyDeviceToHost, st));
+    DCD_HIP(hipStreamSynchronize(st));
+  }
+  if (maxlen_out) *maxlen_out = maxlen;
+  return vocab_sort<CharT>(dev, st, cap, V, tv, P, maxlen, n_sym, d_hist, scan_scr32, out);
 }
 
 }  // namespace dcd
