@@ -1075,6 +1075,13 @@ static int32_t build_phase1(dcd_build* h, bool codes_mode) {
   DevBuf<u32> sample_cnt, hot_hist;           // [cap] / [HOT_BINS + 1] (theta behind the bins)
   DevBuf<u64> hot_excl, hot_scr;
   u32 n_hot = 0;
+  u64* pin = pinned_words();
+  if (!pin) DCD_FAIL(DCD_E_NOMEM, "hipHostMalloc failed");
+  u64* rb_ntok = pin + 16;
+  u64* rb_total = pin + 17;
+  u32* rb_flags = (u32*)(pin + 18);     // 4 words
+  u32* rb_nsym = (u32*)(pin + 20);
+  *rb_ntok = 0; *rb_total = 0; *rb_nsym = 0;
   for (;;) {
     if (cap_log2 > 30) DCD_FAIL(DCD_E_OVERFLOW, "vocabulary does not fit a 2^30-slot table");
     const u64 cap = 1ull << cap_log2;
@@ -1136,7 +1143,7 @@ static int32_t build_phase1(dcd_build* h, bool codes_mode) {
       if (strided) {
         // the tiles' dense offsets and the number of postings, now that the emit kernel has counted
         scan_exclusive<u32, u64>(M.tile_cnt.p, M.tile_off.p, n_tiles, scan_scr64.p, st);
-        DCD_HIP(hipMemcpyAsync(&n_text_tok, scan_scr64.p + scan_nblocks(n_tiles), 8, hipMemcpyDeviceToHost, st));
+        DCD_HIP(hipMemcpyAsync(rb_ntok, scan_scr64.p + scan_nblocks(n_tiles), 8, hipMemcpyDeviceToHost, st));
       }
     }
     if (n_x)
@@ -1145,12 +1152,10 @@ static int32_t build_phase1(dcd_build* h, bool codes_mode) {
     // compaction: dense ids for the used slots
     DCD_TRY(M.slot_excl.alloc(dev, cap));
     DCD_TRY(M.scan_scr32.alloc(dev, std::max<u64>(scan_scratch_elems(cap), scan_scratch_elems((u64)RS_MAX_BLOCKS << 10))));
-    u32 flags[4] = {0, 0, 0, 0};
     u32 v32 = 0;
     if (strided) {
       // maxCoord = coordinate of the last posting added (Build.cs:326): fetched with the counters below, ONE host round trip
       hipLaunchKernelGGL(k_last_strided_coord, dim3(1), dim3(1), 0, st, M.tupA.p, M.tile_cnt.p, n_tiles, M.stride, M.d_flags.p + 2);
-      DCD_HIP(hipMemcpyAsync(&M.last_text_coord, M.d_flags.p + 2, 4, hipMemcpyDeviceToHost, st));
     }
     const bool last_round = fast_end;      // id-keyed builds: phase 1 ends with this round trip (the stage timers stop here)
     auto stop_timers = [&]() -> int32_t {
@@ -1173,15 +1178,14 @@ static int32_t build_phase1(dcd_build* h, bool codes_mode) {
         // first half of the vocabulary finalisation here, so that its two parameters come back with this round trip and
         // phase 2 can queue the ordinal sort without ever blocking (V itself is still on the device: bound = cap / 2 + 1)
         DCD_TRY(vocab_prepare<CharT>(dev, st, M.slots.p, cap, M.slot_excl.p, cap / 2 + 1, tv, M.d_flags.p + 1, &M.vprep, (const u32*)total));
-        DCD_HIP(hipMemcpyAsync(&M.voc_nsym, M.vprep.d_nsym, 4, hipMemcpyDeviceToHost, st));
+        DCD_HIP(hipMemcpyAsync(rb_nsym, M.vprep.d_nsym, 4, hipMemcpyDeviceToHost, st));
         M.vprep_done = true;
         DCD_TRY(stop_timers());
       }
-      u64 tot64 = 0;
-      DCD_HIP(hipMemcpyAsync(flags, M.d_flags.p, 16, hipMemcpyDeviceToHost, st));
-      DCD_HIP(hipMemcpyAsync(&tot64, total, 8, hipMemcpyDeviceToHost, st));
+      DCD_HIP(hipMemcpyAsync(rb_flags, M.d_flags.p, 16, hipMemcpyDeviceToHost, st));
+      DCD_HIP(hipMemcpyAsync(rb_total, total, 8, hipMemcpyDeviceToHost, st));
       DCD_HIP(hipStreamSynchronize(st));
-      M.voc_maxlen = flags[1];
+      const u64 tot64 = *rb_total;
       v32 = (u32)tot64;
       n_hot = (u32)(tot64 >> 32);
     } else {
@@ -1189,15 +1193,22 @@ static int32_t build_phase1(dcd_build* h, bool codes_mode) {
       if (last_round) {
         DCD_TRY(vocab_prepare<CharT>(dev, st, M.slots.p, cap, M.slot_excl.p, cap / 2 + 1, tv, M.d_flags.p + 1, &M.vprep,
                                      (const u32*)(M.scan_scr32.p + scan_nblocks(cap))));
-        DCD_HIP(hipMemcpyAsync(&M.voc_nsym, M.vprep.d_nsym, 4, hipMemcpyDeviceToHost, st));
+        DCD_HIP(hipMemcpyAsync(rb_nsym, M.vprep.d_nsym, 4, hipMemcpyDeviceToHost, st));
         M.vprep_done = true;
         DCD_TRY(stop_timers());
       }
-      DCD_HIP(hipMemcpyAsync(flags, M.d_flags.p, 16, hipMemcpyDeviceToHost, st));
-      DCD_HIP(hipMemcpyAsync(&v32, M.scan_scr32.p + scan_nblocks(cap), 4, hipMemcpyDeviceToHost, st));
+      DCD_HIP(hipMemcpyAsync(rb_flags, M.d_flags.p, 16, hipMemcpyDeviceToHost, st));
+      DCD_HIP(hipMemcpyAsync(rb_total, M.scan_scr32.p + scan_nblocks(cap), 4, hipMemcpyDeviceToHost, st));
       DCD_HIP(hipStreamSynchronize(st));
-      M.voc_maxlen = flags[1];
+      v32 = (u32)*rb_total;
     }
+    // (everything above was read back into pinned words: a copy into pageable memory would hold the host until it has
+    // arrived, i.e. the kernels behind the emit kernel would only be queued once that one has finished)
+    const u32* flags = rb_flags;
+    M.voc_maxlen = flags[1];
+    M.voc_nsym = *rb_nsym;
+    M.last_text_coord = flags[2];
+    if (strided) n_text_tok = *rb_ntok;
     V = v32;
     if (flags[0] || V * 2 > cap) { cap_log2 += 2; continue; }  // overflow or load > 0.5: rebuild larger
     break;
