@@ -53,25 +53,31 @@ LIMITER = {"k_tok_emit": "VALU issue (PMC before the string pool: ~92 % busy, 90
            "k_rs_scatter": "hbm (first pass: fragmented stores of short digit runs)", "k_rs_hist": "hbm + L2 gather (first pass)"}
 
 
+TRAFFIC_FILE = "r02_final_traffic.json"
+
+
 def measured_traffic(kernel, T, N, U):
-    """HBM bytes per launch from the PMC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes,
-    stored in profiles/r01_final_traffic.json; FETCH_SIZE doubled per the gfx950 correction of
-    MI355X_MICROARCH.md).  Only valid for the configuration it was measured on; None otherwise."""
-    path = os.path.join(ROOT, "profiles", "r01_final_traffic.json")
+    """HBM bytes per launch from the PMC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, stored in
+    profiles/r02_final_traffic.json by scripts/traffic_json.py).  FETCH_SIZE counts a streamed read at half its bytes
+    on gfx950 (MI355X_MICROARCH.md, HBM): the streamed part of the kernel's reads (its algorithmic read bytes) is doubled,
+    what it fetches beyond that (table gathers) is taken as counted.  Only valid for the configuration it was measured
+    on; None otherwise."""
+    path = os.path.join(ROOT, "profiles", TRAFFIC_FILE)
     if not os.path.exists(path):
         return None
     tr = json.load(open(path))
     if (tr.get("T"), tr.get("N"), tr.get("U")) != (T, N, U):
         return None
     # names as rocprofv3 prints them (per-launch maxima, i.e. the full-size tuple passes of the radix kernels)
-    names = {"k_rs_scatter": ("k_rs_scatter<",), "k_rs_hist": ("k_rs_hist<",), "k_enc_write": ("k_pack_write",),
-             "k_enc_reduce": ("k_pack_count",), "k_tok_emit": ("k_tok_emit<",), "k_tok_count": ("k_tok_count<",)}
+    names = {"k_rs_scatter": ("k_rs_scatter<",), "k_rs_hist": ("k_rs_hist",), "k_enc_write": ("k_pack_write",),
+             "k_enc_reduce": ("k_pack_count",), "k_tok_emit": ("k_tok_emit<",), "k_tok_count": ("k_tok_count<",),
+             "k_img_units": ("k_img_units",)}
     pref = names.get(kernel, (kernel,))
     hits = [v for n, v in tr["kernels"].items() if n.startswith(pref)]
     if not hits:
         return None
-    k = max(hits, key=lambda v: v["fetch_bytes_x2"] + v["write_bytes"])
-    return int(k["fetch_bytes_x2"] + k["write_bytes"])
+    k = max(hits, key=lambda v: v["traffic_bytes"])
+    return int(k["traffic_bytes"])
 
 
 def cpu_baseline(n_docs_sample):
@@ -276,6 +282,7 @@ def main():
                        "index_bytes": int(img_bytes), "sort_passes": int(passes), "sort": (
                            "by dense vocabulary id, ordinal vocabulary sort on a second stream; %d hot terms (%.1f %% of the postings) final "
                            "after the first radix pass" % (hot_terms, 100.0 * hot_post / max(1, N))) if id_keys else "by ordinal rank",
+                       "hot_postings": int(hot_post),
                        "sharding": "doc-range, global coordinates"},
             "roofline": {"bound": "hbm", "kernel": name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "frac_of_measured_copy": round(achieved / HBM_COPY_GBS, 4),

@@ -147,7 +147,15 @@ __global__ __launch_bounds__(TK_THREADS, DCD_TK_WPE) void k_tok_emit(const CharT
     u32 slot = vt.pool ? vocab_lookup_insert_pooled<CharT>(vt, tv, hs.fin(), len, gpos, wv, word)
                        : vocab_lookup_insert<CharT>(vt, tv, hs.fin(), len, gpos, word);
 #endif
+#if DCD_TOK_NT
+    {
+      typedef u32 u32x2_t __attribute__((ext_vector_type(2)));
+      u32x2_t tv2; tv2.x = slot; tv2.y = coord_of(gpos);
+      __builtin_nontemporal_store(tv2, reinterpret_cast<u32x2_t*>(tuples + obase + k));
+    }
+#else
     tuples[obase + k] = make_uint2(slot, coord_of(gpos));
+#endif
     if (sampled && slot != 0xFFFFFFFFu) atomicAdd(&sample_cnt[slot], 1u);
   }
   wave_sync();                        // the next tile overwrites the wave's LDS slice
