@@ -165,6 +165,10 @@ inline RsTilePlan rs_tile_plan(u64 n_tiles) {
 #ifndef DCD_RS_TU
 #define DCD_RS_TU 4
 #endif
+#ifndef DCD_RS_NT
+#define DCD_RS_NT 1      // pass A reads the tokeniser's tuples with non-temporal loads: they are touched once and would evict the
+                         // 4 MB dense-id table from L2 (measured: histogram 0.77 -> 0.74 ms, scatter 1.36 -> 1.32..1.36)
+#endif
 #ifndef DCD_RSH_WPE
 #define DCD_RSH_WPE 1
 #endif
@@ -199,7 +203,15 @@ __global__ __launch_bounds__(RS_THREADS, DCD_RSH_WPE) void k_rs_hist_strided(con
 #pragma unroll
       for (int k = 0; k < PR; k++) {
         const u32 pi = lane + 64u * k;
+#if DCD_RS_NT
+        if (2 * pi < c[u]) {
+          typedef u32 u32x4_t __attribute__((ext_vector_type(4)));
+          const u32x4_t q = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(tp + pi));
+          kv[u][k] = make_uint4(q.x, q.y, q.z, q.w);
+        } else kv[u][k] = make_uint4(0u, 0u, 0u, 0u);
+#else
         kv[u][k] = 2 * pi < c[u] ? tp[pi] : make_uint4(0u, 0u, 0u, 0u);     // (the second tuple of the last pair may be unused)
+#endif
       }
     }
 #pragma unroll
@@ -300,7 +312,15 @@ __global__ __launch_bounds__(RSS_THREADS) __attribute__((amdgpu_waves_per_eu(DCD
       const u32 j0 = c * 64u;
       const u32 left = ct > j0 ? ct - j0 : 0u;
       vrow[r] = left < 64u ? left : 64u;
+#if DCD_RS_NT
+      if (lane < vrow[r]) {
+        typedef u32 u32x2_t __attribute__((ext_vector_type(2)));
+        const u32x2_t q = __builtin_nontemporal_load(reinterpret_cast<const u32x2_t*>(in + (ta + t) * sd.stride + j0 + lane));
+        item[r] = make_uint2(q.x, q.y);
+      } else item[r] = make_uint2(0xFFFFFFFFu, 0u);
+#else
       item[r] = lane < vrow[r] ? in[(ta + t) * sd.stride + j0 + lane] : make_uint2(0xFFFFFFFFu, 0u);
+#endif
       // next row: the next 64 tuples of this tile, else the first ones of the next non-empty tile
       if (left > 64u) {
         c++;
@@ -426,6 +446,13 @@ __global__ __launch_bounds__(RSS_THREADS) __attribute__((amdgpu_waves_per_eu(DCD
     for (u32 j = threadIdx.x; j < tile_n; j += RSS_THREADS) {
       uint2 it = s_tile[j];
       u32 d = (it.x >> shift) & (NB - 1);
+#if DCD_RS_NT >= 2
+      if (STRIDED) {
+        typedef u32 u32x2_t __attribute__((ext_vector_type(2)));
+        u32x2_t q; q.x = it.x; q.y = it.y;
+        __builtin_nontemporal_store(q, reinterpret_cast<u32x2_t*>(out + (u64)(u32)(s_off[d] + j)));
+      } else
+#endif
       out[(u64)(u32)(s_off[d] + j)] = it;
     }
     // no barrier here: phase A of the next tile touches only the wave's own s_cnt row, and everything that phase D
