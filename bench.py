@@ -48,9 +48,11 @@ def algorithmic_bytes(kernel, T, N, U, n_launch=1, n_hot=0, id_keys=False):
 
 # what actually limits each kernel (PMC runs): the roofline above prices every kernel against HBM, as the
 # contract asks, but the tokeniser kernels are bound by VALU issue, not by bytes
-LIMITER = {"k_tok_emit": "VALU issue (PMC before the string pool: ~92 % busy, 906 wave-instructions per 944-character wave tile) + L2 / Infinity Cache gathers",
+LIMITER = {"k_tok_emit": "VALU issue (profiles/r02_pmc_build.txt: 609 VALU + 279 SALU wave-instructions per 944-character wave tile; "
+                         "SQ_ACTIVE_INST_VALU = 79 % of the kernel's busy cycles per SIMD) + vocabulary gathers that miss the XCD's L2",
            "k_tok_count": "VALU issue (PMC: ~100 % busy; 280 wave-instructions per wave tile)",
-           "k_rs_scatter": "hbm (first pass: fragmented stores of short digit runs)", "k_rs_hist": "hbm + L2 gather (first pass)"}
+           "k_rs_scatter": "VALU issue (ballot ranking, ~50 % busy) + hbm (pass A: slot -> dense id remap, partial lines of short digit runs)",
+           "k_rs_hist": "hbm + L2 gathers of the slot -> dense id remap (pass A)"}
 
 
 TRAFFIC_FILE = "r02_final_traffic.json"

@@ -256,6 +256,7 @@ int32_t dcd_index_n_docs(dcd_index* h, uint64_t* n) { if (!h || !n) DCD_FAIL(DCD
 
 int32_t dcd_index_find(dcd_index* h, const uint16_t* key, size_t len, uint32_t* term) {
   if (!h || (!key && len) || !term) DCD_FAIL(DCD_E_BADARG, "dcd_index_find: NULL argument");
+  DCD_TRY(index_fetch_host(h->ix));     // (host mirrors of a merged index are fetched on first use)
   const DeviceIndex& ix = h->ix;
   // binary search over the ordinally sorted keys (String.CompareOrdinal = UTF-16 code-unit order)
   u64 a = 0, b = ix.n_terms;
@@ -276,6 +277,7 @@ int32_t dcd_index_find(dcd_index* h, const uint16_t* key, size_t len, uint32_t* 
 int32_t dcd_index_key(dcd_index* h, uint32_t term, uint16_t* out, size_t cap, size_t* len) {
   if (!h || !len) DCD_FAIL(DCD_E_BADARG, "dcd_index_key: NULL argument");
   if (term >= h->ix.n_terms) DCD_FAIL(DCD_E_BADARG, "term %u out of range", term);
+  DCD_TRY(index_fetch_host(h->ix));
   size_t n = h->ix.h_term_str_off[term + 1] - h->ix.h_term_str_off[term];
   *len = n;
   if (!out || cap < n) return DCD_E_OVERFLOW;
@@ -286,6 +288,7 @@ int32_t dcd_index_key(dcd_index* h, uint32_t term, uint16_t* out, size_t cap, si
 int32_t dcd_index_get(dcd_index* h, uint32_t term, uint16_t* out, size_t cap, size_t* n_units) {
   if (!h || !n_units) DCD_FAIL(DCD_E_BADARG, "dcd_index_get: NULL argument");
   if (term >= h->ix.n_terms) DCD_FAIL(DCD_E_BADARG, "term %u out of range", term);
+  DCD_TRY(index_fetch_host(h->ix));
   u64 a = h->ix.h_term_unit_start[term], b = h->ix.h_term_unit_start[term + 1];
   *n_units = (size_t)(b - a);
   if (!out || cap < b - a) return DCD_E_OVERFLOW;
@@ -297,6 +300,7 @@ int32_t dcd_index_get(dcd_index* h, uint32_t term, uint16_t* out, size_t cap, si
 int32_t dcd_index_term_count(dcd_index* h, uint32_t term, uint64_t* n_values) {
   if (!h || !n_values) DCD_FAIL(DCD_E_BADARG, "dcd_index_term_count: NULL argument");
   if (term >= h->ix.n_terms) DCD_FAIL(DCD_E_BADARG, "term %u out of range", term);
+  DCD_TRY(index_fetch_host(h->ix));
   *n_values = h->ix.h_term_item_start[term + 1] - h->ix.h_term_item_start[term];
   return DCD_OK;
 }
@@ -428,6 +432,7 @@ int32_t dcd_index_close_words(dcd_index* h, const uint16_t* word, size_t len, ui
 // equals), the first n.  Keys are sorted ordinally, so the candidates are one contiguous range of the dictionary.
 int32_t dcd_index_suggest(dcd_index* h, const uint16_t* prefix, size_t len, uint32_t n, uint32_t* out_terms, uint32_t* n_out) {
   if (!h || (!prefix && len) || !out_terms || !n_out) DCD_FAIL(DCD_E_BADARG, "dcd_index_suggest: NULL argument");
+  DCD_TRY(index_fetch_host(h->ix));
   const DeviceIndex& ix = h->ix;
   auto cmp_prefix = [&](u64 m) -> int {   // key m vs prefix, over the first len units
     const u16* s = ix.h_term_chars.data() + ix.h_term_str_off[m];

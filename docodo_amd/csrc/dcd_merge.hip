@@ -300,11 +300,13 @@ static int32_t export_plan_impl(const void* h, DeviceIndex* ix, hipStream_t st, 
     if (sorted == pa.p) ep->perm = std::move(pa); else ep->perm = std::move(pb);
     hipLaunchKernelGGL(k_owner_totals, dim3((u32)div_up(V, 256)), dim3(256), 0, st, ep->perm.p, V, ix->term_unit_start.p, ix->term_str_off.p,
                        n_owners, totals.p);
+    // (two scratch areas: both totals come back with ONE host round trip)
+    DevBuf<u64> sscr64b;
+    DCD_TRY(sscr64b.alloc(dev, scan_scratch_elems(V)));
     scan_exclusive_f<PermKeyLenF, u64>(PermKeyLenF{ep->perm.p, ix->term_str_off.p}, ep->key_dst.p, V, sscr64.p, st);
+    scan_exclusive_f<PermUnitsF, u64>(PermUnitsF{ep->perm.p, ix->term_unit_start.p}, ep->unit_dst.p, V, sscr64b.p, st);
     DCD_HIP(hipMemcpyAsync(&ep->total_keys, sscr64.p + scan_nblocks(V), 8, hipMemcpyDeviceToHost, st));
-    DCD_HIP(hipStreamSynchronize(st));
-    scan_exclusive_f<PermUnitsF, u64>(PermUnitsF{ep->perm.p, ix->term_unit_start.p}, ep->unit_dst.p, V, sscr64.p, st);
-    DCD_HIP(hipMemcpyAsync(&ep->total_units, sscr64.p + scan_nblocks(V), 8, hipMemcpyDeviceToHost, st));
+    DCD_HIP(hipMemcpyAsync(&ep->total_units, sscr64b.p + scan_nblocks(V), 8, hipMemcpyDeviceToHost, st));
     DCD_HIP(hipMemcpyAsync(tot.data(), totals.p, 64 * 3 * 8, hipMemcpyDeviceToHost, st));
     DCD_HIP(hipStreamSynchronize(st));
     DCD_HIP(hipGetLastError());
@@ -401,6 +403,7 @@ int32_t dcd_merge_begin(int32_t device, uint32_t n_sources, const uint64_t* term
   DCD_TRY(key_off.alloc(device, M + 1)); DCD_TRY(src_off.alloc(device, M + 1));
   DCD_TRY(sscr64.alloc(device, scan_scratch_elems(M ? M : 1)));
   u64 V = 0;
+  u32 maxlen = 0;
   VocabRanks vr;
   DevBuf<u64> slots;
   DevBuf<u32> flags, slot_excl, hist, sscr32;
@@ -432,7 +435,7 @@ int32_t dcd_merge_begin(int32_t device, uint32_t n_sources, const uint64_t* term
     DCD_HIP(hipStreamSynchronize(st));
     if (fl[0]) DCD_FAIL(DCD_E_OVERFLOW, "merge vocabulary table overflow");
     V = v32;
-    DCD_TRY(vocab_rank<u16>(device, st, slots.p, cap, slot_excl.p, V, tv, hist.p, sscr32.p, flags.p + 1, &vr));
+    DCD_TRY(vocab_rank<u16>(device, st, slots.p, cap, slot_excl.p, V, tv, hist.p, sscr32.p, flags.p + 1, &vr, &maxlen));
     sorted = rs_sort(pa.p, pb.p, vr.rank_of_slot.p, M, (int)log2_ceil(V ? V : 1), hist.p, sscr32.p, st);
   }
   // output offsets
@@ -444,43 +447,40 @@ int32_t dcd_merge_begin(int32_t device, uint32_t n_sources, const uint64_t* term
   DCD_TRY(ix.term_last.alloc(device, V ? V : 1));
   u64 Uout = 0, Nout = 0;
   SegPlan sp{sorted, meta};
+  // everything below is queued without a host round trip in between: the two totals come back together at the end, the key
+  // pool is sized for V keys of the longest length, the host mirrors are fetched when the index is first asked for them
+  DevBuf<u64> sscr64b;
+  DevBuf<u32> s32;
+  DCD_TRY(sscr64b.alloc(device, scan_scratch_elems(M ? M : 1)));
+  DCD_TRY(s32.alloc(device, scan_scratch_elems(V ? V : 1)));
+  DCD_TRY(ix.term_str_off.alloc(device, V + 1));
+  DCD_TRY(ix.term_chars.alloc(device, V * (u64)maxlen + 1));
   if (M) {
     scan_exclusive_f<SegUnitsF, u64>(SegUnitsF{sp}, dst_off.p, M, sscr64.p, st);
-    DCD_HIP(hipMemcpyAsync(&Uout, sscr64.p + scan_nblocks(M), 8, hipMemcpyDeviceToHost, st));
-    DCD_HIP(hipStreamSynchronize(st));
-    scan_exclusive_f<SegValuesF, u64>(SegValuesF{sp}, val_off.p, M, sscr64.p, st);
-    DCD_HIP(hipMemcpyAsync(&Nout, sscr64.p + scan_nblocks(M), 8, hipMemcpyDeviceToHost, st));
-    DCD_HIP(hipStreamSynchronize(st));
+    scan_exclusive_f<SegValuesF, u64>(SegValuesF{sp}, val_off.p, M, sscr64b.p, st);
     hipLaunchKernelGGL(k_merge_heads, dim3((u32)div_up(M, 256)), dim3(256), 0, st, sp, M, dst_off.p, val_off.p, ix.term_unit_start.p,
                        ix.term_item_start.p, ix.term_first.p, ix.term_last.p);
+    DCD_HIP(hipMemcpyAsync(ix.term_unit_start.p + V, sscr64.p + scan_nblocks(M), 8, hipMemcpyDeviceToDevice, st));
+    DCD_HIP(hipMemcpyAsync(ix.term_item_start.p + V, sscr64b.p + scan_nblocks(M), 8, hipMemcpyDeviceToDevice, st));
+    DCD_HIP(hipMemcpyAsync(&Uout, sscr64.p + scan_nblocks(M), 8, hipMemcpyDeviceToHost, st));
+    DCD_HIP(hipMemcpyAsync(&Nout, sscr64b.p + scan_nblocks(M), 8, hipMemcpyDeviceToHost, st));
+  } else {
+    DCD_HIP(hipMemsetAsync(ix.term_unit_start.p + V, 0, 8, st));
+    DCD_HIP(hipMemsetAsync(ix.term_item_start.p + V, 0, 8, st));
   }
-  DCD_HIP(hipMemcpyAsync(ix.term_unit_start.p + V, &Uout, 8, hipMemcpyHostToDevice, st));
-  DCD_HIP(hipMemcpyAsync(ix.term_item_start.p + V, &Nout, 8, hipMemcpyHostToDevice, st));
-  DCD_TRY(ix.units.alloc(device, Uout ? Uout : 1));
   // keys in rank order
-  DCD_TRY(ix.term_str_off.alloc(device, V + 1));
-  u32 total_chars = 0;
   if (V) {
-    DevBuf<u32> s32;
-    DCD_TRY(s32.alloc(device, scan_scratch_elems(V)));
     scan_exclusive_f<TermLenF, u32>(TermLenF{vr.rk_word.p}, ix.term_str_off.p, V, s32.p, st);
-    DCD_HIP(hipMemcpyAsync(&total_chars, s32.p + scan_nblocks(V), 4, hipMemcpyDeviceToHost, st));
-    DCD_HIP(hipStreamSynchronize(st));
+    DCD_HIP(hipMemcpyAsync(ix.term_str_off.p + V, s32.p + scan_nblocks(V), 4, hipMemcpyDeviceToDevice, st));
+    hipLaunchKernelGGL((k_term_strings<u16>), dim3((u32)div_up(V, 256)), dim3(256), 0, st, vr.rk_word.p, V, ix.term_str_off.p, tv, ix.term_chars.p);
+  } else {
+    DCD_HIP(hipMemsetAsync(ix.term_str_off.p, 0, 4, st));
   }
-  DCD_HIP(hipMemcpyAsync(ix.term_str_off.p + V, &total_chars, 4, hipMemcpyHostToDevice, st));
-  DCD_TRY(ix.term_chars.alloc(device, total_chars ? total_chars : 1));
-  if (V) hipLaunchKernelGGL((k_term_strings<u16>), dim3((u32)div_up(V, 256)), dim3(256), 0, st, vr.rk_word.p, V, ix.term_str_off.p, tv, ix.term_chars.p);
   DCD_HIP(hipStreamSynchronize(st));
   DCD_HIP(hipGetLastError());
+  DCD_TRY(ix.units.alloc(device, Uout ? Uout : 1));
   ix.n_terms = V; ix.n_units = Uout; ix.n_postings = Nout;
-  ix.h_term_chars.resize(total_chars);
-  ix.h_term_str_off.resize(V + 1);
-  ix.h_term_unit_start.resize(V + 1);
-  ix.h_term_item_start.resize(V + 1);
-  if (total_chars) DCD_HIP(hipMemcpy(ix.h_term_chars.data(), ix.term_chars.p, (size_t)total_chars * 2, hipMemcpyDeviceToHost));
-  DCD_HIP(hipMemcpy(ix.h_term_str_off.data(), ix.term_str_off.p, (V + 1) * 4, hipMemcpyDeviceToHost));
-  DCD_HIP(hipMemcpy(ix.h_term_unit_start.data(), ix.term_unit_start.p, (V + 1) * 8, hipMemcpyDeviceToHost));
-  DCD_HIP(hipMemcpy(ix.h_term_item_start.data(), ix.term_item_start.p, (V + 1) * 8, hipMemcpyDeviceToHost));
+  ix.host_ready = false;
   mg->sp = sp; mg->M = M; mg->U = U; mg->Uout = Uout;
   *out = mg.release();
   return DCD_OK;

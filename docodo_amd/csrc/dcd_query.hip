@@ -1581,6 +1581,7 @@ int32_t dcd_query_batch(dcd_index* h, const int32_t* prog, const uint64_t* prog_
   if (opts) o = *opts; else dcd_query_default_opts(&o);
   std::lock_guard<std::mutex> guard(h->mu);
   DCD_TRY(ensure_device(h->ix.device));
+  DCD_TRY(index_fetch_host(h->ix));     // (host mirrors of a merged index are fetched on first use)
   // The work pool and the scratch arena are sized for the worst case of every operator; a batch whose worst case exceeds
   // three quarters of the free HBM (incl. the library's device cache) is evaluated in consecutive sub-batches (results are
   // concatenated).  Fewer, larger sub-batches are better -- every one costs ~0.7 ms of launches and host round trips --
