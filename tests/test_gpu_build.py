@@ -369,3 +369,39 @@ print("DIGEST", h.hexdigest(), st.n_postings, st.n_terms, st.n_units)
         assert r.returncode == 0, r.stdout + r.stderr
         outs.append([l for l in r.stdout.splitlines() if l.startswith("DIGEST")][0])
     assert len(set(outs)) == 1, outs
+
+
+@pytest.mark.gpu
+def test_hot_cold_split_with_a_vocabulary_beyond_the_remap_cache(oracle_mod):
+    """1.1 M distinct words (dense ids beyond the 2^20 values the LDS remap cache of the first radix pass can hold: the
+    uncached gather runs; 21 cold key bits = three cold passes) mixed with a few very frequent ones (hot terms, final
+    after pass A): the images stay byte-identical to the oracle's."""
+    import docodo_amd
+
+    def word(k):
+        s = ""
+        for _ in range(6):
+            s += chr(97 + k % 26)
+            k //= 26
+        return s
+
+    rng = np.random.default_rng(11)
+    n = 1_100_000
+    hot = ["the", "and", "pickwick", "tupman", "winkle", "snodgrass", "wardle", "jingle"]
+    picks = rng.choice(len(hot), size=n, p=np.array([0.4, 0.25, 0.1, 0.08, 0.07, 0.05, 0.03, 0.02]))
+    parts = []
+    for k in range(n):
+        parts.append(word(k))
+        parts.append(hot[picks[k]])
+        if k % 3 == 0:
+            parts.append(hot[picks[(k * 7) % n]])
+    text = " ".join(parts)
+    pages = [text[i:i + 1_000_000] for i in range(0, len(text), 1_000_000)]
+    docs = [("s", "d", len(pages))]
+    ids = [str(i + 1) for i in range(len(pages))]
+    (oi, ol), ob = _oracle_images(oracle_mod, pages, docs=docs, ids=ids)
+    (gi, gl), gb, st = _gpu_images(pages, docs=docs, ids=ids)
+    assert st.n_terms == ob.n_terms and st.n_terms > (1 << 20)
+    assert st.id_keys == 1 and 1 <= st.n_hot_terms <= 255 and st.n_hot_postings > st.n_postings // 2
+    assert st.sort_passes == 4
+    assert gi == oi and gl == ol
