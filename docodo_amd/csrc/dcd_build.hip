@@ -129,7 +129,7 @@ __global__ __launch_bounds__(TK_THREADS, DCD_TK_WPE) void k_tok_emit(const CharT
       const TokHash hh = hs.fin();
       if (DCD_DIAG_TOK == 1) {          // slot word only: a tag + length match counts as a hit (no string compare)
         slot = hh.idx & vt.mask;
-        const u64 sw = vt.slots[slot];
+        const u64 sw = vt.slots[(u64)slot * vt.stride];
         if ((sw >> 42) != (voc_word(hh.tag, len, gpos) >> 42)) slot ^= 1u;
       } else if (DCD_DIAG_TOK == 2) {   // no table access at all
         slot = hh.idx & vt.mask;
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(TK_THREADS, DCD_TK_WPE) void k_tok_emit(const CharT
         slot = vocab_lookup_insert_pooled<CharT>(vt, tv, hh, len, gpos, wv, word);
       } else {                          // 4: pool entry and slot word in ONE gather (pool only), first probe only
         slot = hh.idx & vt.mask;
-        const uint4 pq = *reinterpret_cast<const uint4*>(vt.pool + (u64)slot * PW);
+        const uint4 pq = *reinterpret_cast<const uint4*>(vt.pool + (u64)slot * vt.pstride);
         if (((pq.x ^ wv[0]) | (pq.y ^ wv[1]) | (pq.z ^ wv[2]) | (pq.w ^ wv[3])) != 0u) slot ^= 1u;
       }
     }
@@ -238,17 +238,18 @@ struct HotUsedF {   // low word: the slot is used; high word: it holds a hot ter
   const u64* slots;
   const u32* cnt;
   const u32* theta;
+  u32 stride;      // u64 units per slot
   __device__ __forceinline__ u64 operator()(u64 i) const {
-    if (!slots[i]) return 0ull;
+    if (!slots[i * stride]) return 0ull;
     return 1ull | ((u64)(cnt[i] >= *theta ? 1u : 0u) << 32);
   }
 };
 __global__ void k_dense_table(const u64* __restrict__ slots, const u32* __restrict__ cnt, const u32* __restrict__ theta,
-                              const u64* __restrict__ excl, const u64* __restrict__ total, u64 cap, u32* __restrict__ dense) {
+                              const u64* __restrict__ excl, const u64* __restrict__ total, u64 cap, u32* __restrict__ dense, u32 stride) {
   u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= cap) return;
   u32 d = 0;
-  if (slots[i]) {
+  if (slots[i * stride]) {
     const u64 e = excl[i];
     const u32 n_hot = (u32)(*total >> 32), hot_before = (u32)(e >> 32), used_before = (u32)e;
     d = cnt[i] >= *theta ? hot_before : n_hot + (used_before - hot_before);
@@ -848,6 +849,7 @@ struct BuildMid {
   DevBuf<u8> d_pool_raw;            // explicit strings on the device (CharT units)
   u64 n_pool = 0;
   DevBuf<u64> slots;
+  u32 slot_stride = 1;              // u64 units per slot: 1, or VocPool::W when the string pool is interleaved (VocabTable)
   DevBuf<u32> d_flags, slot_excl, scan_scr32, d_hist;
   VocabRanks vr;
   VocabPrep vprep;                  // id-keyed builds: first half of the vocabulary finalisation, run at the end of phase 1
@@ -917,7 +919,7 @@ static int32_t build_vocab(dcd_build* h, BuildMid& M, hipStream_t vs, const Text
   u32 maxlen = M.voc_maxlen;
   const bool queued_only = M.vprep_done;
   if (queued_only) DCD_TRY(vocab_sort<CharT>(dev, vs, cap, V, tv, M.vprep, M.voc_maxlen, M.voc_nsym, d_hist, scan_scr32, &M.vr));
-  else DCD_TRY(vocab_rank<CharT>(dev, vs, M.slots.p, cap, M.slot_excl.p, V, tv, d_hist, scan_scr32, M.d_flags.p + 1, &M.vr, &maxlen));
+  else DCD_TRY(vocab_rank<CharT>(dev, vs, M.slots.p, cap, M.slot_excl.p, V, tv, d_hist, scan_scr32, M.d_flags.p + 1, &M.vr, &maxlen, M.slot_stride));
   DCD_TRY(M.word_str_off.alloc(dev, V + 1));
   DCD_TRY(M.word_chars.alloc(dev, V * (u64)maxlen + 1));
   u32 total_chars = 0;
@@ -1070,7 +1072,6 @@ static int32_t build_phase1(dcd_build* h, bool codes_mode) {
   TextView<CharT> tv;
   tv.text = text; tv.n_chars = n_chars; tv.pool = (const CharT*)M.d_pool_raw.p; tv.n_pool = M.n_pool; tv.tab = tab;
   u64 V = 0;
-  DevBuf<u32> voc_pool;                       // first words of every slot's string (vocab_lookup_insert_pooled)
   // hot / cold split (plain text builds): sample counts per slot from every (mask + 1)-th tile, ~1000-2000 tiles in all
   // (~200 k tokens: the 255th term of a Zipf-1.1 vocabulary still shows up ~60 times; every count is an atomic, and those
   // of the top terms hit ONE address each -- 4096 sampled tiles slowed the emit kernel by 6 %)
@@ -1093,19 +1094,22 @@ static int32_t build_phase1(dcd_build* h, bool codes_mode) {
   for (;;) {
     if (cap_log2 > 30) DCD_FAIL(DCD_E_OVERFLOW, "vocabulary does not fit a 2^30-slot table");
     const u64 cap = 1ull << cap_log2;
-    DCD_TRY(M.slots.alloc(dev, cap));
-    DCD_HIP(hipMemsetAsync(M.slots.p, 0, cap * 8, st));
+    static const bool no_pool = getenv("DOCODO_VOCAB_POOL") && atoi(getenv("DOCODO_VOCAB_POOL")) == 0;
+    // The string pool is an accelerator, not a requirement: very large tables (> 2^26 slots: 2-4 GB) or a failed allocation
+    // fall back to a plain slot array and to verifying every hit against the text.  With the pool the table is ONE array of
+    // records {slot word, padding, string} (32 bytes for Latin-1, 64 for UTF-16): the slot word and the string of a term
+    // share a cache line, so a token of a rare term -- the ones that miss the XCD's L2: a tenth of the tokens of a Zipf
+    // corpus -- costs one line from the fabric instead of two.
+    constexpr u32 PWW = VocPool<CharT>::W;
+    M.slot_stride = 1;
+    if (!no_pool && cap_log2 <= 26 && M.slots.alloc(dev, cap * PWW) == DCD_OK) M.slot_stride = PWW;
+    else DCD_TRY(M.slots.alloc(dev, cap));
+    DCD_HIP(hipMemsetAsync(M.slots.p, 0, cap * 8 * M.slot_stride, st));
     DCD_HIP(hipMemsetAsync(M.d_flags.p, 0, 16, st));
     VocabTable vt;
     vt.slots = M.slots.p; vt.mask = (u32)(cap - 1); vt.overflow = M.d_flags.p;
-    vt.pool = nullptr;
-    static const bool no_pool = getenv("DOCODO_VOCAB_POOL") && atoi(getenv("DOCODO_VOCAB_POOL")) == 0;
-    // the string pool is an accelerator, not a requirement: very large tables (> 2^26 slots: 1-2 GB of pool) or a failed
-    // allocation fall back to verifying every hit against the text
-    if (!no_pool && cap_log2 <= 26 && voc_pool.alloc(dev, cap * VocPool<CharT>::W) == DCD_OK) {
-      DCD_HIP(hipMemsetAsync(voc_pool.p, 0, cap * VocPool<CharT>::W * 4, st));
-      vt.pool = voc_pool.p;
-    }
+    vt.pool = nullptr; vt.stride = M.slot_stride; vt.pstride = 0;
+    if (M.slot_stride > 1) { vt.pool = reinterpret_cast<u32*>(M.slots.p) + PWW; vt.pstride = 2 * PWW; }
     if (hot_try) {
       DCD_TRY(sample_cnt.alloc(dev, cap));
       DCD_TRY(hot_hist.alloc(dev, HOT_BINS + 1));
@@ -1178,14 +1182,15 @@ static int32_t build_phase1(dcd_build* h, bool codes_mode) {
       DCD_TRY(hot_scr.alloc(dev, scan_scratch_elems(cap)));
       hipLaunchKernelGGL(k_hot_hist, dim3(512), dim3(256), 0, st, (const u32*)sample_cnt.p, cap, hot_hist.p);
       hipLaunchKernelGGL(k_hot_pick, dim3(1), dim3(1024), 0, st, (const u32*)hot_hist.p, (u32)env_hot, theta);
-      scan_exclusive_f<HotUsedF, u64>(HotUsedF{M.slots.p, sample_cnt.p, theta}, hot_excl.p, cap, hot_scr.p, st);
+      scan_exclusive_f<HotUsedF, u64>(HotUsedF{M.slots.p, sample_cnt.p, theta, M.slot_stride}, hot_excl.p, cap, hot_scr.p, st);
       const u64* total = hot_scr.p + scan_nblocks(cap);
       hipLaunchKernelGGL(k_dense_table, dim3((u32)div_up(cap, 256)), dim3(256), 0, st, (const u64*)M.slots.p, (const u32*)sample_cnt.p,
-                         (const u32*)theta, (const u64*)hot_excl.p, total, cap, M.slot_excl.p);
+                         (const u32*)theta, (const u64*)hot_excl.p, total, cap, M.slot_excl.p, M.slot_stride);
       if (last_round) {
         // first half of the vocabulary finalisation here, so that its two parameters come back with this round trip and
         // phase 2 can queue the ordinal sort without ever blocking (V itself is still on the device: bound = cap / 2 + 1)
-        DCD_TRY(vocab_prepare<CharT>(dev, st, M.slots.p, cap, M.slot_excl.p, cap / 2 + 1, tv, M.d_flags.p + 1, &M.vprep, (const u32*)total));
+        DCD_TRY(vocab_prepare<CharT>(dev, st, M.slots.p, cap, M.slot_excl.p, cap / 2 + 1, tv, M.d_flags.p + 1, &M.vprep, (const u32*)total,
+                                     M.slot_stride));
         DCD_HIP(hipMemcpyAsync(rb_nsym, M.vprep.d_nsym, 4, hipMemcpyDeviceToHost, st));
         M.vprep_done = true;
         DCD_TRY(stop_timers());
@@ -1197,10 +1202,10 @@ static int32_t build_phase1(dcd_build* h, bool codes_mode) {
       v32 = (u32)tot64;
       n_hot = (u32)(tot64 >> 32);
     } else {
-      scan_exclusive_f<SlotUsed, u32>(SlotUsed{M.slots.p}, M.slot_excl.p, cap, M.scan_scr32.p, st);
+      scan_exclusive_f<SlotUsed, u32>(SlotUsed{M.slots.p, M.slot_stride}, M.slot_excl.p, cap, M.scan_scr32.p, st);
       if (last_round) {
         DCD_TRY(vocab_prepare<CharT>(dev, st, M.slots.p, cap, M.slot_excl.p, cap / 2 + 1, tv, M.d_flags.p + 1, &M.vprep,
-                                     (const u32*)(M.scan_scr32.p + scan_nblocks(cap))));
+                                     (const u32*)(M.scan_scr32.p + scan_nblocks(cap)), M.slot_stride));
         DCD_HIP(hipMemcpyAsync(rb_nsym, M.vprep.d_nsym, 4, hipMemcpyDeviceToHost, st));
         M.vprep_done = true;
         DCD_TRY(stop_timers());

@@ -317,10 +317,13 @@ struct TextView {
 };
 
 struct VocabTable {
-  u64* slots;
+  u64* slots;      // slot i's word is slots[i * stride]
   u32 mask;        // capacity - 1
   u32* overflow;   // set to 1 when a probe sequence gets too long
-  u32* pool;       // optional: VOC_PW<CharT> words per slot, zeroed; the first words of the slot's string (see below)
+  u32* pool;       // optional: VocPool<CharT>::W words per slot, zeroed; the first words of the slot's string (see below):
+                   // slot i's entry is pool[i * pstride ...]
+  u32 stride = 1;  // in u64 units.  Pooled tables are arrays of records {slot word, padding, string}: stride = W, and
+  u32 pstride = 0; // pool = (u32*)slots + W with pstride = 2 W -- a token that misses the caches fetches ONE line, not two
 };
 // words of a string kept next to its slot: 16 characters' worth
 template <typename CharT> struct VocPool { static constexpr u32 W = 4 * sizeof(CharT); };
@@ -338,9 +341,10 @@ __device__ __forceinline__ u32 vocab_lookup_insert(const VocabTable& vt, const T
     // hammering one L2 channel.  A slot word only ever changes 0 -> value, so a stale read can only
     // be a stale "empty", which the CAS below repairs (it returns the current value); a non-empty
     // read is final.  Correct for any workgroup -> XCD placement.
-    u64 w = vt.slots[idx];
+    u64* sp = vt.slots + (u64)idx * vt.stride;
+    u64 w = *sp;
     if (w == 0) {
-      u64 old = atomicCAS((unsigned long long*)&vt.slots[idx], 0ull, (unsigned long long)mine);
+      u64 old = atomicCAS((unsigned long long*)sp, 0ull, (unsigned long long)mine);
       if (old == 0) return idx;
       w = old;
     }
@@ -376,10 +380,11 @@ __device__ __forceinline__ u32 vocab_lookup_insert_pooled(const VocabTable& vt, 
   const u32 nbytes = len * (u32)sizeof(CharT), nw = (nbytes + 3u) >> 2;
   u32 idx = h.idx & vt.mask;
   for (u32 probes = 0; probes < 4096u; probes++) {
-    u64 w = vt.slots[idx];
-    uint4* pe = reinterpret_cast<uint4*>(vt.pool + (u64)idx * W);
+    u64* sp = vt.slots + (u64)idx * vt.stride;
+    u64 w = *sp;
+    uint4* pe = reinterpret_cast<uint4*>(vt.pool + (u64)idx * vt.pstride);
     if (w == 0) {
-      u64 old = atomicCAS((unsigned long long*)&vt.slots[idx], 0ull, (unsigned long long)mine);
+      u64 old = atomicCAS((unsigned long long*)sp, 0ull, (unsigned long long)mine);
       if (old == 0) {
 #pragma unroll
         for (u32 q = 0; q < W / 4; q++) pe[q] = make_uint4(wv[4 * q], wv[4 * q + 1], wv[4 * q + 2], wv[4 * q + 3]);

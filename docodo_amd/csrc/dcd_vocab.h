@@ -11,16 +11,17 @@ namespace dcd {
 
 struct SlotUsed {
   const u64* slots;
-  __device__ __forceinline__ u32 operator()(u64 i) const { return slots[i] != 0 ? 1u : 0u; }
+  u32 stride = 1;      // u64 units per slot (VocabTable::stride)
+  __device__ __forceinline__ u32 operator()(u64 i) const { return slots[i * stride] != 0 ? 1u : 0u; }
 };
 
 // (n_out: size of the output arrays -- a caller that runs this before it knows V passes a bound; ids beyond it belong to a
 // table that is about to be discarded for being too full)
 static __global__ void k_vocab_compact(const u64* __restrict__ slots, u64 cap, const u32* __restrict__ excl, u64* __restrict__ term_word,
-                                u32* __restrict__ term_slot, u64 n_out) {
+                                u32* __restrict__ term_slot, u64 n_out, u32 stride) {
   u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= cap) return;
-  u64 w = slots[i];
+  u64 w = slots[i * stride];
   if (w) {
     u32 d = excl[i];
     if (d < n_out) {
@@ -158,7 +159,7 @@ struct VocabPrep {
 template <typename CharT>
 // V_dev != nullptr: V is only an upper bound, the true count is read from the device (the caller has not fetched it yet).
 inline int32_t vocab_prepare(int dev, hipStream_t st, const u64* slots, u64 cap, const u32* slot_excl, u64 V, const TextView<CharT>& tv,
-                             u32* d_maxlen, VocabPrep* P, const u32* V_dev = nullptr) {
+                             u32* d_maxlen, VocabPrep* P, const u32* V_dev = nullptr, u32 slot_stride = 1) {
   DCD_TRY(P->term_word.alloc(dev, V ? V : 1));
   DCD_TRY(P->term_slot.alloc(dev, V ? V : 1));
   DCD_TRY(P->cbits.alloc(dev, 2049));
@@ -166,7 +167,7 @@ inline int32_t vocab_prepare(int dev, hipStream_t st, const u64* slots, u64 cap,
   P->d_maxlen = d_maxlen; P->d_nsym = P->cbits.p + 2048;
   DCD_HIP(hipMemsetAsync(P->cbits.p, 0, 2049 * 4, st));
   if (!V) return DCD_OK;
-  hipLaunchKernelGGL(k_vocab_compact, dim3((u32)div_up(cap, 256)), dim3(256), 0, st, slots, cap, slot_excl, P->term_word.p, P->term_slot.p, V);
+  hipLaunchKernelGGL(k_vocab_compact, dim3((u32)div_up(cap, 256)), dim3(256), 0, st, slots, cap, slot_excl, P->term_word.p, P->term_slot.p, V, slot_stride);
   hipLaunchKernelGGL(k_max_len, dim3((u32)div_up(V, 256)), dim3(256), 0, st, P->term_word.p, V, d_maxlen, V_dev);
   hipLaunchKernelGGL((k_char_used<CharT>), dim3((u32)div_up(V, 256)), dim3(256), 0, st, P->term_word.p, V, tv, P->cbits.p, V_dev);
   hipLaunchKernelGGL(k_char_rank, dim3(1), dim3(1024), 0, st, P->cbits.p, P->crank.p, P->cbits.p + 2048);
@@ -212,9 +213,9 @@ inline int32_t vocab_sort(int dev, hipStream_t st, u64 cap, u64 V, const TextVie
 // both halves with the host round trip in between
 template <typename CharT>
 inline int32_t vocab_rank(int dev, hipStream_t st, const u64* slots, u64 cap, const u32* slot_excl, u64 V, const TextView<CharT>& tv,
-                          u32* d_hist, u32* scan_scr32, u32* d_maxlen, VocabRanks* out, u32* maxlen_out = nullptr) {
+                          u32* d_hist, u32* scan_scr32, u32* d_maxlen, VocabRanks* out, u32* maxlen_out = nullptr, u32 slot_stride = 1) {
   VocabPrep P;
-  DCD_TRY(vocab_prepare<CharT>(dev, st, slots, cap, slot_excl, V, tv, d_maxlen, &P));
+  DCD_TRY(vocab_prepare<CharT>(dev, st, slots, cap, slot_excl, V, tv, d_maxlen, &P, nullptr, slot_stride));
   u32 maxlen = 0, n_sym = 0;
   if (V) {
     DCD_HIP(hipMemcpyAsync(&maxlen, P.d_maxlen, 4, hipMemcpyDeviceToHost, st));
