@@ -1,0 +1,54 @@
+"""Worker of tests/test_gpu_merge.py::test_three_ranks_on_one_gpu_give_the_one_shot_index: the whole N > 1 path -- doc-range
+shards with global coordinates built on the GPU, export, all-to-all, overlapped merge, gather of the hash partitions -- with
+three ranks sharing the one GPU of the box.  RCCL cannot place two ranks on one device, so the collectives run over gloo with
+the device buffers staged through the host (docodo_amd.dist.exchange does that by itself); everything on the device side is the
+code that runs at N > 1 on a multi-GPU node."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import docodo_amd
+    from docodo_amd import dist as ddist, synth
+    per = 7000 + 500 * rank                                   # ragged shards
+    first = sum(7000 + 500 * r for r in range(rank))
+    total = sum(7000 + 500 * r for r in range(world))
+    d = torch.empty(per * synth.DOC_BYTES, dtype=torch.uint8, device="cuda")
+    synth.corpus_dev(d.data_ptr(), per, first_doc=first)
+    for rnd in range(2):                                      # twice: both allocators recycle their buffers
+        b = docodo_amd.Builder(coord_base=first * synth.DOC_BYTES)
+        b.AddUniformPagesDev(d.data_ptr(), per, synth.DOC_BYTES, first_doc=first)
+        b.Finish()
+        owned = ddist.distributed_merge(b, device_index=0)
+        got = ddist.gather_index(owned, dst=0, device_index=0)
+        if rank == 0:
+            text = synth.corpus_host(total)
+            off = np.arange(total + 1, dtype=np.uint64) * synth.DOC_BYTES
+            one = docodo_amd.Builder()
+            one.AddPages(text, off, docs_per_page=True)
+            one.Finish()
+            assert got.index_image() == one.index_image(), "gathered .index differs from the one-shot build (round %d)" % rnd
+            ddist.set_uniform_pages(got, total, synth.DOC_BYTES)
+            assert got.list_image() == one.list_image()
+            assert got.Count == one.stats.n_terms
+            one.close()
+            got.close()
+        owned.close()
+        b.close()
+        dist.barrier()
+    dist.destroy_process_group()
+    print("rank %d ok" % rank, flush=True)
+
+
+if __name__ == "__main__":
+    main()

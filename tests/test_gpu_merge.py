@@ -161,3 +161,17 @@ def test_distributed_merge_over_rccl_world1():
     r = subprocess.run([sys.executable, os.path.join(root, "tests", "helpers", "rccl_world1_worker.py")], env=env, capture_output=True,
                        text=True, timeout=300)
     assert r.returncode == 0 and "rccl world1 ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_three_ranks_on_one_gpu_give_the_one_shot_index():
+    """Three processes (ragged doc ranges, global coordinates) build, exchange, merge and gather on ONE GPU over gloo: the
+    gathered `.index` / `.index.list` are byte-identical to a single builder's over the whole corpus."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3", "--master-addr", "127.0.0.1",
+                        "--master-port", "29683", os.path.join(root, "tests", "helpers", "gpu_dist_worker.py")], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and all("rank %d ok" % k in r.stdout for k in range(3)), r.stdout[-2000:] + r.stderr[-4000:]
