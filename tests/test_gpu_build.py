@@ -405,3 +405,23 @@ def test_hot_cold_split_with_a_vocabulary_beyond_the_remap_cache(oracle_mod):
     assert st.id_keys == 1 and 1 <= st.n_hot_terms <= 255 and st.n_hot_postings > st.n_postings // 2
     assert st.sort_passes == 4
     assert gi == oi and gl == ol
+
+
+@pytest.mark.gpu
+def test_utf16_and_latin1_builds_of_one_corpus_agree():
+    """The synthetic corpus as 16-bit code units (what a C# string pins; 64-byte vocabulary records, hot / cold split active)
+    gives the images of its Latin-1 form."""
+    import docodo_amd
+    from docodo_amd import synth
+    n_docs = 20000
+    text = synth.corpus_host(n_docs)
+    off = np.arange(n_docs + 1, dtype=np.uint64) * synth.DOC_BYTES
+    a = docodo_amd.Builder()
+    a.AddPages(text, off, docs_per_page=True)
+    sa = a.Finish()
+    b = docodo_amd.Builder(encoding=docodo_amd.DCD_ENC_UTF16LE)
+    b.AddPages(text.astype(np.uint16), off, docs_per_page=True)
+    sb = b.Finish()
+    assert sa.n_hot_terms > 0 and sb.n_hot_terms > 0 and sb.id_keys == 1
+    assert (sa.n_postings, sa.n_terms, sa.n_units) == (sb.n_postings, sb.n_terms, sb.n_units)
+    assert a.index_image() == b.index_image() and a.list_image() == b.list_image()
