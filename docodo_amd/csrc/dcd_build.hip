@@ -28,6 +28,7 @@ constexpr u32 MAX_CODE_LEN = 63;   // explicit index codes (Builder.Add); text t
                                    // prefetched take 1.67 / 1.88 / 1.73 ms against 1.58 -- one tile per wave and many waves win)
 #endif
 constexpr u32 TK_TPW = DCD_TK_TPW;
+constexpr u32 UNRES_CAP = 4096;    // tiles on the fix-up list of an id-numbering build (beyond that the fix-up pass walks all tiles)
 #ifndef DCD_TK_WPE
 #define DCD_TK_WPE 8               // waves per SIMD the emit kernel is compiled for (register budget)
 #endif
@@ -56,7 +57,7 @@ template <typename CharT>
 __global__ __launch_bounds__(TK_THREADS, DCD_TK_WPE) void k_tok_emit(const CharT* __restrict__ text, TokParams P, CharTables16 tab,
                                                         TextView<CharT> tv, VocabTable vt, const u64* __restrict__ tile_off,
                                                         uint2* __restrict__ tuples, u64 n_tiles, u32 stride, u32* __restrict__ tile_cnt,
-                                                        u64 tile0, u32* __restrict__ sample_cnt, u32 sample_mask) {
+                                                        u64 tile0, u32* __restrict__ sample_cnt, u32 sample_mask, u32* __restrict__ unres) {
   // stride != 0: no counting pass ran; the tile's tuples go to tuples[tile * stride ...] and their number to tile_cnt
   // (the first sort pass compacts, RsStrided in dcd_sort.h).  stride == 0: dense output at tile_off[tile].
   // The launch covers the tiles [tile0, n_tiles) (see the seed launch in build_phase1).
@@ -108,6 +109,7 @@ __global__ __launch_bounds__(TK_THREADS, DCD_TK_WPE) void k_tok_emit(const CharT
     }
     return coord;
   };
+  bool any_unres = false;
   for (u32 k = lane; k < total; k += 64) {
     const u32 t = S.tok[k];
     const u32 i = t & 0xFFFFu, len = t >> 16;
@@ -144,8 +146,11 @@ __global__ __launch_bounds__(TK_THREADS, DCD_TK_WPE) void k_tok_emit(const CharT
       }
     }
 #else
-    u32 slot = vt.pool ? vocab_lookup_insert_pooled<CharT>(vt, tv, hs.fin(), len, gpos, wv, word)
-                       : vocab_lookup_insert<CharT>(vt, tv, hs.fin(), len, gpos, word);
+    // (a table that numbers its terms returns the term's id, i.e. the sort key itself -- or VOC_UNRESOLVED | slot)
+    u32 slot = vt.id_ctr ? vocab_lookup_insert_ids<CharT>(vt, tv, hs.fin(), len, gpos, wv, word, (blockIdx.x & (VOC_SHARDS - 1u)) * VOC_CTR_STRIDE)
+               : vt.pool ? vocab_lookup_insert_pooled<CharT>(vt, tv, hs.fin(), len, gpos, wv, word)
+                         : vocab_lookup_insert<CharT>(vt, tv, hs.fin(), len, gpos, word);
+    any_unres |= vt.id_ctr != nullptr && slot != 0xFFFFFFFFu && (slot & VOC_UNRESOLVED) != 0u;
 #endif
 #if DCD_TOK_NT
     {
@@ -157,6 +162,11 @@ __global__ __launch_bounds__(TK_THREADS, DCD_TK_WPE) void k_tok_emit(const CharT
     tuples[obase + k] = make_uint2(slot, coord_of(gpos));
 #endif
     if (sampled && slot != 0xFFFFFFFFu) atomicAdd(&sample_cnt[slot], 1u);
+  }
+  // tiles that hold unresolved keys go on the fix-up list: unres[0] = their number, unres[1 ..] = the first UNRES_CAP of them
+  if (unres != nullptr && ballot64(any_unres) != 0ull && lane == 0) {
+    const u32 k = atomicAdd(unres, 1u);
+    if (k < UNRES_CAP) unres[1 + k] = (u32)tile;
   }
   wave_sync();                        // the next tile overwrites the wave's LDS slice
   }
@@ -195,6 +205,35 @@ __global__ void k_term_first_last(const uint2* __restrict__ sorted, const u64* _
   if (t >= n_terms) return;
   first[t] = base + sorted[item_start[t]].y;
   last[t] = base + sorted[item_start[t + 1] - 1].y;
+}
+// ---- early ids: the table numbers its terms (vocab_lookup_insert_ids) ---------------------------------------------------------
+// id = local * VOC_SHARDS + shard with local < cnt[shard].  The DENSE id of a term is the number of used ids below its id, so
+// that the order of the ids (the sort order of the tuples) is the order of the dense ids; with the VOC_SHARDS counts it is
+// that many min / add operations -- tabulated once per build (beside the tuple sort), looked up at term heads only.
+__global__ __launch_bounds__(256) void k_id_dense_table(IdCounts n, u32 id_range, u32* __restrict__ dense) {
+  const u32 id = blockIdx.x * 256u + threadIdx.x;
+  if (id < id_range) dense[id] = dense_of_id(n, id);
+}
+// unresolved keys (VOC_UNRESOLVED | slot) -> ids, now that every inserter has published its id; one wave per listed tile, or --
+// when the list overflowed -- every tile
+__global__ __launch_bounds__(256) void k_fix_unresolved(uint2* __restrict__ tuples, const u32* __restrict__ tile_cnt, u64 n_tiles, u32 stride,
+                                                        const u32* __restrict__ unres, const u64* __restrict__ slots, u32 slot_stride) {
+  const u32 n = unres[0];
+  if (n == 0) return;
+  const u64 wave = (u64)blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = (u64)gridDim.x * 4;
+  const bool all = n > UNRES_CAP;
+  const u64 count = all ? n_tiles : n;
+  for (u64 k = wave; k < count; k += n_waves) {
+    const u64 t = all ? k : unres[1 + k];
+    const u32 c = tile_cnt[t];
+    for (u32 j = lane_id(); j < c; j += 64) {
+      const u32 x = tuples[t * stride + j].x;
+      if (x != 0xFFFFFFFFu && (x & VOC_UNRESOLVED)) {
+        const u32 slot = x & ~VOC_UNRESOLVED;
+        tuples[t * stride + j].x = reinterpret_cast<const u32*>(slots + (u64)slot * slot_stride)[2] - 1u;
+      }
+    }
+  }
 }
 // ---- hot / cold split of the vocabulary ---------------------------------------------------------------------------
 // The H slots with the largest sample counts are "hot" (Zipf: a few hundred terms hold most postings).  Dense ids: hot
@@ -844,6 +883,8 @@ struct BuildMid {
   // ordinal sort runs on a second stream beside the tuple sort; term order is restored when the units are copied out
   bool id_keys = false;
   u32 n_hot = 0;                    // hot / cold split: dense ids 0 .. n_hot-1 are the hot terms (0 = no split)
+  bool early_ids = false;           // the tuples carry ids the table handed out while it was filled (id_cnt: per shard)
+  IdCounts id_cnt{};
   DevBuf<u32> tile_cnt;
   DevBuf<u64> tile_off;
   DevBuf<u8> d_pool_raw;            // explicit strings on the device (CharT units)
@@ -1077,8 +1118,16 @@ static int32_t build_phase1(dcd_build* h, bool codes_mode) {
   // of the top terms hit ONE address each -- 4096 sampled tiles slowed the emit kernel by 6 %)
   static const int env_hot = getenv("DOCODO_BUILD_HOT") ? atoi(getenv("DOCODO_BUILD_HOT")) : 255;   // hot terms at most; 0 = off
   static const bool env_rank_keys0 = getenv("DOCODO_BUILD_RANK_KEYS") && atoi(getenv("DOCODO_BUILD_RANK_KEYS")) != 0;
-  const bool hot_try = strided && !env_rank_keys0 && env_hot > 0;
+  // early ids (default for plain text builds): the table numbers its terms while it is filled and the tokeniser writes the
+  // sort key itself -- no slot -> id table, no remap gathers in the first radix pass, no hot / cold selection.
+  // DOCODO_BUILD_EARLY_IDS=0: ids from the table scan after the emit kernel (+ hot / cold split), as before.
+  static const bool env_early = !(getenv("DOCODO_BUILD_EARLY_IDS") && atoi(getenv("DOCODO_BUILD_EARLY_IDS")) == 0);
+  bool early_ids = strided && !env_rank_keys0 && env_early;
   const bool fast_end = strided && !env_rank_keys0;
+  // VOC_SHARDS id counters VOC_CTR_STRIDE words apart, then: the counts again, densely, + their sum V (k_vocab_compact_ids),
+  // then the fix-up list: count + UNRES_CAP tiles
+  DevBuf<u32> id_ctr;
+  constexpr u32 ID_CTR_WORDS = VOC_SHARDS * VOC_CTR_STRIDE;
   u32 sample_mask = 0;
   while (((u64)sample_mask + 1) * DCD_HOT_SAMPLE_TILES < n_tiles) sample_mask = sample_mask * 2 + 1;
   DevBuf<u32> sample_cnt, hot_hist;           // [cap] / [HOT_BINS + 1] (theta behind the bins)
@@ -1090,6 +1139,7 @@ static int32_t build_phase1(dcd_build* h, bool codes_mode) {
   u64* rb_total = pin + 17;
   u32* rb_flags = (u32*)(pin + 18);     // 4 words
   u32* rb_nsym = (u32*)(pin + 20);
+  u32* rb_ids = (u32*)(pin + 24);       // VOC_SHARDS + 1 words
   *rb_ntok = 0; *rb_total = 0; *rb_nsym = 0;
   for (;;) {
     if (cap_log2 > 30) DCD_FAIL(DCD_E_OVERFLOW, "vocabulary does not fit a 2^30-slot table");
@@ -1110,6 +1160,15 @@ static int32_t build_phase1(dcd_build* h, bool codes_mode) {
     vt.slots = M.slots.p; vt.mask = (u32)(cap - 1); vt.overflow = M.d_flags.p;
     vt.pool = nullptr; vt.stride = M.slot_stride; vt.pstride = 0;
     if (M.slot_stride > 1) { vt.pool = reinterpret_cast<u32*>(M.slots.p) + PWW; vt.pstride = 2 * PWW; }
+    if (early_ids && M.slot_stride == 1) early_ids = false;       // (no record table: very large vocabulary or no memory)
+    const bool hot_try = strided && !env_rank_keys0 && env_hot > 0 && !early_ids;
+    u32* unres = nullptr;
+    if (early_ids) {
+      DCD_TRY(id_ctr.alloc(dev, ID_CTR_WORDS + VOC_SHARDS + 2 + UNRES_CAP + 1));
+      DCD_HIP(hipMemsetAsync(id_ctr.p, 0, (ID_CTR_WORDS + VOC_SHARDS + 2 + 1) * 4, st));
+      vt.id_ctr = id_ctr.p;
+      unres = id_ctr.p + ID_CTR_WORDS + VOC_SHARDS + 2;
+    }
     if (hot_try) {
       DCD_TRY(sample_cnt.alloc(dev, cap));
       DCD_TRY(hot_hist.alloc(dev, HOT_BINS + 1));
@@ -1126,12 +1185,12 @@ static int32_t build_phase1(dcd_build* h, bool codes_mode) {
       const u64 n_seed = n_tiles > 2 * seed_tiles ? seed_tiles : 0;   // small builds: one launch
       if (n_seed) {   // (not a DCD_K_TOK_EMIT probe: per-launch averages are quoted for the main launch)
         hipLaunchKernelGGL((k_tok_emit<CharT>), dim3((u32)div_up(n_seed, TK_WAVES * TK_TPW)), dim3(TK_THREADS), 0, st, text, P, tab, tv, vt,
-                           M.tile_off.p, M.tupA.p, n_seed, M.stride, M.tile_cnt.p, (u64)0, sample_cnt.p, sample_mask);
+                           M.tile_off.p, M.tupA.p, n_seed, M.stride, M.tile_cnt.p, (u64)0, sample_cnt.p, sample_mask, unres);
       }
       probes.begin(DCD_K_TOK_EMIT);
       if (n_tiles > n_seed)
         hipLaunchKernelGGL((k_tok_emit<CharT>), dim3((u32)div_up(n_tiles - n_seed, TK_WAVES * TK_TPW)), dim3(TK_THREADS), 0, st, text, P, tab, tv, vt,
-                           M.tile_off.p, M.tupA.p, n_tiles, M.stride, M.tile_cnt.p, n_seed, sample_cnt.p, sample_mask);
+                           M.tile_off.p, M.tupA.p, n_tiles, M.stride, M.tile_cnt.p, n_seed, sample_cnt.p, sample_mask, unres);
       probes.end();
 #if defined(DCD_DIAG_TOK)
       if (DCD_DIAG_TOK == 6) {          // second launch: every term is in the table, no CAS, no insert storm
@@ -1141,7 +1200,7 @@ static int32_t build_phase1(dcd_build* h, bool codes_mode) {
         fprintf(stderr, "DIAG_TOK mode 6: first launch %.3f ms\n", msa[DCD_K_TOK_EMIT]);
         probes.begin(DCD_K_TOK_EMIT);
         hipLaunchKernelGGL((k_tok_emit<CharT>), dim3((u32)div_up(n_tiles, TK_WAVES * TK_TPW)), dim3(TK_THREADS), 0, st, text, P, tab, tv, vt,
-                           M.tile_off.p, M.tupA.p, n_tiles, M.stride, M.tile_cnt.p, (u64)0, sample_cnt.p, sample_mask);
+                           M.tile_off.p, M.tupA.p, n_tiles, M.stride, M.tile_cnt.p, (u64)0, sample_cnt.p, sample_mask, unres);
         probes.end();
       }
       {
@@ -1152,6 +1211,9 @@ static int32_t build_phase1(dcd_build* h, bool codes_mode) {
         DCD_FAIL(DCD_E_STATE, "diagnostic build (DCD_DIAG_TOK): timing only");
       }
 #endif
+      if (early_ids)   // keys whose id was not visible when the token was looked up (VOC_UNRESOLVED | slot) -> ids
+        hipLaunchKernelGGL(k_fix_unresolved, dim3(256), dim3(256), 0, st, M.tupA.p, (const u32*)M.tile_cnt.p, n_tiles, M.stride, (const u32*)unres,
+                           (const u64*)M.slots.p, M.slot_stride);
       if (strided) {
         // the tiles' dense offsets and the number of postings, now that the emit kernel has counted
         scan_exclusive<u32, u64>(M.tile_cnt.p, M.tile_off.p, n_tiles, scan_scr64.p, st);
@@ -1174,7 +1236,20 @@ static int32_t build_phase1(dcd_build* h, bool codes_mode) {
       DCD_TRY(t_tok.stop()); DCD_TRY(t_voc.start()); DCD_TRY(t_voc.stop()); DCD_TRY(t_all.stop());
       return DCD_OK;
     };
-    if (hot_try) {
+    if (early_ids) {
+      // the counters are the vocabulary: V = their sum; dense arrays for the ordinal sort straight from the ids
+      u32* counts = id_ctr.p + ID_CTR_WORDS;
+      DCD_TRY(vocab_prepare<CharT>(dev, st, M.slots.p, cap, nullptr, cap / 2 + 1, tv, M.d_flags.p + 1, &M.vprep, (const u32*)counts + VOC_SHARDS,
+                                   M.slot_stride, (const u32*)id_ctr.p, counts));
+      DCD_HIP(hipMemcpyAsync(rb_nsym, M.vprep.d_nsym, 4, hipMemcpyDeviceToHost, st));
+      M.vprep_done = true;
+      DCD_TRY(stop_timers());
+      DCD_HIP(hipMemcpyAsync(rb_flags, M.d_flags.p, 16, hipMemcpyDeviceToHost, st));
+      DCD_HIP(hipMemcpyAsync(rb_ids, counts, (VOC_SHARDS + 1) * 4, hipMemcpyDeviceToHost, st));
+      DCD_HIP(hipStreamSynchronize(st));
+      for (u32 s = 0; s < VOC_SHARDS; s++) M.id_cnt.c[s] = rb_ids[s];
+      v32 = rb_ids[VOC_SHARDS];
+    } else if (hot_try) {
       // hot terms first: theta from the histogram of the sample counts, ONE 64-bit scan counts used and hot slots, the
       // dense-id table (hot terms 0 .. n_hot-1, then the others in slot order) takes the place of the plain "used" scan
       u32* theta = hot_hist.p + HOT_BINS;
@@ -1243,6 +1318,7 @@ static int32_t build_phase1(dcd_build* h, bool codes_mode) {
   // DOCODO_BUILD_RANK_KEYS=1 keeps the ordinal rank as the sort key (vocabulary first, as explicit postings / word codes need).
   static const bool env_rank_keys = getenv("DOCODO_BUILD_RANK_KEYS") && atoi(getenv("DOCODO_BUILD_RANK_KEYS")) != 0;
   M.id_keys = strided && !env_rank_keys && V != 0;
+  M.early_ids = M.id_keys && early_ids;
   // the split pays when the cold vocabulary is much larger than the hot set (and fits the 2^20 remap-cache values)
   // (without the split the table is still a bijection slot -> [0, V): any such ids sort the tuples by term)
   M.n_hot = (M.id_keys && n_hot && V > 4ull * n_hot) ? n_hot : 0;
@@ -1314,7 +1390,8 @@ static int32_t build_phase2(dcd_build* h) {
   // tuple.x = hash slot -> sort key: the ordinal rank of the word, or (id-keyed plain text builds) its dense id = the number of
   // used slots before it, which the scan behind the emit kernel left in slot_excl -- no vocabulary sort needed to start
   const bool idk = M.id_keys;
-  const u32* remap = idk ? M.slot_excl.p : M.vr.rank_of_slot.p;
+  const bool early = idk && M.early_ids;         // the tuples already carry their sort keys (ids of the numbering table)
+  const u32* remap = early ? nullptr : idk ? M.slot_excl.p : M.vr.rank_of_slot.p;
   bool coord_sort = M.n_xdev != 0;            // mixed input is not in coordinate order
   DevBuf<uint2> expA, expB;
   u64 n_text_postings = M.n_text_tok;          // postings that came from the text (they precede the explicit ones)
@@ -1407,7 +1484,11 @@ static int32_t build_phase2(dcd_build* h) {
   // pass A (hot / cold builds): the chain runs beside the histogram kernel, but the scatter kernel fills the LDS of every CU
   // for a millisecond and small kernels that need LDS would wait behind it (measured: the chain then takes 1.1-1.5 ms
   // instead of 0.5 and slows the scatter kernel by 0.1 ms).  Without the split the wait sits in front of the unit copy.
-  DevBuf<u32> side_hist, side_scr;
+  DevBuf<u32> side_hist, side_scr, id_dense;
+  u64 id_range = 1;                    // early ids: they are dense per shard; the largest one + 1
+  if (early)
+    for (u32 s = 0; s < VOC_SHARDS; s++)
+      if (M.id_cnt.c[s]) id_range = std::max<u64>(id_range, (u64)(M.id_cnt.c[s] - 1) * VOC_SHARDS + s + 1);
   hipStream_t vs = nullptr;
   hipEvent_t ev_side = nullptr;
   EvTimer t_vs;
@@ -1432,6 +1513,10 @@ static int32_t build_phase2(dcd_build* h) {
     DCD_TRY(side_scr.alloc(dev, scan_scratch_elems((u64)RS_MAX_BLOCKS << 10) + scan_scratch_elems(V) + 8));
     DCD_TRY(t_vs.init(vs, dev));
     DCD_TRY(t_vs.start());
+    if (early) {                       // id -> dense id, for the term heads of the pack kernels
+      DCD_TRY(id_dense.alloc(dev, id_range));
+      hipLaunchKernelGGL(k_id_dense_table, dim3((u32)div_up(id_range, 256)), dim3(256), 0, vs, M.id_cnt, (u32)id_range, id_dense.p);
+    }
     DCD_TRY(build_vocab<CharT>(h, M, vs, tv, side_hist.p, side_scr.p));
     DCD_TRY(t_vs.stop());
     DCD_HIP(hipEventRecord(ev_side, vs));
@@ -1472,7 +1557,7 @@ static int32_t build_phase2(dcd_build* h) {
     rp.ev = &sort_events; rp.device = dev;
     RsStrided sd;
     sd.cnt = M.tile_cnt.p; sd.stride = M.stride; sd.n_tiles = M.n_tiles;
-    const bool strided = M.strided && a == M.tupA.p && remap != nullptr;     // (codes mode sorts its own expanded tuples)
+    const bool strided = M.strided && a == M.tupA.p && (remap != nullptr || early);     // (codes mode sorts its own expanded tuples)
     const bool cache_ok = remap != nullptr && rs_cache_ok(1ull << M.cap_log2, V);
     hot_n = (idk && strided && M.n_hot && V > M.n_hot) ? M.n_hot : 0;
     if (hot_n) {
@@ -1519,8 +1604,20 @@ static int32_t build_phase2(dcd_build* h) {
       }
       sorted = b;
     } else {
-      sorted = rs_sort(a, b, remap, N, (int)log2_ceil(V ? V : 1), M.d_hist.p, M.scan_scr32.p, st, &p2, rp, 9, cache_ok, strided ? &sd : nullptr);
+      const u64 key_range = early ? id_range : V ? V : 1;
+      // id-keyed: the vocabulary chain is queued behind the first histogram kernel and the main stream ordered behind it in
+      // front of the first scatter kernel (see queue_vocab_side); the hook fires on every pass, the wait happens once
+      struct SideHook { std::function<int32_t()>* fn; int32_t status; } sh;
+      std::function<int32_t()> side_fn = wait_vocab_side;
+      sh.fn = &side_fn; sh.status = DCD_OK;
+      RsProbe rps = rp;
+      if (idk) {
+        rps.after_scan_arg = &sh;
+        rps.after_scan = [](void* arg, hipStream_t) { SideHook* s = (SideHook*)arg; if (s->status == DCD_OK) s->status = (*s->fn)(); };
+      }
+      sorted = rs_sort(a, b, remap, N, (int)log2_ceil(key_range), M.d_hist.p, M.scan_scr32.p, st, &p2, rps, 9, cache_ok, strided ? &sd : nullptr);
       passes += p2;
+      DCD_TRY(sh.status);
     }
   }
   DCD_TRY(t_sort.stop());
@@ -1550,6 +1647,7 @@ static int32_t build_phase2(dcd_build* h) {
   src.term_unit_start = idk ? us_id.p : ix.term_unit_start.p;
   src.term_item_start = idk ? is_id.p : ix.term_item_start.p;
   src.hot_n = hot_n; src.hot_s = hot_s;
+  src.id_dense = early ? id_dense.p : nullptr;
   u64* d_U = enc_scr.p + scan_nblocks(enb);        // the scan leaves the number of units here
   if (N) {
     probes.begin(DCD_K_ENC_REDUCE);
@@ -1690,7 +1788,7 @@ static int32_t build_phase2(dcd_build* h) {
   s.ms_tokenize = M.ms_tok; s.ms_vocab = M.ms_voc; s.ms_sort = t_sort.ms(); s.ms_pack = t_pack.ms(); s.ms_image = t_img.ms();
   s.ms_total = M.ms_total + t_all.ms();
   s.sort_passes = (u32)passes; s.vocab_capacity_log2 = M.cap_log2;
-  s.id_keys = idk ? 1u : 0u; s.n_hot_terms = hot_n; s.n_hot_postings = n_hot_postings;
+  s.id_keys = early ? 2u : idk ? 1u : 0u; s.n_hot_terms = hot_n; s.n_hot_postings = n_hot_postings;
   for (int k = 0; k < 8; k++) { s.ms_kernel[k] = M.ms_kernel[k]; s.n_launch[k] = M.n_launch[k]; }
   probes.collect(s.ms_kernel, s.n_launch);
   for (size_t i = 0; i + 3 < sort_events.size(); i += 4) {

@@ -36,7 +36,11 @@ struct EncSrcPairs {
   u64* term_item_start;  // [n_terms+1]
   // hot / cold split keys (RsStrided::hot_n / hot_s, dcd_sort.h): x is the transformed key, the directory is indexed by the dense id
   u32 hot_n = 0, hot_s = 0;
+  // ... or ids of a numbering vocabulary table (id_dense != nullptr): the directory is indexed by the dense id = number of used
+  // ids below x, tabulated (term heads only gather from it)
+  const u32* id_dense = nullptr;
   __device__ __forceinline__ u32 id_of(u32 x) const {
+    if (id_dense) return id_dense[x];
     if (!hot_s) return x;
     const u32 hi = x >> hot_s;
     return hi < hot_n ? hi : hot_n + (x - (hot_n << hot_s));

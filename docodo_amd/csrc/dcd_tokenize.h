@@ -324,7 +324,9 @@ struct VocabTable {
                    // slot i's entry is pool[i * pstride ...]
   u32 stride = 1;  // in u64 units.  Pooled tables are arrays of records {slot word, padding, string}: stride = W, and
   u32 pstride = 0; // pool = (u32*)slots + W with pstride = 2 W -- a token that misses the caches fetches ONE line, not two
+  u32* id_ctr = nullptr;   // optional (record tables only): VOC_SHARDS counters -- the table NUMBERS its terms (see vocab_lookup_insert_ids)
 };
+constexpr u32 VOC_UNRESOLVED = 0x80000000u;   // tuple key = VOC_UNRESOLVED | slot: the term's id was not visible yet (fixed up after the launch)
 // words of a string kept next to its slot: 16 characters' worth
 template <typename CharT> struct VocPool { static constexpr u32 W = 4 * sizeof(CharT); };
 
@@ -411,6 +413,77 @@ __device__ __forceinline__ u32 vocab_lookup_insert_pooled(const VocabTable& vt, 
           for (u32 q = 0; q < W / 4; q++) pe[q] = make_uint4(wv[4 * q], wv[4 * q + 1], wv[4 * q + 2], wv[4 * q + 3]);
         }
         return idx;
+      }
+    }
+    idx = (idx + 1) & vt.mask;
+  }
+  *vt.overflow = 1u;
+  return 0xFFFFFFFFu;
+}
+
+// The same for a record table that NUMBERS its terms while it is filled (VocabTable::id_ctr): the lane that wins the slot
+// takes the next number of its shard and publishes id + 1 in the record's padding word, next to the slot word.  A later token
+// of the term gets the id from the 16 bytes {slot word, id + 1, -} it loads anyway: the slot word agrees on tag and length,
+// the string granule confirms the characters (granule words are only ever 0 or final, token words are never 0), and a non-zero
+// id word is final, whatever the caches did to the record.  An id that is not visible (this CU / XCD holds the line from
+// before it was written -- plain loads are served by L1 and by the XCD's own L2, which nobody refreshes) is fetched with an
+// atomic, executed at the memory side where the inserter put it, and the lane then stores it into the padding word itself,
+// which heals its own cache hierarchy for the tokens that follow; if the inserter is still between its compare-and-swap and
+// its publish, the lane returns VOC_UNRESOLVED | slot, which a fix-up pass behind the launch replaces.  The tuples then carry
+// the sort key straight from the tokeniser: no slot -> id table, no remap gathers in the first radix pass.
+// shard_off = shard * VOC_CTR_STRIDE.  Returns the id, VOC_UNRESOLVED | slot, or 0xFFFFFFFF on table overflow.
+template <typename CharT, typename GetWord>
+__device__ __forceinline__ u32 vocab_lookup_insert_ids(const VocabTable& vt, const TextView<CharT>& tv, TokHash h, u32 len, u64 pos,
+                                                       const u32 (&wv)[VocPool<CharT>::W], GetWord get, u32 shard_off) {
+  constexpr u32 W = VocPool<CharT>::W;
+  const u64 mine = voc_word(h.tag, len, pos);
+  const u32 nbytes = len * (u32)sizeof(CharT), nw = (nbytes + 3u) >> 2;
+  u32 idx = h.idx & vt.mask;
+  for (u32 probes = 0; probes < 4096u; probes++) {
+    u64* sp = vt.slots + (u64)idx * vt.stride;
+    const uint4 head = *reinterpret_cast<const uint4*>(sp);                      // slot word, id + 1, -
+    u64 w = (u64)head.x | ((u64)head.y << 32);
+    u32 idw = head.z;
+    u32* pad = reinterpret_cast<u32*>(sp) + 2;
+    uint4* pe = reinterpret_cast<uint4*>(vt.pool + (u64)idx * vt.pstride);
+    if (w == 0) {
+      u64 old = atomicCAS((unsigned long long*)sp, 0ull, (unsigned long long)mine);
+      if (old == 0) {
+        const u32 id = atomicAdd(vt.id_ctr + shard_off, 1u) * VOC_SHARDS + shard_off / VOC_CTR_STRIDE;
+        atomicExch(pad, id + 1u);          // published at the memory side, like the slot word
+#pragma unroll
+        for (u32 q = 0; q < W / 4; q++) pe[q] = make_uint4(wv[4 * q], wv[4 * q + 1], wv[4 * q + 2], wv[4 * q + 3]);
+        return id;
+      }
+      w = old;
+      idw = 0;
+    }
+    if ((w >> 42) == (mine >> 42)) {  // tag and length agree
+      u32 diff = 0;
+#pragma unroll
+      for (u32 q = 0; q < W / 4; q++) {
+        const uint4 p = pe[q];
+        diff |= (p.x ^ wv[4 * q]) | (p.y ^ wv[4 * q + 1]) | (p.z ^ wv[4 * q + 2]) | (p.w ^ wv[4 * q + 3]);
+      }
+      bool eq = diff == 0 && nw <= W;
+      if (eq && idw != 0) return idw - 1u;
+      if (!eq) {
+        const u64 cp = voc_pos(w);
+        eq = true;
+        for (u32 k = 0; k < nw; k++) {
+          if (((tv.canon_word(cp, k) ^ get(k)) & tail_mask(nbytes, k)) != 0u) { eq = false; break; }
+        }
+      }
+      if (eq) {
+        if (diff != 0) {
+#pragma unroll
+          for (u32 q = 0; q < W / 4; q++) pe[q] = make_uint4(wv[4 * q], wv[4 * q + 1], wv[4 * q + 2], wv[4 * q + 3]);
+        }
+        if (idw) return idw - 1u;
+        const u32 idp = atomicOr(pad, 0u);
+        if (!idp) return VOC_UNRESOLVED | idx;      // the inserter is between its compare-and-swap and its atomicExch
+        *pad = idp;
+        return idp - 1u;
       }
     }
     idx = (idx + 1) & vt.mask;

@@ -166,8 +166,10 @@ typedef struct dcd_build_stats {
    * [4] k_enc_reduce  [5] k_enc_write  [6] k_img_units  [7] vocabulary string sort (all kernels) */
   float ms_kernel[8];
   uint32_t n_launch[8];
-  /* how the tuples were sorted: id_keys = 1: by dense vocabulary id, the ordinal vocabulary sort ran beside the tuple sort
-   * ([7] is then overlapped time) and k_img_units also copies the units into term order; n_hot_terms > 0: the first radix
+  /* how the tuples were sorted: id_keys = 2: by the ids the vocabulary table hands out while the tokeniser fills it (the tuples
+   * carry their sort keys from the start), 1: by dense ids taken from a scan of the table afterwards; either way the ordinal
+   * vocabulary sort ran beside the tuple sort ([7] is then overlapped time) and k_img_units also copies the units into term
+   * order; 0: by ordinal rank.  n_hot_terms > 0 (id_keys = 1 only): the first radix
    * pass gave that many frequent terms a bucket of their own (n_hot_postings tuples, final after one pass) and only the
    * other n_postings - n_hot_postings tuples took the remaining sort_passes - 1 passes */
   uint32_t id_keys, n_hot_terms;
