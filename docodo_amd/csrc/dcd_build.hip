@@ -1479,31 +1479,39 @@ static int32_t build_phase2(dcd_build* h) {
   }
 
   // ---- id-keyed builds: the vocabulary on a second (high-priority) stream, beside the tuple sort ------------------
-  // Phase 1 ran the first half and fetched the two host-side parameters, so the whole chain (~30 small kernels) is queued
-  // here without blocking; `ev_side` marks its end.  The main stream waits for that event in front of the scatter kernel of
-  // pass A (hot / cold builds): the chain runs beside the histogram kernel, but the scatter kernel fills the LDS of every CU
-  // for a millisecond and small kernels that need LDS would wait behind it (measured: the chain then takes 1.1-1.5 ms
-  // instead of 0.5 and slows the scatter kernel by 0.1 ms).  Without the split the wait sits in front of the unit copy.
+  // Phase 1 ran the first half and fetched the two host-side parameters, so the chain (~40 small kernels, 0.15-0.2 ms of host
+  // time to queue) is queued here without blocking; `ev_side` marks its end and the main stream waits for it in front of the
+  // unit copy (step 6).  WHERE it is queued matters, because the kernels of the tuple sort fill every CU:
+  //  * hot / cold builds queue it between the scan and the scatter kernel of pass A and order the main stream behind it
+  //    right there: it runs beside the (long, 0.47 ms) histogram kernel, not beside the scatter kernel, which fills the LDS of
+  //    every CU for a millisecond (the chain then takes 1.1-1.5 ms instead of 0.3-0.5 and slows the scatter kernel by 0.1 ms);
+  //  * the others (early ids: histogram kernel of pass A 0.22 ms, shorter than the chain) queue it BEHIND the launch of the
+  //    scatter kernel of pass A and order nothing: the first kernels of the chain run beside the histogram kernel, the rest
+  //    squeeze in beside the scatter kernel, which they slow by ~0.05 ms -- measured against ordering the main stream behind
+  //    the chain in front of that kernel (+0.14 ms of idle main stream) and against queueing the chain in two portions, one
+  //    beside each histogram kernel (the histogram kernel of pass B occupies every wave slot until it ends: +0.12 ms).
   DevBuf<u32> side_hist, side_scr, id_dense;
   u64 id_range = 1;                    // early ids: they are dense per shard; the largest one + 1
   if (early)
     for (u32 s = 0; s < VOC_SHARDS; s++)
       if (M.id_cnt.c[s]) id_range = std::max<u64>(id_range, (u64)(M.id_cnt.c[s] - 1) * VOC_SHARDS + s + 1);
   hipStream_t vs = nullptr;
-  hipEvent_t ev_side = nullptr;
+  hipEvent_t ev_side = nullptr, ev_dense = nullptr;     // (ev_dense: id_dense is ready -- the pack kernels wait for it)
   EvTimer t_vs;
-  struct SideGuard {                   // stream and event go back to their caches (drained) however this function is left
-    int dev; hipStream_t* s; hipEvent_t* e;
+  struct SideGuard {                   // stream and events go back to their caches (drained) however this function is left
+    int dev; hipStream_t* s; hipEvent_t* e[2];
     ~SideGuard() {
       if (*s) { stream_release_high(dev, *s); *s = nullptr; }
-      if (*e) { event_release(dev, *e); *e = nullptr; }
+      for (hipEvent_t* x : e) if (*x) { event_release(dev, *x); *x = nullptr; }
     }
-  } side_guard{dev, &vs, &ev_side};
+  } side_guard{dev, &vs, {&ev_side, &ev_dense}};
   bool side_waited = false;
   auto queue_vocab_side = [&]() -> int32_t {
+    if (ev_side) return DCD_OK;        // (queued already)
     DCD_TRY(stream_acquire_high(dev, &vs));
     ev_side = event_acquire(dev);
-    if (!ev_side) DCD_FAIL(DCD_E_HIP, "hipEventCreate failed");
+    ev_dense = event_acquire(dev);
+    if (!ev_side || !ev_dense) DCD_FAIL(DCD_E_HIP, "hipEventCreate failed");
     StreamScope ss_v(vs);              // allocations below belong to the side stream
     TextView<CharT> tv;
     tv.text = (const CharT*)h->text_dev; tv.n_chars = h->n_chars; tv.pool = (const CharT*)M.d_pool_raw.p; tv.n_pool = M.n_pool;
@@ -1516,6 +1524,7 @@ static int32_t build_phase2(dcd_build* h) {
     if (early) {                       // id -> dense id, for the term heads of the pack kernels
       DCD_TRY(id_dense.alloc(dev, id_range));
       hipLaunchKernelGGL(k_id_dense_table, dim3((u32)div_up(id_range, 256)), dim3(256), 0, vs, M.id_cnt, (u32)id_range, id_dense.p);
+      DCD_HIP(hipEventRecord(ev_dense, vs));
     }
     DCD_TRY(build_vocab<CharT>(h, M, vs, tv, side_hist.p, side_scr.p));
     DCD_TRY(t_vs.stop());
@@ -1525,7 +1534,7 @@ static int32_t build_phase2(dcd_build* h) {
   auto wait_vocab_side = [&]() -> int32_t {   // queues the chain (if that has not happened yet) and orders the main stream
     if (side_waited) return DCD_OK;           // behind it; no host blocking
     side_waited = true;
-    if (!ev_side) DCD_TRY(queue_vocab_side());
+    DCD_TRY(queue_vocab_side());
     DCD_HIP(hipStreamWaitEvent(st, ev_side, 0));
     return DCD_OK;
   };
@@ -1605,15 +1614,15 @@ static int32_t build_phase2(dcd_build* h) {
       sorted = b;
     } else {
       const u64 key_range = early ? id_range : V ? V : 1;
-      // id-keyed: the vocabulary chain is queued behind the first histogram kernel and the main stream ordered behind it in
-      // front of the first scatter kernel (see queue_vocab_side); the hook fires on every pass, the wait happens once
+      // id-keyed: the vocabulary chain is queued behind the launch of the first scatter kernel (see queue_vocab_side);
+      // the hook fires in front of every pass but the first, the chain is queued once
       struct SideHook { std::function<int32_t()>* fn; int32_t status; } sh;
-      std::function<int32_t()> side_fn = wait_vocab_side;
+      std::function<int32_t()> side_fn = queue_vocab_side;
       sh.fn = &side_fn; sh.status = DCD_OK;
       RsProbe rps = rp;
       if (idk) {
         rps.after_scan_arg = &sh;
-        rps.after_scan = [](void* arg, hipStream_t) { SideHook* s = (SideHook*)arg; if (s->status == DCD_OK) s->status = (*s->fn)(); };
+        rps.before_pass = [](void* arg, hipStream_t) { SideHook* s = (SideHook*)arg; if (s->status == DCD_OK) s->status = (*s->fn)(); };
       }
       sorted = rs_sort(a, b, remap, N, (int)log2_ceil(key_range), M.d_hist.p, M.scan_scr32.p, st, &p2, rps, 9, cache_ok, strided ? &sd : nullptr);
       passes += p2;
@@ -1621,6 +1630,10 @@ static int32_t build_phase2(dcd_build* h) {
     }
   }
   DCD_TRY(t_sort.stop());
+  if (idk) {
+    DCD_TRY(queue_vocab_side());       // (one-pass sorts: the hook never fired)
+    if (early) DCD_HIP(hipStreamWaitEvent(st, ev_dense, 0));
+  }
   tr.mark("sort-enqueue");
 
   // ---- 5. pack: deltas -> var-ushort units (IndexSequence.Builder.Add) -----------------------

@@ -469,7 +469,10 @@ struct RsProbe {
   // optional: called between the scan of the histogram and the scatter kernel of a pass (the scanned counts are final
   // there: a caller can queue a read-back of bucket boundaries that completes while the scatter kernel still runs)
   void (*after_scan)(void* arg, hipStream_t st) = nullptr;
-  void* after_scan_arg = nullptr;
+  // optional: called by rs_sort in front of every pass but the first (the scatter kernel of the pass before is then the last
+  // thing queued on the stream)
+  void (*before_pass)(void* arg, hipStream_t st) = nullptr;
+  void* after_scan_arg = nullptr;        // (the argument of both)
   void rec(hipStream_t st) const {
     if (!ev) return;
     hipEvent_t e = event_acquire(device);
@@ -567,6 +570,7 @@ inline uint2* rs_sort(uint2* buf_a, uint2* buf_b, const u32* remap, u64 n, int t
   int shift = 0;
   uint2 *in = buf_a, *out = buf_b;
   for (int i = 0; i < sc.npass; i++) {
+    if (i && pr.before_pass) pr.before_pass(pr.after_scan_arg, st);
     rs_pass_dyn(sc.width[i], in, out, i == 0 ? remap : nullptr, n, shift, hist, scan_scratch, st, pr, remap_cache,
                 i == 0 ? strided : nullptr);
     shift += sc.width[i];
