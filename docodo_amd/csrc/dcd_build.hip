@@ -214,24 +214,47 @@ __global__ __launch_bounds__(256) void k_id_dense_table(IdCounts n, u32 id_range
   const u32 id = blockIdx.x * 256u + threadIdx.x;
   if (id < id_range) dense[id] = dense_of_id(n, id);
 }
-// unresolved keys (VOC_UNRESOLVED | slot) -> ids, now that every inserter has published its id; one wave per listed tile, or --
-// when the list overflowed -- every tile
-__global__ __launch_bounds__(256) void k_fix_unresolved(uint2* __restrict__ tuples, const u32* __restrict__ tile_cnt, u64 n_tiles, u32 stride,
-                                                        const u32* __restrict__ unres, const u64* __restrict__ slots, u32 slot_stride) {
+// Behind the emit kernel of a build with early ids, ONE launch:
+//  * unresolved keys (VOC_UNRESOLVED | slot) -> ids, now that every inserter has published its id; one wave per listed tile,
+//    or -- when the list overflowed -- every tile;
+//  * the number of postings = sum of the tile counts (*n_tok, zeroed; one atomic per workgroup);
+//  * the coordinate of the last posting (maxCoord, Build.cs:326).
+__global__ __launch_bounds__(256) void k_emit_epilogue(uint2* __restrict__ tuples, const u32* __restrict__ tile_cnt, u64 n_tiles, u32 stride,
+                                                       const u32* __restrict__ unres, const u64* __restrict__ slots, u32 slot_stride,
+                                                       u64* __restrict__ n_tok, u32* __restrict__ last_coord) {
+  __shared__ u64 s_sum[4];
   const u32 n = unres[0];
-  if (n == 0) return;
-  const u64 wave = (u64)blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = (u64)gridDim.x * 4;
-  const bool all = n > UNRES_CAP;
-  const u64 count = all ? n_tiles : n;
-  for (u64 k = wave; k < count; k += n_waves) {
-    const u64 t = all ? k : unres[1 + k];
-    const u32 c = tile_cnt[t];
-    for (u32 j = lane_id(); j < c; j += 64) {
-      const u32 x = tuples[t * stride + j].x;
-      if (x != 0xFFFFFFFFu && (x & VOC_UNRESOLVED)) {
-        const u32 slot = x & ~VOC_UNRESOLVED;
-        tuples[t * stride + j].x = reinterpret_cast<const u32*>(slots + (u64)slot * slot_stride)[2] - 1u;
+  if (n) {
+    const u64 wave = (u64)blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = (u64)gridDim.x * 4;
+    const bool all = n > UNRES_CAP;
+    const u64 count = all ? n_tiles : n;
+    for (u64 k = wave; k < count; k += n_waves) {
+      const u64 t = all ? k : unres[1 + k];
+      const u32 c = tile_cnt[t];
+      for (u32 j = lane_id(); j < c; j += 64) {
+        const u32 x = tuples[t * stride + j].x;
+        if (x != 0xFFFFFFFFu && (x & VOC_UNRESOLVED)) {
+          const u32 slot = x & ~VOC_UNRESOLVED;
+          tuples[t * stride + j].x = reinterpret_cast<const u32*>(slots + (u64)slot * slot_stride)[2] - 1u;
+        }
       }
+    }
+  }
+  u64 s = 0;
+  for (u64 t = (u64)blockIdx.x * 256 + threadIdx.x; t < n_tiles; t += (u64)gridDim.x * 256) s += tile_cnt[t];
+  s = wave_sum(s);
+  if (lane_id() == 0) s_sum[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const u64 tot = s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3];
+    if (tot) atomicAdd((unsigned long long*)n_tok, (unsigned long long)tot);
+    if (blockIdx.x == 0) {       // (the last non-empty tile is almost always the last one)
+      u32 y = 0;
+      for (u64 t = n_tiles; t-- > 0;) {
+        const u32 c = tile_cnt[t];
+        if (c) { y = tuples[t * stride + c - 1].y; break; }
+      }
+      *last_coord = y;
     }
   }
 }
@@ -1075,7 +1098,7 @@ static int32_t build_phase1(dcd_build* h, bool codes_mode) {
   u64 n_text_tok = 0;
   if (n_tiles) {
     DCD_TRY(M.tile_cnt.alloc(dev, n_tiles));
-    DCD_TRY(M.tile_off.alloc(dev, n_tiles));
+    DCD_TRY(M.tile_off.alloc(dev, n_tiles));                         // (builds with early ids use neither: the pool keeps them)
     DCD_TRY(scan_scr64.alloc(dev, scan_scratch_elems(n_tiles)));
   }
   if (n_tiles && !strided) {
@@ -1124,10 +1147,17 @@ static int32_t build_phase1(dcd_build* h, bool codes_mode) {
   static const bool env_early = !(getenv("DOCODO_BUILD_EARLY_IDS") && atoi(getenv("DOCODO_BUILD_EARLY_IDS")) == 0);
   bool early_ids = strided && !env_rank_keys0 && env_early;
   const bool fast_end = strided && !env_rank_keys0;
-  // VOC_SHARDS id counters VOC_CTR_STRIDE words apart, then: the counts again, densely, + their sum V (k_vocab_compact_ids),
-  // then the fix-up list: count + UNRES_CAP tiles
+  // Early ids: ONE buffer holds the small device-side state of the round, so that one fill zeroes it and one copy fetches
+  // its results.  VOC_SHARDS id counters VOC_CTR_STRIDE words apart, then the results R[0 .. EI_WORDS): the counts again,
+  // densely, + their sum V (k_vocab_compact_ids), the two parameters of the ordinal sort, maxCoord, the number of postings,
+  // the overflow flag; then the character bitmap and the count of the fix-up list (all of that zeroed), its UNRES_CAP tiles
+  // and the per-workgroup key-length maxima.
   DevBuf<u32> id_ctr;
   constexpr u32 ID_CTR_WORDS = VOC_SHARDS * VOC_CTR_STRIDE;
+  constexpr u32 EI_V = VOC_SHARDS, EI_NSYM = EI_V + 1, EI_MAXLEN = EI_V + 2, EI_LASTC = EI_V + 3, EI_NTOK = EI_V + 4 /* u64 */, EI_OVF = EI_V + 6,
+                EI_WORDS = EI_V + 8, EI_CBITS = EI_WORDS, EI_UNRES = EI_CBITS + 2052, EI_ZEROED = EI_UNRES + 1, EI_BLOCKMAX = EI_ZEROED + UNRES_CAP;
+  static_assert(EI_WORDS * 4 <= (64 - 24) * 8, "the results must fit the pinned words behind pin[24]");
+  static_assert(EI_NTOK % 2 == 0 && EI_CBITS % 4 == 0, "alignment of the 64-bit count / the bitmap");
   u32 sample_mask = 0;
   while (((u64)sample_mask + 1) * DCD_HOT_SAMPLE_TILES < n_tiles) sample_mask = sample_mask * 2 + 1;
   DevBuf<u32> sample_cnt, hot_hist;           // [cap] / [HOT_BINS + 1] (theta behind the bins)
@@ -1139,7 +1169,7 @@ static int32_t build_phase1(dcd_build* h, bool codes_mode) {
   u64* rb_total = pin + 17;
   u32* rb_flags = (u32*)(pin + 18);     // 4 words
   u32* rb_nsym = (u32*)(pin + 20);
-  u32* rb_ids = (u32*)(pin + 24);       // VOC_SHARDS + 1 words
+  u32* rb_ids = (u32*)(pin + 24);       // early ids: EI_WORDS words (the results of the round)
   *rb_ntok = 0; *rb_total = 0; *rb_nsym = 0;
   for (;;) {
     if (cap_log2 > 30) DCD_FAIL(DCD_E_OVERFLOW, "vocabulary does not fit a 2^30-slot table");
@@ -1155,19 +1185,20 @@ static int32_t build_phase1(dcd_build* h, bool codes_mode) {
     if (!no_pool && cap_log2 <= 26 && M.slots.alloc(dev, cap * PWW) == DCD_OK) M.slot_stride = PWW;
     else DCD_TRY(M.slots.alloc(dev, cap));
     DCD_HIP(hipMemsetAsync(M.slots.p, 0, cap * 8 * M.slot_stride, st));
-    DCD_HIP(hipMemsetAsync(M.d_flags.p, 0, 16, st));
+    if (early_ids && M.slot_stride == 1) early_ids = false;       // (no record table: very large vocabulary or no memory)
+    if (!early_ids) DCD_HIP(hipMemsetAsync(M.d_flags.p, 0, 16, st));      // (early ids keep their flags with the id counters)
     VocabTable vt;
     vt.slots = M.slots.p; vt.mask = (u32)(cap - 1); vt.overflow = M.d_flags.p;
     vt.pool = nullptr; vt.stride = M.slot_stride; vt.pstride = 0;
     if (M.slot_stride > 1) { vt.pool = reinterpret_cast<u32*>(M.slots.p) + PWW; vt.pstride = 2 * PWW; }
-    if (early_ids && M.slot_stride == 1) early_ids = false;       // (no record table: very large vocabulary or no memory)
     const bool hot_try = strided && !env_rank_keys0 && env_hot > 0 && !early_ids;
     u32* unres = nullptr;
     if (early_ids) {
-      DCD_TRY(id_ctr.alloc(dev, ID_CTR_WORDS + VOC_SHARDS + 2 + UNRES_CAP + 1));
-      DCD_HIP(hipMemsetAsync(id_ctr.p, 0, (ID_CTR_WORDS + VOC_SHARDS + 2 + 1) * 4, st));
+      DCD_TRY(id_ctr.alloc(dev, ID_CTR_WORDS + EI_BLOCKMAX + div_up(cap / 2 + 1, 256) + 1));
+      DCD_HIP(hipMemsetAsync(id_ctr.p, 0, (size_t)(ID_CTR_WORDS + EI_ZEROED) * 4, st));
       vt.id_ctr = id_ctr.p;
-      unres = id_ctr.p + ID_CTR_WORDS + VOC_SHARDS + 2;
+      vt.overflow = id_ctr.p + ID_CTR_WORDS + EI_OVF;
+      unres = id_ctr.p + ID_CTR_WORDS + EI_UNRES;
     }
     if (hot_try) {
       DCD_TRY(sample_cnt.alloc(dev, cap));
@@ -1211,10 +1242,12 @@ static int32_t build_phase1(dcd_build* h, bool codes_mode) {
         DCD_FAIL(DCD_E_STATE, "diagnostic build (DCD_DIAG_TOK): timing only");
       }
 #endif
-      if (early_ids)   // keys whose id was not visible when the token was looked up (VOC_UNRESOLVED | slot) -> ids
-        hipLaunchKernelGGL(k_fix_unresolved, dim3(256), dim3(256), 0, st, M.tupA.p, (const u32*)M.tile_cnt.p, n_tiles, M.stride, (const u32*)unres,
-                           (const u64*)M.slots.p, M.slot_stride);
-      if (strided) {
+      u32* R = early_ids ? id_ctr.p + ID_CTR_WORDS : nullptr;
+      if (early_ids) {
+        // keys whose id was not visible when the token was looked up -> ids; the number of postings; maxCoord
+        hipLaunchKernelGGL(k_emit_epilogue, dim3(256), dim3(256), 0, st, M.tupA.p, (const u32*)M.tile_cnt.p, n_tiles, M.stride, (const u32*)unres,
+                           (const u64*)M.slots.p, M.slot_stride, (u64*)(R + EI_NTOK), R + EI_LASTC);
+      } else if (strided) {
         // the tiles' dense offsets and the number of postings, now that the emit kernel has counted
         scan_exclusive<u32, u64>(M.tile_cnt.p, M.tile_off.p, n_tiles, scan_scr64.p, st);
         DCD_HIP(hipMemcpyAsync(rb_ntok, scan_scr64.p + scan_nblocks(n_tiles), 8, hipMemcpyDeviceToHost, st));
@@ -1227,7 +1260,7 @@ static int32_t build_phase1(dcd_build* h, bool codes_mode) {
     DCD_TRY(M.slot_excl.alloc(dev, cap));
     DCD_TRY(M.scan_scr32.alloc(dev, std::max<u64>(scan_scratch_elems(cap), scan_scratch_elems((u64)RS_MAX_BLOCKS << 10))));
     u32 v32 = 0;
-    if (strided) {
+    if (strided && !early_ids) {
       // maxCoord = coordinate of the last posting added (Build.cs:326): fetched with the counters below, ONE host round trip
       hipLaunchKernelGGL(k_last_strided_coord, dim3(1), dim3(1), 0, st, M.tupA.p, M.tile_cnt.p, n_tiles, M.stride, M.d_flags.p + 2);
     }
@@ -1237,18 +1270,20 @@ static int32_t build_phase1(dcd_build* h, bool codes_mode) {
       return DCD_OK;
     };
     if (early_ids) {
-      // the counters are the vocabulary: V = their sum; dense arrays for the ordinal sort straight from the ids
-      u32* counts = id_ctr.p + ID_CTR_WORDS;
-      DCD_TRY(vocab_prepare<CharT>(dev, st, M.slots.p, cap, nullptr, cap / 2 + 1, tv, M.d_flags.p + 1, &M.vprep, (const u32*)counts + VOC_SHARDS,
-                                   M.slot_stride, (const u32*)id_ctr.p, counts));
-      DCD_HIP(hipMemcpyAsync(rb_nsym, M.vprep.d_nsym, 4, hipMemcpyDeviceToHost, st));
+      // the counters are the vocabulary: V = their sum; dense arrays for the ordinal sort straight from the ids; ONE copy
+      // brings everything the host needs
+      u32* R = id_ctr.p + ID_CTR_WORDS;
+      DCD_TRY(vocab_prepare_ids<CharT>(dev, st, M.slots.p, cap, cap / 2 + 1, tv, &M.vprep, M.slot_stride, (const u32*)id_ctr.p, R, R + EI_CBITS,
+                                       R + EI_BLOCKMAX, R + EI_NSYM, R + EI_MAXLEN));
       M.vprep_done = true;
       DCD_TRY(stop_timers());
-      DCD_HIP(hipMemcpyAsync(rb_flags, M.d_flags.p, 16, hipMemcpyDeviceToHost, st));
-      DCD_HIP(hipMemcpyAsync(rb_ids, counts, (VOC_SHARDS + 1) * 4, hipMemcpyDeviceToHost, st));
+      DCD_HIP(hipMemcpyAsync(rb_ids, R, EI_WORDS * 4, hipMemcpyDeviceToHost, st));
       DCD_HIP(hipStreamSynchronize(st));
       for (u32 s = 0; s < VOC_SHARDS; s++) M.id_cnt.c[s] = rb_ids[s];
-      v32 = rb_ids[VOC_SHARDS];
+      v32 = rb_ids[EI_V];
+      *rb_nsym = rb_ids[EI_NSYM];
+      rb_flags[0] = rb_ids[EI_OVF]; rb_flags[1] = rb_ids[EI_MAXLEN]; rb_flags[2] = rb_ids[EI_LASTC];
+      *rb_ntok = *(const u64*)(rb_ids + EI_NTOK);
     } else if (hot_try) {
       // hot terms first: theta from the histogram of the sample counts, ONE 64-bit scan counts used and hot slots, the
       // dense-id table (hot terms 0 .. n_hot-1, then the others in slot order) takes the place of the plain "used" scan

@@ -71,14 +71,23 @@ static __global__ __launch_bounds__(256) void k_max_len(const u64* __restrict__ 
 // proportional to (key length) x (bits per character).  The characters that actually occur are ranked (order
 // preserving, 0 = "past the end"), so a character costs ceil(log2(#distinct + 1)) bits instead of 8 / 16:
 // 6 bits for lower-case ASCII + digits -> five characters per 32-bit chunk.
+// blockmax != nullptr: the workgroup also leaves the length of its longest key in blockmax[blockIdx.x] (k_char_rank reduces
+// them: no atomics, and no k_max_len launch).  Workgroups past the n_dev terms do nothing.
 template <typename CharT>
 __global__ __launch_bounds__(256) void k_char_used(const u64* __restrict__ term_word, u64 n, TextView<CharT> tv, u32* __restrict__ bitmap,
-                                                   const u32* __restrict__ n_dev) {
+                                                   const u32* __restrict__ n_dev, u32* __restrict__ blockmax = nullptr) {
   __shared__ u32 s_bits[2048];      // per-workgroup bitmap in LDS; only its non-zero words reach the global one
+  __shared__ u32 s_max;
   if (n_dev) n = *n_dev < n ? *n_dev : n;
+  if ((u64)blockIdx.x * blockDim.x >= n) return;
   for (u32 x = threadIdx.x; x < 2048; x += 256) s_bits[x] = 0;
+  if (threadIdx.x == 0) s_max = 0;
   __syncthreads();
   u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (blockmax) {
+    const u32 l = wave_max(i < n ? voc_len(term_word[i]) : 0u);
+    if (lane_id() == 0) atomicMax(&s_max, l);
+  }
   if (i < n) {
     u64 w = term_word[i];
     u32 len = voc_len(w);
@@ -91,11 +100,28 @@ __global__ __launch_bounds__(256) void k_char_used(const u64* __restrict__ term_
   }
   __syncthreads();
   for (u32 x = threadIdx.x; x < 2048; x += 256) { u32 v = s_bits[x]; if (v) atomicOr(&bitmap[x], v); }
+  if (blockmax && threadIdx.x == 0) blockmax[blockIdx.x] = s_max;
 }
 // one workgroup: rank[c] = 1 + number of used characters below c (0 for unused ones); *n_sym = number of used characters
-static __global__ __launch_bounds__(1024) void k_char_rank(const u32* __restrict__ bitmap, u16* __restrict__ rank, u32* __restrict__ n_sym) {
+// blockmax != nullptr: also *maxlen = the largest of the ceil(*n_dev / 256) per-workgroup maxima k_char_used left
+static __global__ __launch_bounds__(1024) void k_char_rank(const u32* __restrict__ bitmap, u16* __restrict__ rank, u32* __restrict__ n_sym,
+                                                           const u32* __restrict__ blockmax = nullptr, const u32* __restrict__ n_dev = nullptr,
+                                                           u64 n_bound = 0, u32* __restrict__ maxlen = nullptr) {
   __shared__ u32 lds[17];
+  __shared__ u32 s_max;
   const u32 t = threadIdx.x;
+  if (blockmax) {
+    if (t == 0) s_max = 0;
+    __syncthreads();
+    const u64 n = *n_dev < n_bound ? *n_dev : n_bound;
+    const u32 nb = (u32)((n + 255) / 256);
+    u32 m = 0;
+    for (u32 b = t; b < nb; b += 1024) m = max(m, blockmax[b]);
+    m = wave_max(m);
+    if (lane_id() == 0 && m) atomicMax(&s_max, m);
+    __syncthreads();
+    if (t == 0) *maxlen = s_max;
+  }
   const u32 w0 = bitmap[2 * t], w1 = bitmap[2 * t + 1];
   u32 tot;
   u32 ex = block_scan_excl<u32, 16>((u32)__popc(w0) + (u32)__popc(w1), lds, &tot);
@@ -198,6 +224,24 @@ inline int32_t vocab_prepare(int dev, hipStream_t st, const u64* slots, u64 cap,
   hipLaunchKernelGGL(k_max_len, dim3((u32)div_up(V, 256)), dim3(256), 0, st, P->term_word.p, V, d_maxlen, V_dev);
   hipLaunchKernelGGL((k_char_used<CharT>), dim3((u32)div_up(V, 256)), dim3(256), 0, st, P->term_word.p, V, tv, P->cbits.p, V_dev);
   hipLaunchKernelGGL(k_char_rank, dim3(1), dim3(1024), 0, st, P->cbits.p, P->crank.p, P->cbits.p + 2048);
+  return DCD_OK;
+}
+// The same for a table that numbered its terms (k_vocab_compact_ids), with the launches cut to three: `zeroed` = 2052
+// zeroed words (the character bitmap), blockmax = div_up(V_bound, 256) words of scratch, counts[VOC_SHARDS + 1] receives
+// the id counts and V, *d_nsym / *d_maxlen the two parameters of the ordinal sort.
+template <typename CharT>
+inline int32_t vocab_prepare_ids(int dev, hipStream_t st, const u64* slots, u64 cap, u64 V_bound, const TextView<CharT>& tv, VocabPrep* P,
+                                 u32 slot_stride, const u32* id_ctr, u32* counts, u32* zeroed, u32* blockmax, u32* d_nsym, u32* d_maxlen) {
+  DCD_TRY(P->term_word.alloc(dev, V_bound ? V_bound : 1));
+  DCD_TRY(P->term_slot.alloc(dev, V_bound ? V_bound : 1));
+  DCD_TRY(P->crank.alloc(dev, 65536));
+  P->d_maxlen = d_maxlen; P->d_nsym = d_nsym;
+  const u32* V_dev = counts + VOC_SHARDS;
+  hipLaunchKernelGGL(k_vocab_compact_ids, dim3((u32)div_up(cap, 256)), dim3(256), 0, st, slots, cap, slot_stride, id_ctr, P->term_word.p,
+                     P->term_slot.p, V_bound, counts);
+  hipLaunchKernelGGL((k_char_used<CharT>), dim3((u32)div_up(V_bound ? V_bound : 1, 256)), dim3(256), 0, st, P->term_word.p, V_bound, tv, zeroed, V_dev,
+                     blockmax);
+  hipLaunchKernelGGL(k_char_rank, dim3(1), dim3(1024), 0, st, (const u32*)zeroed, P->crank.p, d_nsym, (const u32*)blockmax, V_dev, V_bound, d_maxlen);
   return DCD_OK;
 }
 // d_hist / scan_scr32 as rs_sort needs them.  Nothing in here blocks the host.
