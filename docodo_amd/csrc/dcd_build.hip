@@ -376,6 +376,100 @@ struct RecSizeF {
   }
 };
 
+// ---- id-keyed builds: the whole term directory in ordinal order in THREE launches ------------------------------------------
+// Per rank r (d = dense_of_rank[r]) three lengths -- units, items, bytes of the ".index" record -- are scanned together
+// (reduce -> scan of the partials -> apply); the apply kernel also leaves the source position of the term's units and its
+// first / last coordinate.  (Before: three scans of three launches each + five small kernels, ~0.1 ms of launch latency.)
+struct PermDirF {
+  const u32* dense_of_rank;
+  const u64* us_id;        // [V] unit start per dense id (the entry [V] would be *n_units)
+  const u64* is_id;        // [V] item start per dense id (the entry [V] would be n_items)
+  const u64* n_units;      // device: total number of units
+  u64 n_items, V;
+  const u16* chars;        // the terms' strings, ordinal order
+  const u32* str_off;
+  __device__ __forceinline__ void operator()(u64 r, u64& units, u64& items, u64& rec, u32* d_out = nullptr) const {
+    const u32 d = dense_of_rank[r];
+    const bool last = (u64)d + 1 == V;
+    units = (last ? *n_units : us_id[d + 1]) - us_id[d];
+    items = (last ? n_items : is_id[d + 1]) - is_id[d];
+    const u32 kb = utf8_len_units(chars + str_off[r], str_off[r + 1] - str_off[r]);
+    rec = (u64)(kb < 128 ? 1 : 2) + kb + 4 + 2 * units;           // (as RecSizeF)
+    if (d_out) *d_out = d;
+  }
+};
+// partial: three arrays of `pstride` entries (units, items, bytes), one entry per workgroup
+__global__ __launch_bounds__(SCAN_THREADS) void k_dir_reduce(PermDirF f, u64 n, u64* __restrict__ partial, u64 pstride) {
+  __shared__ u64 lds[3][4];
+  const u64 base = (u64)blockIdx.x * SCAN_TILE;
+  u64 a = 0, b = 0, c = 0;
+#pragma unroll
+  for (int j = 0; j < SCAN_ITEMS; j++) {
+    const u64 i = base + (u64)j * SCAN_THREADS + threadIdx.x;
+    if (i < n) { u64 x, y, z; f(i, x, y, z); a += x; b += y; c += z; }
+  }
+  a = wave_sum(a); b = wave_sum(b); c = wave_sum(c);
+  if (lane_id() == 0) { lds[0][threadIdx.x >> 6] = a; lds[1][threadIdx.x >> 6] = b; lds[2][threadIdx.x >> 6] = c; }
+  __syncthreads();
+  if (threadIdx.x < 3) partial[threadIdx.x * pstride + blockIdx.x] = lds[threadIdx.x][0] + lds[threadIdx.x][1] + lds[threadIdx.x][2] + lds[threadIdx.x][3];
+}
+// one workgroup: the three partial arrays -> exclusive in place; totals[0..3) = the grand totals (units, items, bytes)
+__global__ __launch_bounds__(1024) void k_dir_partials(u64* __restrict__ partial, u64 pstride, u64 nb, u64* __restrict__ totals) {
+  constexpr int PER = 8;
+  __shared__ u64 lds[17];
+  for (int c = 0; c < 3; c++) {
+    u64* p = partial + (u64)c * pstride;
+    u64 carry = 0;
+    for (u64 b0 = 0; b0 < nb; b0 += 1024 * PER) {
+      const u64 i0 = b0 + (u64)threadIdx.x * PER;
+      u64 v[PER], s = 0;
+#pragma unroll
+      for (int j = 0; j < PER; j++) { v[j] = i0 + j < nb ? p[i0 + j] : 0ull; s += v[j]; }
+      u64 tot;
+      u64 ex = carry + block_scan_excl<u64, 16>(s, lds, &tot);
+#pragma unroll
+      for (int j = 0; j < PER; j++) { if (i0 + j < nb) p[i0 + j] = ex; ex += v[j]; }
+      carry += tot;
+    }
+    if (threadIdx.x == 0) totals[c] = carry;
+  }
+}
+// unit_start / item_start / rec_off [n + 1] (the last entries = the totals), src_start / first / last [n]
+__global__ __launch_bounds__(SCAN_THREADS) void k_dir_apply(PermDirF f, u64 n, const u64* __restrict__ partial, u64 pstride, const u64* __restrict__ totals,
+                                                           u64* __restrict__ unit_start, u64* __restrict__ item_start, u64* __restrict__ rec_off,
+                                                           u64* __restrict__ src_start, const uint2* __restrict__ sorted, u64 base_coord,
+                                                           u64* __restrict__ first, u64* __restrict__ last) {
+  __shared__ u64 lds[5];
+  const u64 base = (u64)blockIdx.x * SCAN_TILE + (u64)threadIdx.x * SCAN_ITEMS;
+  u64 va[SCAN_ITEMS], vb[SCAN_ITEMS], vc[SCAN_ITEMS];
+  u64 sa = 0, sb = 0, sc = 0;
+#pragma unroll
+  for (int j = 0; j < SCAN_ITEMS; j++) {
+    const u64 i = base + j;
+    va[j] = vb[j] = vc[j] = 0;
+    if (i < n) {
+      u32 d;
+      f(i, va[j], vb[j], vc[j], &d);
+      const u64 is = f.is_id[d];
+      src_start[i] = f.us_id[d];
+      first[i] = base_coord + sorted[is].y;
+      last[i] = base_coord + sorted[is + vb[j] - 1].y;
+    }
+    sa += va[j]; sb += vb[j]; sc += vc[j];
+  }
+  u64 tot;
+  u64 ea = block_scan_excl<u64, 4>(sa, lds, &tot) + partial[blockIdx.x];
+  u64 eb = block_scan_excl<u64, 4>(sb, lds, &tot) + partial[pstride + blockIdx.x];
+  u64 ec = block_scan_excl<u64, 4>(sc, lds, &tot) + partial[2 * pstride + blockIdx.x];
+#pragma unroll
+  for (int j = 0; j < SCAN_ITEMS; j++) {
+    const u64 i = base + j;
+    if (i < n) { unit_start[i] = ea; item_start[i] = eb; rec_off[i] = ec; }
+    ea += va[j]; eb += vb[j]; ec += vc[j];
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) { unit_start[n] = totals[0]; item_start[n] = totals[1]; rec_off[n] = totals[2]; }
+}
+
 __global__ void k_img_headers(const u16* __restrict__ chars, const u32* __restrict__ str_off, const u64* __restrict__ unit_start,
                               const u64* __restrict__ rec_off, u64 n, u64 img_base, u8* __restrict__ img, u64* __restrict__ pay_off) {
   u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1728,8 +1822,7 @@ static int32_t build_phase2(dcd_build* h) {
     if (V) hipLaunchKernelGGL(k_term_first_last, dim3((u32)div_up(V, 256)), dim3(256), 0, st, sorted, ix.term_item_start.p, V,
                               h->opts.coord_base, ix.term_first.p, ix.term_last.p);
   } else {
-    hipLaunchKernelGGL(k_copy_u64, dim3(1), dim3(1), 0, st, us_id.p + V, (const u64*)d_U);
-    hipLaunchKernelGGL(k_set_u64, dim3(1), dim3(1), 0, st, is_id.p + V, N);
+    // (id-keyed: the entries [V] of the id-ordered starts are never read -- PermDirF takes the totals instead)
   }
   DCD_TRY(t_pack.stop());
 
@@ -1747,37 +1840,36 @@ static int32_t build_phase2(dcd_build* h) {
   DCD_TRY(scr64b.alloc(dev, scan_scratch_elems(V ? V : 1)));
   u64 rec_total_pin = 0;
   if (idk) {
-    // term order: unit / item starts by ordinal rank = scans of the id-ordered lengths through dense_of_rank
-    // What the host is waiting for (the number of units and the size of the image) is queued first and read back into
-    // pinned memory behind an event; the rest of the directory (item starts, source positions, first / last coordinate)
-    // runs while the host takes that round trip.
+    // term order: unit / item starts and record offsets by ordinal rank = ONE scan of three lengths through dense_of_rank
+    // (k_dir_*).  What the host is waiting for (the number of units and the size of the image) is read back into pinned
+    // memory behind an event as soon as the partials are scanned; the apply kernel runs while the host takes that round trip.
     const u32* dor = M.vr.dense_of_rank.p;
-    u64* tot = scr64b.p + scan_nblocks(V);
     u64* pin = pinned_words();
     hipEvent_t ev = event_acquire(dev);
     if (!pin || !ev) { if (ev) event_release(dev, ev); DCD_FAIL(DCD_E_NOMEM, "pinned read-back buffer / event"); }
-    scan_exclusive_f<PermLenF, u64>(PermLenF{dor, us_id.p}, ix.term_unit_start.p, V, scr64b.p, st);
-    hipLaunchKernelGGL(k_copy_u64, dim3(1), dim3(1), 0, st, ix.term_unit_start.p + V, (const u64*)tot);
-    scan_exclusive_f<RecSizeF, u64>(RecSizeF{ix.term_chars.p, ix.term_str_off.p, ix.term_unit_start.p}, rec_off.p, V, scr64b.p, st);
-    hipError_t e1 = hipMemcpyAsync(pin + 8, tot, 8, hipMemcpyDeviceToHost, st);
-    hipError_t e2 = hipMemcpyAsync(pin + 9, d_U, 8, hipMemcpyDeviceToHost, st);
-    hipError_t e3 = hipEventRecord(ev, st);
-    DCD_TRY(src_start.alloc(dev, V));
-    DevBuf<u64> scr_items;
-    int32_t a1 = scr_items.alloc(dev, scan_scratch_elems(V));
-    if (a1 == DCD_OK) {
-      scan_exclusive_f<PermLenF, u64>(PermLenF{dor, is_id.p}, ix.term_item_start.p, V, scr_items.p, st);
-      hipLaunchKernelGGL(k_copy_u64, dim3(1), dim3(1), 0, st, ix.term_item_start.p + V, (const u64*)(scr_items.p + scan_nblocks(V)));
-      hipLaunchKernelGGL(k_perm_src_start, dim3((u32)div_up(V, 256)), dim3(256), 0, st, dor, (const u64*)us_id.p, V, src_start.p);
-      hipLaunchKernelGGL(k_term_first_last_perm, dim3((u32)div_up(V, 256)), dim3(256), 0, st, sorted, (const u64*)is_id.p, dor, V,
-                         h->opts.coord_base, ix.term_first.p, ix.term_last.p);
+    const u64 nbd = scan_nblocks(V), pstride = nbd + 1;
+    DevBuf<u64> dir_scr;
+    int32_t a1 = dir_scr.alloc(dev, 3 * pstride + 4);
+    int32_t a2 = src_start.alloc(dev, V ? V : 1);
+    hipError_t e1 = hipSuccess, e3 = hipSuccess;
+    if (a1 == DCD_OK && a2 == DCD_OK) {
+      u64* totals = dir_scr.p + 3 * pstride;
+      const PermDirF f{dor, us_id.p, is_id.p, (const u64*)d_U, N, V, ix.term_chars.p, ix.term_str_off.p};
+      hipLaunchKernelGGL(k_dir_reduce, dim3((u32)nbd), dim3(SCAN_THREADS), 0, st, f, V, dir_scr.p, pstride);
+      hipLaunchKernelGGL(k_dir_partials, dim3(1), dim3(1024), 0, st, dir_scr.p, pstride, nbd, totals);
+      e1 = hipMemcpyAsync(pin + 8, totals, 24, hipMemcpyDeviceToHost, st);        // units, items, bytes
+      e3 = hipEventRecord(ev, st);
+      hipLaunchKernelGGL(k_dir_apply, dim3((u32)nbd), dim3(SCAN_THREADS), 0, st, f, V, (const u64*)dir_scr.p, pstride, (const u64*)totals,
+                         ix.term_unit_start.p, ix.term_item_start.p, rec_off.p, src_start.p, (const uint2*)sorted, h->opts.coord_base,
+                         ix.term_first.p, ix.term_last.p);
     }
-    hipError_t e4 = (e1 == hipSuccess && e2 == hipSuccess && e3 == hipSuccess) ? hipEventSynchronize(ev) : hipErrorUnknown;
+    hipError_t e4 = (a1 == DCD_OK && a2 == DCD_OK && e1 == hipSuccess && e3 == hipSuccess) ? hipEventSynchronize(ev) : hipErrorUnknown;
     event_release(dev, ev);
     DCD_TRY(a1);
+    DCD_TRY(a2);
     if (e4 != hipSuccess) { (void)hipGetLastError(); DCD_FAIL(DCD_E_HIP, "reading back the image size failed"); }
-    rec_total_pin = pin[8];
-    U = pin[9];
+    U = pin[8];
+    rec_total_pin = pin[10];
   }
   u64 rec_total = rec_total_pin;
   if (V && !idk) {
