@@ -1049,8 +1049,11 @@ struct Probes {
   hipStream_t st;
   int dev;
   explicit Probes(hipStream_t s, int device) : st(s), dev(device) {}
-  void begin(int id) { P p{id, event_acquire(dev), event_acquire(dev)}; if (p.a) (void)hipEventRecord(p.a, st); v.push_back(p); }
-  void end() { if (v.back().b) (void)hipEventRecord(v.back().b, st); }
+  void begin(int id) {
+    if (event_level() < 2) return;
+    P p{id, event_acquire(dev), event_acquire(dev)}; if (p.a) (void)hipEventRecord(p.a, st); v.push_back(p);
+  }
+  void end() { if (event_level() >= 2 && v.back().b) (void)hipEventRecord(v.back().b, st); }
   void collect(float* ms, u32* n) {   // after the stream was synchronised
     for (auto& p : v) {
       float t = 0;
@@ -1161,7 +1164,7 @@ static int32_t build_phase1(dcd_build* h, bool codes_mode) {
   tr.mark("setup");
   DCD_TRY(t_all.start());
   // ---- 1. tokenise: count pass -------------------------------------------------------------------
-  DCD_TRY(t_tok.start());
+  t_tok.start_at_start_of(t_all);
   TokParams P;
   P.n_chars = n_chars;
   P.page_off = d_page_off.p;
@@ -1184,6 +1187,7 @@ static int32_t build_phase1(dcd_build* h, bool codes_mode) {
   // TK_TILE characters holds at most TK_TILE / min_word_length + 1 kept tokens.  DOCODO_TOK_TWO_PASS=1 forces the
   // counting pass.
   static const bool env_two_pass = getenv("DOCODO_TOK_TWO_PASS") && atoi(getenv("DOCODO_TOK_TWO_PASS")) != 0;
+  // (kept tokens may follow each other WITHOUT a separator -- a class change, "abc123" -- so they start min_len apart at least)
   const u32 stride_need = ((u32)(TK_TILE / (P.min_len ? P.min_len : 1u)) + 2u + 1u) & ~1u;     // even: tiles start 16-byte aligned
   const bool strided = !env_two_pass && !codes_mode && n_x == 0 && n_tiles != 0 && stride_need <= (u32)RS_STRIDE_MAX &&
                        rs_tile_plan(n_tiles).tpb <= (u32)RS_TPB_MAX;
@@ -1360,7 +1364,8 @@ static int32_t build_phase1(dcd_build* h, bool codes_mode) {
     }
     const bool last_round = fast_end;      // id-keyed builds: phase 1 ends with this round trip (the stage timers stop here)
     auto stop_timers = [&]() -> int32_t {
-      DCD_TRY(t_tok.stop()); DCD_TRY(t_voc.start()); DCD_TRY(t_voc.stop()); DCD_TRY(t_all.stop());
+      // (one event: the vocabulary timer is empty here -- id-keyed builds take its time from the side stream in phase 2)
+      DCD_TRY(t_tok.stop()); t_voc.start_at_stop_of(t_tok); t_voc.stop_at_stop_of(t_tok); t_all.stop_at_stop_of(t_tok);
       return DCD_OK;
     };
     if (early_ids) {
@@ -1550,7 +1555,7 @@ static int32_t build_phase2(dcd_build* h) {
     const u64 K = keys.size();
     // ---- device: expand the word postings ----
     DCD_TRY(t_all.start());
-    DCD_TRY(t_sort.start());
+    t_sort.start_at_start_of(t_all);
     DevBuf<u32> d_code_off, d_code_key, d_cnt;
     DevBuf<u64> d_off, d_scr;
     DCD_TRY(d_code_off.alloc(dev, V + 1)); DCD_TRY(d_code_key.alloc(dev, code_key.size() + 1));
@@ -1604,7 +1609,7 @@ static int32_t build_phase2(dcd_build* h) {
     N = NT; V = K;
   } else {
     DCD_TRY(t_all.start());
-    DCD_TRY(t_sort.start());
+    t_sort.start_at_start_of(t_all);
   }
 
   // ---- id-keyed builds: the vocabulary on a second (high-priority) stream, beside the tuple sort ------------------
@@ -1769,7 +1774,7 @@ static int32_t build_phase2(dcd_build* h) {
   // id-keyed: the units come out in dense-id order into a scratch array sized for the worst case (a delta inside a term is
   // < 2^32: <= 3 units; the first posting of a term <= 5), so that no host round trip sits between the sort and the pack;
   // step 6 copies them into ordinal term order.
-  DCD_TRY(t_pack.start());
+  t_pack.start_at_stop_of(t_sort);
   DCD_TRY(ix.term_unit_start.alloc(dev, V + 1));
   DCD_TRY(ix.term_item_start.alloc(dev, V + 1));
   DevBuf<u64> us_id, is_id;            // id-keyed: unit / item starts per dense id
@@ -1831,7 +1836,7 @@ static int32_t build_phase2(dcd_build* h) {
   DevBuf<u64> src_start;               // [V] first unit (in units_id) of the term with rank r
 
   // ---- 6. keys + ".index" image -----------------------------------------------------------------
-  DCD_TRY(t_img.start());
+  t_img.start_at_stop_of(t_pack);      // (includes waiting for the vocabulary chain, if the main stream has to)
   ix.term_str_off = std::move(M.word_str_off);
   ix.term_chars = std::move(M.word_chars);
   DevBuf<u64> rec_off, pay_off, scr64b;
@@ -1906,7 +1911,7 @@ static int32_t build_phase2(dcd_build* h) {
     }
   }
   DCD_TRY(t_img.stop());
-  DCD_TRY(t_all.stop());
+  t_all.stop_at_stop_of(t_img);
   DCD_HIP(hipStreamSynchronize(st));
   DCD_HIP(hipGetLastError());
   tr.mark("image");

@@ -6,6 +6,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -113,10 +114,24 @@ struct DevBuf {
 };
 
 // ---- HIP event timer ------------------------------------------------------------------------
+// How many events a build records (every record is a marker packet the stream stops at: ~5 us each, ~30 per build at
+// level 2).  DOCODO_BUILD_EVENTS: 2 = stage timers + per-kernel probes (default), 1 = stage timers, 0 = none (the ms_* fields
+// of the stats are then 0).
+inline int event_level() {
+  static const int lv = [] { const char* e = getenv("DOCODO_BUILD_EVENTS"); return e ? atoi(e) : 2; }();
+  return lv;
+}
 struct EvTimer {
   hipEvent_t a = nullptr, b = nullptr;
   hipStream_t s = nullptr;
   int device = 0;
+  // A timer may share a boundary with another one instead of recording its own event (every record is a marker packet the
+  // stream stops at): pa / pb point at the events ms() reads.
+  const hipEvent_t* pa = &a;
+  const hipEvent_t* pb = &b;
+  EvTimer() = default;
+  EvTimer(const EvTimer&) = delete;
+  EvTimer& operator=(const EvTimer&) = delete;
   int32_t init(hipStream_t st, int dev = 0) {
     s = st;
     device = dev;
@@ -125,11 +140,15 @@ struct EvTimer {
     if (!a || !b) DCD_FAIL(DCD_E_HIP, "hipEventCreate failed");
     return DCD_OK;
   }
-  int32_t start() { DCD_HIP(hipEventRecord(a, s)); return DCD_OK; }
-  int32_t stop() { DCD_HIP(hipEventRecord(b, s)); return DCD_OK; }
-  float ms() {  // call after the stream was synchronised
+  int32_t start() { pa = &a; if (event_level() >= 1) DCD_HIP(hipEventRecord(a, s)); return DCD_OK; }
+  int32_t stop() { pb = &b; if (event_level() >= 1) DCD_HIP(hipEventRecord(b, s)); return DCD_OK; }
+  void start_at_start_of(const EvTimer& o) { pa = o.pa; }
+  void start_at_stop_of(const EvTimer& o) { pa = o.pb; }
+  void stop_at_stop_of(const EvTimer& o) { pb = o.pb; }
+  float ms() {  // call after the stream was synchronised (and while the timers it shares boundaries with are alive)
+    if (event_level() < 1) return 0.f;
     float t = 0;
-    if (hipEventElapsedTime(&t, a, b) != hipSuccess) return -1.f;
+    if (hipEventElapsedTime(&t, *pa, *pb) != hipSuccess) return -1.f;
     return t;
   }
   ~EvTimer() {

@@ -474,7 +474,7 @@ struct RsProbe {
   void (*before_pass)(void* arg, hipStream_t st) = nullptr;
   void* after_scan_arg = nullptr;        // (the argument of both)
   void rec(hipStream_t st) const {
-    if (!ev) return;
+    if (!ev || event_level() < 2) return;
     hipEvent_t e = event_acquire(device);
     if (e) { (void)hipEventRecord(e, st); ev->push_back(e); }
   }
