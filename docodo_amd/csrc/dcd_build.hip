@@ -23,11 +23,6 @@ constexpr u32 MAX_CODE_LEN = 63;   // explicit index codes (Builder.Add); text t
 #ifndef DCD_CAPDIV
 #define DCD_CAPDIV 256             // first guess of the vocabulary table: one slot per DCD_CAPDIV postings
 #endif
-#ifndef DCD_TK_TPW
-#define DCD_TK_TPW 1               // tiles per wave of k_tok_emit (measured: 2 / 4 / 8 tiles with the next tile's characters
-                                   // prefetched take 1.67 / 1.88 / 1.73 ms against 1.58 -- one tile per wave and many waves win)
-#endif
-constexpr u32 TK_TPW = DCD_TK_TPW;
 constexpr u32 UNRES_CAP = 4096;    // tiles on the fix-up list of an id-numbering build (beyond that the fix-up pass walks all tiles)
 #ifndef DCD_TK_WPE
 #define DCD_TK_WPE 8               // waves per SIMD the emit kernel is compiled for (register budget)
@@ -58,48 +53,53 @@ __global__ __launch_bounds__(TK_THREADS, DCD_TK_WPE) void k_tok_emit(const CharT
                                                         TextView<CharT> tv, VocabTable vt, const u64* __restrict__ tile_off,
                                                         uint2* __restrict__ tuples, u64 n_tiles, u32 stride, u32* __restrict__ tile_cnt,
                                                         u64 tile0, u32* __restrict__ sample_cnt, u32 sample_mask, u32* __restrict__ unres) {
-  // stride != 0: no counting pass ran; the tile's tuples go to tuples[tile * stride ...] and their number to tile_cnt
-  // (the first sort pass compacts, RsStrided in dcd_sort.h).  stride == 0: dense output at tile_off[tile].
-  // The launch covers the tiles [tile0, n_tiles) (see the seed launch in build_phase1).
-  // A wave owns TK_TPW consecutive tiles (1 by default); with more than one it fetches the next tile's characters before it
-  // works on the current one.  That did NOT pay (see DCD_TK_TPW): the register cost of the loop takes more occupancy
-  // than the prefetch hides latency.
+  // A workgroup owns TK_WAVES consecutive wave tiles -- one GROUP.  Every wave tokenises its own tile (no barrier in there);
+  // then the group's tokens, in text order, are dealt out to the lanes of the whole workgroup: token k goes to thread
+  // k mod 256.  (Before, every wave looked up its own tile's tokens, 64 at a time: a tile of this corpus holds 129 of them
+  // on average -- three rounds, the third nearly empty.  A group holds 516: nine wave rounds instead of twelve.)
+  // stride != 0: no counting pass ran; the group's tuples go to tuples[group * stride ...] and their number to
+  // tile_cnt[group] (the first sort pass compacts, RsStrided in dcd_sort.h).  stride == 0: dense output at
+  // tile_off[first tile of the group].  The launch covers the tiles [tile0, n_tiles), tile0 a multiple of TK_WAVES (see the
+  // seed launch in build_phase1).
   __shared__ TokLds<CharT, true> SW[TK_WAVES];
-  const u64 tile_first = tile0 + ((u64)blockIdx.x * TK_WAVES + (threadIdx.x >> 6)) * TK_TPW;
-  if (tile_first >= n_tiles) return;
-  TokLds<CharT, true>& S = SW[threadIdx.x >> 6];
-  const u32 lane = lane_id();
-  Chunk<CharT> nxt;
-  nxt.fetch(text, tile_lane_g0(tile_first), P.n_chars, tile_inside(tile_first, P.n_chars));
-#pragma unroll 1
-  for (u32 tw = 0; tw < TK_TPW; tw++) {
-  const u64 tile = tile_first + tw;
-  if (tile >= n_tiles) break;
-  Chunk<CharT> cur = nxt;
-  if (tw + 1 < TK_TPW && tile + 1 < n_tiles) nxt.fetch(text, tile_lane_g0(tile + 1), P.n_chars, tile_inside(tile + 1, P.n_chars));
-  // every (sample_mask + 1)-th tile counts its tokens per vocabulary slot: the frequency sample behind the hot / cold
-  // split of the tuple sort (build_phase2)
-  const bool sampled = sample_cnt != nullptr && ((u32)tile & sample_mask) == 0u;
-  u32 keep;
-  u64 bnd;
-  tokenize_chunk<CharT, true>(text, P, tab, tile, S, &keep, &bnd, &cur);
-  const u32 mine = (u32)__builtin_popcount(keep);
-  const u32 incl = wave_scan_incl(mine);
-  const u32 total = __shfl(incl, 63, 64);
-  u32 ex = incl - mine;
-  for (u32 m = keep; m;) {
-    u32 j = (u32)__builtin_ctz(m);
-    m &= m - 1;
-    u32 len = (u32)__builtin_ctzll(bnd >> (j + 1)) + 1u;
-    S.tok[ex++] = (lane * TK_CPT + j) | (len << 16);   // staged position
+  __shared__ u32 s_wtot[TK_WAVES];
+  const u32 w = threadIdx.x >> 6, lane = lane_id();
+  const u64 group = tile0 / TK_WAVES + blockIdx.x;
+  const u64 tile = group * TK_WAVES + w;
+  TokLds<CharT, true>& S = SW[w];
+  u32 total = 0;
+  if (tile < n_tiles) {
+    Chunk<CharT> cur;
+    cur.fetch(text, tile_lane_g0(tile), P.n_chars, tile_inside(tile, P.n_chars));
+    u32 keep;
+    u64 bnd;
+    tokenize_chunk<CharT, true>(text, P, tab, tile, S, &keep, &bnd, &cur);
+    const u32 mine = (u32)__builtin_popcount(keep);
+    const u32 incl = wave_scan_incl(mine);
+    total = __shfl(incl, 63, 64);
+    u32 ex = incl - mine;
+    for (u32 m = keep; m;) {
+      u32 j = (u32)__builtin_ctz(m);
+      m &= m - 1;
+      u32 len = (u32)__builtin_ctzll(bnd >> (j + 1)) + 1u;
+      S.tok[ex++] = (lane * TK_CPT + j) | (len << 16);   // staged position
+    }
   }
-  wave_sync();
-  const int64_t org = tile_origin(tile);
-  const u64 obase = stride ? tile * stride : tile_off[tile];
-  if (stride && lane == 0) tile_cnt[tile] = total;
+  if (lane == 0) s_wtot[w] = total;
+  __syncthreads();
+  // prefix of the waves' token counts: token k of the group belongs to the wave ws with pre[ws] <= k < pre[ws + 1]
+  u32 pre[TK_WAVES + 1];
+  pre[0] = 0;
+#pragma unroll
+  for (int k = 0; k < TK_WAVES; k++) pre[k + 1] = pre[k] + s_wtot[k];
+  const u32 gtotal = pre[TK_WAVES];
+  // every (sample_mask + 1)-th group counts its tokens per vocabulary slot: the frequency sample behind the hot / cold
+  // split of the tuple sort (build_phase2)
+  const bool sampled = sample_cnt != nullptr && ((u32)group & sample_mask) == 0u;
+  const u64 obase = stride ? group * stride : tile_off[group * TK_WAVES];
+  if (stride && threadIdx.x == 0) tile_cnt[group] = gtotal;
   constexpr u32 CS = sizeof(CharT);
   constexpr u32 PW = VocPool<CharT>::W;
-  const u32* txt = S.txt;
   auto coord_of = [&](u64 gpos) -> u32 {
     u32 coord = (u32)gpos;
     if (P.n_runs) {
@@ -110,8 +110,13 @@ __global__ __launch_bounds__(TK_THREADS, DCD_TK_WPE) void k_tok_emit(const CharT
     return coord;
   };
   bool any_unres = false;
-  for (u32 k = lane; k < total; k += 64) {
-    const u32 t = S.tok[k];
+  for (u32 k = threadIdx.x; k < gtotal; k += TK_THREADS) {
+    u32 ws = 0;
+#pragma unroll
+    for (int q = 1; q < TK_WAVES; q++) ws += k >= pre[q] ? 1u : 0u;
+    const u32 t = SW[ws].tok[k - pre[ws]];
+    const u32* txt = SW[ws].txt;
+    const int64_t org = tile_origin(group * TK_WAVES + ws);
     const u32 i = t & 0xFFFFu, len = t >> 16;
     const u32 nbytes = len * CS, nw = (nbytes + 3u) >> 2;
     auto word = [txt, i, nbytes](u32 q) -> u32 { return lds_word(txt, i * CS, q) & tail_mask(nbytes, q); };
@@ -163,12 +168,11 @@ __global__ __launch_bounds__(TK_THREADS, DCD_TK_WPE) void k_tok_emit(const CharT
 #endif
     if (sampled && slot != 0xFFFFFFFFu) atomicAdd(&sample_cnt[slot], 1u);
   }
-  // tiles that hold unresolved keys go on the fix-up list: unres[0] = their number, unres[1 ..] = the first UNRES_CAP of them
+  // groups that hold unresolved keys go on the fix-up list: unres[0] = their number, unres[1 ..] = the first UNRES_CAP of them
+  // (a wave reports its group; the list may name a group more than once -- the fix-up is idempotent)
   if (unres != nullptr && ballot64(any_unres) != 0ull && lane == 0) {
     const u32 k = atomicAdd(unres, 1u);
-    if (k < UNRES_CAP) unres[1 + k] = (u32)tile;
-  }
-  wave_sync();                        // the next tile overwrites the wave's LDS slice
+    if (k < UNRES_CAP) unres[1 + k] = (u32)group;
   }
 }
 
@@ -1189,9 +1193,12 @@ static int32_t build_phase1(dcd_build* h, bool codes_mode) {
   static const bool env_two_pass = getenv("DOCODO_TOK_TWO_PASS") && atoi(getenv("DOCODO_TOK_TWO_PASS")) != 0;
   // (kept tokens may follow each other WITHOUT a separator -- a class change, "abc123" -- so they start min_len apart at least)
   const u32 stride_need = ((u32)(TK_TILE / (P.min_len ? P.min_len : 1u)) + 2u + 1u) & ~1u;     // even: tiles start 16-byte aligned
-  const bool strided = !env_two_pass && !codes_mode && n_x == 0 && n_tiles != 0 && stride_need <= (u32)RS_STRIDE_MAX &&
-                       rs_tile_plan(n_tiles).tpb <= (u32)RS_TPB_MAX;
-  M.strided = strided; M.stride = strided ? stride_need : 0u; M.n_tiles = n_tiles;
+  // The unit of the strided tuple buffer (a "tile" of the first sort pass) is the GROUP of TK_WAVES wave tiles one workgroup
+  // of the emit kernel handles: n_st of them, TK_WAVES * stride_need tuple slots each.
+  const u64 n_st = div_up(n_tiles, TK_WAVES);
+  const bool strided = !env_two_pass && !codes_mode && n_x == 0 && n_tiles != 0 && (u64)TK_WAVES * stride_need <= (u64)RS_STRIDE_MAX &&
+                       rs_tile_plan(n_st).tpb <= (u32)RS_TPB_MAX;
+  M.strided = strided; M.stride = strided ? (u32)TK_WAVES * stride_need : 0u; M.n_tiles = strided ? n_st : n_tiles;
   DevBuf<u64> scan_scr64;
   u64 n_text_tok = 0;
   if (n_tiles) {
@@ -1214,7 +1221,7 @@ static int32_t build_phase1(dcd_build* h, bool codes_mode) {
 
   // ---- 2. vocabulary table + emit ---------------------------------------------------------------
   if (strided) {
-    DCD_TRY(M.tupA.alloc(dev, n_tiles * (u64)M.stride));
+    DCD_TRY(M.tupA.alloc(dev, n_st * (u64)M.stride));
   } else {
     DCD_TRY(M.tupA.alloc(dev, N ? N : 1));
     DCD_TRY(M.tupB.alloc(dev, N ? N : 1));
@@ -1257,7 +1264,7 @@ static int32_t build_phase1(dcd_build* h, bool codes_mode) {
   static_assert(EI_WORDS * 4 <= (64 - 24) * 8, "the results must fit the pinned words behind pin[24]");
   static_assert(EI_NTOK % 2 == 0 && EI_CBITS % 4 == 0, "alignment of the 64-bit count / the bitmap");
   u32 sample_mask = 0;
-  while (((u64)sample_mask + 1) * DCD_HOT_SAMPLE_TILES < n_tiles) sample_mask = sample_mask * 2 + 1;
+  while (((u64)sample_mask + 1) * DCD_HOT_SAMPLE_TILES < n_st) sample_mask = sample_mask * 2 + 1;     // (groups of TK_WAVES tiles)
   DevBuf<u32> sample_cnt, hot_hist;           // [cap] / [HOT_BINS + 1] (theta behind the bins)
   DevBuf<u64> hot_excl, hot_scr;
   u32 n_hot = 0;
@@ -1311,14 +1318,14 @@ static int32_t build_phase1(dcd_build* h, bool codes_mode) {
       // one).  256 tiles (~33 k tokens) insert the head of the distribution with 1/28 of the contention; the main launch
       // then finds those slots populated (a kernel boundary makes them visible to every XCD).
       static const u64 seed_tiles = getenv("DOCODO_TOK_SEED_TILES") ? strtoull(getenv("DOCODO_TOK_SEED_TILES"), nullptr, 10) : 256;
-      const u64 n_seed = n_tiles > 2 * seed_tiles ? seed_tiles : 0;   // small builds: one launch
+      const u64 n_seed = n_tiles > 2 * seed_tiles ? (seed_tiles & ~(u64)(TK_WAVES - 1)) : 0;   // small builds: one launch (whole groups)
       if (n_seed) {   // (not a DCD_K_TOK_EMIT probe: per-launch averages are quoted for the main launch)
-        hipLaunchKernelGGL((k_tok_emit<CharT>), dim3((u32)div_up(n_seed, TK_WAVES * TK_TPW)), dim3(TK_THREADS), 0, st, text, P, tab, tv, vt,
+        hipLaunchKernelGGL((k_tok_emit<CharT>), dim3((u32)div_up(n_seed, TK_WAVES)), dim3(TK_THREADS), 0, st, text, P, tab, tv, vt,
                            M.tile_off.p, M.tupA.p, n_seed, M.stride, M.tile_cnt.p, (u64)0, sample_cnt.p, sample_mask, unres);
       }
       probes.begin(DCD_K_TOK_EMIT);
       if (n_tiles > n_seed)
-        hipLaunchKernelGGL((k_tok_emit<CharT>), dim3((u32)div_up(n_tiles - n_seed, TK_WAVES * TK_TPW)), dim3(TK_THREADS), 0, st, text, P, tab, tv, vt,
+        hipLaunchKernelGGL((k_tok_emit<CharT>), dim3((u32)div_up(n_tiles - n_seed, TK_WAVES)), dim3(TK_THREADS), 0, st, text, P, tab, tv, vt,
                            M.tile_off.p, M.tupA.p, n_tiles, M.stride, M.tile_cnt.p, n_seed, sample_cnt.p, sample_mask, unres);
       probes.end();
 #if defined(DCD_DIAG_TOK)
@@ -1328,7 +1335,7 @@ static int32_t build_phase1(dcd_build* h, bool codes_mode) {
         probes.collect(msa, nla);
         fprintf(stderr, "DIAG_TOK mode 6: first launch %.3f ms\n", msa[DCD_K_TOK_EMIT]);
         probes.begin(DCD_K_TOK_EMIT);
-        hipLaunchKernelGGL((k_tok_emit<CharT>), dim3((u32)div_up(n_tiles, TK_WAVES * TK_TPW)), dim3(TK_THREADS), 0, st, text, P, tab, tv, vt,
+        hipLaunchKernelGGL((k_tok_emit<CharT>), dim3((u32)div_up(n_tiles, TK_WAVES)), dim3(TK_THREADS), 0, st, text, P, tab, tv, vt,
                            M.tile_off.p, M.tupA.p, n_tiles, M.stride, M.tile_cnt.p, (u64)0, sample_cnt.p, sample_mask, unres);
         probes.end();
       }
@@ -1343,12 +1350,12 @@ static int32_t build_phase1(dcd_build* h, bool codes_mode) {
       u32* R = early_ids ? id_ctr.p + ID_CTR_WORDS : nullptr;
       if (early_ids) {
         // keys whose id was not visible when the token was looked up -> ids; the number of postings; maxCoord
-        hipLaunchKernelGGL(k_emit_epilogue, dim3(256), dim3(256), 0, st, M.tupA.p, (const u32*)M.tile_cnt.p, n_tiles, M.stride, (const u32*)unres,
+        hipLaunchKernelGGL(k_emit_epilogue, dim3(256), dim3(256), 0, st, M.tupA.p, (const u32*)M.tile_cnt.p, n_st, M.stride, (const u32*)unres,
                            (const u64*)M.slots.p, M.slot_stride, (u64*)(R + EI_NTOK), R + EI_LASTC);
       } else if (strided) {
         // the tiles' dense offsets and the number of postings, now that the emit kernel has counted
-        scan_exclusive<u32, u64>(M.tile_cnt.p, M.tile_off.p, n_tiles, scan_scr64.p, st);
-        DCD_HIP(hipMemcpyAsync(rb_ntok, scan_scr64.p + scan_nblocks(n_tiles), 8, hipMemcpyDeviceToHost, st));
+        scan_exclusive<u32, u64>(M.tile_cnt.p, M.tile_off.p, n_st, scan_scr64.p, st);
+        DCD_HIP(hipMemcpyAsync(rb_ntok, scan_scr64.p + scan_nblocks(n_st), 8, hipMemcpyDeviceToHost, st));
       }
     }
     if (n_x)
@@ -1360,7 +1367,7 @@ static int32_t build_phase1(dcd_build* h, bool codes_mode) {
     u32 v32 = 0;
     if (strided && !early_ids) {
       // maxCoord = coordinate of the last posting added (Build.cs:326): fetched with the counters below, ONE host round trip
-      hipLaunchKernelGGL(k_last_strided_coord, dim3(1), dim3(1), 0, st, M.tupA.p, M.tile_cnt.p, n_tiles, M.stride, M.d_flags.p + 2);
+      hipLaunchKernelGGL(k_last_strided_coord, dim3(1), dim3(1), 0, st, M.tupA.p, M.tile_cnt.p, n_st, M.stride, M.d_flags.p + 2);
     }
     const bool last_round = fast_end;      // id-keyed builds: phase 1 ends with this round trip (the stage timers stop here)
     auto stop_timers = [&]() -> int32_t {

@@ -151,7 +151,7 @@ struct RsStrided {
   u32 hot_n = 0, hot_s = 0;
 };
 __device__ __forceinline__ u32 rs_hot_key(u32 d, u32 hot_n, u32 hot_s) { return d < hot_n ? d << hot_s : (hot_n << hot_s) + (d - hot_n); }
-constexpr int RS_STRIDE_MAX = 320;       // largest tile population handled (the host checks its stride against it)
+constexpr int RS_STRIDE_MAX = 4096;      // largest tile population handled (the host checks its stride against it; counts travel as u16)
 constexpr int RS_TPB_MAX = 2304;         // tiles per block (LDS slice of the tile table in the scatter kernel)
 struct RsTilePlan { u32 nblk, tpb; };
 inline RsTilePlan rs_tile_plan(u64 n_tiles) {
@@ -163,8 +163,12 @@ inline RsTilePlan rs_tile_plan(u64 n_tiles) {
 }
 
 #ifndef DCD_RS_TU
-#define DCD_RS_TU 4
+#define DCD_RS_TU 2
 #endif
+#ifndef DCD_RS_HPR
+#define DCD_RS_HPR 5
+#endif
+constexpr int RS_HPR = DCD_RS_HPR;
 #ifndef DCD_RS_NT
 #define DCD_RS_NT 1      // pass A reads the tokeniser's tuples with non-temporal loads: they are touched once and would evict the
                          // 4 MB dense-id table from L2 (measured: histogram 0.77 -> 0.74 ms, scatter 1.36 -> 1.32..1.36)
@@ -190,8 +194,10 @@ __global__ __launch_bounds__(RS_THREADS, DCD_RSH_WPE) void k_rs_hist_strided(con
   u32* hl = h + (threadIdx.x % HC) * HS;
   const u32 lane = lane_id(), w = threadIdx.x >> 6;
   const u64 ta = (u64)blockIdx.x * tpb, tb = ta + tpb < sd.n_tiles ? ta + tpb : sd.n_tiles;
-  // a wave takes DCD_RS_TU tiles at a time; a lane reads tuple pairs (16 B; the stride is even, so tiles start 16-byte aligned)
-  constexpr int TU = DCD_RS_TU, PR = (RS_STRIDE_MAX / 2 + 63) / 64;     // pair rounds per tile
+  // a wave takes DCD_RS_TU tiles at a time; a lane reads tuple pairs (16 B; the stride is even, so tiles start 16-byte aligned),
+  // RS_HPR rounds of 64 pairs per tile in flight (640 tuples: a group of four wave tiles of the tokeniser holds ~520 on
+  // the benchmark corpus); what a fuller tile holds beyond that is read by the loop behind
+  constexpr int TU = DCD_RS_TU, PR = RS_HPR;
   for (u64 t0 = ta + (u64)w * TU; t0 < tb; t0 += (u64)RS_WAVES * TU) {
     u32 c[TU];
     uint4 kv[TU][PR];
@@ -221,6 +227,14 @@ __global__ __launch_bounds__(RS_THREADS, DCD_RSH_WPE) void k_rs_hist_strided(con
         const u32 pi = lane + 64u * k;
         if (2 * pi < c[u]) atomicAdd(&hl[(key_of(kv[u][k].x) >> shift) & (NB - 1)], 1u);
         if (2 * pi + 1 < c[u]) atomicAdd(&hl[(key_of(kv[u][k].z) >> shift) & (NB - 1)], 1u);
+      }
+      if (c[u] > 128u * PR) {          // (wave-uniform)
+        const uint4* tp = reinterpret_cast<const uint4*>(in + (t0 + u) * sd.stride);
+        for (u32 pi = lane + 64u * PR; 2 * pi < c[u]; pi += 64u) {
+          const uint4 q = tp[pi];
+          atomicAdd(&hl[(key_of(q.x) >> shift) & (NB - 1)], 1u);
+          if (2 * pi + 1 < c[u]) atomicAdd(&hl[(key_of(q.z) >> shift) & (NB - 1)], 1u);
+        }
       }
     }
   }
