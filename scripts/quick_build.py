@@ -9,7 +9,7 @@ d = torch.empty(n * 1024, dtype=torch.uint8, device="cuda")
 t = time.time(); synth.corpus_dev(d.data_ptr(), n); print("gen %.3fs" % (time.time() - t), flush=True)
 for r in range(reps):
     t = time.time()
-    b = docodo_amd.Builder()
+    b = docodo_amd.Builder(vocab_capacity_log2=int(os.environ.get("QB_CAP", "0")))
     b.AddUniformPagesDev(d.data_ptr(), n, 1024)
     st = b.Finish()
     wall = time.time() - t
