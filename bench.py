@@ -48,11 +48,11 @@ def algorithmic_bytes(kernel, T, N, U, n_launch=1, n_hot=0, id_keys=False):
 
 # what actually limits each kernel (PMC runs): the roofline above prices every kernel against HBM, as the
 # contract asks, but the tokeniser kernels are bound by VALU issue, not by bytes
-LIMITER = {"k_tok_emit": "VALU issue (profiles/r02_pmc_build.txt: 622 VALU + 280 SALU wave-instructions per 944-character wave tile; "
-                         "SQ_ACTIVE_INST_VALU = 87 % of the kernel's busy cycles per SIMD)",
+LIMITER = {"k_tok_emit": "VALU issue + the latency of one table gather per token (profiles/r02_pmc_build.txt; scripts/diag_tok.py: front half -- "
+                         "classification, boundaries, token list -- 0.53 ms, hashing + tuple stores +0.30 ms, table lookup +0.35 ms)",
            "k_tok_count": "VALU issue (PMC: ~100 % busy; 280 wave-instructions per wave tile)",
-           "k_rs_scatter": "VALU issue (ballot ranking, ~50 % busy) + hbm (pass A: slot -> dense id remap, partial lines of short digit runs)",
-           "k_rs_hist": "hbm + L2 gathers of the slot -> dense id remap (pass A)"}
+           "k_rs_scatter": "VALU issue (match-any ballot ranking, ~50 % busy) + hbm (first pass: partial lines of short digit runs)",
+           "k_rs_hist": "LDS atomics + hbm"}
 
 
 TRAFFIC_FILE = "r02_final_traffic.json"

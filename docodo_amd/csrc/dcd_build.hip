@@ -113,6 +113,9 @@ __global__ __launch_bounds__(TK_THREADS, DCD_TK_WPE) void k_tok_emit(const CharT
 #if defined(DCD_DIAG_TOK) && DCD_DIAG_TOK == 7    // (timing only: the front half -- classification, boundaries, token list)
   if (gtotal != 0xFFFFFFFFu) return;
 #endif
+#if defined(DCD_DIAG_TOK) && DCD_DIAG_TOK == 7    // (timing only: the front half -- classification, boundaries, token list)
+  if (gtotal != 0xFFFFFFFFu) return;
+#endif
   for (u32 k = threadIdx.x; k < gtotal; k += TK_THREADS) {
     u32 ws = 0;
 #pragma unroll
