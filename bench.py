@@ -285,8 +285,9 @@ def main():
                                    "full index build, text resident in HBM -> .index image resident in HBM" % D,
                        "docs_per_gpu": D, "text_bytes_per_gpu": T, "postings": int(N), "terms": int(V), "units": int(U),
                        "index_bytes": int(img_bytes), "sort_passes": int(passes), "sort": (
-                           "by the term ids the vocabulary table hands out while the tokeniser fills it (tuples carry their sort keys); "
-                           "ordinal vocabulary sort on a second stream" if id_keys == 2 else
+                           ("by the term ids the vocabulary table hands out while the tokeniser fills it (tuples carry their sort keys); "
+                            "ordinal vocabulary sort on a second stream" + ("; %d hot terms chosen by a sampling launch (%.1f %% of the postings) "
+                            "final after the first radix pass" % (hot_terms, 100.0 * hot_post / max(1, N)) if hot_terms else "")) if id_keys == 2 else
                            "by dense vocabulary id, ordinal vocabulary sort on a second stream; %d hot terms (%.1f %% of the postings) final "
                            "after the first radix pass" % (hot_terms, 100.0 * hot_post / max(1, N))) if id_keys else "by ordinal rank",
                        "hot_postings": int(hot_post),

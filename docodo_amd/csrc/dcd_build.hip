@@ -48,11 +48,12 @@ __global__ __launch_bounds__(TK_THREADS) void k_tok_count(const CharT* __restric
   if (lane_id() == 0) tile_count[tile] = c;
 }
 
-template <typename CharT>
+template <typename CharT, bool SAMPLE = false>
 __global__ __launch_bounds__(TK_THREADS, DCD_TK_WPE) void k_tok_emit(const CharT* __restrict__ text, TokParams P, CharTables16 tab,
                                                         TextView<CharT> tv, VocabTable vt, const u64* __restrict__ tile_off,
                                                         uint2* __restrict__ tuples, u64 n_tiles, u32 stride, u32* __restrict__ tile_cnt,
-                                                        u64 tile0, u32* __restrict__ sample_cnt, u32 sample_mask, u32* __restrict__ unres) {
+                                                        u64 tile0, u32* __restrict__ sample_cnt, u32 sample_mask, u32* __restrict__ unres,
+                                                        u32 sample_step) {
   // A workgroup owns TK_WAVES consecutive wave tiles -- one GROUP.  Every wave tokenises its own tile (no barrier in there);
   // then the group's tokens, in text order, are dealt out to the lanes of the whole workgroup: token k goes to thread
   // k mod 256.  (Before, every wave looked up its own tile's tokens, 64 at a time: a tile of this corpus holds 129 of them
@@ -64,7 +65,10 @@ __global__ __launch_bounds__(TK_THREADS, DCD_TK_WPE) void k_tok_emit(const CharT
   __shared__ TokLds<CharT, true> SW[TK_WAVES];
   __shared__ u32 s_wtot[TK_WAVES];
   const u32 w = threadIdx.x >> 6, lane = lane_id();
-  const u64 group = tile0 / TK_WAVES + blockIdx.x;
+  // SAMPLE: a SAMPLING launch (builds with early ids, in front of the real one): workgroup b takes group b *
+  // sample_step, looks its tokens up / inserts them WITHOUT numbering them and counts them in their records (word 3); it
+  // writes no tuples.  k_hot_select then makes the most frequent terms the hot set.
+  const u64 group = SAMPLE ? (u64)blockIdx.x * sample_step : tile0 / TK_WAVES + blockIdx.x;
   const u64 tile = group * TK_WAVES + w;
   TokLds<CharT, true>& S = SW[w];
   u32 total = 0;
@@ -96,8 +100,8 @@ __global__ __launch_bounds__(TK_THREADS, DCD_TK_WPE) void k_tok_emit(const CharT
   // every (sample_mask + 1)-th group counts its tokens per vocabulary slot: the frequency sample behind the hot / cold
   // split of the tuple sort (build_phase2)
   const bool sampled = sample_cnt != nullptr && ((u32)group & sample_mask) == 0u;
-  const u64 obase = stride ? group * stride : tile_off[group * TK_WAVES];
-  if (stride && threadIdx.x == 0) tile_cnt[group] = gtotal;
+  const u64 obase = SAMPLE ? 0 : stride ? group * stride : tile_off[group * TK_WAVES];
+  if (!SAMPLE && stride && threadIdx.x == 0) tile_cnt[group] = gtotal;
   constexpr u32 CS = sizeof(CharT);
   constexpr u32 PW = VocPool<CharT>::W;
   auto coord_of = [&](u64 gpos) -> u32 {
@@ -157,6 +161,20 @@ __global__ __launch_bounds__(TK_THREADS, DCD_TK_WPE) void k_tok_emit(const CharT
       }
     }
 #else
+    if (SAMPLE) {
+      // one atomic per distinct term and wave round, not per token: the top term of a Zipf corpus is every seventh token, and
+      // same-address atomics execute one after the other (measured: the launch 0.10 -> 0.05 ms)
+      const u32 sl = vocab_lookup_insert_pooled<CharT>(vt, tv, hs.fin(), len, gpos, wv, word);
+      u64 act = ballot64(sl != 0xFFFFFFFFu);
+      while (act) {
+        const u32 lead = (u32)__builtin_ctzll(act);
+        const u32 s0 = __shfl(sl, lead, 64);
+        const u64 m = ballot64(sl == s0) & act;
+        if (lane == lead) atomicAdd(reinterpret_cast<u32*>(vt.slots + (u64)s0 * vt.stride) + 3, (u32)__builtin_popcountll(m));
+        act &= ~m;
+      }
+      continue;
+    }
     // (a table that numbers its terms returns the term's id, i.e. the sort key itself -- or VOC_UNRESOLVED | slot)
     u32 slot = vt.id_ctr ? vocab_lookup_insert_ids<CharT>(vt, tv, hs.fin(), len, gpos, wv, word, (blockIdx.x & (VOC_SHARDS - 1u)) * VOC_CTR_STRIDE)
                : vt.pool ? vocab_lookup_insert_pooled<CharT>(vt, tv, hs.fin(), len, gpos, wv, word)
@@ -220,9 +238,9 @@ __global__ void k_term_first_last(const uint2* __restrict__ sorted, const u64* _
 // id = local * VOC_SHARDS + shard with local < cnt[shard].  The DENSE id of a term is the number of used ids below its id, so
 // that the order of the ids (the sort order of the tuples) is the order of the dense ids; with the VOC_SHARDS counts it is
 // that many min / add operations -- tabulated once per build (beside the tuple sort), looked up at term heads only.
-__global__ __launch_bounds__(256) void k_id_dense_table(IdCounts n, u32 id_range, u32* __restrict__ dense) {
+__global__ __launch_bounds__(256) void k_id_dense_table(IdCounts n, u32 n_hot, u32 id_range, u32* __restrict__ dense) {
   const u32 id = blockIdx.x * 256u + threadIdx.x;
-  if (id < id_range) dense[id] = dense_of_id(n, id);
+  if (id < id_range) dense[id] = dense_of_key(n.c, n_hot, id);
 }
 // Behind the emit kernel of a build with early ids, ONE launch:
 //  * unresolved keys (VOC_UNRESOLVED | slot) -> ids, now that every inserter has published its id; one wave per listed tile,
@@ -305,6 +323,71 @@ __global__ __launch_bounds__(1024) void k_hot_pick(const u32* __restrict__ hist,
   }
   __syncthreads();
   if (t == 0) *theta = s_best;
+}
+// Builds with early ids, behind the SAMPLING launch of the emit kernel (which counted the tokens of a few groups in their
+// records and listed the slots it claimed): ONE workgroup picks theta as k_hot_pick does and numbers the sampled terms -- those
+// that reach theta 0 .. n_hot - 1, the others from n_hot on through the id counters, like the real launch will (they stay in the
+// table: emptied again, the next few thousand terms of the distribution would meet the real launch as an insert storm).
+// The hot terms are then exactly the ids below n_hot: the first radix pass gives each a bucket of its own (RsStrided::hot_n).
+__global__ __launch_bounds__(1024) void k_hot_select(u64* __restrict__ slots, u32 stride, const u32* __restrict__ list, u32 H, u32* __restrict__ n_hot_out,
+                                                     u32* __restrict__ id_ctr) {
+  __shared__ u32 s_h[HOT_BINS];
+  __shared__ u32 lds[17];
+  __shared__ u32 s_best, s_nhot, s_n, s_c;
+  constexpr int PER = HOT_BINS / 1024;
+  constexpr int K = 4;                 // list entries a thread keeps in registers (4096 sampled terms; beyond that: re-read)
+  const u32 t = threadIdx.x, n = list[0];
+  for (u32 i = t; i < HOT_BINS; i += 1024) s_h[i] = 0;
+  if (t == 0) { s_best = 0xFFFFFFFFu; s_nhot = 0; s_n = 0; s_c = 0; }
+  __syncthreads();
+  u32 sl[K], cn[K];
+#pragma unroll
+  for (int k = 0; k < K; k++) { const u32 i = t + 1024u * k; sl[k] = i < n ? list[1 + i] : 0xFFFFFFFFu; }
+#pragma unroll
+  for (int k = 0; k < K; k++) cn[k] = sl[k] != 0xFFFFFFFFu ? reinterpret_cast<const u32*>(slots + (u64)sl[k] * stride)[3] : 0u;
+#pragma unroll
+  for (int k = 0; k < K; k++) if (sl[k] != 0xFFFFFFFFu) atomicAdd(&s_h[cn[k] < HOT_BINS ? cn[k] : HOT_BINS - 1], 1u);
+  for (u32 i = t + 1024u * K; i < n; i += 1024) {
+    const u32 c = reinterpret_cast<const u32*>(slots + (u64)list[1 + i] * stride)[3];
+    atomicAdd(&s_h[c < HOT_BINS ? c : HOT_BINS - 1], 1u);
+  }
+  __syncthreads();
+  u32 v[PER], s = 0;
+#pragma unroll
+  for (int k = 0; k < PER; k++) { v[k] = t * PER + k ? s_h[t * PER + k] : 0u; s += v[k]; }
+  u32 tot;
+  u32 before = block_scan_excl<u32, 16>(s, lds, &tot);          // slots in lower bins
+  u32 reach[PER];
+#pragma unroll
+  for (int k = 0; k < PER; k++) {
+    const u32 b = t * PER + k;
+    reach[k] = tot - before;                                      // slots with count >= b
+    if (b >= 1 && reach[k] <= H) atomicMin(&s_best, b);
+    before += v[k];
+  }
+  __syncthreads();
+  const u32 theta = s_best;
+#pragma unroll
+  for (int k = 0; k < PER; k++) if (t * PER + k == theta) s_nhot = reach[k];
+  __syncthreads();
+  // hot terms 0 .. n_hot - 1; the other sampled terms n_hot + j, j = 0 .. n_cold - 1 -- which is what the id counters hand out
+  // (id = n_hot + local * VOC_SHARDS + shard) once counter s stands at the number of j with j mod VOC_SHARDS == s
+  const u32 n_hot = s_nhot;
+  auto number = [&](u32 slot, u32 c) {
+    u32* r32 = reinterpret_cast<u32*>(slots + (u64)slot * stride);
+    const bool hot = c >= theta;
+    const u32 j = atomicAdd(hot ? &s_n : &s_c, 1u);
+    *reinterpret_cast<uint2*>(r32 + 2) = make_uint2((hot ? j : n_hot + j) + 1u, 0u);      // id + 1, count word back to 0
+  };
+#pragma unroll
+  for (int k = 0; k < K; k++) if (sl[k] != 0xFFFFFFFFu) number(sl[k], cn[k]);
+  for (u32 i = t + 1024u * K; i < n; i += 1024) {
+    const u32 slot = list[1 + i];
+    number(slot, reinterpret_cast<const u32*>(slots + (u64)slot * stride)[3]);
+  }
+  __syncthreads();
+  if (t < VOC_SHARDS) id_ctr[t * VOC_CTR_STRIDE] = (s_c + (VOC_SHARDS - 1u) - t) / VOC_SHARDS;
+  if (t == 0) *n_hot_out = n_hot;
 }
 struct HotUsedF {   // low word: the slot is used; high word: it holds a hot term
   const u64* slots;
@@ -1012,6 +1095,7 @@ struct BuildMid {
   u32 n_hot = 0;                    // hot / cold split: dense ids 0 .. n_hot-1 are the hot terms (0 = no split)
   bool early_ids = false;           // the tuples carry ids the table handed out while it was filled (id_cnt: per shard)
   IdCounts id_cnt{};
+  u32 id_hot = 0;                   // ... the ids below id_hot belong to the hot terms (k_hot_select), the counters number the others from there
   DevBuf<u32> tile_cnt;
   DevBuf<u64> tile_off;
   DevBuf<u8> d_pool_raw;            // explicit strings on the device (CharT units)
@@ -1261,14 +1345,21 @@ static int32_t build_phase1(dcd_build* h, bool codes_mode) {
   // Early ids: ONE buffer holds the small device-side state of the round, so that one fill zeroes it and one copy fetches
   // its results.  VOC_SHARDS id counters VOC_CTR_STRIDE words apart, then the results R[0 .. EI_WORDS): the counts again,
   // densely, + their sum V (k_vocab_compact_ids), the two parameters of the ordinal sort, maxCoord, the number of postings,
-  // the overflow flag; then the character bitmap and the count of the fix-up list (all of that zeroed), its UNRES_CAP tiles
-  // and the per-workgroup key-length maxima.
+  // the number of hot terms, the overflow flag; then the character bitmap, the fix-up list (count + UNRES_CAP tiles) and the
+  // count of the sampling launch's slot list (all of that zeroed), the list itself and the per-workgroup key-length maxima.
   DevBuf<u32> id_ctr;
   constexpr u32 ID_CTR_WORDS = VOC_SHARDS * VOC_CTR_STRIDE;
   constexpr u32 EI_V = VOC_SHARDS, EI_NSYM = EI_V + 1, EI_MAXLEN = EI_V + 2, EI_LASTC = EI_V + 3, EI_NTOK = EI_V + 4 /* u64 */, EI_OVF = EI_V + 6,
-                EI_WORDS = EI_V + 8, EI_CBITS = EI_WORDS, EI_UNRES = EI_CBITS + 2052, EI_ZEROED = EI_UNRES + 1, EI_BLOCKMAX = EI_ZEROED + UNRES_CAP;
+                EI_NHOT = EI_V + 7, EI_WORDS = EI_V + 8, EI_CBITS = EI_WORDS, EI_UNRES = EI_CBITS + 2052, EI_LIST = EI_UNRES + 1 + UNRES_CAP,
+                EI_ZEROED = EI_LIST + 1;       // (then: the sampled slots, the per-workgroup key-length maxima)
   static_assert(EI_WORDS * 4 <= (64 - 24) * 8, "the results must fit the pinned words behind pin[24]");
   static_assert(EI_NTOK % 2 == 0 && EI_CBITS % 4 == 0, "alignment of the 64-bit count / the bitmap");
+  // early ids: the sampling launch in front of the real one (k_hot_select): DOCODO_TOK_SAMPLE_GROUPS groups of TK_WAVES tiles,
+  // evenly spaced over the text (0, or a text of fewer than four times as many groups: no sampling, no hot set)
+  static const u32 env_sample_groups = getenv("DOCODO_TOK_SAMPLE_GROUPS") ? (u32)atoi(getenv("DOCODO_TOK_SAMPLE_GROUPS")) : 64u;
+  const u32 n_sample = (env_hot > 0 && n_st >= 4ull * env_sample_groups) ? env_sample_groups : 0u;
+  const u32 sample_step = n_sample ? (u32)(n_st / n_sample) : 0u;
+  const u64 list_cap = (u64)n_sample * TK_WAVES * stride_need + 1;          // (every sampled token a new term, at worst)
   u32 sample_mask = 0;
   while (((u64)sample_mask + 1) * DCD_HOT_SAMPLE_TILES < n_st) sample_mask = sample_mask * 2 + 1;     // (groups of TK_WAVES tiles)
   DevBuf<u32> sample_cnt, hot_hist;           // [cap] / [HOT_BINS + 1] (theta behind the bins)
@@ -1305,7 +1396,7 @@ static int32_t build_phase1(dcd_build* h, bool codes_mode) {
     const bool hot_try = strided && !env_rank_keys0 && env_hot > 0 && !early_ids;
     u32* unres = nullptr;
     if (early_ids) {
-      DCD_TRY(id_ctr.alloc(dev, ID_CTR_WORDS + EI_BLOCKMAX + div_up(cap / 2 + 1, 256) + 1));
+      DCD_TRY(id_ctr.alloc(dev, ID_CTR_WORDS + EI_ZEROED + list_cap + div_up(cap / 2 + 1, 256) + 1));
       DCD_HIP(hipMemsetAsync(id_ctr.p, 0, (size_t)(ID_CTR_WORDS + EI_ZEROED) * 4, st));
       vt.id_ctr = id_ctr.p;
       vt.overflow = id_ctr.p + ID_CTR_WORDS + EI_OVF;
@@ -1325,15 +1416,37 @@ static int32_t build_phase1(dcd_build* h, bool codes_mode) {
       // then finds those slots populated (a kernel boundary makes them visible to every XCD).
       static const u64 seed_tiles = getenv("DOCODO_TOK_SEED_TILES") ? strtoull(getenv("DOCODO_TOK_SEED_TILES"), nullptr, 10) : 256;
       const u64 n_seed = n_tiles > 2 * seed_tiles ? (seed_tiles & ~(u64)(TK_WAVES - 1)) : 0;   // small builds: one launch (whole groups)
-      if (n_seed) {   // (not a DCD_K_TOK_EMIT probe: per-launch averages are quoted for the main launch)
-        hipLaunchKernelGGL((k_tok_emit<CharT>), dim3((u32)div_up(n_seed, TK_WAVES)), dim3(TK_THREADS), 0, st, text, P, tab, tv, vt,
-                           M.tile_off.p, M.tupA.p, n_seed, M.stride, M.tile_cnt.p, (u64)0, sample_cnt.p, sample_mask, unres);
+      if (early_ids) {
+        // Early ids: the SAMPLING launch takes the seed launch's place -- it fills the table with the head of the
+        // distribution just as well -- and k_hot_select turns its counts into the hot set; the real launch then covers every
+        // tile (the sampled groups are tokenised twice: 64 of 270 k).
+        u32* R = id_ctr.p + ID_CTR_WORDS;
+        if (n_sample) {
+          VocabTable vs_ = vt;
+          vs_.id_ctr = nullptr; vs_.new_slots = R + EI_LIST;
+          hipLaunchKernelGGL((k_tok_emit<CharT, true>), dim3(n_sample), dim3(TK_THREADS), 0, st, text, P, tab, tv, vs_, M.tile_off.p, M.tupA.p, n_tiles,
+                             M.stride, M.tile_cnt.p, (u64)0, (u32*)nullptr, 0u, (u32*)nullptr, sample_step);
+          hipLaunchKernelGGL(k_hot_select, dim3(1), dim3(1024), 0, st, M.slots.p, M.slot_stride, (const u32*)(R + EI_LIST), (u32)std::min(env_hot, 255),
+                             R + EI_NHOT, id_ctr.p);
+        }
+        vt.id_base = R + EI_NHOT;
       }
-      probes.begin(DCD_K_TOK_EMIT);
-      if (n_tiles > n_seed)
-        hipLaunchKernelGGL((k_tok_emit<CharT>), dim3((u32)div_up(n_tiles - n_seed, TK_WAVES)), dim3(TK_THREADS), 0, st, text, P, tab, tv, vt,
-                           M.tile_off.p, M.tupA.p, n_tiles, M.stride, M.tile_cnt.p, n_seed, sample_cnt.p, sample_mask, unres);
-      probes.end();
+      if (early_ids && n_sample) {
+        probes.begin(DCD_K_TOK_EMIT);
+        hipLaunchKernelGGL((k_tok_emit<CharT>), dim3((u32)div_up(n_tiles, TK_WAVES)), dim3(TK_THREADS), 0, st, text, P, tab, tv, vt,
+                           M.tile_off.p, M.tupA.p, n_tiles, M.stride, M.tile_cnt.p, (u64)0, sample_cnt.p, sample_mask, unres, 0u);
+        probes.end();
+      } else {
+        if (n_seed) {   // (not a DCD_K_TOK_EMIT probe: per-launch averages are quoted for the main launch)
+          hipLaunchKernelGGL((k_tok_emit<CharT>), dim3((u32)div_up(n_seed, TK_WAVES)), dim3(TK_THREADS), 0, st, text, P, tab, tv, vt,
+                             M.tile_off.p, M.tupA.p, n_seed, M.stride, M.tile_cnt.p, (u64)0, sample_cnt.p, sample_mask, unres, 0u);
+        }
+        probes.begin(DCD_K_TOK_EMIT);
+        if (n_tiles > n_seed)
+          hipLaunchKernelGGL((k_tok_emit<CharT>), dim3((u32)div_up(n_tiles - n_seed, TK_WAVES)), dim3(TK_THREADS), 0, st, text, P, tab, tv, vt,
+                             M.tile_off.p, M.tupA.p, n_tiles, M.stride, M.tile_cnt.p, n_seed, sample_cnt.p, sample_mask, unres, 0u);
+        probes.end();
+      }
 #if defined(DCD_DIAG_TOK)
       if (DCD_DIAG_TOK == 6) {          // second launch: every term is in the table, no CAS, no insert storm
         DCD_HIP(hipStreamSynchronize(st));
@@ -1342,7 +1455,7 @@ static int32_t build_phase1(dcd_build* h, bool codes_mode) {
         fprintf(stderr, "DIAG_TOK mode 6: first launch %.3f ms\n", msa[DCD_K_TOK_EMIT]);
         probes.begin(DCD_K_TOK_EMIT);
         hipLaunchKernelGGL((k_tok_emit<CharT>), dim3((u32)div_up(n_tiles, TK_WAVES)), dim3(TK_THREADS), 0, st, text, P, tab, tv, vt,
-                           M.tile_off.p, M.tupA.p, n_tiles, M.stride, M.tile_cnt.p, (u64)0, sample_cnt.p, sample_mask, unres);
+                           M.tile_off.p, M.tupA.p, n_tiles, M.stride, M.tile_cnt.p, (u64)0, sample_cnt.p, sample_mask, unres, 0u);
         probes.end();
       }
       {
@@ -1386,13 +1499,14 @@ static int32_t build_phase1(dcd_build* h, bool codes_mode) {
       // brings everything the host needs
       u32* R = id_ctr.p + ID_CTR_WORDS;
       DCD_TRY(vocab_prepare_ids<CharT>(dev, st, M.slots.p, cap, cap / 2 + 1, tv, &M.vprep, M.slot_stride, (const u32*)id_ctr.p, R, R + EI_CBITS,
-                                       R + EI_BLOCKMAX, R + EI_NSYM, R + EI_MAXLEN));
+                                       R + EI_ZEROED + list_cap, R + EI_NSYM, R + EI_MAXLEN, R + EI_NHOT));
       M.vprep_done = true;
       DCD_TRY(stop_timers());
       DCD_HIP(hipMemcpyAsync(rb_ids, R, EI_WORDS * 4, hipMemcpyDeviceToHost, st));
       DCD_HIP(hipStreamSynchronize(st));
       for (u32 s = 0; s < VOC_SHARDS; s++) M.id_cnt.c[s] = rb_ids[s];
       v32 = rb_ids[EI_V];
+      n_hot = rb_ids[EI_NHOT];
       *rb_nsym = rb_ids[EI_NSYM];
       rb_flags[0] = rb_ids[EI_OVF]; rb_flags[1] = rb_ids[EI_MAXLEN]; rb_flags[2] = rb_ids[EI_LASTC];
       *rb_ntok = *(const u64*)(rb_ids + EI_NTOK);
@@ -1469,6 +1583,7 @@ static int32_t build_phase1(dcd_build* h, bool codes_mode) {
   // the split pays when the cold vocabulary is much larger than the hot set (and fits the 2^20 remap-cache values)
   // (without the split the table is still a bijection slot -> [0, V): any such ids sort the tuples by term)
   M.n_hot = (M.id_keys && n_hot && V > 4ull * n_hot) ? n_hot : 0;
+  M.id_hot = M.early_ids ? n_hot : 0;
   DCD_TRY(M.d_hist.alloc(dev, (u64)RS_MAX_BLOCKS << 10));
   if (!M.id_keys) {
     if (M.vprep_done) { M.vprep_done = false; DCD_HIP(hipMemsetAsync(M.d_flags.p + 1, 0, 4, st)); }   // (V == 0: redone below)
@@ -1639,9 +1754,11 @@ static int32_t build_phase2(dcd_build* h) {
   //    beside each histogram kernel (the histogram kernel of pass B occupies every wave slot until it ends: +0.12 ms).
   DevBuf<u32> side_hist, side_scr, id_dense;
   u64 id_range = 1;                    // early ids: they are dense per shard; the largest one + 1
-  if (early)
+  if (early) {
+    id_range = std::max<u64>(1, M.id_hot);
     for (u32 s = 0; s < VOC_SHARDS; s++)
-      if (M.id_cnt.c[s]) id_range = std::max<u64>(id_range, (u64)(M.id_cnt.c[s] - 1) * VOC_SHARDS + s + 1);
+      if (M.id_cnt.c[s]) id_range = std::max<u64>(id_range, (u64)M.id_hot + (u64)(M.id_cnt.c[s] - 1) * VOC_SHARDS + s + 1);
+  }
   hipStream_t vs = nullptr;
   hipEvent_t ev_side = nullptr, ev_dense = nullptr;     // (ev_dense: id_dense is ready -- the pack kernels wait for it)
   EvTimer t_vs;
@@ -1670,7 +1787,7 @@ static int32_t build_phase2(dcd_build* h) {
     DCD_TRY(t_vs.start());
     if (early) {                       // id -> dense id, for the term heads of the pack kernels
       DCD_TRY(id_dense.alloc(dev, id_range));
-      hipLaunchKernelGGL(k_id_dense_table, dim3((u32)div_up(id_range, 256)), dim3(256), 0, vs, M.id_cnt, (u32)id_range, id_dense.p);
+      hipLaunchKernelGGL(k_id_dense_table, dim3((u32)div_up(id_range, 256)), dim3(256), 0, vs, M.id_cnt, M.id_hot, (u32)id_range, id_dense.p);
       DCD_HIP(hipEventRecord(ev_dense, vs));
     }
     DCD_TRY(build_vocab<CharT>(h, M, vs, tv, side_hist.p, side_scr.p));
@@ -1720,7 +1837,7 @@ static int32_t build_phase2(dcd_build* h) {
       // Hot / cold split.  Pass A scatters by the digit (key >> hot_s): every hot term gets a bucket of its own, all cold
       // tuples share the bucket hot_n.  A hot term is then complete -- contiguous, in coordinate order -- after ONE pass,
       // and only the cold region (a third of the tuples of a Zipf corpus) is sorted further, by the low hot_s bits.
-      hot_s = std::max<u32>(1, log2_ceil(V - hot_n));
+      hot_s = std::max<u32>(1, log2_ceil((early ? id_range : V) - hot_n));
       int bits_a = (int)log2_ceil((u64)hot_n + 1);
       if (bits_a < 6) bits_a = 6;
       sd.hot_n = hot_n; sd.hot_s = hot_s;
@@ -1735,16 +1852,17 @@ static int32_t build_phase2(dcd_build* h) {
       // ... and the vocabulary chain is queued right there, behind the histogram kernel it is to run beside, and the main
       // stream ordered behind it (see queue_vocab_side)
       std::function<int32_t()> side_fn = wait_vocab_side;
-      nh.side = &side_fn; nh.side_status = DCD_OK;
+      nh.side = early ? nullptr : &side_fn; nh.side_status = DCD_OK;     // (early ids: the chain goes behind the scatter kernel's launch, below)
       RsProbe rpa = rp;
       rpa.after_scan_arg = &nh;
       rpa.after_scan = [](void* arg, hipStream_t s) {
         NhRead* r = (NhRead*)arg;
         if (hipMemcpyAsync(r->dst, r->src, 4, hipMemcpyDeviceToHost, s) != hipSuccess || hipEventRecord(r->ev, s) != hipSuccess) r->status = DCD_E_HIP;
-        r->side_status = (*r->side)();
+        if (r->side) r->side_status = (*r->side)();
       };
       rs_pass_dyn(bits_a, a, b, remap, N, (int)hot_s, M.d_hist.p, M.scan_scr32.p, st, rpa, cache_ok, &sd);
       passes++;
+      if (early) nh.side_status = queue_vocab_side();
       int32_t vst = nh.side_status;
       if (vst == DCD_OK && nh.status == DCD_OK && hipEventSynchronize(nh.ev) != hipSuccess) nh.status = DCD_E_HIP;
       event_release(dev, nh.ev);

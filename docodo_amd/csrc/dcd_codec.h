@@ -40,10 +40,9 @@ struct EncSrcPairs {
   // ids below x, tabulated (term heads only gather from it)
   const u32* id_dense = nullptr;
   __device__ __forceinline__ u32 id_of(u32 x) const {
-    if (id_dense) return id_dense[x];
-    if (!hot_s) return x;
-    const u32 hi = x >> hot_s;
-    return hi < hot_n ? hi : hot_n + (x - (hot_n << hot_s));
+    u32 id = x;
+    if (hot_s) { const u32 hi = x >> hot_s; id = hi < hot_n ? hi : hot_n + (x - (hot_n << hot_s)); }
+    return id_dense ? id_dense[id] : id;
   }
   __device__ __forceinline__ bool head(u64 i) const { return i == 0 || p[i].x != p[i - 1].x; }
   __device__ __forceinline__ u64 delta(u64 i) const {

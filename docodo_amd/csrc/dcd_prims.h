@@ -120,5 +120,9 @@ __host__ __device__ __forceinline__ u32 dense_of_id(const u32* __restrict__ c, u
   return d;
 }
 __host__ __device__ __forceinline__ u32 dense_of_id(const IdCounts& n, u32 id) { return dense_of_id(n.c, id); }
+// ... with a hot set: the ids below n_hot belong to the hot terms (all of them in use), the table numbers the others from n_hot
+__host__ __device__ __forceinline__ u32 dense_of_key(const u32* __restrict__ c, u32 n_hot, u32 id) {
+  return id < n_hot ? id : n_hot + dense_of_id(c, id - n_hot);
+}
 
 }  // namespace dcd

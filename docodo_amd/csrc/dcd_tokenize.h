@@ -325,6 +325,8 @@ struct VocabTable {
   u32 stride = 1;  // in u64 units.  Pooled tables are arrays of records {slot word, padding, string}: stride = W, and
   u32 pstride = 0; // pool = (u32*)slots + W with pstride = 2 W -- a token that misses the caches fetches ONE line, not two
   u32* id_ctr = nullptr;   // optional (record tables only): VOC_SHARDS counters -- the table NUMBERS its terms (see vocab_lookup_insert_ids)
+  const u32* id_base = nullptr;   // ... new terms are numbered from *id_base (the ids below it belong to the hot terms, k_hot_select)
+  u32* new_slots = nullptr;       // sampling launch: [0] = number of slots it claimed, [1 ..] = the slots
 };
 constexpr u32 VOC_UNRESOLVED = 0x80000000u;   // tuple key = VOC_UNRESOLVED | slot: the term's id was not visible yet (fixed up after the launch)
 // words of a string kept next to its slot: 16 characters' worth
@@ -390,6 +392,7 @@ __device__ __forceinline__ u32 vocab_lookup_insert_pooled(const VocabTable& vt, 
       if (old == 0) {
 #pragma unroll
         for (u32 q = 0; q < W / 4; q++) pe[q] = make_uint4(wv[4 * q], wv[4 * q + 1], wv[4 * q + 2], wv[4 * q + 3]);
+        if (vt.new_slots) vt.new_slots[1u + atomicAdd(vt.new_slots, 1u)] = idx;      // (sampling launch: the caller sized the list for every token)
         return idx;
       }
       w = old;
@@ -454,7 +457,7 @@ __device__ __forceinline__ u32 vocab_lookup_insert_ids(const VocabTable& vt, con
     if (w == 0) {
       u64 old = atomicCAS((unsigned long long*)sp, 0ull, (unsigned long long)mine);
       if (old == 0) {
-        const u32 id = atomicAdd(vt.id_ctr + shard_off, 1u) * VOC_SHARDS + shard_off / VOC_CTR_STRIDE;
+        const u32 id = (vt.id_base ? *vt.id_base : 0u) + atomicAdd(vt.id_ctr + shard_off, 1u) * VOC_SHARDS + shard_off / VOC_CTR_STRIDE;
         atomicExch(pad, id + 1u);          // published at the memory side, like the slot word
 #pragma unroll
         for (u32 q = 0; q < W / 4; q++) pe[q] = make_uint4(wv[4 * q], wv[4 * q + 1], wv[4 * q + 2], wv[4 * q + 3]);

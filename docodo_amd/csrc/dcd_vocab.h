@@ -31,23 +31,26 @@ static __global__ void k_vocab_compact(const u64* __restrict__ slots, u64 cap, c
   }
 }
 // dense arrays of the vocabulary from a numbering table (the counterpart of k_vocab_compact)
-// id_ctr: the VOC_SHARDS counters, VOC_CTR_STRIDE words apart; counts[VOC_SHARDS + 1] receives them densely + their sum (= V)
+// id_ctr: the VOC_SHARDS counters, VOC_CTR_STRIDE words apart; counts[VOC_SHARDS + 1] receives them densely + V = their sum
+// + *n_hot (the hot terms hold the ids below *n_hot, the counters number the others from there: dense_of_key)
 static __global__ __launch_bounds__(256) void k_vocab_compact_ids(const u64* __restrict__ slots, u64 cap, u32 stride, const u32* __restrict__ id_ctr,
-                                    u64* __restrict__ term_word, u32* __restrict__ term_slot, u64 n_out, u32* __restrict__ counts) {
+                                    u64* __restrict__ term_word, u32* __restrict__ term_slot, u64 n_out, u32* __restrict__ counts,
+                                    const u32* __restrict__ n_hot_dev) {
   __shared__ u32 n[VOC_SHARDS];
   if (threadIdx.x < VOC_SHARDS) n[threadIdx.x] = id_ctr[threadIdx.x * VOC_CTR_STRIDE];
   __syncthreads();
+  const u32 n_hot = *n_hot_dev;
   u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   if (blockIdx.x == 0 && threadIdx.x < VOC_SHARDS) counts[threadIdx.x] = n[threadIdx.x];
   if (i == 0) {
-    u32 sum = 0;
+    u32 sum = n_hot;
     for (u32 s = 0; s < VOC_SHARDS; s++) sum += n[s];
     counts[VOC_SHARDS] = sum;
   }
   if (i >= cap) return;
   const u64 w = slots[i * stride];
   if (w) {
-    const u32 d = dense_of_id(n, reinterpret_cast<const u32*>(slots + i * stride)[2] - 1u);
+    const u32 d = dense_of_key(n, n_hot, reinterpret_cast<const u32*>(slots + i * stride)[2] - 1u);
     if (d < n_out) { term_word[d] = w; term_slot[d] = (u32)i; }
   }
 }
@@ -207,8 +210,7 @@ struct VocabPrep {
 template <typename CharT>
 // V_dev != nullptr: V is only an upper bound, the true count is read from the device (the caller has not fetched it yet).
 inline int32_t vocab_prepare(int dev, hipStream_t st, const u64* slots, u64 cap, const u32* slot_excl, u64 V, const TextView<CharT>& tv,
-                             u32* d_maxlen, VocabPrep* P, const u32* V_dev = nullptr, u32 slot_stride = 1, const u32* id_ctr = nullptr,
-                             u32* id_total = nullptr) {
+                             u32* d_maxlen, VocabPrep* P, const u32* V_dev = nullptr, u32 slot_stride = 1) {
   DCD_TRY(P->term_word.alloc(dev, V ? V : 1));
   DCD_TRY(P->term_slot.alloc(dev, V ? V : 1));
   DCD_TRY(P->cbits.alloc(dev, 2049));
@@ -216,11 +218,7 @@ inline int32_t vocab_prepare(int dev, hipStream_t st, const u64* slots, u64 cap,
   P->d_maxlen = d_maxlen; P->d_nsym = P->cbits.p + 2048;
   DCD_HIP(hipMemsetAsync(P->cbits.p, 0, 2049 * 4, st));
   if (!V) return DCD_OK;
-  if (id_ctr)   // a table that numbered its terms: dense ids from the ids (id_total[VOC_SHARDS + 1] receives the counts and V; V_dev may point to the latter)
-    hipLaunchKernelGGL(k_vocab_compact_ids, dim3((u32)div_up(cap, 256)), dim3(256), 0, st, slots, cap, slot_stride, id_ctr, P->term_word.p,
-                       P->term_slot.p, V, id_total);
-  else
-    hipLaunchKernelGGL(k_vocab_compact, dim3((u32)div_up(cap, 256)), dim3(256), 0, st, slots, cap, slot_excl, P->term_word.p, P->term_slot.p, V, slot_stride);
+  hipLaunchKernelGGL(k_vocab_compact, dim3((u32)div_up(cap, 256)), dim3(256), 0, st, slots, cap, slot_excl, P->term_word.p, P->term_slot.p, V, slot_stride);
   hipLaunchKernelGGL(k_max_len, dim3((u32)div_up(V, 256)), dim3(256), 0, st, P->term_word.p, V, d_maxlen, V_dev);
   hipLaunchKernelGGL((k_char_used<CharT>), dim3((u32)div_up(V, 256)), dim3(256), 0, st, P->term_word.p, V, tv, P->cbits.p, V_dev);
   hipLaunchKernelGGL(k_char_rank, dim3(1), dim3(1024), 0, st, P->cbits.p, P->crank.p, P->cbits.p + 2048);
@@ -231,14 +229,15 @@ inline int32_t vocab_prepare(int dev, hipStream_t st, const u64* slots, u64 cap,
 // the id counts and V, *d_nsym / *d_maxlen the two parameters of the ordinal sort.
 template <typename CharT>
 inline int32_t vocab_prepare_ids(int dev, hipStream_t st, const u64* slots, u64 cap, u64 V_bound, const TextView<CharT>& tv, VocabPrep* P,
-                                 u32 slot_stride, const u32* id_ctr, u32* counts, u32* zeroed, u32* blockmax, u32* d_nsym, u32* d_maxlen) {
+                                 u32 slot_stride, const u32* id_ctr, u32* counts, u32* zeroed, u32* blockmax, u32* d_nsym, u32* d_maxlen,
+                                 const u32* n_hot_dev) {
   DCD_TRY(P->term_word.alloc(dev, V_bound ? V_bound : 1));
   DCD_TRY(P->term_slot.alloc(dev, V_bound ? V_bound : 1));
   DCD_TRY(P->crank.alloc(dev, 65536));
   P->d_maxlen = d_maxlen; P->d_nsym = d_nsym;
   const u32* V_dev = counts + VOC_SHARDS;
   hipLaunchKernelGGL(k_vocab_compact_ids, dim3((u32)div_up(cap, 256)), dim3(256), 0, st, slots, cap, slot_stride, id_ctr, P->term_word.p,
-                     P->term_slot.p, V_bound, counts);
+                     P->term_slot.p, V_bound, counts, n_hot_dev);
   hipLaunchKernelGGL((k_char_used<CharT>), dim3((u32)div_up(V_bound ? V_bound : 1, 256)), dim3(256), 0, st, P->term_word.p, V_bound, tv, zeroed, V_dev,
                      blockmax);
   hipLaunchKernelGGL(k_char_rank, dim3(1), dim3(1024), 0, st, (const u32*)zeroed, P->crank.p, d_nsym, (const u32*)blockmax, V_dev, V_bound, d_maxlen);

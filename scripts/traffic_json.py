@@ -30,6 +30,7 @@ out = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separa
        "T": T, "N": N, "U": U, "kernels": {}}
 # bytes every kernel reads as a stream (largest launch of the name)
 STREAM = [("k_tok_emit", T), ("k_tok_count", T), ("k_rs_hist_strided", 8 * N), ("k_rs_scatter<8, true, true>", 8 * N),
+          ("k_rs_scatter<8, false, true>", 8 * N), ("k_rs_scatter<9, false, true>", 8 * N),      # (strided = the first pass: all tuples)
           ("k_rs_scatter<9, true, true>", 8 * N), ("k_rs_scatter<10, true, true>", 8 * N),
           ("k_rs_hist", 8 * (NC if NC != N else N)), ("k_rs_scatter", 8 * (NC if NC != N else N)),
           ("k_pack_count", 8 * N), ("k_pack_write", 8 * N), ("k_img_units", 2 * U)]
