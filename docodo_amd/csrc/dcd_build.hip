@@ -48,7 +48,10 @@ __global__ __launch_bounds__(TK_THREADS) void k_tok_count(const CharT* __restric
   if (lane_id() == 0) tile_count[tile] = c;
 }
 
-template <typename CharT, bool SAMPLE = false>
+// FAST: the configuration of a plain text build with early ids, known at compile time -- strided output, a numbering table,
+// no coordinate runs, no per-slot sample counts: the kernel has ~35 scalar arguments and an 80-SGPR budget (8 waves / SIMD),
+// and every argument that is dead here is one the compiler does not have to spill to VGPR lanes around the token loop.
+template <typename CharT, bool SAMPLE = false, bool FAST = false>
 __global__ __launch_bounds__(TK_THREADS, DCD_TK_WPE) void k_tok_emit(const CharT* __restrict__ text, TokParams P, CharTables16 tab,
                                                         TextView<CharT> tv, VocabTable vt, const u64* __restrict__ tile_off,
                                                         uint2* __restrict__ tuples, u64 n_tiles, u32 stride, u32* __restrict__ tile_cnt,
@@ -99,14 +102,14 @@ __global__ __launch_bounds__(TK_THREADS, DCD_TK_WPE) void k_tok_emit(const CharT
   const u32 gtotal = pre[TK_WAVES];
   // every (sample_mask + 1)-th group counts its tokens per vocabulary slot: the frequency sample behind the hot / cold
   // split of the tuple sort (build_phase2)
-  const bool sampled = sample_cnt != nullptr && ((u32)group & sample_mask) == 0u;
-  const u64 obase = SAMPLE ? 0 : stride ? group * stride : tile_off[group * TK_WAVES];
-  if (!SAMPLE && stride && threadIdx.x == 0) tile_cnt[group] = gtotal;
+  const bool sampled = !FAST && sample_cnt != nullptr && ((u32)group & sample_mask) == 0u;
+  const u64 obase = SAMPLE ? 0 : (FAST || stride) ? group * stride : tile_off[group * TK_WAVES];
+  if (!SAMPLE && (FAST || stride) && threadIdx.x == 0) tile_cnt[group] = gtotal;
   constexpr u32 CS = sizeof(CharT);
   constexpr u32 PW = VocPool<CharT>::W;
   auto coord_of = [&](u64 gpos) -> u32 {
     u32 coord = (u32)gpos;
-    if (P.n_runs) {
+    if (!FAST && P.n_runs) {
       u32 a = 0, b = P.n_runs;   // last run with run_off <= gpos
       while (a + 1 < b) { u32 m = (a + b) >> 1; if (P.run_off[m] <= (u32)gpos) a = m; else b = m; }
       coord += P.run_delta[a];
@@ -176,10 +179,10 @@ __global__ __launch_bounds__(TK_THREADS, DCD_TK_WPE) void k_tok_emit(const CharT
       continue;
     }
     // (a table that numbers its terms returns the term's id, i.e. the sort key itself -- or VOC_UNRESOLVED | slot)
-    u32 slot = vt.id_ctr ? vocab_lookup_insert_ids<CharT>(vt, tv, hs.fin(), len, gpos, wv, word, (blockIdx.x & (VOC_SHARDS - 1u)) * VOC_CTR_STRIDE)
+    u32 slot = (FAST || vt.id_ctr) ? vocab_lookup_insert_ids<CharT>(vt, tv, hs.fin(), len, gpos, wv, word, (blockIdx.x & (VOC_SHARDS - 1u)) * VOC_CTR_STRIDE)
                : vt.pool ? vocab_lookup_insert_pooled<CharT>(vt, tv, hs.fin(), len, gpos, wv, word)
                          : vocab_lookup_insert<CharT>(vt, tv, hs.fin(), len, gpos, word);
-    any_unres |= vt.id_ctr != nullptr && slot != 0xFFFFFFFFu && (slot & VOC_UNRESOLVED) != 0u;
+    any_unres |= (FAST || vt.id_ctr != nullptr) && slot != 0xFFFFFFFFu && (slot & VOC_UNRESOLVED) != 0u;
 #endif
 #if DCD_TOK_NT
     {
@@ -194,7 +197,7 @@ __global__ __launch_bounds__(TK_THREADS, DCD_TK_WPE) void k_tok_emit(const CharT
   }
   // groups that hold unresolved keys go on the fix-up list: unres[0] = their number, unres[1 ..] = the first UNRES_CAP of them
   // (a wave reports its group; the list may name a group more than once -- the fix-up is idempotent)
-  if (unres != nullptr && ballot64(any_unres) != 0ull && lane == 0) {
+  if ((FAST || unres != nullptr) && ballot64(any_unres) != 0ull && lane == 0) {
     const u32 k = atomicAdd(unres, 1u);
     if (k < UNRES_CAP) unres[1 + k] = (u32)group;
   }
@@ -1433,8 +1436,12 @@ static int32_t build_phase1(dcd_build* h, bool codes_mode) {
       }
       if (early_ids && n_sample) {
         probes.begin(DCD_K_TOK_EMIT);
-        hipLaunchKernelGGL((k_tok_emit<CharT>), dim3((u32)div_up(n_tiles, TK_WAVES)), dim3(TK_THREADS), 0, st, text, P, tab, tv, vt,
-                           M.tile_off.p, M.tupA.p, n_tiles, M.stride, M.tile_cnt.p, (u64)0, sample_cnt.p, sample_mask, unres, 0u);
+        if (P.n_runs == 0)      // (early ids imply strided output and no per-slot sample counts)
+          hipLaunchKernelGGL((k_tok_emit<CharT, false, true>), dim3((u32)div_up(n_tiles, TK_WAVES)), dim3(TK_THREADS), 0, st, text, P, tab, tv, vt,
+                             M.tile_off.p, M.tupA.p, n_tiles, M.stride, M.tile_cnt.p, (u64)0, (u32*)nullptr, 0u, unres, 0u);
+        else
+          hipLaunchKernelGGL((k_tok_emit<CharT>), dim3((u32)div_up(n_tiles, TK_WAVES)), dim3(TK_THREADS), 0, st, text, P, tab, tv, vt,
+                             M.tile_off.p, M.tupA.p, n_tiles, M.stride, M.tile_cnt.p, (u64)0, sample_cnt.p, sample_mask, unres, 0u);
         probes.end();
       } else {
         if (n_seed) {   // (not a DCD_K_TOK_EMIT probe: per-launch averages are quoted for the main launch)
