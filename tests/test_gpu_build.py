@@ -363,9 +363,11 @@ print("DIGEST", h.hexdigest(), st.n_postings, st.n_terms, st.n_units)
 ''' % (ROOT, n_docs)
     outs = []
     # ordinal-rank keys; dense-id keys from a scan of the finished table without the hot / cold split, with a split of at
-    # most 5 / 255 hot terms; ids handed out by the table while it is filled (default)
+    # most 5 / 255 hot terms; ids handed out by the table while it is filled: default (hot set from a sampling launch of 64
+    # groups), a hot set of at most 5 terms, of a sample of 2 groups, none; without any event records
     E0 = {"DOCODO_BUILD_EARLY_IDS": "0"}
-    for extra in ({"DOCODO_BUILD_RANK_KEYS": "1"}, dict(E0, DOCODO_BUILD_HOT="0"), dict(E0, DOCODO_BUILD_HOT="5"), E0, {}):
+    for extra in ({"DOCODO_BUILD_RANK_KEYS": "1"}, dict(E0, DOCODO_BUILD_HOT="0"), dict(E0, DOCODO_BUILD_HOT="5"), E0, {},
+                  {"DOCODO_BUILD_HOT": "5"}, {"DOCODO_TOK_SAMPLE_GROUPS": "2"}, {"DOCODO_BUILD_HOT": "0"}, {"DOCODO_BUILD_EVENTS": "0"}):
         env = dict(os.environ, **extra)
         r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
         assert r.returncode == 0, r.stdout + r.stderr
