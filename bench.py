@@ -185,6 +185,10 @@ def main():
     ap.add_argument("--and3", type=int, default=20_000, help="3-term AND queries in the extra query batch")
     ap.add_argument("--inflight", type=int, default=2, help="extra (untimed for `value`) leg: this many builders at once, as the "
                     "reference's MaxDegreeOfParallelism index tasks (Index.cs:127, 464-465); 0/1 = skip")
+    ap.add_argument("--pipeline", type=int, default=int(os.environ.get("DOCODO_BENCH_PIPELINE", "1")),
+                    help="N > 1: 1 = the exchange + merge of step i runs on a second host thread beside the build of step i + 1 "
+                    "(every merge completes inside the timed region); 0 = one after the other")
+    ap.add_argument("--force-exchange", action="store_true", help="rehearsal: run the N > 1 step (exchange + merge) with one rank")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -197,9 +201,11 @@ def main():
         local_rank, backend = 0, "gloo"
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    exchange = world > 1 or args.force_exchange
+    if exchange:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29671")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
@@ -219,29 +225,70 @@ def main():
     from docodo_amd import dist as ddist
     merge_ms = []
 
+    def merge(b):
+        # exchange step: per-term segments travel to their owner (hash(key) % world) with RCCL
+        # all-to-all over xGMI and are merged there; part of the timed step
+        t0 = time.perf_counter()
+        owned = ddist.distributed_merge(b, device_index=local_rank)
+        merge_ms.append((time.perf_counter() - t0) * 1e3)      # (host time of the calls; the device side is covered by the fence)
+        owned.close()
+        b.close()
+
+    # N > 1, pipelined: ONE worker thread takes the finished builders in step order and runs their exchange + merge while the
+    # main thread builds the next shard.  Every collective inside the timed region is issued by that thread, in the same
+    # order on every rank; the main thread joins it before it meets the other ranks at a barrier.
+    worker = None
+    if exchange and args.pipeline:
+        import queue
+        import threading
+        jobs = queue.Queue(maxsize=1)          # (at most one merge waiting: bounds the memory of finished builders)
+        failed = []
+
+        def work():
+            torch.cuda.set_device(local_rank)
+            while True:
+                b = jobs.get()
+                try:
+                    if b is None:
+                        return
+                    if not failed:
+                        merge(b)
+                except BaseException as e:     # (keep consuming: the main thread must never block on a full queue)
+                    failed.append(e)
+                finally:
+                    jobs.task_done()
+
+        worker = threading.Thread(target=work, daemon=True)
+        worker.start()
+
+    def drain():
+        if worker is not None:
+            jobs.join()
+            if failed:
+                raise failed[0]
+
     def step():
         b = docodo_amd.Builder(coord_base=coord_base, device=local_rank)
         b.AddUniformPagesDev(text.data_ptr(), D, synth.DOC_BYTES, first_doc=first_doc)
         st = b.Finish()
-        if world > 1:
-            # exchange step: per-term segments travel to their owner (hash(key) % world) with RCCL
-            # all-to-all over xGMI and are merged there; part of the timed step
-            t0 = time.perf_counter()
-            owned = ddist.distributed_merge(b, device_index=local_rank)
+        if not exchange:
+            b.close()
+        elif worker is not None:
+            jobs.put(b)
+        else:
+            merge(b)
             torch.cuda.synchronize()
-            merge_ms.append((time.perf_counter() - t0) * 1e3)
-            owned.close()
-        return b, st
+        return st
 
     def fence():
+        drain()
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
             torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        b, st = step()
-        b.close()
+        step()
     fence()
     t0 = time.perf_counter()
     ksum = np.zeros(8)
@@ -249,14 +296,15 @@ def main():
     stage = np.zeros(6)
     last = None
     for _ in range(args.steps):
-        b, st = step()
+        st = step()
         ksum += np.array(list(st.ms_kernel))
         kcnt += np.array(list(st.n_launch))
         stage += np.array([st.ms_tokenize, st.ms_vocab, st.ms_sort, st.ms_pack, st.ms_image, st.ms_total])
         last = (st.n_postings, st.n_terms, st.n_units, st.index_bytes, st.sort_passes, st.id_keys, st.n_hot_terms, st.n_hot_postings)
-        b.close()
     fence()
     dt = time.perf_counter() - t0
+    if worker is not None:
+        jobs.put(None)                     # (the worker leaves)
     if dist is not None:
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -306,14 +354,17 @@ def main():
             "kernel_ms_per_step": {KERNEL_NAMES[k]: round(per_step[k], 4) for k in range(8)},
             "postings_per_s": round(world * N / (dt / args.steps), 0),
         }
-        if world > 1:
+        if exchange:
             out["exchange_merge_ms_per_step_rank0"] = round(float(np.mean(merge_ms[args.warmup:])), 3)
-            out["config"]["exchange"] = "RCCL all-to-all of per-term segments (meta, keys, units) to owner = hash(key) % world; dcd_merge_begin overlaps the unit exchange, then dcd_merge_finish"
-        if world == 1 and args.inflight > 1:
+            out["config"]["exchange"] = ("RCCL all-to-all of per-term segments (meta, keys, units) to owner = hash(key) % world; dcd_merge_begin overlaps "
+                                         "the unit exchange, then dcd_merge_finish" +
+                                         ("; the exchange + merge of step i runs on a second host thread beside the build of step i + 1, all of them inside the timed region"
+                                          if worker is not None else ""))
+        if world == 1 and args.inflight > 1 and not exchange:
             out["builders_in_flight"] = inflight_bench(args.inflight, args.steps, text, D, local_rank, T)
-        if world == 1 and args.cpu_docs > 0:
+        if world == 1 and args.cpu_docs > 0 and not exchange:
             out["cpu_baseline"] = cpu_baseline(min(args.cpu_docs, D))
-        if world == 1 and args.queries > 0:
+        if world == 1 and args.queries > 0 and not exchange:
             # query leg of configs[1], outside the timed build steps
             bq, _ = step()
             img, lst = (bq.index_image(), bq.list_image()) if args.cpu_docs > 0 else (None, None)
