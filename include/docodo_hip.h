@@ -169,7 +169,7 @@ typedef struct dcd_build_stats {
   /* how the tuples were sorted: id_keys = 2: by the ids the vocabulary table hands out while the tokeniser fills it (the tuples
    * carry their sort keys from the start), 1: by dense ids taken from a scan of the table afterwards; either way the ordinal
    * vocabulary sort ran beside the tuple sort ([7] is then overlapped time) and k_img_units also copies the units into term
-   * order; 0: by ordinal rank.  n_hot_terms > 0 (id_keys = 1 only): the first radix
+   * order; 0: by ordinal rank.  n_hot_terms > 0 (id_keys = 1: chosen from sample counts of the filled table; id_keys = 2: by a sampling launch in front of the tokeniser, whose most frequent terms get the ids 0 .. n_hot_terms - 1): the first radix
    * pass gave that many frequent terms a bucket of their own (n_hot_postings tuples, final after one pass) and only the
    * other n_postings - n_hot_postings tuples took the remaining sort_passes - 1 passes */
   uint32_t id_keys, n_hot_terms;
