@@ -268,7 +268,8 @@ def main():
                 raise failed[0]
 
     def step():
-        b = docodo_amd.Builder(coord_base=coord_base, device=local_rank)
+        # (N > 1: the shard is exported and merged, never serialised on its own -- no ".index" image, no term-ordered copy)
+        b = docodo_amd.Builder(coord_base=coord_base, device=local_rank, shard_only=exchange)
         b.AddUniformPagesDev(text.data_ptr(), D, synth.DOC_BYTES, first_doc=first_doc)
         st = b.Finish()
         if not exchange:

@@ -11,7 +11,7 @@ namespace Docodo
 
         [StructLayout(LayoutKind.Sequential)]
         public struct BuildOpts { public int device, min_word_length, max_word_length, encoding;
-                                  public ulong coord_base; public uint vocab_capacity_log2, reserved; }
+                                  public ulong coord_base; public uint vocab_capacity_log2, flags; }   // flags: 1 = DCD_BUILD_SHARD_ONLY
         [StructLayout(LayoutKind.Sequential)]
         public struct QueryOpts { public int max_found_pages, max_found_docs; public float doc_rank_multiply; public int want_sequences;
                                   public byte* doc_match; public ulong n_doc_match; }   // -filter: one byte per document, null = none

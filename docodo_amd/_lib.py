@@ -22,10 +22,13 @@ class DocodoError(RuntimeError):
         self.code = code
 
 
+DCD_BUILD_SHARD_ONLY = 1
+
+
 class BuildOpts(C.Structure):
     _fields_ = [("device", C.c_int32), ("min_word_length", C.c_int32), ("max_word_length", C.c_int32),
                 ("encoding", C.c_int32), ("coord_base", C.c_uint64), ("vocab_capacity_log2", C.c_uint32),
-                ("reserved", C.c_uint32)]
+                ("flags", C.c_uint32)]
 
 
 class BuildStats(C.Structure):

@@ -725,7 +725,7 @@ namespace dcd {
 int32_t get_char_tables16(int device, CharTables16* out);
 void host_char_tables16(const u8** cls, const u16** lower);
 DeviceIndex* build_take_index(dcd_build* b) {
-  if (!b->finished || b->adopted) return nullptr;
+  if (!b->finished || b->adopted || b->ix.units_by_key.p) return nullptr;      // (a shard-only build has no index to hand over)
   b->adopted = true;
   return &b->ix;
 }
@@ -2021,7 +2021,10 @@ static int32_t build_phase2(dcd_build* h) {
   }
   if (!idk) DCD_HIP(hipStreamSynchronize(st));
   tr.mark("pack");
-  if (idk) DCD_TRY(ix.units.alloc(dev, U ? U : 1));
+  // DCD_BUILD_SHARD_ONLY (id-keyed builds): the shard is exported, not serialised or queried -- no image, no copy of the units
+  // into term order; the export reads them where the pack kernel left them (units_by_key + unit_src_start)
+  const bool shard_only = idk && (h->opts.flags & DCD_BUILD_SHARD_ONLY) != 0;
+  if (idk && !shard_only) DCD_TRY(ix.units.alloc(dev, U ? U : 1));
   u64 max_coord = 0;
   {
     // coordinate of the last Add call: the later of (last explicit posting, last text token)
@@ -2031,10 +2034,15 @@ static int32_t build_phase2(dcd_build* h) {
     else if (n_text_postings) max_coord = text_last;
     else if (any_x) max_coord = h->last_explicit_coord;
   }
-  h->image_bytes = 8 + rec_total;
+  h->image_bytes = shard_only ? 0 : 8 + rec_total;
+  if (shard_only) {
+    ix.units_by_key = std::move(units_id);
+    ix.unit_src_start = std::move(src_start);
+  } else {
   DCD_TRY(h->image.alloc(dev, h->image_bytes));
   hipLaunchKernelGGL(k_put_u64_bytes, dim3(1), dim3(1), 0, st, h->image.p, max_coord);
-  if (V) {
+  }
+  if (V && !shard_only) {
     hipLaunchKernelGGL(k_img_headers, dim3((u32)div_up(V, 256)), dim3(256), 0, st, ix.term_chars.p, ix.term_str_off.p,
                        ix.term_unit_start.p, rec_off.p, V, (u64)8, h->image.p, pay_off.p);
     if (U) {
@@ -2151,6 +2159,7 @@ int32_t dcd_build_get_stats(dcd_build* h, dcd_build_stats* out) {
 int32_t dcd_build_index_image(dcd_build* h, uint8_t* out, size_t cap, size_t* n) {
   if (!h || !n) DCD_FAIL(DCD_E_BADARG, "dcd_build_index_image: NULL argument");
   if (!h->finished) DCD_FAIL(DCD_E_STATE, "dcd_build_finish has not run");
+  if (h->ix.units_by_key.p) DCD_FAIL(DCD_E_STATE, "a DCD_BUILD_SHARD_ONLY build has no .index image");
   *n = (size_t)h->image_bytes;
   if (!out || cap < h->image_bytes) return DCD_E_OVERFLOW;
   DCD_TRY(ensure_device(h->device));
@@ -2171,6 +2180,7 @@ int32_t dcd_build_list_image(dcd_build* h, uint8_t* out, size_t cap, size_t* n) 
 int32_t dcd_build_save(dcd_build* h, const char* dir_utf8) {
   if (!h || !dir_utf8) DCD_FAIL(DCD_E_BADARG, "dcd_build_save: NULL argument");
   if (!h->finished) DCD_FAIL(DCD_E_STATE, "dcd_build_finish has not run");
+  if (h->ix.units_by_key.p) DCD_FAIL(DCD_E_STATE, "a DCD_BUILD_SHARD_ONLY build cannot be saved");
   std::vector<u8> img(h->image_bytes);
   size_t n = 0;
   DCD_TRY(dcd_build_index_image(h, img.data(), img.size(), &n));

@@ -49,6 +49,10 @@ struct DeviceIndex {
   DevBuf<u32> term_str_off;      // [n_terms + 1]
   DevBuf<u64> page_end;          // [n_pages] END coordinates (device copy of PageTable::end)
   DevBuf<u64> term_first, term_last;  // [n_terms] first / last absolute coordinate per term (shard merge)
+  // DCD_BUILD_SHARD_ONLY builds (export only): `units` is empty; the units lie where the pack kernel left them (by sort key)
+  // and term r's run starts at units_by_key[unit_src_start[r]]
+  DevBuf<u16> units_by_key;
+  DevBuf<u64> unit_src_start;    // [n_terms]
   // host mirrors (small): keys for dcd_index_find, offsets
   std::vector<u16> h_term_chars;
   std::vector<u32> h_term_str_off;

@@ -203,6 +203,7 @@ int32_t dcd_index_from_build(dcd_build* b, dcd_index** out) {
   // everything that can fail happens while the build still owns its index: a failed call leaves the builder usable
   DeviceIndex* peek = build_peek_index(b);
   if (!peek) DCD_FAIL(DCD_E_STATE, "build is not finished or its index was already adopted");
+  if (peek->units_by_key.p) DCD_FAIL(DCD_E_STATE, "a DCD_BUILD_SHARD_ONLY build can only be exported");
   DCD_TRY(index_fetch_host(*peek));
   hipStream_t st = nullptr;
   DCD_TRY(stream_acquire(peek->device, &st));

@@ -334,8 +334,10 @@ static int32_t export_fill_impl(const void* h, DeviceIndex* ix, hipStream_t st, 
     hipLaunchKernelGGL(k_export_meta, dim3((u32)div_up(V, 256)), dim3(256), 0, st, ep->perm.p, V, ix->term_unit_start.p, ix->term_item_start.p,
                        ix->term_str_off.p, ix->term_chars.p, ix->term_first.p, ix->term_last.p, ep->key_dst.p, (dcd_term_meta*)meta_dev, keys_dev);
     if (ep->total_units)
+      // (a DCD_BUILD_SHARD_ONLY build keeps its units in sort-key order: term r's run starts at unit_src_start[r])
       hipLaunchKernelGGL(k_export_units, dim3((u32)div_up(ep->total_units, CP_TILE)), dim3(CP_THREADS), 0, st, ep->perm.p, V, ep->unit_dst.p,
-                         ep->total_units, ix->term_unit_start.p, ix->units.p, units_dev);
+                         ep->total_units, ix->units_by_key.p ? ix->unit_src_start.p : ix->term_unit_start.p,
+                         ix->units_by_key.p ? ix->units_by_key.p : ix->units.p, units_dev);
   }
   DCD_HIP(hipStreamSynchronize(st));
   DCD_HIP(hipGetLastError());

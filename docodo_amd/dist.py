@@ -255,7 +255,7 @@ class SegmentedBuilder:
         while done < n_pages:
             k = min(self.max_pages, n_pages - done)
             first = self.n_pages + done
-            b = Builder(coord_base=first * self.page_chars, device=self.device)
+            b = Builder(coord_base=first * self.page_chars, device=self.device, shard_only=True)      # (exported and merged below)
             b.AddUniformPagesDev(text_dev_ptr + done * self.page_chars, k, self.page_chars, first_doc=first, source=self.source)
             st = b.Finish()
             self.n_postings += st.n_postings

@@ -27,7 +27,7 @@ class Builder:
     """Index.Builder (Build.cs:258-437) fused with the IndexTask page loop (Build.cs:445-564)."""
 
     def __init__(self, encoding=_lib.DCD_ENC_LATIN1, coord_base=0, device=0, min_word_length=3, max_word_length=32,
-                 vocab_capacity_log2=0, get_word_codes=None):
+                 vocab_capacity_log2=0, get_word_codes=None, shard_only=False):
         """get_word_codes: callable word -> list of index codes (GetWordCodes, Build.cs:175-247; see
         docodo_amd.wordcodes.WordCoder).  None = identity codes (Stemmers.Clear(), no vocabulary, no stop words)."""
         self.get_word_codes = get_word_codes
@@ -36,6 +36,9 @@ class Builder:
         o.device, o.encoding, o.coord_base = device, encoding, coord_base
         o.min_word_length, o.max_word_length = min_word_length, max_word_length
         o.vocab_capacity_log2 = vocab_capacity_log2
+        # shard_only: one doc-range shard of a distributed build -- exported (dist.export_shard) and merged elsewhere, never
+        # saved or queried on its own: Finish then skips the ".index" image and the term-ordered posting array
+        o.flags = _lib.DCD_BUILD_SHARD_ONLY if shard_only else 0
         self.encoding = encoding
         self.device = device
         self.h = C.c_void_p()

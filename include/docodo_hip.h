@@ -91,8 +91,14 @@ typedef struct dcd_build_opts {
   uint64_t coord_base;      /* global coordinate of the first character (doc-range shards: text
                                length of all previous shards; 0 for a single builder) */
   uint32_t vocab_capacity_log2; /* 0 = auto; hash-table slots = 2^n (grown automatically on overflow) */
-  uint32_t reserved;
+  uint32_t flags;           /* DCD_BUILD_* (was: reserved, 0) */
 } dcd_build_opts;
+/* The build is one doc-range shard of a distributed build: it will be exported (dcd_build_export_plan / _fill) and merged
+ * elsewhere, never serialised or queried on its own.  dcd_build_finish then stops in front of the ".index" image and the
+ * term-ordered posting array (a third of a gigabyte read and two written at 1 M documents) and the export reads the posting
+ * units where the pack kernel left them; dcd_build_index_image, dcd_build_save and dcd_index_from_build fail with
+ * DCD_E_STATE on such a handle. */
+#define DCD_BUILD_SHARD_ONLY 1u
 
 void dcd_build_default_opts(dcd_build_opts* o);
 int32_t dcd_build_create(const dcd_build_opts* opts, dcd_build** out);

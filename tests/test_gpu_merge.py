@@ -53,6 +53,33 @@ def test_fake_shards_equal_one_shot_build(oracle_mod, G, n_docs):
     assert full_img == oi and full_lst == ol
 
 
+@pytest.mark.parametrize("G,n_docs", [(1, 700), (3, 5000), (4, 40000)])
+def test_shard_only_builds_export_the_same_buffers(G, n_docs):
+    """DCD_BUILD_SHARD_ONLY (Builder(shard_only=True)): Finish stops in front of the ".index" image and the term-ordered posting
+    array, the export reads the units where the pack kernel left them.  Same export buffers as a full build, byte for byte;
+    what needs the image or the index fails loudly."""
+    import docodo_amd
+    from docodo_amd import dist, synth
+    text = synth.corpus_host(n_docs)
+    off = np.arange(n_docs + 1, dtype=np.uint64) * synth.DOC_BYTES
+    outs = []
+    for shard_only in (False, True):
+        b = docodo_amd.Builder(coord_base=5 * synth.DOC_BYTES, shard_only=shard_only)
+        b.AddPages(text, off, docs_per_page=True, first_doc=5)
+        st = b.Finish()
+        if shard_only:
+            assert st.index_bytes == 0
+            with pytest.raises(docodo_amd.DocodoError):
+                b.index_image()
+            with pytest.raises(docodo_amd.DocodoError):
+                b.Build()
+        e = dist.export_shard(b, G)
+        outs.append((e.term_count.tolist(), e.key_count.tolist(), e.unit_count.tolist(), e.meta.cpu().numpy().tobytes(),
+                     e.keys.cpu().numpy().tobytes(), e.units.cpu().numpy().tobytes(), e.max_coord, st.n_postings, st.n_terms, st.n_units))
+        b.close()
+    assert outs[0] == outs[1]
+
+
 @pytest.mark.parametrize("G,n_docs", [(2, 2000), (5, 6003)])
 def test_gathered_partitions_give_the_one_shot_index_file(G, n_docs):
     """Doc-range shards -> per-owner merge (hash partitions) -> gather of the partitions on one GPU: ".index" and
