@@ -367,7 +367,9 @@ def main():
             out["cpu_baseline"] = cpu_baseline(min(args.cpu_docs, D))
         if world == 1 and args.queries > 0 and not exchange:
             # query leg of configs[1], outside the timed build steps
-            bq, _ = step()
+            bq = docodo_amd.Builder(coord_base=coord_base, device=local_rank)
+            bq.AddUniformPagesDev(text.data_ptr(), D, synth.DOC_BYTES, first_doc=first_doc)
+            bq.Finish()
             img, lst = (bq.index_image(), bq.list_image()) if args.cpu_docs > 0 else (None, None)
             ixq = bq.Build()
             out["queries"] = query_bench(ixq, args.queries, args.and3, 3000 if args.cpu_docs > 0 else 0, img, lst)
