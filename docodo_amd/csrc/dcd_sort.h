@@ -104,28 +104,35 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const uint2* __restrict_
   // The order of the items inside a block does not matter for the counts: every lane reads TWO tuples per load
   // (16 B) and keeps four loads in flight, so that enough bytes are outstanding to cover the HBM latency.
   constexpr int UN = DCD_RS_UN;
-  const u64 span = end > beg ? end - beg : 0;
-  if ((reinterpret_cast<uintptr_t>(in) & 15) == 0) {          // beg is a multiple of RS_TILE: pairs stay aligned
-    const uint4* in2 = reinterpret_cast<const uint4*>(in + beg);
-    const u64 pairs = (span + 1) >> 1;
+  // (beg is a multiple of RS_TILE, but `in` itself may be only 8-byte aligned -- the cold region of a hot / cold sort starts
+  // behind an arbitrary number of hot tuples: a block then peels its first tuple, so that the pairs are 16-byte aligned;
+  // a last tuple without a partner is counted by itself, so that no load reaches past `end`)
+  if (end > beg) {
+    u64 b0 = beg;
+    if ((reinterpret_cast<uintptr_t>(in + beg) & 15) != 0) {
+      if (threadIdx.x == 0) atomicAdd(&hl[(key_of(in[beg].x) >> shift) & (NB - 1)], 1u);
+      b0 = beg + 1;
+    }
+    const u64 span = end - b0;
+    const uint4* in2 = reinterpret_cast<const uint4*>(in + b0);
+    const u64 pairs = span >> 1;                               // full pairs
+    if ((span & 1) && threadIdx.x == 64) atomicAdd(&hl[(key_of(in[end - 1].x) >> shift) & (NB - 1)], 1u);
     for (u64 o = 0; o < pairs; o += (u64)RS_THREADS * UN) {
       uint4 kv[UN];
       u64 p[UN];
 #pragma unroll
       for (int u = 0; u < UN; u++) {
         p[u] = o + (u64)u * RS_THREADS + threadIdx.x;
-        // the second tuple of the last pair may lie past `end` but never past the 16-byte granule of the buffer
         kv[u] = p[u] < pairs ? in2[p[u]] : make_uint4(0u, 0u, 0u, 0u);
       }
 #pragma unroll
       for (int u = 0; u < UN; u++) {
-        if (2 * p[u] < span) atomicAdd(&hl[(key_of(kv[u].x) >> shift) & (NB - 1)], 1u);
-        if (2 * p[u] + 1 < span) atomicAdd(&hl[(key_of(kv[u].z) >> shift) & (NB - 1)], 1u);
+        if (p[u] < pairs) {
+          atomicAdd(&hl[(key_of(kv[u].x) >> shift) & (NB - 1)], 1u);
+          atomicAdd(&hl[(key_of(kv[u].z) >> shift) & (NB - 1)], 1u);
+        }
       }
     }
-  } else {
-    for (u64 o = threadIdx.x; o < span; o += RS_THREADS)
-      atomicAdd(&hl[(key_of(in[beg + o].x) >> shift) & (NB - 1)], 1u);
   }
   __syncthreads();
   for (int d = threadIdx.x; d < NB; d += RS_THREADS) {
