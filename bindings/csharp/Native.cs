@@ -26,6 +26,7 @@ namespace Docodo
         [DllImport(Lib)] public static extern int dcd_device_count(out int n);
         // device-memory cache of the library: Index.Dispose() trims it so that the memory goes back to the driver
         [DllImport(Lib)] public static extern int dcd_pool_trim(int device);
+        [DllImport(Lib)] public static extern int dcd_set_build_events(int level, uint kernel_mask);
         [DllImport(Lib)] public static extern int dcd_pool_cached_bytes(int device, out ulong bytes);
 
         // IndexSequence.cs

@@ -66,6 +66,7 @@ SIGNATURES = {
     "dcd_last_error": (_i32, [C.c_char_p, _sz]),
     "dcd_device_count": (_i32, [_pi32]),
     "dcd_pool_trim": (_i32, [_i32]),
+    "dcd_set_build_events": (_i32, [_i32, C.c_uint32]),
     "dcd_pool_cached_bytes": (_i32, [_i32, _pu64]),
     "dcd_seq_encode": (_i32, [_vp, _sz, _vp, _sz, _pz]),
     "dcd_seq_decode": (_i32, [_vp, _sz, _vp, _sz, _pz]),
@@ -163,6 +164,12 @@ def last_error():
     buf = C.create_string_buffer(2048)
     lib().dcd_last_error(buf, len(buf))
     return buf.value.decode("utf-8", "replace")
+
+
+def set_build_events(level=2, kernel_mask=0):
+    """dcd_set_build_events: which HIP events builds record for their stats (2 = everything, 1 = stage timers, 0 = none;
+    kernel_mask: DCD_K_* bits measured whatever the level)."""
+    check(lib().dcd_set_build_events(level, kernel_mask))
 
 
 def pool_trim(device=0):

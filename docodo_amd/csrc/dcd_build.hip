@@ -1146,11 +1146,13 @@ struct Probes {
   hipStream_t st;
   int dev;
   explicit Probes(hipStream_t s, int device) : st(s), dev(device) {}
+  bool open_ = false;
   void begin(int id) {
-    if (event_level() < 2) return;
+    open_ = event_probe_on(id);
+    if (!open_) return;
     P p{id, event_acquire(dev), event_acquire(dev)}; if (p.a) (void)hipEventRecord(p.a, st); v.push_back(p);
   }
-  void end() { if (event_level() >= 2 && v.back().b) (void)hipEventRecord(v.back().b, st); }
+  void end() { if (open_ && v.back().b) (void)hipEventRecord(v.back().b, st); open_ = false; }
   void collect(float* ms, u32* n) {   // after the stream was synchronised
     for (auto& p : v) {
       float t = 0;
@@ -1816,7 +1818,7 @@ static int32_t build_phase2(dcd_build* h) {
   int passes = 0;
   u32 hot_n = 0, hot_s = 0;
   u64 n_hot_postings = 0;
-  std::vector<hipEvent_t> sort_events;
+  std::vector<hipEvent_t> hist_events, scatter_events;
   if (N) {
     if (coord_sort) {
       // mixed input is not in coordinate order: LSD over the coordinate bits first
@@ -1834,7 +1836,7 @@ static int32_t build_phase2(dcd_build* h) {
     }
     int p2 = 0;
     RsProbe rp;
-    rp.ev = &sort_events; rp.device = dev;
+    rp.ev_hist = &hist_events; rp.ev_scatter = &scatter_events; rp.device = dev; rp.k_hist = DCD_K_RS_HIST; rp.k_scatter = DCD_K_RS_SCATTER;
     RsStrided sd;
     sd.cnt = M.tile_cnt.p; sd.stride = M.stride; sd.n_tiles = M.n_tiles;
     const bool strided = M.strided && a == M.tupA.p && (remap != nullptr || early);     // (codes mode sorts its own expanded tuples)
@@ -2082,12 +2084,15 @@ static int32_t build_phase2(dcd_build* h) {
   s.id_keys = early ? 2u : idk ? 1u : 0u; s.n_hot_terms = hot_n; s.n_hot_postings = n_hot_postings;
   for (int k = 0; k < 8; k++) { s.ms_kernel[k] = M.ms_kernel[k]; s.n_launch[k] = M.n_launch[k]; }
   probes.collect(s.ms_kernel, s.n_launch);
-  for (size_t i = 0; i + 3 < sort_events.size(); i += 4) {
-    float t = 0;
-    if (hipEventElapsedTime(&t, sort_events[i], sort_events[i + 1]) == hipSuccess) { s.ms_kernel[DCD_K_RS_HIST] += t; s.n_launch[DCD_K_RS_HIST]++; }
-    if (hipEventElapsedTime(&t, sort_events[i + 2], sort_events[i + 3]) == hipSuccess) { s.ms_kernel[DCD_K_RS_SCATTER] += t; s.n_launch[DCD_K_RS_SCATTER]++; }
+  for (int which = 0; which < 2; which++) {
+    std::vector<hipEvent_t>& ev = which ? scatter_events : hist_events;
+    const int k = which ? DCD_K_RS_SCATTER : DCD_K_RS_HIST;
+    for (size_t i = 0; i + 1 < ev.size(); i += 2) {
+      float t = 0;
+      if (hipEventElapsedTime(&t, ev[i], ev[i + 1]) == hipSuccess) { s.ms_kernel[k] += t; s.n_launch[k]++; }
+    }
+    for (auto e : ev) event_release(dev, e);
   }
-  for (auto e : sort_events) event_release(dev, e);
   tr.mark("mirrors+stats");
   h->mid.reset();
   tr.mark("free");
@@ -2101,6 +2106,7 @@ int32_t dcd_build_finish(dcd_build* h) {
   if (!h) DCD_FAIL(DCD_E_BADARG, "dcd_build_finish: NULL handle");
   if (h->finished) DCD_FAIL(DCD_E_STATE, "build already finished");
   DCD_TRY(ensure_device(h->device));
+  EventScope ev_;            // (one setting for the whole build, whatever dcd_set_build_events does meanwhile)
   const bool wide = h->opts.encoding == DCD_ENC_UTF16LE;
   if (!h->mid) DCD_TRY(wide ? build_phase1<u16>(h, false) : build_phase1<u8>(h, false));
   return wide ? build_phase2<u16>(h) : build_phase2<u8>(h);

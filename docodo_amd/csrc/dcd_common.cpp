@@ -1,5 +1,6 @@
 // dcd_common.cpp -- error state, device check and the caching device allocator.
 #include "dcd_common.h"
+#include <atomic>
 
 #include <cstdlib>
 #include <map>
@@ -269,6 +270,23 @@ void stream_release(int device, hipStream_t st) {
   std::lock_guard<std::mutex> g(H.mu);
   H.streams[device].push_back(st);
 }
+// ---- event configuration (dcd_common.h) ----------------------------------------------------------------------------------
+static std::atomic<int> g_ev_level{-1};
+static std::atomic<uint32_t> g_ev_mask{0};
+EventCfg event_cfg_global() {
+  int lv = g_ev_level.load(std::memory_order_relaxed);
+  if (lv < 0) {
+    const char* e = getenv("DOCODO_BUILD_EVENTS");
+    lv = e ? atoi(e) : 2;
+    if (lv < 0) lv = 0;
+    g_ev_level.store(lv, std::memory_order_relaxed);
+  }
+  return EventCfg{lv, g_ev_mask.load(std::memory_order_relaxed)};
+}
+void event_cfg_set_global(int level, uint32_t mask) {
+  g_ev_level.store(level < 0 ? 0 : level, std::memory_order_relaxed);
+  g_ev_mask.store(mask, std::memory_order_relaxed);
+}
 // A few pinned host words per thread: read-backs into pinned memory are truly asynchronous (a D2H copy into pageable memory
 // holds the calling thread until the data has arrived, i.e. until everything queued before it has run).
 u64* pinned_words() {
@@ -331,6 +349,11 @@ int32_t dcd_last_error(char* buf, size_t cap) {
     buf[n] = 0;
   }
   return (int32_t)e.size();
+}
+int32_t dcd_set_build_events(int32_t level, uint32_t kernel_mask) {
+  if (level < 0 || level > 2 || (kernel_mask >> 8)) DCD_FAIL(DCD_E_BADARG, "dcd_set_build_events: level 0..2, mask of DCD_K_* bits");
+  dcd::event_cfg_set_global(level, kernel_mask);
+  return DCD_OK;
 }
 int32_t dcd_pool_trim(int32_t device) {
   int n = 0;

@@ -114,12 +114,25 @@ struct DevBuf {
 };
 
 // ---- HIP event timer ------------------------------------------------------------------------
-// How many events a build records (every record is a marker packet the stream stops at: ~5 us each, ~30 per build at
-// level 2).  DOCODO_BUILD_EVENTS: 2 = stage timers + per-kernel probes (default), 1 = stage timers, 0 = none (the ms_* fields
-// of the stats are then 0).
-inline int event_level() {
-  static const int lv = [] { const char* e = getenv("DOCODO_BUILD_EVENTS"); return e ? atoi(e) : 2; }();
-  return lv;
+// How many events a build records (every record is a marker packet the stream stops at: ~5 us each, ~30 per build with
+// everything on: 0.12 ms of a 4 ms build).  Process-wide setting, dcd_set_build_events(level, kernel_mask) / DOCODO_BUILD_EVENTS:
+// level 2 = stage timers + all per-kernel probes (default), 1 = stage timers, 0 = no stage timers (the ms_* stage fields of the
+// stats are then 0); kernel_mask: the probes of kernel DCD_K_* k are recorded if level >= 2 or bit k of the mask is set.
+// A build takes its setting once, when dcd_build_finish starts (EventScope), so that one build is consistent in itself.
+struct EventCfg { int level; uint32_t mask; };
+EventCfg event_cfg_global();
+void event_cfg_set_global(int level, uint32_t mask);
+inline EventCfg& event_cfg_tl() { static thread_local EventCfg c{-1, 0}; return c; }
+struct EventScope {      // the calling thread uses a snapshot of the global setting until the scope ends
+  EventCfg saved;
+  EventScope() : saved(event_cfg_tl()) { event_cfg_tl() = event_cfg_global(); }
+  ~EventScope() { event_cfg_tl() = saved; }
+};
+inline int event_level() { const EventCfg& c = event_cfg_tl(); return c.level >= 0 ? c.level : event_cfg_global().level; }
+inline bool event_probe_on(int kernel) {
+  const EventCfg& t = event_cfg_tl();
+  const EventCfg c = t.level >= 0 ? t : event_cfg_global();
+  return c.level >= 2 || ((c.mask >> kernel) & 1u);
 }
 struct EvTimer {
   hipEvent_t a = nullptr, b = nullptr;

@@ -485,8 +485,10 @@ inline u64 rs_hist_elems(u64 n, int bits) { return (u64)rs_plan(n).nblk << bits;
 
 // optional per-kernel event probes (build stats): pairs of events recorded around the two kernels
 struct RsProbe {
-  std::vector<hipEvent_t>* ev = nullptr;  // appended: hist_begin, hist_end, scatter_begin, scatter_end per pass
+  std::vector<hipEvent_t>* ev_hist = nullptr;     // appended: begin, end per pass (if the kernel's probes are on: event_probe_on)
+  std::vector<hipEvent_t>* ev_scatter = nullptr;
   int device = 0;
+  int k_hist = 0, k_scatter = 0;                  // the kernels' DCD_K_* ids
   // optional: called between the scan of the histogram and the scatter kernel of a pass (the scanned counts are final
   // there: a caller can queue a read-back of bucket boundaries that completes while the scatter kernel still runs)
   void (*after_scan)(void* arg, hipStream_t st) = nullptr;
@@ -494,8 +496,9 @@ struct RsProbe {
   // thing queued on the stream)
   void (*before_pass)(void* arg, hipStream_t st) = nullptr;
   void* after_scan_arg = nullptr;        // (the argument of both)
-  void rec(hipStream_t st) const {
-    if (!ev || event_level() < 2) return;
+  void rec(hipStream_t st, bool scatter) const {
+    std::vector<hipEvent_t>* ev = scatter ? ev_scatter : ev_hist;
+    if (!ev || !event_probe_on(scatter ? k_scatter : k_hist)) return;
     hipEvent_t e = event_acquire(device);
     if (e) { (void)hipEventRecord(e, st); ev->push_back(e); }
   }
@@ -505,7 +508,7 @@ template <int BITS>
 inline void rs_pass(const uint2* in, uint2* out, const u32* remap, u64 n, int shift, u32* hist, u32* scan_scratch,
                     hipStream_t st, const RsProbe& pr, bool remap_cache, const RsStrided* sd = nullptr) {
   RsPlan p = rs_plan(n);
-  pr.rec(st);
+  pr.rec(st, false);
   if (sd) {
     // tile-strided input: blocks own tiles, not tuples
     const RsTilePlan tp = rs_tile_plan(sd->n_tiles);
@@ -513,35 +516,35 @@ inline void rs_pass(const uint2* in, uint2* out, const u32* remap, u64 n, int sh
       hipLaunchKernelGGL((k_rs_hist_strided<BITS, true>), dim3(tp.nblk), dim3(RS_THREADS), 0, st, in, *sd, remap, tp.tpb, tp.nblk, shift, hist);
     else
       hipLaunchKernelGGL((k_rs_hist_strided<BITS, false>), dim3(tp.nblk), dim3(RS_THREADS), 0, st, in, *sd, remap, tp.tpb, tp.nblk, shift, hist);
-    pr.rec(st);
+    pr.rec(st, false);
     u64 ne = (u64)tp.nblk << BITS;
     scan_exclusive<u32, u32>(hist, hist, ne, scan_scratch, st);
     if (pr.after_scan) pr.after_scan(pr.after_scan_arg, st);
-    pr.rec(st);
+    pr.rec(st, true);
     if (remap && remap_cache)
       hipLaunchKernelGGL((k_rs_scatter<BITS, true, true>), dim3(tp.nblk), dim3(RSS_THREADS), 0, st, in, remap, n, (u64)0, tp.nblk, shift, hist, out, *sd,
                          tp.tpb);
     else
       hipLaunchKernelGGL((k_rs_scatter<BITS, false, true>), dim3(tp.nblk), dim3(RSS_THREADS), 0, st, in, remap, n, (u64)0, tp.nblk, shift, hist, out, *sd,
                          tp.tpb);
-    pr.rec(st);
+    pr.rec(st, true);
     return;
   }
   if (remap && remap_cache)
     hipLaunchKernelGGL((k_rs_hist<BITS, true>), dim3(p.nblk), dim3(RS_THREADS), 0, st, in, remap, n, p.ipb, p.nblk, shift, hist);
   else
     hipLaunchKernelGGL((k_rs_hist<BITS, false>), dim3(p.nblk), dim3(RS_THREADS), 0, st, in, remap, n, p.ipb, p.nblk, shift, hist);
-  pr.rec(st);
+  pr.rec(st, false);
   u64 ne = (u64)p.nblk << BITS;
   scan_exclusive<u32, u32>(hist, hist, ne, scan_scratch, st);
-  pr.rec(st);
+  pr.rec(st, true);
   if (remap && remap_cache)
     hipLaunchKernelGGL((k_rs_scatter<BITS, true, false>), dim3(p.nblk), dim3(RSS_THREADS), 0, st, in, remap, n, p.ipb, p.nblk, shift, hist, out,
                        RsStrided{nullptr, 0, 0}, 0u);
   else
     hipLaunchKernelGGL((k_rs_scatter<BITS, false, false>), dim3(p.nblk), dim3(RSS_THREADS), 0, st, in, remap, n, p.ipb, p.nblk, shift, hist, out,
                        RsStrided{nullptr, 0, 0}, 0u);
-  pr.rec(st);
+  pr.rec(st, true);
 }
 
 inline void rs_pass_dyn(int bits, const uint2* in, uint2* out, const u32* remap, u64 n, int shift, u32* hist,

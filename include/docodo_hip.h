@@ -57,6 +57,12 @@ int32_t dcd_device_count(int32_t* n);
  * Index.Dispose(); the cache never holds more than DOCODO_POOL_MAX_CACHED bytes (default: half of the device memory).
  * No reference counterpart: the C# reference leaves this to the garbage collector. */
 int32_t dcd_pool_trim(int32_t device);
+/* How many HIP events the builds of this process record for dcd_build_stats (every record is a marker packet the build's
+ * stream stops at: ~30 of them cost 0.12 ms of a 4 ms build).  level 2 (default; DOCODO_BUILD_EVENTS): the stage timers
+ * ms_tokenize .. ms_total and ms_kernel[] / n_launch[] of every kernel; 1: the stage timers only; 0: neither (the fields are
+ * 0).  kernel_mask: bit DCD_K_* k set = ms_kernel[k] is measured whatever the level.  A build takes the setting that is in
+ * force when dcd_build_finish starts. */
+int32_t dcd_set_build_events(int32_t level, uint32_t kernel_mask);
 int32_t dcd_pool_cached_bytes(int32_t device, uint64_t* bytes);
 
 /* ------------------------------------------------------------------------------------------

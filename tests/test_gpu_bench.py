@@ -37,6 +37,12 @@ def test_default_run_prints_the_contract_line():
     assert out["config"]["postings"] > 0 and out["config"]["workload"].startswith("configs[1]")
 
 
+def test_lean_events_run():
+    out = _run(["--cpu-docs", "0", "--queries", "0", "--inflight", "0", "--lean-events", "1"], 29735)
+    assert "dominant kernel only" in out["events"] and out["roofline"]["avg_launch_ms"] > 0
+    assert out["device_ms_per_step"]["total"] > 0          # (from the instrumented warm-up step)
+
+
 @pytest.mark.parametrize("pipeline", [0, 1])
 def test_exchange_step_with_one_rank(pipeline):
     out = _run(["--cpu-docs", "0", "--force-exchange", "--pipeline", str(pipeline)], 29732 + pipeline)
