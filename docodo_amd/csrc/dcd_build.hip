@@ -129,7 +129,8 @@ __global__ __launch_bounds__(TK_THREADS, DCD_TK_WPE) void k_tok_emit(const CharT
     for (int q = 1; q < TK_WAVES; q++) ws += k >= pre[q] ? 1u : 0u;
     const u32 t = SW[ws].tok[k - pre[ws]];
     const u32* txt = SW[ws].txt;
-    const int64_t org = tile_origin(group * TK_WAVES + ws);
+    // (a segment holds < 2^32 characters: 32-bit positions; the origin of tile 0 wraps, the positions of its tokens do not)
+    const u32 org32 = (u32)(group * TK_WAVES) * (u32)TK_TILE - (u32)(TK_PRE * TK_CPT) + __umul24(ws, (u32)TK_TILE);
     const u32 i = t & 0xFFFFu, len = t >> 16;
     const u32 nbytes = len * CS, nw = (nbytes + 3u) >> 2;
     auto word = [txt, i, nbytes](u32 q) -> u32 { return lds_word(txt, i * CS, q) & tail_mask(nbytes, q); };
@@ -142,7 +143,7 @@ __global__ __launch_bounds__(TK_THREADS, DCD_TK_WPE) void k_tok_emit(const CharT
       if (q < nw) hs.add(wv[q]);
     }
     for (u32 q = PW; q < nw; q++) hs.add(word(q));
-    const u64 gpos = (u64)(org + (int64_t)i);
+    const u64 gpos = (u64)(org32 + i);
 #if defined(DCD_DIAG_TOK)   // timing-only builds (scripts/diag_tok.py): the outputs are wrong on purpose
     u32 slot;
     {
