@@ -602,14 +602,19 @@ __device__ __forceinline__ void tokenize_chunk(const CharT* __restrict__ text, c
       u32 r = (Sz & (Sz - 1u)) == 0u ? (g32 & (Sz - 1u)) : (g32 % Sz);
       for (u32 o = r ? Sz - r : 0u; o < 64u; o += Sz) bnd |= 1ull << o;
     }
-    u32 starts = (u32)(bnd & (L64 | D64)) & 0xFFFFu;
-    for (u32 m = starts; m;) {
-      u32 j = (u32)__builtin_ctz(m);
-      m &= m - 1;
-      u64 rest = bnd >> (j + 1);
-      u32 len = rest ? (u32)__builtin_ctzll(rest) + 1u : 99u;
-      if (len >= P.min_len && len <= P.max_len) keep |= 1u << j;
-    }
+    // A token that starts at bit j ends at the next boundary behind j; it is kept if its length lies in [min_len, max_len]:
+    // no boundary among the bits j+1 .. j+min_len-1 (SHORT = OR of bnd >> 1 .. min_len-1) and one among j+1 .. j+max_len
+    // (ENDS = OR of bnd >> 1 .. max_len) -- for all sixteen starts of the chunk at once, the ORs by doubling (wave-uniform
+    // trip counts) instead of one ctz / shift / compare round per start of the lane with the most starts.
+    // (j <= 15 and max_len <= 32: every bit looked at lies inside the 64-bit window)
+    auto or_shifts = [](u64 b, u32 R) -> u64 {     // OR of b >> 1 .. b >> R (0 for R == 0)
+      if (R == 0) return 0ull;
+      u64 x = b >> 1;
+      for (u32 c = 1; c < R;) { const u32 sft = c < R - c ? c : R - c; x |= x >> sft; c += sft; }
+      return x;
+    };
+    const u32 starts = (u32)(bnd & (L64 | D64)) & 0xFFFFu;
+    keep = starts & ~(u32)or_shifts(bnd, P.min_len - 1u) & (u32)or_shifts(bnd, P.max_len);
   }
   *keep_out = keep;
   *bnd_out = bnd;
