@@ -2,7 +2,7 @@
 exponent, word lengths, letters / digits / upper case / Latin-1 letters), separators (also none at a class change), ragged
 documents, word-length limits, both encodings, texts large enough for the sampling launch and the hot / cold sort as well as
 tiny ones.  ".index" and ".index.list" byte for byte.  Not collected by pytest (long); run on a GPU box:
-    python tests/stress_build.py [n_cases] [seed]"""
+    python tests/stress_build.py [n_cases] [seed] [size_scale]"""
 import os
 import sys
 import time
@@ -14,6 +14,7 @@ import docodo_amd
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 24
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+scale = int(sys.argv[3]) if len(sys.argv) > 3 else 1          # multiplies the text sizes (8: up to 48 MB per case)
 rng = np.random.default_rng(seed)
 LETTERS = np.frombuffer(b"abcdefghijklmnopqrstuvwxyzABCDEFGHIJKLMNOPQRSTUVWXYZ" + bytes([0xE9, 0xC9, 0xF1, 0xDF, 0xB5, 0xD7, 0xF7]), np.uint8)
 DIGITS = np.frombuffer(b"0123456789" + bytes([0xB2, 0xBC]), np.uint8)
@@ -52,7 +53,7 @@ def make_text(total, V, s, max_len):
 bad = 0
 t_start = time.time()
 for case in range(n_cases):
-    total = int(rng.choice([300, 20_000, 1_500_000, 3_000_000, 6_000_000]))
+    total = int(rng.choice([300, 20_000, 1_500_000, 3_000_000, 6_000_000])) * scale
     V = int(rng.choice([3, 40, 300, 5000, 100_000, 400_000]))
     s = float(rng.choice([0.0, 0.8, 1.1, 1.6]))
     wl = int(rng.choice([4, 9, 20, 40]))
