@@ -1380,6 +1380,7 @@ static int32_t build_phase1(dcd_build* h, bool codes_mode) {
   u32* rb_ids = (u32*)(pin + 24);       // early ids: EI_WORDS words (the results of the round)
   *rb_ntok = 0; *rb_total = 0; *rb_nsym = 0;
   for (;;) {
+    n_hot = 0;                          // (a round that ends without a hot set must not inherit the one of the round before)
     if (cap_log2 > 30) DCD_FAIL(DCD_E_OVERFLOW, "vocabulary does not fit a 2^30-slot table");
     const u64 cap = 1ull << cap_log2;
     static const bool no_pool = getenv("DOCODO_VOCAB_POOL") && atoi(getenv("DOCODO_VOCAB_POOL")) == 0;
