@@ -120,9 +120,6 @@ __global__ __launch_bounds__(TK_THREADS, DCD_TK_WPE) void k_tok_emit(const CharT
 #if defined(DCD_DIAG_TOK) && DCD_DIAG_TOK == 7    // (timing only: the front half -- classification, boundaries, token list)
   if (gtotal != 0xFFFFFFFFu) return;
 #endif
-#if defined(DCD_DIAG_TOK) && DCD_DIAG_TOK == 7    // (timing only: the front half -- classification, boundaries, token list)
-  if (gtotal != 0xFFFFFFFFu) return;
-#endif
   for (u32 k = threadIdx.x; k < gtotal; k += TK_THREADS) {
     u32 ws = 0;
 #pragma unroll
@@ -823,6 +820,9 @@ int32_t dcd_build_create(const dcd_build_opts* opts, dcd_build** out) {
     DCD_FAIL(DCD_E_UNSUPPORTED, "unsupported text encoding %d (supported: LATIN1, UTF16LE)", o.encoding);
   if (o.min_word_length < 1 || o.max_word_length > 32 || o.min_word_length > o.max_word_length)
     DCD_FAIL(DCD_E_BADARG, "word length limits must satisfy 1 <= min <= max <= 32");
+  // (`flags` used to be a reserved word: a caller that never initialised the struct with dcd_build_default_opts must not end
+  // up with a shard-only build whose image / save / from_build fail much later)
+  if (o.flags & ~DCD_BUILD_SHARD_ONLY) DCD_FAIL(DCD_E_BADARG, "dcd_build_create: unknown flags 0x%x (initialise dcd_build_opts with dcd_build_default_opts)", o.flags);
   DCD_TRY(ensure_device(o.device));
   dcd_build* h = new dcd_build();
   h->opts = o;
@@ -1844,6 +1844,10 @@ static int32_t build_phase2(dcd_build* h) {
     const bool strided = M.strided && a == M.tupA.p && (remap != nullptr || early);     // (codes mode sorts its own expanded tuples)
     const bool cache_ok = remap != nullptr && rs_cache_ok(1ull << M.cap_log2, V);
     hot_n = (idk && strided && M.n_hot && V > M.n_hot) ? M.n_hot : 0;
+    // rs_hot_key packs {digit of pass A, cold id} into 32 bits: (hot_n << hot_s) + (d - hot_n) needs
+    // log2_ceil(hot_n + 1) + hot_s of them.  A cold id range beyond 2^24 with 255 hot terms would wrap -- distinct hot terms would
+    // share a key and their lists would be merged -- so such a build sorts by the plain ids (no split).
+    if (hot_n && !rs_hot_key_fits(hot_n, std::max<u32>(1, log2_ceil((early ? id_range : V) - hot_n)))) hot_n = 0;
     if (hot_n) {
       // Hot / cold split.  Pass A scatters by the digit (key >> hot_s): every hot term gets a bucket of its own, all cold
       // tuples share the bucket hot_n.  A hot term is then complete -- contiguous, in coordinate order -- after ONE pass,

@@ -39,9 +39,13 @@ struct EncSrcPairs {
   // ... or ids of a numbering vocabulary table (id_dense != nullptr): the directory is indexed by the dense id = number of used
   // ids below x, tabulated (term heads only gather from it)
   const u32* id_dense = nullptr;
+  // inverse of rs_hot_key (dcd_sort.h)
+  static __host__ __device__ __forceinline__ u32 hot_key_id(u32 x, u32 hot_n, u32 hot_s) {
+    const u32 hi = x >> hot_s;
+    return hi < hot_n ? hi : hot_n + (x - (hot_n << hot_s));
+  }
   __device__ __forceinline__ u32 id_of(u32 x) const {
-    u32 id = x;
-    if (hot_s) { const u32 hi = x >> hot_s; id = hi < hot_n ? hi : hot_n + (x - (hot_n << hot_s)); }
+    const u32 id = hot_s ? hot_key_id(x, hot_n, hot_s) : x;
     return id_dense ? id_dense[id] : id;
   }
   __device__ __forceinline__ bool head(u64 i) const { return i == 0 || p[i].x != p[i - 1].x; }

@@ -1465,15 +1465,16 @@ static int32_t run_batch(dcd_index* h, const int32_t* prog, const u64* prog_off,
     R->seq_R = finalR;
     std::vector<u64> cnt(n_counts ? n_counts : 1);
     if (n_counts) DCD_HIP(hipMemcpy(cnt.data(), counts.p, (size_t)n_counts * 8, hipMemcpyDeviceToHost));
+    // tests: fail AFTER the result arrays were filled (the caller must not keep anything of this attempt); read once per call
+    const char* inj_env = getenv("DOCODO_QUERY_TEST_NOMEM_LATE");
+    const bool inj_late = inj_env && nq > (size_t)atoll(inj_env);
     for (size_t q = 0; q < nq; q++) {
       const Seg& s = finals[q].s;
       u64 n = s.cnt_ref == NONE32 ? s.cnt_imm : cnt[s.cnt_ref];
       const u64* src = (s.kind == 0 ? idx_values : pool.p) + s.off;
       size_t base = R->seq_units.size();
       if (n) {
-        // tests: fail AFTER the result arrays were filled (the caller must not keep anything of this attempt)
-        if (const char* inj = getenv("DOCODO_QUERY_TEST_NOMEM_LATE"))
-          if (nq > (size_t)atoll(inj)) DCD_FAIL(DCD_E_NOMEM, "injected late out-of-memory (DOCODO_QUERY_TEST_NOMEM_LATE)");
+        if (inj_late) DCD_FAIL(DCD_E_NOMEM, "injected late out-of-memory (DOCODO_QUERY_TEST_NOMEM_LATE)");
         DevBuf<u64> part;
         DevBuf<u16> du;
         u64 nb = encode_nblocks(n);

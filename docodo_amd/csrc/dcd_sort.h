@@ -157,7 +157,9 @@ struct RsStrided {
   // the digit (key >> hot_s) gives every hot term a bucket of its own and all cold terms the bucket hot_n
   u32 hot_n = 0, hot_s = 0;
 };
-__device__ __forceinline__ u32 rs_hot_key(u32 d, u32 hot_n, u32 hot_s) { return d < hot_n ? d << hot_s : (hot_n << hot_s) + (d - hot_n); }
+__host__ __device__ __forceinline__ u32 rs_hot_key(u32 d, u32 hot_n, u32 hot_s) { return d < hot_n ? d << hot_s : (hot_n << hot_s) + (d - hot_n); }
+// the key has to fit 32 bits: digits 0 .. hot_n above hot_s bits of cold id (the host gives up the split otherwise)
+inline bool rs_hot_key_fits(u32 hot_n, u32 hot_s) { return hot_s < 32 && (((u64)hot_n << hot_s) + ((1ull << hot_s) - 1)) <= 0xFFFFFFFFull; }
 constexpr int RS_STRIDE_MAX = 4096;      // largest tile population handled (the host checks its stride against it; counts travel as u16)
 constexpr int RS_TPB_MAX = 2304;         // tiles per block (LDS slice of the tile table in the scatter kernel)
 struct RsTilePlan { u32 nblk, tpb; };

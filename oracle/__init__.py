@@ -86,6 +86,11 @@ def lib():
         sig("orc_builder_n_terms", sz, vp)
         sig("orc_builder_save", None, vp, C.POINTER(vp), C.POINTER(sz), C.POINTER(vp), C.POINTER(sz))
         sig("orc_free", None, vp)
+        sig("orc_builder_set_max_items", None, vp, C.c_longlong)
+        sig("orc_builder_n_tmp", sz, vp)
+        sig("orc_builder_save_merged", None, vp, C.POINTER(vp), C.POINTER(sz))
+        sig("orc_builder_tmp", vp, vp, sz, C.POINTER(sz))
+        sig("orc_merge_files", None, vp, vp, sz, C.c_int, vp, C.POINTER(vp), C.POINTER(sz))
         sig("orc_prepare_result", vp, vp, vp, sz, vp)
         sig("orc_result_intersect_docs", None, vp, vp, vp)
         sig("orc_result_finish", None, vp, vp)
@@ -189,6 +194,37 @@ def seq_and(a, Ra, b, Rb):
 
 def seq_or(a, Ra, b, Rb):
     return _binop(lib().orc_seq_or, a, Ra, b, Rb)
+
+
+def merge_files(images, shift_coords=False, shifts=None):
+    """MergeFiles (Index.cs:577-689) over ".tmpind" / ".index" byte images, literally -- INCLUDING its quirk with three or more
+    inputs (see oracle.cpp).  shifts=None: the reference's own shifts (running sum of the inputs' MaxCoord, :589-593)."""
+    n = len(images)
+    bufs = [np.frombuffer(b, np.uint8) for b in images]
+    ptrs = (C.c_void_p * n)(*[b.ctypes.data for b in bufs])
+    sizes = (C.c_size_t * n)(*[b.size for b in bufs])
+    sh = np.ascontiguousarray(shifts, np.uint64) if shifts is not None else None
+    ob, on = C.c_void_p(), C.c_size_t()
+    lib().orc_merge_files(ptrs, sizes, n, 1 if shift_coords else 0, sh.ctypes.data if sh is not None else None, C.byref(ob), C.byref(on))
+    try:
+        return C.string_at(ob.value, on.value)
+    finally:
+        lib().orc_free(ob)
+
+
+def merge_pairwise(images, shifts=None):
+    """A correct k-way merge out of the reference's own two-input MergeFiles (which is unaffected by the >= 3-input quirk):
+    neighbours are merged pairwise, round by round, in input order.  shifts: coordinate base of every input (the
+    multi-GPU / multi-task canonical mode: text length of everything in front of it); None = the inputs
+    already share one coordinate space (MergeAll, Index.cs:537-573)."""
+    items = [(img, 0 if shifts is None else int(shifts[i])) for i, img in enumerate(images)]
+    if shifts is not None:                  # bring every input into the global space first: Shift is per input (Index.cs:671)
+        items = [(merge_files([img], True, [sh]), 0) for img, sh in items]
+    imgs = [img for img, _ in items]
+    while len(imgs) > 1:
+        nxt = [merge_files(imgs[i:i + 2], False) if i + 1 < len(imgs) else imgs[i] for i in range(0, len(imgs), 2)]
+        imgs = nxt
+    return imgs[0]
 
 
 # --------------------------------------------------------------------------------------------
@@ -597,6 +633,32 @@ class Builder:
     @property
     def n_terms(self):
         return self.L.orc_builder_n_terms(self.h)
+
+    def set_max_items(self, n):
+        """Index.MaxTmpIndexItems (Index.cs:120): a temp index is flushed whenever TotalCount exceeds n (Build.cs:335-340)."""
+        self.L.orc_builder_set_max_items(self.h, int(n))
+
+    @property
+    def n_tmp(self):
+        return self.L.orc_builder_n_tmp(self.h)
+
+    def tmp_images(self):
+        """The flushed N.tmpind files, in creation order."""
+        out = []
+        for i in range(self.n_tmp):
+            n = C.c_size_t()
+            p = self.L.orc_builder_tmp(self.h, i, C.byref(n))
+            out.append(C.string_at(p, n.value))
+        return out
+
+    def save_merged(self):
+        """".index" bytes of a task that flushed temp indexes: Save of the rest + MergeAll (Build.cs:541, Index.cs:488, 537-573)."""
+        ib, inn = C.c_void_p(), C.c_size_t()
+        self.L.orc_builder_save_merged(self.h, C.byref(ib), C.byref(inn))
+        try:
+            return C.string_at(ib.value, inn.value)
+        finally:
+            self.L.orc_free(ib)
 
     def save(self):
         """-> (bytes of .index, bytes of .index.list)  (Build.cs:370-386, 99-118)."""

@@ -398,12 +398,19 @@ struct Builder {
   int nTmpIndex = 0;
   long long MaxItems = (1ll << 62);                     // parity mode: no temp flush
 
+  std::vector<std::vector<u8>> tmpind;                  // the N.tmpind files of Path, in creation order (Build.cs:370-386)
+
   void Add(const ustr& code, u64 c) {                   // Build.cs:324-341
     maxCoord = c;
     dict[code].Add(c);
     TotalCount++;
-    if ((long long)TotalCount > MaxItems) { nTmpIndex++; /* temp flush not modelled: see header */ }
+    if ((long long)TotalCount > MaxItems) {             // :335-340: Save(false); Clear(); TotalCount = 0
+      SaveTmp();
+      dict.clear();                                     // every term's Builder restarts with Last = 0
+      TotalCount = 0;
+    }
   }
+  void SaveTmp();                                       // Builder.Save, Build.cs:370-386 (defined behind SaveIndex)
   void AddWord(const ustr& word, u64 c) {               // Build.cs:302-316 (suff is always null, :198,:237)
     std::vector<ustr> codes;
     if (GetWordCodes(*Parent, word, codes))
@@ -494,6 +501,96 @@ struct Builder {
     }
   }
 };
+
+void Builder::SaveTmp() {                               // Build.cs:370-386: Interlocked.Increment(ref nTmpIndex); "{nTmpIndex}.tmpind"
+  nTmpIndex++;
+  BinW w; SaveIndex(w);
+  tmpind.push_back(std::move(w.b));
+}
+
+// MergeFiles, Index.cs:577-689 -- literal: k-way merge of ".tmpind" images by ordinal key; equal keys are concatenated in FILE
+// order through a fresh IndexSequence.Builder (AddRange re-codes every value, so the first delta of an appended input is
+// taken against the previous input's last value); shift_coords: every input's sequence is Shift()ed by shifts[q] first.
+// shifts[q] = shifts[q-1] + maxCoords[q-1] (:589-593) unless `shifts_override` is given (the multi-task quirk of SURVEY
+// Appendix E.3: canonical parity uses text-length bases).  Output header = max of the inputs' MaxCoord (:596).
+std::vector<u8> merge_files(const std::vector<std::pair<const u8*, size_t>>& files, bool shift_coords, const u64* shifts_override) {
+  const size_t F = files.size();
+  std::vector<BinR> bins; bins.reserve(F);
+  std::vector<u64> maxCoords(F), shifts(F, 0);
+  for (size_t q = 0; q < F; q++) {
+    bins.emplace_back(files[q].first, files[q].second);
+    maxCoords[q] = bins[q].u64le();
+    if (q > 0) shifts[q] = shifts[q - 1] + maxCoords[q - 1];
+  }
+  if (shifts_override) for (size_t q = 0; q < F; q++) shifts[q] = shifts_override[q];
+  BinW wr;
+  u64 mx = 0; for (u64 m : maxCoords) mx = std::max(mx, m);
+  wr.u64le(mx);
+  std::vector<ustr> s(F, ustr(u" "));                  // next words
+  std::vector<Seq> arr(F);
+  std::vector<char> readnext(F, 1);
+  auto s_end = [&]() { size_t n = 0; for (auto& x : s) n += !x.empty(); return n; };
+  do {
+    for (size_t q = 0; q < F; q++)
+      if (readnext[q] && !s[q].empty()) {             // read next string & array if previous was read
+        ustr k = bins[q].str();
+        if (bins[q].eof) { s[q].clear(); continue; }   // EndOfStreamException -> s[q] = ""
+        int32_t n = bins[q].i32le();
+        if (bins[q].eof) { s[q].clear(); continue; }
+        s[q] = k;
+        BinR& r = bins[q];
+        if (r.i + 2ull * (size_t)n > r.n) n = (int32_t)((r.n - r.i) / 2);
+        arr[q].self.resize((size_t)n);
+        memcpy(arr[q].self.data(), r.p + r.i, 2ull * (size_t)n);
+        r.i += 2ull * (size_t)n;
+      }
+    std::vector<std::pair<const ustr*, size_t>> list;
+    for (size_t q = 0; q < F; q++) if (!s[q].empty()) list.emplace_back(&s[q], q);
+    std::stable_sort(list.begin(), list.end(), [&](const std::pair<const ustr*, size_t>& a, const std::pair<const ustr*, size_t>& b) {
+      int i = a.first->compare(*b.first);               // String.CompareOrdinal (UTF-16 code units)
+      if (i == 0) return shift_coords ? maxCoords[a.second] < maxCoords[b.second] : shifts[a.second] < shifts[b.second];
+      return i < 0;
+    });
+    std::fill(readnext.begin(), readnext.end(), 0);
+    if (!list.empty()) {
+      readnext[list[0].second] = 1;
+      for (size_t q = 1; q < list.size(); q++)
+        if (*list[q].first == *list[q - 1].first) readnext[list[q].second] = 1;
+      // QUIRK kept literal (Index.cs:655-660): list[q] is marked whenever it equals list[q-1], wherever q is -- with three or
+      // more inputs whose heads are  a < b == b  the second "b" is appended under key "a" and lost for "b".  Merges of TWO
+      // inputs are unaffected (the reference's default MaxDegreeOfParallelism = 2 and its tests never merge more); callers
+      // that want a correct k-way result merge pairwise (see oracle.merge_pairwise).
+      wr.str(s[list[0].second]);
+      SeqBuilder bldr;
+      for (size_t q = 0; q < F; q++)
+        if (readnext[q]) {
+          if (shift_coords) seq_shift(arr[q], shifts[q]);
+          SeqEnum en(arr[q]);
+          while (en.MoveNext()) bldr.Add(en.Current());  // AddRange, IndexSequence.cs:86-90
+        }
+      wr.seq(bldr.seq);
+    }
+  } while (s_end() > 0);
+  return std::move(wr.b);
+}
+
+// MergeAll, Index.cs:537-573: while more than one ".tmpind" is left, merge groups of nMax = 5 consecutive files (creation
+// order: SURVEY Appendix E.2) into the first file of the group.
+std::vector<u8> merge_all(std::vector<std::vector<u8>> files) {
+  while (files.size() > 1) {
+    std::vector<std::vector<u8>> next;
+    const size_t nMax = 5;
+    size_t q = 0;
+    for (; q + 1 < files.size(); q += nMax) {           // for (q = 0; q < files.Length - 1; q += nMax)
+      std::vector<std::pair<const u8*, size_t>> grp;
+      for (size_t k = q; k < std::min(q + nMax, files.size()); k++) grp.emplace_back(files[k].data(), files[k].size());
+      next.push_back(merge_files(grp, false, nullptr));
+    }
+    for (; q < files.size(); q++) next.push_back(std::move(files[q]));   // (a last file left alone stays as it is)
+    files = std::move(next);
+  }
+  return files.empty() ? std::vector<u8>() : std::move(files[0]);
+}
 
 // IndexPageList.Load (Build.cs:119-148) and Index.Load InMemory branch (Index.cs:312-343)
 bool index_load(Index& ix, const u8* ib, size_t in, const u8* lb, size_t ln) {
@@ -814,6 +911,27 @@ void orc_builder_save(void* bp, u8** ib, size_t* in, u8** lb, size_t* ln) {
   *ln = wl.b.size(); *lb = (u8*)malloc(wl.b.size() + 1); memcpy(*lb, wl.b.data(), wl.b.size());
 }
 void orc_free(void* p) { free(p); }
+// Index.MaxTmpIndexItems (Index.cs:120): the builder flushes a temp index whenever TotalCount exceeds it (Build.cs:335-340)
+void orc_builder_set_max_items(void* b, long long n) { ((Builder*)b)->MaxItems = n; }
+size_t orc_builder_n_tmp(void* b) { return ((Builder*)b)->tmpind.size(); }
+// bytes of temp index #i (library-owned; valid until the builder is freed)
+const u8* orc_builder_tmp(void* b, size_t i, size_t* n) { auto& v = ((Builder*)b)->tmpind[i]; *n = v.size(); return v.data(); }
+// What CreateAsync leaves for ONE index task that flushed temp indexes (Build.cs:541 Save -> Index.cs:488 MergeAll): the
+// remaining postings are saved as the last N.tmpind, then MergeAll.  Returns the merged ".index" bytes (malloc'd).
+void orc_builder_save_merged(void* bp, u8** ib, size_t* in) {
+  Builder* b = (Builder*)bp;
+  std::vector<std::vector<u8>> files = b->tmpind;
+  { BinW w; b->SaveIndex(w); files.push_back(std::move(w.b)); }
+  std::vector<u8> out = merge_all(std::move(files));
+  *in = out.size(); *ib = (u8*)malloc(out.size() + 1); memcpy(*ib, out.data(), out.size());
+}
+// MergeFiles over n images (Index.cs:577-689); shifts == NULL: the reference's own shifts (running sum of MaxCoord)
+void orc_merge_files(const u8* const* imgs, const size_t* sizes, size_t n, int shift_coords, const u64* shifts, u8** ob, size_t* on) {
+  std::vector<std::pair<const u8*, size_t>> files;
+  for (size_t q = 0; q < n; q++) files.emplace_back(imgs[q], sizes[q]);
+  std::vector<u8> out = merge_files(files, shift_coords != 0, shifts);
+  *on = out.size(); *ob = (u8*)malloc(out.size() + 1); memcpy(*ob, out.data(), out.size());
+}
 
 // ---- Results ---------------------------------------------------------------------------------
 // PrepareSearchResult + doc ranks for one result sequence.  Returns an opaque Result*.

@@ -103,6 +103,36 @@ def test_header_is_plain_c_and_the_demo_links(tmp_path):
         assert r.returncode == 1 and "failed: status" in r.stderr     # DCD_E_HIP from the first compute call, no fallback
 
 
+def test_hot_key_packing_host_unit(tmp_path):
+    """tests/cpp/test_hot_key.cpp: the hot / cold sort key (dcd_sort.h rs_hot_key, dcd_codec.h hot_key_id) round-trips and keeps
+    its order at every width the build may choose, and rs_hot_key_fits refuses the widths where 32 bits would wrap (255 hot
+    terms over a cold id range of 2^25 .. 2^29: the build then sorts by plain ids).  Host code compiled by hipcc; runs on the CPU."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    exe = str(tmp_path / "test_hot_key")
+    subprocess.run([hipcc, "-O1", "-std=c++17", "--offload-arch=gfx950", "-Wno-unused-function", "-Wno-pass-failed",
+                    "-I", os.path.join(ROOT, "docodo_amd", "csrc"), "-I", os.path.join(ROOT, "include"), "-x", "hip",
+                    os.path.join(ROOT, "tests", "cpp", "test_hot_key.cpp"), "-o", exe], check=True)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "hot key ok" in r.stdout, r.stdout[-2000:]
+
+
+def test_build_flags_are_validated():
+    """dcd_build_opts.flags was `reserved`: a caller that never zeroed it must not silently get a shard-only build."""
+    import docodo_amd
+    from docodo_amd import _lib
+    o = _lib.BuildOpts()
+    docodo_amd.lib().dcd_build_default_opts(C.byref(o))
+    assert o.flags == 0
+    o.flags = 0x40
+    h = C.c_void_p()
+    assert docodo_amd.lib().dcd_build_create(C.byref(o), C.byref(h)) == _lib.DCD_E_BADARG
+    assert not h.value
+
+
 @pytest.mark.gpu
 def test_abi_demo_runs_from_plain_c(tmp_path):
     import subprocess
