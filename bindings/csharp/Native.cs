@@ -65,6 +65,9 @@ namespace Docodo
         // doc-range shards (Index.cs:537-752): export -> exchange (RCCL, outside the library) -> merge; gather -> one .index
         [DllImport(Lib)] public static extern int dcd_build_export_plan(IntPtr h, uint nOwners, ulong* termCount, ulong* keyCount, ulong* unitCount);
         [DllImport(Lib)] public static extern int dcd_build_export_fill(IntPtr h, void* metaDev, ushort* keysDev, ushort* unitsDev);
+        [DllImport(Lib)] public static extern int dcd_build_export_heavy(IntPtr h, ulong minUnits, ulong* fp, ulong* nUnits, UIntPtr cap, out UIntPtr nOut);
+        [DllImport(Lib)] public static extern int dcd_build_export_plan_balanced(IntPtr h, uint nOwners, ulong* overFp, uint* overOwner, UIntPtr nOver,
+                                                                                 ulong* termCount, ulong* keyCount, ulong* unitCount);
         [DllImport(Lib)] public static extern int dcd_index_export_plan(IntPtr h, uint nOwners, ulong* termCount, ulong* keyCount, ulong* unitCount);
         [DllImport(Lib)] public static extern int dcd_index_export_fill(IntPtr h, void* metaDev, ushort* keysDev, ushort* unitsDev);
         [DllImport(Lib)] public static extern int dcd_merge_shards(int device, uint nSources, ulong* termCount, ulong* keyCount, ulong* unitCount,

@@ -112,6 +112,8 @@ SIGNATURES = {
     "dcd_results_free": (None, [_vp]),
     "dcd_build_export_plan": (_i32, [_vp, _u32, _vp, _vp, _vp]),
     "dcd_build_export_fill": (_i32, [_vp, _vp, _vp, _vp]),
+    "dcd_build_export_heavy": (_i32, [_vp, C.c_uint64, _vp, _vp, C.c_size_t, _vp]),
+    "dcd_build_export_plan_balanced": (_i32, [_vp, _u32, _vp, _vp, C.c_size_t, _vp, _vp, _vp]),
     "dcd_merge_shards": (_i32, [_i32, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _u64, C.POINTER(_vp)]),
     "dcd_merge_begin": (_i32, [_i32, _u32, _vp, _vp, _vp, _vp, _vp, _u64, C.POINTER(_vp)]),
     "dcd_merge_finish": (_i32, [_vp, _vp, C.POINTER(_vp)]),

@@ -38,13 +38,43 @@ __device__ __forceinline__ u32 key_hash16(const u16* s, u32 n) {
   return fmix32(h ^ n);
 }
 
+// 64-bit fingerprint of a key (FNV-1a over the UTF-16 units + a finaliser): names a HEAVY term in the owner overrides of a
+// balanced export.  Two keys with one fingerprint simply share an owner -- any function of the key is a valid assignment.
+__device__ __forceinline__ u64 key_fp64(const u16* s, u32 n) {
+  u64 h = 0xCBF29CE484222325ull;
+  for (u32 i = 0; i < n; i++) h = (h ^ s[i]) * 0x100000001B3ull;
+  h ^= n;
+  h ^= h >> 33; h *= 0xFF51AFD7ED558CCDull; h ^= h >> 33; h *= 0xC4CEB9FE1A85EC53ull; h ^= h >> 33;
+  return h;
+}
+
 // ---- export ------------------------------------------------------------------------------------
+// owner(term) = hash(key) % n_owners, unless the key's fingerprint is in the (sorted, small) override table
 __global__ void k_owner_pairs(const u16* __restrict__ chars, const u32* __restrict__ str_off, u64 n_terms, u32 n_owners,
-                              uint2* __restrict__ pairs) {
+                              const u64* __restrict__ over_fp, const u32* __restrict__ over_owner, u32 n_over, uint2* __restrict__ pairs) {
   u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n_terms) return;
-  u32 o = key_hash16(chars + str_off[t], str_off[t + 1] - str_off[t]) % n_owners;
+  const u16* k = chars + str_off[t];
+  const u32 len = str_off[t + 1] - str_off[t];
+  u32 o = key_hash16(k, len) % n_owners;
+  if (n_over) {
+    const u64 fp = key_fp64(k, len);
+    u32 a = 0, b = n_over;                     // first entry >= fp
+    while (a < b) { u32 m = (a + b) >> 1; if (over_fp[m] < fp) a = m + 1; else b = m; }
+    if (a < n_over && over_fp[a] == fp) o = over_owner[a];
+  }
   pairs[t] = make_uint2(o, (u32)t);
+}
+
+// the terms with at least min_units posting units: fingerprint + units each (order of arrival; the host sorts)
+__global__ void k_heavy_terms(const u16* __restrict__ chars, const u32* __restrict__ str_off, const u64* __restrict__ unit_start, u64 n_terms,
+                              u64 min_units, u32 cap, u32* __restrict__ count, u64* __restrict__ out) {
+  u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_terms) return;
+  const u64 u = unit_start[t + 1] - unit_start[t];
+  if (u < min_units) return;
+  const u32 slot = atomicAdd(count, 1u);
+  if (slot < cap) { out[2 * slot] = key_fp64(chars + str_off[t], str_off[t + 1] - str_off[t]); out[2 * slot + 1] = u; }
 }
 
 struct PermUnitsF {   // units of the term at export position j
@@ -272,8 +302,16 @@ static std::mutex g_export_mu;
 
 // export of a device-resident index (a finished build, or an index handle: the owned partition after a merge)
 static int32_t export_plan_impl(const void* h, DeviceIndex* ix, hipStream_t st, uint32_t n_owners, uint64_t* term_count, uint64_t* key_count,
-                                uint64_t* unit_count) {
+                                uint64_t* unit_count, const uint64_t* over_fp = nullptr, const uint32_t* over_owner = nullptr, size_t n_over = 0) {
   if (n_owners == 0 || n_owners > 64) DCD_FAIL(DCD_E_BADARG, "n_owners must be in [1, 64]");
+  if (n_over > 4096 || (n_over && (!over_fp || !over_owner))) DCD_FAIL(DCD_E_BADARG, "owner overrides: at most 4096 entries, both arrays given");
+  // the override table, sorted by fingerprint (the kernel searches it); an owner out of range is the caller's bug
+  std::vector<std::pair<u64, u32>> over(n_over);
+  for (size_t i = 0; i < n_over; i++) {
+    if (over_owner[i] >= n_owners) DCD_FAIL(DCD_E_BADARG, "owner override %zu names owner %u of %u", i, over_owner[i], n_owners);
+    over[i] = {over_fp[i], over_owner[i]};
+  }
+  std::sort(over.begin(), over.end());
   if (ix->n_terms && (!ix->term_first.p || !ix->term_last.p)) DCD_FAIL(DCD_E_STATE, "this index carries no first/last coordinates per term (loaded from files)");
   const int dev = ix->device;
   DCD_TRY(ensure_device(dev));
@@ -294,8 +332,19 @@ static int32_t export_plan_impl(const void* h, DeviceIndex* ix, hipStream_t st, 
   DCD_TRY(ep->key_dst.alloc(dev, V + 1)); DCD_TRY(ep->unit_dst.alloc(dev, V + 1));
   DCD_HIP(hipMemsetAsync(totals.p, 0, 64 * 3 * 8, st));
   std::vector<unsigned long long> tot(64 * 3, 0);
+  DevBuf<u64> d_ofp;
+  DevBuf<u32> d_oown;
+  if (V && n_over) {
+    std::vector<u64> f(n_over); std::vector<u32> o(n_over);
+    for (size_t i = 0; i < n_over; i++) { f[i] = over[i].first; o[i] = over[i].second; }
+    DCD_TRY(d_ofp.alloc(dev, n_over)); DCD_TRY(d_oown.alloc(dev, n_over));
+    DCD_HIP(hipMemcpyAsync(d_ofp.p, f.data(), n_over * 8, hipMemcpyHostToDevice, st));
+    DCD_HIP(hipMemcpyAsync(d_oown.p, o.data(), n_over * 4, hipMemcpyHostToDevice, st));
+    DCD_HIP(hipStreamSynchronize(st));                  // (the staging vectors die with this scope)
+  }
   if (V) {
-    hipLaunchKernelGGL(k_owner_pairs, dim3((u32)div_up(V, 256)), dim3(256), 0, st, ix->term_chars.p, ix->term_str_off.p, V, n_owners, pa.p);
+    hipLaunchKernelGGL(k_owner_pairs, dim3((u32)div_up(V, 256)), dim3(256), 0, st, ix->term_chars.p, ix->term_str_off.p, V, n_owners,
+                       (const u64*)d_ofp.p, (const u32*)d_oown.p, (u32)n_over, pa.p);
     uint2* sorted = rs_sort(pa.p, pb.p, nullptr, V, 6, hist.p, sscr.p, st);
     if (sorted == pa.p) ep->perm = std::move(pa); else ep->perm = std::move(pb);
     hipLaunchKernelGGL(k_owner_totals, dim3((u32)div_up(V, 256)), dim3(256), 0, st, ep->perm.p, V, ix->term_unit_start.p, ix->term_str_off.p,
@@ -351,6 +400,44 @@ int32_t dcd_build_export_plan(dcd_build* h, uint32_t n_owners, uint64_t* term_co
   DeviceIndex* ix = build_peek_index(h);
   if (!ix) DCD_FAIL(DCD_E_STATE, "build is not finished (or its index was adopted)");
   return export_plan_impl(h, ix, build_stream(h), n_owners, term_count, key_count, unit_count);
+}
+int32_t dcd_build_export_plan_balanced(dcd_build* h, uint32_t n_owners, const uint64_t* over_fp, const uint32_t* over_owner, size_t n_over,
+                                       uint64_t* term_count, uint64_t* key_count, uint64_t* unit_count) {
+  if (!h || !term_count || !key_count || !unit_count) DCD_FAIL(DCD_E_BADARG, "dcd_build_export_plan_balanced: NULL argument");
+  DeviceIndex* ix = build_peek_index(h);
+  if (!ix) DCD_FAIL(DCD_E_STATE, "build is not finished (or its index was adopted)");
+  return export_plan_impl(h, ix, build_stream(h), n_owners, term_count, key_count, unit_count, over_fp, over_owner, n_over);
+}
+int32_t dcd_build_export_heavy(dcd_build* h, uint64_t min_units, uint64_t* fp, uint64_t* n_units, size_t cap, size_t* n_out) {
+  if (!h || !n_out || (cap && (!fp || !n_units))) DCD_FAIL(DCD_E_BADARG, "dcd_build_export_heavy: NULL argument");
+  DeviceIndex* ix = build_peek_index(h);
+  if (!ix) DCD_FAIL(DCD_E_STATE, "build is not finished (or its index was adopted)");
+  if (cap > 65536) cap = 65536;
+  const int dev = ix->device;
+  DCD_TRY(ensure_device(dev));
+  hipStream_t st = build_stream(h);
+  StreamScope ss_(st);
+  const u64 V = ix->n_terms;
+  *n_out = 0;
+  if (!V) return DCD_OK;
+  DevBuf<u32> cnt;
+  DevBuf<u64> out;
+  DCD_TRY(cnt.alloc(dev, 1)); DCD_TRY(out.alloc(dev, 2 * (cap ? cap : 1)));
+  DCD_HIP(hipMemsetAsync(cnt.p, 0, 4, st));
+  hipLaunchKernelGGL(k_heavy_terms, dim3((u32)div_up(V, 256)), dim3(256), 0, st, ix->term_chars.p, ix->term_str_off.p, ix->term_unit_start.p, V,
+                     min_units, (u32)cap, cnt.p, out.p);
+  u32 n = 0;
+  DCD_HIP(hipMemcpyAsync(&n, cnt.p, 4, hipMemcpyDeviceToHost, st));
+  DCD_HIP(hipStreamSynchronize(st));
+  std::vector<u64> host(2 * (size_t)std::min<u64>(n, cap));
+  if (!host.empty()) DCD_HIP(hipMemcpy(host.data(), out.p, host.size() * 8, hipMemcpyDeviceToHost));
+  std::vector<std::pair<u64, u64>> v(host.size() / 2);
+  for (size_t i = 0; i < v.size(); i++) v[i] = {host[2 * i], host[2 * i + 1]};
+  std::sort(v.begin(), v.end());                         // (deterministic order: by fingerprint)
+  for (size_t i = 0; i < v.size(); i++) { fp[i] = v[i].first; n_units[i] = v[i].second; }
+  *n_out = n;
+  if (n > cap) DCD_FAIL(DCD_E_OVERFLOW, "dcd_build_export_heavy: %u terms reach %llu units, cap is %zu", n, (unsigned long long)min_units, cap);
+  return DCD_OK;
 }
 int32_t dcd_build_export_fill(dcd_build* h, void* meta_dev, uint16_t* keys_dev, uint16_t* units_dev) {
   if (!h) DCD_FAIL(DCD_E_BADARG, "dcd_build_export_fill: NULL handle");

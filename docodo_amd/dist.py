@@ -32,12 +32,71 @@ class ShardExport:
         return (self.term_count * META_BYTES).tolist(), (self.key_count * 2).tolist(), (self.unit_count * 2).tolist()
 
 
-def export_shard(builder, n_owners, device=None):
-    """dcd_build_export_plan + dcd_build_export_fill into torch-owned device buffers."""
+def heavy_terms(builder, min_units, cap):
+    """dcd_build_export_heavy: (fingerprints, units) of the shard's terms with at least min_units posting units."""
+    fp, un = np.zeros(max(1, cap), np.uint64), np.zeros(max(1, cap), np.uint64)
+    n = C.c_size_t(0)
+    check(lib().dcd_build_export_heavy(builder.h, int(min_units), fp.ctypes.data, un.ctypes.data, cap, C.byref(n)))
+    return fp[:n.value].copy(), un[:n.value].copy()
+
+
+def assign_heavy(lists, totals, n_owners):
+    """Owner table of the heavy terms.  lists = per rank (fingerprints, units), totals = per rank posting units.  Terms are
+    taken largest first (ties: smaller fingerprint) and given to the least loaded owner (ties: lower rank), every owner
+    starting from its share of the light terms, which hash(key) % n_owners spreads evenly.  Pure function of its arguments:
+    every rank computes the same table from the all-gathered lists.  -> (fingerprints, owners), sorted by fingerprint."""
+    units = {}
+    for fp, un in lists:
+        for f, u in zip(fp.tolist(), un.tolist()):
+            units[f] = units.get(f, 0) + u
+    light = max(0, int(sum(int(t) for t in totals)) - sum(units.values()))
+    load = [light / n_owners] * n_owners
+    owner = {}
+    for f, u in sorted(units.items(), key=lambda x: (-x[1], x[0])):
+        o = min(range(n_owners), key=lambda i: (load[i], i))
+        owner[f] = o
+        load[o] += u
+    fps = sorted(owner)
+    return np.array(fps, np.uint64), np.array([owner[f] for f in fps], np.uint32)
+
+
+def balance_owners(builder, group=None):
+    """One small all-gather: every rank's heavy terms (at least 1 / (8 N) of its shard's posting units: at most 8 N of them)
+    -> the same owner table on every rank (assign_heavy).  With Zipf-1.1 the first term alone is 13 % of all units; under
+    hash(key) % 8 its owner receives 1.9 x the mean, and the all-to-all and the merge wait for that rank."""
+    import torch.distributed as dist
+    G = dist.get_world_size(group)
+    if G == 1:
+        return None
+    U = int(builder.stats.n_units)
+    cap = 8 * G
+    fp, un = heavy_terms(builder, max(1, -(-U // cap)), cap)       # (>= ceil(U / 8N) units each: no more than 8N terms)
+    mine = np.zeros(2 + 2 * cap, np.int64)
+    mine[0], mine[1] = fp.size, U
+    mine[2:2 + fp.size] = fp.view(np.int64)
+    mine[2 + cap:2 + cap + un.size] = un.view(np.int64)
+    backend = dist.get_backend(group)
+    dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
+    t = torch.from_numpy(mine).to(dev)
+    parts = [torch.empty_like(t) for _ in range(G)]
+    dist.all_gather(parts, t, group=group)
+    allm = torch.stack(parts).cpu().numpy()
+    lists = [(allm[r, 2:2 + allm[r, 0]].view(np.uint64), allm[r, 2 + cap:2 + cap + allm[r, 0]].view(np.uint64)) for r in range(G)]
+    return assign_heavy(lists, allm[:, 1], G)
+
+
+def export_shard(builder, n_owners, device=None, overrides=None):
+    """dcd_build_export_plan (overrides = (fingerprints, owners) of the heavy terms: dcd_build_export_plan_balanced) +
+    dcd_build_export_fill into torch-owned device buffers."""
     tc = np.zeros(n_owners, np.uint64)
     kc = np.zeros(n_owners, np.uint64)
     uc = np.zeros(n_owners, np.uint64)
-    check(lib().dcd_build_export_plan(builder.h, n_owners, tc.ctypes.data, kc.ctypes.data, uc.ctypes.data))
+    if overrides is not None and len(overrides[0]):
+        ofp, oow = np.ascontiguousarray(overrides[0], np.uint64), np.ascontiguousarray(overrides[1], np.uint32)
+        check(lib().dcd_build_export_plan_balanced(builder.h, n_owners, ofp.ctypes.data, oow.ctypes.data, ofp.size, tc.ctypes.data,
+                                                   kc.ctypes.data, uc.ctypes.data))
+    else:
+        check(lib().dcd_build_export_plan(builder.h, n_owners, tc.ctypes.data, kc.ctypes.data, uc.ctypes.data))
     dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
     meta = torch.empty(int(tc.sum()) * META_BYTES, dtype=torch.uint8, device=dev)
     keys = torch.empty(int(kc.sum()) * 2, dtype=torch.uint8, device=dev)
@@ -190,13 +249,14 @@ def _host_wait(work, dev):
         torch.cuda.current_stream(dev).synchronize()
 
 
-def distributed_merge(builder, group=None, device_index=None):
-    """export -> all-to-all (RCCL) -> merge.  Returns this rank's owned sub-index."""
+def distributed_merge(builder, group=None, device_index=None, balanced=True):
+    """export -> all-to-all (RCCL) -> merge.  Returns this rank's owned sub-index.  balanced: the heavy terms are assigned to
+    owners by posting units (balance_owners: one small all-gather in front of the export), the others by hash."""
     import torch.distributed as dist
     G = dist.get_world_size(group)
     if device_index is None:
         device_index = torch.cuda.current_device()
-    e = export_shard(builder, G)
+    e = export_shard(builder, G, overrides=balance_owners(builder, group) if balanced else None)
     # vocabulary / ranks / layout of the merge run while the posting units are still being exchanged
     tc, kc, uc, meta, keys, units, mx, wait_units = exchange(e, group, overlap=True)
     pending = PendingMerge(tc, kc, uc, meta, keys, mx, device_index)
@@ -229,6 +289,50 @@ def gather_index(owned, dst=0, group=None, device_index=None):
     if me != dst:
         return None
     return merge_received(rtc, rkc, ruc, meta, keys, units, mx, device_index)
+
+
+def allgather_export(e, group=None):
+    """All-gather of a ONE-owner export (export_index(ix, 1)): every rank receives every rank's three buffers, back to back in
+    rank order.  Returns (term_count, key_count, unit_count per SOURCE, meta, keys, units, global max_coord) -- the arguments of
+    merge_received.  CUDA tensors over nccl (= RCCL ring over xGMI), CPU tensors over gloo; CUDA tensors over gloo
+    (rehearsals: N ranks on one GPU) are staged through the host."""
+    import torch.distributed as dist
+    G, me = dist.get_world_size(group), dist.get_rank(group)
+    dev = e.meta.device
+    staged = dev.type == "cuda" and dist.get_backend(group) == "gloo"
+    cdev = torch.device("cpu") if staged else dev
+    mine = torch.tensor([int(e.term_count[0]), int(e.key_count[0]), int(e.unit_count[0]), int(e.max_coord)], dtype=torch.int64, device=cdev)
+    allc = [torch.empty_like(mine) for _ in range(G)]
+    dist.all_gather(allc, mine, group=group)
+    allc = torch.stack(allc).cpu().numpy()                                 # [G, 4]
+    tc, kc, uc = (allc[:, i].astype(np.uint64) for i in range(3))
+    mx = int(allc[:, 3].max())
+    out = []
+    for buf, counts, width in ((e.meta, tc, META_BYTES), (e.keys, kc, 2), (e.units, uc, 2)):
+        sizes = [int(c) * width for c in counts]
+        pad = max(max(sizes), 1)
+        # all-gather wants equal parts: pad to the largest partition (partitions are balanced by postings, see balance_owners),
+        # then close the gaps with one copy
+        src = torch.zeros(pad, dtype=torch.uint8, device=cdev)
+        src[:sizes[me]] = buf.to(cdev) if staged else buf
+        parts = [torch.empty(pad, dtype=torch.uint8, device=cdev) for _ in range(G)]
+        dist.all_gather(parts, src, group=group)
+        got = torch.cat([parts[s][:sizes[s]] for s in range(G)])
+        out.append(got.to(dev) if staged else got)
+    return tc, kc, uc, out[0], out[1], out[2], mx
+
+
+def allgather_index(owned, group=None, device_index=None):
+    """Every rank ends with a REPLICA of the complete index (what CreateAsync ends with: one searchable index, Index.cs:488,
+    512 -- here on every GPU, so that query batches shard by query with no routing).  Every rank exports its owned
+    hash partition once (one owner), the three buffers travel with ONE all-gather each (every rank receives (N - 1) / N of the
+    index), and every rank merges what it received -- every term has exactly one segment, so the merge is the ordinal sort of
+    the union vocabulary plus one copy of the units.  The ".index" of a replica is what a single builder writes for the whole
+    corpus.  (Attach the page table with Index.set_list_image or dist.set_uniform_pages.)"""
+    if device_index is None:
+        device_index = torch.cuda.current_device()
+    tc, kc, uc, meta, keys, units, mx = allgather_export(export_index(owned, 1), group)
+    return merge_received(tc, kc, uc, meta, keys, units, mx, device_index)
 
 
 def set_uniform_pages(index, n_pages, page_chars, first_doc=0, source="syn"):

@@ -38,9 +38,29 @@ def main():
     exp = [fake_export(s, world) for s in range(world)]
     for overlap in (False, True):
         check_exchange(rank, world, mine, exp, overlap)
+    check_allgather(rank, world)
     dist.barrier()
     dist.destroy_process_group()
     print("rank %d ok" % rank)
+
+
+def check_allgather(rank, world):
+    """docodo_amd.dist.allgather_export: ragged one-owner exports (one of them empty) -> every rank holds all of them, in rank order."""
+    from docodo_amd.dist import META_BYTES, ShardExport, allgather_export
+
+    def one(r):
+        n = 0 if r == 1 else 3 + 5 * r                               # rank 1 owns nothing
+        f = lambda scale, kind: torch.from_numpy(((np.arange(n * scale) * 11 + r * 17 + kind * 3) % 251).astype(np.uint8))
+        u = np.uint64
+        return ShardExport(np.array([n], u), np.array([n * 4], u), np.array([n * 9], u), f(META_BYTES, 0), f(4 * 2, 1), f(9 * 2, 2), 500 + 7 * r)
+
+    tc, kc, uc, meta, keys, units, mx = allgather_export(one(rank))
+    exp = [one(r) for r in range(world)]
+    assert mx == 500 + 7 * (world - 1)
+    assert tc.tolist() == [int(e.term_count[0]) for e in exp] and kc.tolist() == [int(e.key_count[0]) for e in exp]
+    assert uc.tolist() == [int(e.unit_count[0]) for e in exp]
+    for got, name in ((meta, "meta"), (keys, "keys"), (units, "units")):
+        assert torch.equal(got, torch.cat([getattr(e, name) for e in exp])), (rank, name)
 
 
 def check_exchange(rank, world, mine, exp, overlap):

@@ -41,8 +41,24 @@ def main():
             ddist.set_uniform_pages(got, total, synth.DOC_BYTES)
             assert got.list_image() == one.list_image()
             assert got.Count == one.stats.n_terms
+            import hashlib
+            want_digest = hashlib.sha256(one.index_image()).digest() + hashlib.sha256(one.list_image()).digest()
             one.close()
             got.close()
+        # ... and the replica route: EVERY rank ends with the complete index (query batches shard by query)
+        rep = ddist.allgather_index(owned, device_index=0)
+        ddist.set_uniform_pages(rep, total, synth.DOC_BYTES)
+        import hashlib
+        digest = hashlib.sha256(rep.index_image()).digest() + hashlib.sha256(rep.list_image()).digest()
+        all_d = [None] * world
+        dist.all_gather_object(all_d, digest)
+        assert all(x == all_d[0] for x in all_d), "replicas differ between ranks"
+        if rank == 0:
+            assert digest == want_digest, "replica .index / .index.list differ from the one-shot build (round %d)" % rnd
+        w = synth.term(3 + rank)
+        res = rep.query_batch([docodo_amd.DCD_OP_TERM, rep.find(w), 255 + len(w)], [0, 3])
+        assert res.status[0] == 0 and len(res.pages(0)) > 0
+        rep.close()
         owned.close()
         b.close()
         dist.barrier()

@@ -237,7 +237,8 @@ def test_queries_beyond_2_32(high_index, oracle_mod):
     assert oix2.load(ix.index_image(), short)
     w = synth.term(1)
     r2 = ix2.query_batch(_prog(ix2, [w], [near(w)], []), [0, 3])
-    assert r2.status[0] == docodo_amd.DCD_E_NOTFOUND and not oix2.search(w).Success
+    from docodo_amd import _lib
+    assert r2.status[0] == _lib.DCD_E_NOTFOUND and not oix2.search(w).Success
 
 
 N10M = 10_000_000

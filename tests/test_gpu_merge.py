@@ -202,3 +202,41 @@ def test_three_ranks_on_one_gpu_give_the_one_shot_index():
                         "--master-port", "29683", os.path.join(root, "tests", "helpers", "gpu_dist_worker.py")], env=env,
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and all("rank %d ok" % k in r.stdout for k in range(3)), r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_balanced_owner_table_and_export(oracle_mod):
+    """Owners balanced by posting units (dcd_build_export_heavy + dist.assign_heavy + dcd_build_export_plan_balanced): the heavy
+    terms of a Zipf vocabulary move to the least loaded owners, every other term stays with hash(key) % n_owners, the merged +
+    gathered ".index" is still the one-shot one, and the largest owner share drops."""
+    import docodo_amd
+    from docodo_amd import dist, synth
+    n_docs, G = 12000, 8
+    text = synth.corpus_host(n_docs)
+    full = _build(text, n_docs)
+    bounds = [n_docs * g // G for g in range(G + 1)]
+    shards = [_build(text[bounds[g] * 1024:bounds[g + 1] * 1024], bounds[g + 1] - bounds[g], first_doc=bounds[g]) for g in range(G)]
+    lists, totals = [], []
+    for b in shards:
+        U = int(b.stats.n_units)
+        fp, un = dist.heavy_terms(b, -(-U // (8 * G)), 8 * G)
+        assert 1 <= fp.size <= 8 * G and np.all(un >= U // (8 * G)) and np.all(fp[1:] > fp[:-1])
+        lists.append((fp, un))
+        totals.append(U)
+    with pytest.raises(docodo_amd.DocodoError):                   # more heavy terms than the caller made room for
+        dist.heavy_terms(shards[0], 1, 4)
+    ofp, oow = dist.assign_heavy(lists, totals, G)
+    ofp2, oow2 = dist.assign_heavy(lists[::-1], totals[::-1], G)  # (a pure function of the gathered data, whatever its order)
+    assert np.array_equal(ofp, ofp2) and np.array_equal(oow, oow2)
+    plain = [dist.export_shard(b, G) for b in shards]
+    bal = [dist.export_shard(b, G, overrides=(ofp, oow)) for b in shards]
+    share = lambda ex: np.sum([e.unit_count for e in ex], axis=0).astype(np.float64)
+    sp, sb = share(plain), share(bal)
+    assert sp.sum() == sb.sum()
+    assert sb.max() / sb.mean() < 1.15 < sp.max() / sp.mean()     # hash: the owner of term 1 holds ~1.9 x the mean
+    owned = [dist.local_merge(bal, o) for o in range(G)]
+    whole = dist.local_gather(owned)
+    assert whole.index_image() == full.index_image()
+    # a term is owned by exactly one owner, the one the table (or the hash) names on EVERY shard
+    top = synth.term(1)
+    holders = [o for o, ix in enumerate(owned) if ix.find(top) is not None]
+    assert len(holders) == 1
