@@ -70,6 +70,9 @@ namespace Docodo
                                                                                  ulong* termCount, ulong* keyCount, ulong* unitCount);
         [DllImport(Lib)] public static extern int dcd_index_export_plan(IntPtr h, uint nOwners, ulong* termCount, ulong* keyCount, ulong* unitCount);
         [DllImport(Lib)] public static extern int dcd_index_export_fill(IntPtr h, void* metaDev, ushort* keysDev, ushort* unitsDev);
+        [DllImport(Lib)] public static extern int dcd_index_export_heavy(IntPtr h, ulong minUnits, ulong* fp, ulong* nUnits, UIntPtr cap, out UIntPtr nOut);
+        [DllImport(Lib)] public static extern int dcd_index_export_plan_balanced(IntPtr h, uint nOwners, ulong* overFp, uint* overOwner, UIntPtr nOver,
+                                                                                 ulong* termCount, ulong* keyCount, ulong* unitCount);
         [DllImport(Lib)] public static extern int dcd_merge_shards(int device, uint nSources, ulong* termCount, ulong* keyCount, ulong* unitCount,
                                                                    void* metaDev, ushort* keysDev, ushort* unitsDev, ulong maxCoord, out IntPtr index);
         // the same merge in two halves: begin needs only meta + keys and can run while the units are still in flight
@@ -81,6 +84,7 @@ namespace Docodo
         [DllImport(Lib)] public static extern int dcd_index_from_images(byte* indexImg, UIntPtr nIndex, byte* listImg, UIntPtr nList, int device, out IntPtr h);
         [DllImport(Lib)] public static extern int dcd_index_count(IntPtr h, out ulong nTerms);       // Index.Count
         [DllImport(Lib)] public static extern int dcd_index_max_coord(IntPtr h, out ulong v);        // Index.MaxCoord
+        [DllImport(Lib)] public static extern int dcd_index_n_units(IntPtr h, out ulong n);
         [DllImport(Lib)] public static extern int dcd_index_n_pages(IntPtr h, out ulong n);
         [DllImport(Lib)] public static extern int dcd_index_n_docs(IntPtr h, out ulong n);
         [DllImport(Lib)] public static extern int dcd_index_key(IntPtr h, uint term, char* outp, UIntPtr cap, out UIntPtr len);

@@ -98,6 +98,7 @@ SIGNATURES = {
     "dcd_index_free": (None, [_vp]),
     "dcd_index_count": (_i32, [_vp, _pu64]),
     "dcd_index_max_coord": (_i32, [_vp, _pu64]),
+    "dcd_index_n_units": (_i32, [_vp, _pu64]),
     "dcd_index_n_pages": (_i32, [_vp, _pu64]),
     "dcd_index_n_docs": (_i32, [_vp, _pu64]),
     "dcd_index_find": (_i32, [_vp, _vp, _sz, _pu32]),
@@ -122,6 +123,8 @@ SIGNATURES = {
     "dcd_index_suggest": (_i32, [_vp, _vp, _sz, C.c_uint32, _vp, _vp]),
     "dcd_index_export_plan": (_i32, [_vp, C.c_uint32, _vp, _vp, _vp]),
     "dcd_index_export_fill": (_i32, [_vp, _vp, _vp, _vp]),
+    "dcd_index_export_heavy": (_i32, [_vp, C.c_uint64, _vp, _vp, C.c_size_t, _vp]),
+    "dcd_index_export_plan_balanced": (_i32, [_vp, C.c_uint32, _vp, _vp, C.c_size_t, _vp, _vp, _vp]),
     "dcd_index_image": (_i32, [_vp, _vp, _sz, _vp]),
     "dcd_index_list_image": (_i32, [_vp, _vp, _sz, _vp]),
     "dcd_index_set_list_image": (_i32, [_vp, _vp, _sz]),

@@ -252,6 +252,7 @@ void dcd_index_free(dcd_index* h) {
 
 int32_t dcd_index_count(dcd_index* h, uint64_t* n) { if (!h || !n) DCD_FAIL(DCD_E_BADARG, "NULL argument"); *n = h->ix.n_terms; return DCD_OK; }
 int32_t dcd_index_max_coord(dcd_index* h, uint64_t* v) { if (!h || !v) DCD_FAIL(DCD_E_BADARG, "NULL argument"); *v = h->ix.max_coord; return DCD_OK; }
+int32_t dcd_index_n_units(dcd_index* h, uint64_t* n) { if (!h || !n) DCD_FAIL(DCD_E_BADARG, "NULL argument"); *n = h->ix.n_units; return DCD_OK; }
 int32_t dcd_index_n_pages(dcd_index* h, uint64_t* n) { if (!h || !n) DCD_FAIL(DCD_E_BADARG, "NULL argument"); *n = h->ix.pages.n_pages(); return DCD_OK; }
 int32_t dcd_index_n_docs(dcd_index* h, uint64_t* n) { if (!h || !n) DCD_FAIL(DCD_E_BADARG, "NULL argument"); *n = h->ix.pages.n_docs(); return DCD_OK; }
 

@@ -393,29 +393,10 @@ static int32_t export_fill_impl(const void* h, DeviceIndex* ix, hipStream_t st, 
   return DCD_OK;
 }
 
-extern "C" {
-
-int32_t dcd_build_export_plan(dcd_build* h, uint32_t n_owners, uint64_t* term_count, uint64_t* key_count, uint64_t* unit_count) {
-  if (!h || !term_count || !key_count || !unit_count) DCD_FAIL(DCD_E_BADARG, "dcd_build_export_plan: NULL argument");
-  DeviceIndex* ix = build_peek_index(h);
-  if (!ix) DCD_FAIL(DCD_E_STATE, "build is not finished (or its index was adopted)");
-  return export_plan_impl(h, ix, build_stream(h), n_owners, term_count, key_count, unit_count);
-}
-int32_t dcd_build_export_plan_balanced(dcd_build* h, uint32_t n_owners, const uint64_t* over_fp, const uint32_t* over_owner, size_t n_over,
-                                       uint64_t* term_count, uint64_t* key_count, uint64_t* unit_count) {
-  if (!h || !term_count || !key_count || !unit_count) DCD_FAIL(DCD_E_BADARG, "dcd_build_export_plan_balanced: NULL argument");
-  DeviceIndex* ix = build_peek_index(h);
-  if (!ix) DCD_FAIL(DCD_E_STATE, "build is not finished (or its index was adopted)");
-  return export_plan_impl(h, ix, build_stream(h), n_owners, term_count, key_count, unit_count, over_fp, over_owner, n_over);
-}
-int32_t dcd_build_export_heavy(dcd_build* h, uint64_t min_units, uint64_t* fp, uint64_t* n_units, size_t cap, size_t* n_out) {
-  if (!h || !n_out || (cap && (!fp || !n_units))) DCD_FAIL(DCD_E_BADARG, "dcd_build_export_heavy: NULL argument");
-  DeviceIndex* ix = build_peek_index(h);
-  if (!ix) DCD_FAIL(DCD_E_STATE, "build is not finished (or its index was adopted)");
+static int32_t export_heavy_impl(DeviceIndex* ix, hipStream_t st, uint64_t min_units, uint64_t* fp, uint64_t* n_units, size_t cap, size_t* n_out) {
   if (cap > 65536) cap = 65536;
   const int dev = ix->device;
   DCD_TRY(ensure_device(dev));
-  hipStream_t st = build_stream(h);
   StreamScope ss_(st);
   const u64 V = ix->n_terms;
   *n_out = 0;
@@ -438,6 +419,37 @@ int32_t dcd_build_export_heavy(dcd_build* h, uint64_t min_units, uint64_t* fp, u
   *n_out = n;
   if (n > cap) DCD_FAIL(DCD_E_OVERFLOW, "dcd_build_export_heavy: %u terms reach %llu units, cap is %zu", n, (unsigned long long)min_units, cap);
   return DCD_OK;
+}
+
+extern "C" {
+
+int32_t dcd_build_export_plan(dcd_build* h, uint32_t n_owners, uint64_t* term_count, uint64_t* key_count, uint64_t* unit_count) {
+  if (!h || !term_count || !key_count || !unit_count) DCD_FAIL(DCD_E_BADARG, "dcd_build_export_plan: NULL argument");
+  DeviceIndex* ix = build_peek_index(h);
+  if (!ix) DCD_FAIL(DCD_E_STATE, "build is not finished (or its index was adopted)");
+  return export_plan_impl(h, ix, build_stream(h), n_owners, term_count, key_count, unit_count);
+}
+int32_t dcd_build_export_plan_balanced(dcd_build* h, uint32_t n_owners, const uint64_t* over_fp, const uint32_t* over_owner, size_t n_over,
+                                       uint64_t* term_count, uint64_t* key_count, uint64_t* unit_count) {
+  if (!h || !term_count || !key_count || !unit_count) DCD_FAIL(DCD_E_BADARG, "dcd_build_export_plan_balanced: NULL argument");
+  DeviceIndex* ix = build_peek_index(h);
+  if (!ix) DCD_FAIL(DCD_E_STATE, "build is not finished (or its index was adopted)");
+  return export_plan_impl(h, ix, build_stream(h), n_owners, term_count, key_count, unit_count, over_fp, over_owner, n_over);
+}
+int32_t dcd_build_export_heavy(dcd_build* h, uint64_t min_units, uint64_t* fp, uint64_t* n_units, size_t cap, size_t* n_out) {
+  if (!h || !n_out || (cap && (!fp || !n_units))) DCD_FAIL(DCD_E_BADARG, "dcd_build_export_heavy: NULL argument");
+  DeviceIndex* ix = build_peek_index(h);
+  if (!ix) DCD_FAIL(DCD_E_STATE, "build is not finished (or its index was adopted)");
+  return export_heavy_impl(ix, build_stream(h), min_units, fp, n_units, cap, n_out);
+}
+int32_t dcd_index_export_heavy(dcd_index* h, uint64_t min_units, uint64_t* fp, uint64_t* n_units, size_t cap, size_t* n_out) {
+  if (!h || !n_out || (cap && (!fp || !n_units))) DCD_FAIL(DCD_E_BADARG, "dcd_index_export_heavy: NULL argument");
+  return export_heavy_impl(&h->ix, h->st, min_units, fp, n_units, cap, n_out);
+}
+int32_t dcd_index_export_plan_balanced(dcd_index* h, uint32_t n_owners, const uint64_t* over_fp, const uint32_t* over_owner, size_t n_over,
+                                       uint64_t* term_count, uint64_t* key_count, uint64_t* unit_count) {
+  if (!h || !term_count || !key_count || !unit_count) DCD_FAIL(DCD_E_BADARG, "dcd_index_export_plan_balanced: NULL argument");
+  return export_plan_impl(h, &h->ix, h->st, n_owners, term_count, key_count, unit_count, over_fp, over_owner, n_over);
 }
 int32_t dcd_build_export_fill(dcd_build* h, void* meta_dev, uint16_t* keys_dev, uint16_t* units_dev) {
   if (!h) DCD_FAIL(DCD_E_BADARG, "dcd_build_export_fill: NULL handle");

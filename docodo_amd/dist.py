@@ -36,7 +36,8 @@ def heavy_terms(builder, min_units, cap):
     """dcd_build_export_heavy: (fingerprints, units) of the shard's terms with at least min_units posting units."""
     fp, un = np.zeros(max(1, cap), np.uint64), np.zeros(max(1, cap), np.uint64)
     n = C.c_size_t(0)
-    check(lib().dcd_build_export_heavy(builder.h, int(min_units), fp.ctypes.data, un.ctypes.data, cap, C.byref(n)))
+    fn = lib().dcd_index_export_heavy if isinstance(builder, Index) else lib().dcd_build_export_heavy
+    check(fn(builder.h, int(min_units), fp.ctypes.data, un.ctypes.data, cap, C.byref(n)))
     return fp[:n.value].copy(), un[:n.value].copy()
 
 
@@ -68,7 +69,7 @@ def balance_owners(builder, group=None):
     G = dist.get_world_size(group)
     if G == 1:
         return None
-    U = int(builder.stats.n_units)
+    U = int(builder.n_units if isinstance(builder, Index) else builder.stats.n_units)
     cap = 8 * G
     fp, un = heavy_terms(builder, max(1, -(-U // cap)), cap)       # (>= ceil(U / 8N) units each: no more than 8N terms)
     mine = np.zeros(2 + 2 * cap, np.int64)
@@ -91,6 +92,8 @@ def export_shard(builder, n_owners, device=None, overrides=None):
     tc = np.zeros(n_owners, np.uint64)
     kc = np.zeros(n_owners, np.uint64)
     uc = np.zeros(n_owners, np.uint64)
+    if isinstance(builder, Index):               # (a shard that is itself a merged index: several segments of one rank)
+        return export_index(builder, n_owners, device, overrides)
     if overrides is not None and len(overrides[0]):
         ofp, oow = np.ascontiguousarray(overrides[0], np.uint64), np.ascontiguousarray(overrides[1], np.uint32)
         check(lib().dcd_build_export_plan_balanced(builder.h, n_owners, ofp.ctypes.data, oow.ctypes.data, ofp.size, tc.ctypes.data,
@@ -106,12 +109,18 @@ def export_shard(builder, n_owners, device=None, overrides=None):
     return ShardExport(tc, kc, uc, meta, keys, units, builder.stats.max_coord)
 
 
-def export_index(index, n_owners=1, device=None):
+# (export_shard hands index handles over to export_index)
+def export_index(index, n_owners=1, device=None, overrides=None):
     """Export of an index handle (the owned partition after a merge): same buffers as export_shard."""
     tc = np.zeros(n_owners, np.uint64)
     kc = np.zeros(n_owners, np.uint64)
     uc = np.zeros(n_owners, np.uint64)
-    check(lib().dcd_index_export_plan(index.h, n_owners, tc.ctypes.data, kc.ctypes.data, uc.ctypes.data))
+    if overrides is not None and len(overrides[0]):
+        ofp, oow = np.ascontiguousarray(overrides[0], np.uint64), np.ascontiguousarray(overrides[1], np.uint32)
+        check(lib().dcd_index_export_plan_balanced(index.h, n_owners, ofp.ctypes.data, oow.ctypes.data, ofp.size, tc.ctypes.data,
+                                                   kc.ctypes.data, uc.ctypes.data))
+    else:
+        check(lib().dcd_index_export_plan(index.h, n_owners, tc.ctypes.data, kc.ctypes.data, uc.ctypes.data))
     dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
     meta = torch.empty(int(tc.sum()) * META_BYTES, dtype=torch.uint8, device=dev)
     keys = torch.empty(int(kc.sum()) * 2, dtype=torch.uint8, device=dev)
@@ -250,7 +259,8 @@ def _host_wait(work, dev):
 
 
 def distributed_merge(builder, group=None, device_index=None, balanced=True):
-    """export -> all-to-all (RCCL) -> merge.  Returns this rank's owned sub-index.  balanced: the heavy terms are assigned to
+    """export -> all-to-all (RCCL) -> merge.  Returns this rank's owned sub-index.  `builder`: a finished Builder, or an Index
+    handle that holds this rank's shard (several segments merged on the device).  balanced: the heavy terms are assigned to
     owners by posting units (balance_owners: one small all-gather in front of the export), the others by hash."""
     import torch.distributed as dist
     G = dist.get_world_size(group)
@@ -345,32 +355,63 @@ class SegmentedBuilder:
     MaxTmpIndexItems postings and merges them at the end (Build.cs:335-340, Index.cs:537-689); here every segment is a
     doc-range shard with GLOBAL coordinates, built and exported on the device, and `finish` merges the exports
     (dcd_merge_shards: first delta of every appended segment re-coded) into one index.  Uniform device-resident pages
-    (the synthetic corpora); one document per page."""
+    (the synthetic corpora); one document per page.  first_page: this builder covers the pages from first_page on (one rank's
+    doc range of a distributed build)."""
 
-    def __init__(self, page_chars, max_segment_chars=3_584_000_000, device=0, source="syn"):
+    def __init__(self, page_chars, max_segment_chars=3_584_000_000, device=0, source="syn", first_page=0, defer_export=False):
         self.page_chars, self.device, self.source = page_chars, device, source
         self.max_pages = max(1, max_segment_chars // page_chars)
-        self.exports, self.n_pages, self.n_postings, self.device_ms = [], 0, 0, 0.0
+        self.first_page = first_page
+        self.defer_export = defer_export           # keep the finished builders (finish_distributed exports a single segment directly)
+        self.exports, self.builders, self.n_pages, self.n_postings, self.device_ms = [], [], 0, 0, 0.0
 
     def add_pages_dev(self, text_dev_ptr, n_pages):
-        """Pages [self.n_pages, self.n_pages + n_pages) of the corpus, resident at text_dev_ptr."""
+        """Pages [first_page + self.n_pages, ... + n_pages) of the corpus, resident at text_dev_ptr."""
         from .index import Builder
         done = 0
         while done < n_pages:
             k = min(self.max_pages, n_pages - done)
-            first = self.n_pages + done
+            first = self.first_page + self.n_pages + done
             b = Builder(coord_base=first * self.page_chars, device=self.device, shard_only=True)      # (exported and merged below)
             b.AddUniformPagesDev(text_dev_ptr + done * self.page_chars, k, self.page_chars, first_doc=first, source=self.source)
             st = b.Finish()
             self.n_postings += st.n_postings
             self.device_ms += st.ms_total
-            self.exports.append(export_shard(b, 1))
-            b.close()
+            if self.defer_export:
+                self.builders.append(b)
+            else:
+                self.exports.append(export_shard(b, 1))
+                b.close()
             done += k
         self.n_pages += n_pages
 
-    def finish(self):
+    @property
+    def n_segments(self):
+        return len(self.exports) + len(self.builders)
+
+    def _export_all(self):
+        for b in self.builders:
+            self.exports.append(export_shard(b, 1))
+            b.close()
+        self.builders = []
+
+    def finish(self, pages=True):
+        self._export_all()
         ix = local_merge(self.exports, 0, self.device)
         self.exports = []
-        set_uniform_pages(ix, self.n_pages, self.page_chars, 0, self.source)
+        if pages:
+            set_uniform_pages(ix, self.n_pages, self.page_chars, self.first_page, self.source)
         return ix
+
+    def finish_distributed(self, group=None, balanced=True):
+        """This rank's doc range -> its hash partition of the global index (export -> all-to-all -> merge).  One segment: the
+        builder is exported to the owners directly; several: they are merged on this device first (one shard per rank)."""
+        if len(self.builders) == 1 and not self.exports:
+            b = self.builders.pop()
+            owned = distributed_merge(b, group, self.device, balanced)
+            b.close()
+            return owned
+        part = self.finish(pages=False)
+        owned = distributed_merge(part, group, self.device, balanced)
+        part.close()
+        return owned

@@ -278,6 +278,11 @@ class Index:
         return self._u64(lib().dcd_index_max_coord)
 
     @property
+    def n_units(self):
+        """Posting units of all lists together."""
+        return self._u64(lib().dcd_index_n_units)
+
+    @property
     def n_pages(self):
         return self._u64(lib().dcd_index_n_pages)
 
@@ -317,6 +322,12 @@ class Index:
         v = C.c_uint64(0)
         check(lib().dcd_index_term_count(self.h, term, C.byref(v)))
         return v.value
+
+    def term_units(self, term):
+        """IndexSequence.Count of this[key]: the number of ushort UNITS of the posting list (IndexSequence.cs:43-45)."""
+        n = C.c_size_t(0)
+        lib().dcd_index_get(self.h, term, None, 0, C.byref(n))
+        return n.value
 
     def page_info(self, page):
         end, doc, n = C.c_uint64(0), C.c_uint32(0), C.c_size_t(0)
@@ -368,8 +379,9 @@ class Index:
         return out[:n.value].tobytes().decode("utf-16-le", "surrogatepass")
 
     def query_batch(self, prog, prog_off, max_found_pages=30000, max_found_docs=500, doc_rank_multiply=10.0,
-                    want_sequences=False, keep_handle=False, doc_match=None):
-        """doc_match: optional uint8 array, one entry per document: 1 = the document passes the request's -filter:."""
+                    want_sequences=False, keep_handle=False, doc_match=None, totals=False):
+        """doc_match: optional uint8 array, one entry per document: 1 = the document passes the request's -filter:.
+        keep_handle: only the device time comes back; totals: {ms, n_pages, n_pos, n_docs} of the batch (measurements)."""
         prog = np.ascontiguousarray(prog, np.int32)
         off = np.ascontiguousarray(prog_off, np.uint64)
         o = QueryOpts()
@@ -385,6 +397,11 @@ class Index:
         try:
             v = ResultsView()
             check(lib().dcd_results_get(r, C.byref(v)))
+            if totals:
+                nq = int(v.n_queries)
+                n_pages = int(v.page_off[nq]) if nq else 0
+                return {"ms": float(v.ms_device), "n_pages": n_pages, "n_pos": int(v.pos_off[n_pages]) if nq else 0,
+                        "n_docs": int(v.doc_off[nq]) if nq else 0}
             if keep_handle:
                 return v.ms_device
             return QueryBatchResult(v)

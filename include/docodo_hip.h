@@ -216,6 +216,7 @@ int32_t dcd_index_from_images(const uint8_t* index_img, size_t n_index, const ui
 void dcd_index_free(dcd_index* h);
 int32_t dcd_index_count(dcd_index* h, uint64_t* n_terms);              /* Index.Count */
 int32_t dcd_index_max_coord(dcd_index* h, uint64_t* v);                /* Index.MaxCoord */
+int32_t dcd_index_n_units(dcd_index* h, uint64_t* n);                  /* ushort units of all posting lists together */
 int32_t dcd_index_n_pages(dcd_index* h, uint64_t* n);
 int32_t dcd_index_n_docs(dcd_index* h, uint64_t* n);
 /* ordinal position of a key in the sorted dictionary (SortedList keys, Index.cs:151); DCD_E_NOTFOUND */
@@ -339,6 +340,10 @@ void dcd_merge_free(dcd_merge* m);
  * dcd_index_set_uniform_pages. */
 int32_t dcd_index_export_plan(dcd_index* h, uint32_t n_owners, uint64_t* term_count, uint64_t* key_count, uint64_t* unit_count);
 int32_t dcd_index_export_fill(dcd_index* h, void* meta_dev, uint16_t* keys_dev, uint16_t* units_dev);
+/* (as dcd_build_export_heavy / dcd_build_export_plan_balanced, for a shard that is itself a merged index) */
+int32_t dcd_index_export_heavy(dcd_index* h, uint64_t min_units, uint64_t* fp, uint64_t* n_units, size_t cap, size_t* n_out);
+int32_t dcd_index_export_plan_balanced(dcd_index* h, uint32_t n_owners, const uint64_t* over_fp, const uint32_t* over_owner, size_t n_over,
+                                       uint64_t* term_count, uint64_t* key_count, uint64_t* unit_count);
 int32_t dcd_index_image(dcd_index* h, uint8_t* out, size_t cap, size_t* n);
 int32_t dcd_index_list_image(dcd_index* h, uint8_t* out, size_t cap, size_t* n);
 int32_t dcd_index_set_list_image(dcd_index* h, const uint8_t* list_img, size_t n_list);
