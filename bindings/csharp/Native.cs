@@ -66,12 +66,12 @@ namespace Docodo
         [DllImport(Lib)] public static extern int dcd_build_export_plan(IntPtr h, uint nOwners, ulong* termCount, ulong* keyCount, ulong* unitCount);
         [DllImport(Lib)] public static extern int dcd_build_export_fill(IntPtr h, void* metaDev, ushort* keysDev, ushort* unitsDev);
         [DllImport(Lib)] public static extern int dcd_build_export_heavy(IntPtr h, ulong minUnits, ulong* fp, ulong* nUnits, UIntPtr cap, out UIntPtr nOut);
-        [DllImport(Lib)] public static extern int dcd_build_export_plan_balanced(IntPtr h, uint nOwners, ulong* overFp, uint* overOwner, UIntPtr nOver,
+        [DllImport(Lib)] public static extern int dcd_build_export_plan_balanced(IntPtr h, uint nOwners, ulong* overFp, uint* overOwner, UIntPtr nOver, uint* lightThr,
                                                                                  ulong* termCount, ulong* keyCount, ulong* unitCount);
         [DllImport(Lib)] public static extern int dcd_index_export_plan(IntPtr h, uint nOwners, ulong* termCount, ulong* keyCount, ulong* unitCount);
         [DllImport(Lib)] public static extern int dcd_index_export_fill(IntPtr h, void* metaDev, ushort* keysDev, ushort* unitsDev);
         [DllImport(Lib)] public static extern int dcd_index_export_heavy(IntPtr h, ulong minUnits, ulong* fp, ulong* nUnits, UIntPtr cap, out UIntPtr nOut);
-        [DllImport(Lib)] public static extern int dcd_index_export_plan_balanced(IntPtr h, uint nOwners, ulong* overFp, uint* overOwner, UIntPtr nOver,
+        [DllImport(Lib)] public static extern int dcd_index_export_plan_balanced(IntPtr h, uint nOwners, ulong* overFp, uint* overOwner, UIntPtr nOver, uint* lightThr,
                                                                                  ulong* termCount, ulong* keyCount, ulong* unitCount);
         [DllImport(Lib)] public static extern int dcd_merge_shards(int device, uint nSources, ulong* termCount, ulong* keyCount, ulong* unitCount,
                                                                    void* metaDev, ushort* keysDev, ushort* unitsDev, ulong maxCoord, out IntPtr index);

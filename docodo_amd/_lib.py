@@ -114,7 +114,7 @@ SIGNATURES = {
     "dcd_build_export_plan": (_i32, [_vp, _u32, _vp, _vp, _vp]),
     "dcd_build_export_fill": (_i32, [_vp, _vp, _vp, _vp]),
     "dcd_build_export_heavy": (_i32, [_vp, C.c_uint64, _vp, _vp, C.c_size_t, _vp]),
-    "dcd_build_export_plan_balanced": (_i32, [_vp, _u32, _vp, _vp, C.c_size_t, _vp, _vp, _vp]),
+    "dcd_build_export_plan_balanced": (_i32, [_vp, _u32, _vp, _vp, C.c_size_t, _vp, _vp, _vp, _vp]),
     "dcd_merge_shards": (_i32, [_i32, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _u64, C.POINTER(_vp)]),
     "dcd_merge_begin": (_i32, [_i32, _u32, _vp, _vp, _vp, _vp, _vp, _u64, C.POINTER(_vp)]),
     "dcd_merge_finish": (_i32, [_vp, _vp, C.POINTER(_vp)]),
@@ -124,7 +124,7 @@ SIGNATURES = {
     "dcd_index_export_plan": (_i32, [_vp, C.c_uint32, _vp, _vp, _vp]),
     "dcd_index_export_fill": (_i32, [_vp, _vp, _vp, _vp]),
     "dcd_index_export_heavy": (_i32, [_vp, C.c_uint64, _vp, _vp, C.c_size_t, _vp]),
-    "dcd_index_export_plan_balanced": (_i32, [_vp, C.c_uint32, _vp, _vp, C.c_size_t, _vp, _vp, _vp]),
+    "dcd_index_export_plan_balanced": (_i32, [_vp, C.c_uint32, _vp, _vp, C.c_size_t, _vp, _vp, _vp, _vp]),
     "dcd_index_image": (_i32, [_vp, _vp, _sz, _vp]),
     "dcd_index_list_image": (_i32, [_vp, _vp, _sz, _vp]),
     "dcd_index_set_list_image": (_i32, [_vp, _vp, _sz]),

@@ -50,13 +50,21 @@ __device__ __forceinline__ u64 key_fp64(const u16* s, u32 n) {
 
 // ---- export ------------------------------------------------------------------------------------
 // owner(term) = hash(key) % n_owners, unless the key's fingerprint is in the (sorted, small) override table
+// light_thr != nullptr: the light terms are spread by WEIGHT -- owner = first o with hash(key) <= light_thr[o] (ascending, last =
+// 2^32 - 1): an owner that holds a heavy term gets a smaller slice of the hash space
 __global__ void k_owner_pairs(const u16* __restrict__ chars, const u32* __restrict__ str_off, u64 n_terms, u32 n_owners,
-                              const u64* __restrict__ over_fp, const u32* __restrict__ over_owner, u32 n_over, uint2* __restrict__ pairs) {
+                              const u64* __restrict__ over_fp, const u32* __restrict__ over_owner, u32 n_over,
+                              const u32* __restrict__ light_thr, uint2* __restrict__ pairs) {
   u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n_terms) return;
   const u16* k = chars + str_off[t];
   const u32 len = str_off[t + 1] - str_off[t];
-  u32 o = key_hash16(k, len) % n_owners;
+  const u32 hk = key_hash16(k, len);
+  u32 o = hk % n_owners;
+  if (light_thr) {
+    o = 0;
+    while (o + 1 < n_owners && hk > light_thr[o]) o++;
+  }
   if (n_over) {
     const u64 fp = key_fp64(k, len);
     u32 a = 0, b = n_over;                     // first entry >= fp
@@ -302,7 +310,8 @@ static std::mutex g_export_mu;
 
 // export of a device-resident index (a finished build, or an index handle: the owned partition after a merge)
 static int32_t export_plan_impl(const void* h, DeviceIndex* ix, hipStream_t st, uint32_t n_owners, uint64_t* term_count, uint64_t* key_count,
-                                uint64_t* unit_count, const uint64_t* over_fp = nullptr, const uint32_t* over_owner = nullptr, size_t n_over = 0) {
+                                uint64_t* unit_count, const uint64_t* over_fp = nullptr, const uint32_t* over_owner = nullptr, size_t n_over = 0,
+                                const uint32_t* light_thr = nullptr) {
   if (n_owners == 0 || n_owners > 64) DCD_FAIL(DCD_E_BADARG, "n_owners must be in [1, 64]");
   if (n_over > 4096 || (n_over && (!over_fp || !over_owner))) DCD_FAIL(DCD_E_BADARG, "owner overrides: at most 4096 entries, both arrays given");
   // the override table, sorted by fingerprint (the kernel searches it); an owner out of range is the caller's bug
@@ -333,7 +342,16 @@ static int32_t export_plan_impl(const void* h, DeviceIndex* ix, hipStream_t st, 
   DCD_HIP(hipMemsetAsync(totals.p, 0, 64 * 3 * 8, st));
   std::vector<unsigned long long> tot(64 * 3, 0);
   DevBuf<u64> d_ofp;
-  DevBuf<u32> d_oown;
+  DevBuf<u32> d_oown, d_thr;
+  if (light_thr) {
+    for (u32 o = 0; o + 1 < n_owners; o++) if (light_thr[o] > light_thr[o + 1]) DCD_FAIL(DCD_E_BADARG, "light_thr must ascend");
+    if (light_thr[n_owners - 1] != 0xFFFFFFFFu) DCD_FAIL(DCD_E_BADARG, "light_thr must end with 2^32 - 1");
+    if (V) {
+      DCD_TRY(d_thr.alloc(dev, n_owners));
+      DCD_HIP(hipMemcpyAsync(d_thr.p, light_thr, n_owners * 4, hipMemcpyHostToDevice, st));
+      DCD_HIP(hipStreamSynchronize(st));
+    }
+  }
   if (V && n_over) {
     std::vector<u64> f(n_over); std::vector<u32> o(n_over);
     for (size_t i = 0; i < n_over; i++) { f[i] = over[i].first; o[i] = over[i].second; }
@@ -344,7 +362,7 @@ static int32_t export_plan_impl(const void* h, DeviceIndex* ix, hipStream_t st, 
   }
   if (V) {
     hipLaunchKernelGGL(k_owner_pairs, dim3((u32)div_up(V, 256)), dim3(256), 0, st, ix->term_chars.p, ix->term_str_off.p, V, n_owners,
-                       (const u64*)d_ofp.p, (const u32*)d_oown.p, (u32)n_over, pa.p);
+                       (const u64*)d_ofp.p, (const u32*)d_oown.p, (u32)n_over, (const u32*)d_thr.p, pa.p);
     uint2* sorted = rs_sort(pa.p, pb.p, nullptr, V, 6, hist.p, sscr.p, st);
     if (sorted == pa.p) ep->perm = std::move(pa); else ep->perm = std::move(pb);
     hipLaunchKernelGGL(k_owner_totals, dim3((u32)div_up(V, 256)), dim3(256), 0, st, ep->perm.p, V, ix->term_unit_start.p, ix->term_str_off.p,
@@ -430,11 +448,11 @@ int32_t dcd_build_export_plan(dcd_build* h, uint32_t n_owners, uint64_t* term_co
   return export_plan_impl(h, ix, build_stream(h), n_owners, term_count, key_count, unit_count);
 }
 int32_t dcd_build_export_plan_balanced(dcd_build* h, uint32_t n_owners, const uint64_t* over_fp, const uint32_t* over_owner, size_t n_over,
-                                       uint64_t* term_count, uint64_t* key_count, uint64_t* unit_count) {
+                                       const uint32_t* light_thr, uint64_t* term_count, uint64_t* key_count, uint64_t* unit_count) {
   if (!h || !term_count || !key_count || !unit_count) DCD_FAIL(DCD_E_BADARG, "dcd_build_export_plan_balanced: NULL argument");
   DeviceIndex* ix = build_peek_index(h);
   if (!ix) DCD_FAIL(DCD_E_STATE, "build is not finished (or its index was adopted)");
-  return export_plan_impl(h, ix, build_stream(h), n_owners, term_count, key_count, unit_count, over_fp, over_owner, n_over);
+  return export_plan_impl(h, ix, build_stream(h), n_owners, term_count, key_count, unit_count, over_fp, over_owner, n_over, light_thr);
 }
 int32_t dcd_build_export_heavy(dcd_build* h, uint64_t min_units, uint64_t* fp, uint64_t* n_units, size_t cap, size_t* n_out) {
   if (!h || !n_out || (cap && (!fp || !n_units))) DCD_FAIL(DCD_E_BADARG, "dcd_build_export_heavy: NULL argument");
@@ -447,9 +465,9 @@ int32_t dcd_index_export_heavy(dcd_index* h, uint64_t min_units, uint64_t* fp, u
   return export_heavy_impl(&h->ix, h->st, min_units, fp, n_units, cap, n_out);
 }
 int32_t dcd_index_export_plan_balanced(dcd_index* h, uint32_t n_owners, const uint64_t* over_fp, const uint32_t* over_owner, size_t n_over,
-                                       uint64_t* term_count, uint64_t* key_count, uint64_t* unit_count) {
+                                       const uint32_t* light_thr, uint64_t* term_count, uint64_t* key_count, uint64_t* unit_count) {
   if (!h || !term_count || !key_count || !unit_count) DCD_FAIL(DCD_E_BADARG, "dcd_index_export_plan_balanced: NULL argument");
-  return export_plan_impl(h, &h->ix, h->st, n_owners, term_count, key_count, unit_count, over_fp, over_owner, n_over);
+  return export_plan_impl(h, &h->ix, h->st, n_owners, term_count, key_count, unit_count, over_fp, over_owner, n_over, light_thr);
 }
 int32_t dcd_build_export_fill(dcd_build* h, void* meta_dev, uint16_t* keys_dev, uint16_t* units_dev) {
   if (!h) DCD_FAIL(DCD_E_BADARG, "dcd_build_export_fill: NULL handle");

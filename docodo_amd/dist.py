@@ -42,29 +42,43 @@ def heavy_terms(builder, min_units, cap):
 
 
 def assign_heavy(lists, totals, n_owners):
-    """Owner table of the heavy terms.  lists = per rank (fingerprints, units), totals = per rank posting units.  Terms are
-    taken largest first (ties: smaller fingerprint) and given to the least loaded owner (ties: lower rank), every owner
-    starting from its share of the light terms, which hash(key) % n_owners spreads evenly.  Pure function of its arguments:
-    every rank computes the same table from the all-gathered lists.  -> (fingerprints, owners), sorted by fingerprint."""
+    """Owner table of a balanced export.  lists = per rank (fingerprints, units) of its heavy terms, totals = per rank posting
+    units.  Heavy terms are taken largest first (ties: smaller fingerprint) and given to the owner with the least heavy units so
+    far (ties: lower rank); the LIGHT terms -- everything else, spread by hash -- then fill every owner up to the mean: owner o
+    gets the slice of the 32-bit hash space proportional to max(0, mean - heavy_o).  Pure integer function of its arguments:
+    every rank computes the same table from the all-gathered lists.  -> (fingerprints, owners, light_thr): fingerprints sorted,
+    light_thr[o] = last hash value of owner o's slice (ascending, light_thr[-1] = 2^32 - 1)."""
     units = {}
     for fp, un in lists:
         for f, u in zip(fp.tolist(), un.tolist()):
             units[f] = units.get(f, 0) + u
-    light = max(0, int(sum(int(t) for t in totals)) - sum(units.values()))
-    load = [light / n_owners] * n_owners
+    total = int(sum(int(t) for t in totals))
+    load = [0] * n_owners
     owner = {}
     for f, u in sorted(units.items(), key=lambda x: (-x[1], x[0])):
         o = min(range(n_owners), key=lambda i: (load[i], i))
         owner[f] = o
         load[o] += u
+    # light capacity per owner: what is missing to the mean (an owner whose heavy terms already exceed it gets no light term)
+    cap = [max(0, total - n_owners * l) for l in load]              # (= n_owners * (mean - heavy_o), kept integral)
+    if sum(cap) == 0:
+        cap = [1] * n_owners
+    thr, cum, tot = [], 0, sum(cap)
+    for o in range(n_owners):
+        cum += cap[o]
+        thr.append(max(0, (cum << 32) // tot - 1))
+    thr[-1] = 0xFFFFFFFF
+    for o in range(n_owners - 2, -1, -1):                           # an owner without capacity: an empty slice (never below its left neighbour)
+        thr[o] = min(thr[o], thr[o + 1])
     fps = sorted(owner)
-    return np.array(fps, np.uint64), np.array([owner[f] for f in fps], np.uint32)
+    return np.array(fps, np.uint64), np.array([owner[f] for f in fps], np.uint32), np.array(thr, np.uint32)
 
 
 def balance_owners(builder, group=None):
     """One small all-gather: every rank's heavy terms (at least 1 / (8 N) of its shard's posting units: at most 8 N of them)
-    -> the same owner table on every rank (assign_heavy).  With Zipf-1.1 the first term alone is 13 % of all units; under
-    hash(key) % 8 its owner receives 1.9 x the mean, and the all-to-all and the merge wait for that rank."""
+    -> the same owner table on every rank (assign_heavy: heavy terms to the least loaded owners, the light ones weighted so
+    that every owner ends near the mean).  With Zipf-1.1 the first term alone is 13 % of all units; under hash(key) % 8 its
+    owner receives 1.9 x the mean, and the all-to-all and the merge wait for that rank."""
     import torch.distributed as dist
     G = dist.get_world_size(group)
     if G == 1:
@@ -87,17 +101,18 @@ def balance_owners(builder, group=None):
 
 
 def export_shard(builder, n_owners, device=None, overrides=None):
-    """dcd_build_export_plan (overrides = (fingerprints, owners) of the heavy terms: dcd_build_export_plan_balanced) +
+    """dcd_build_export_plan (overrides = (fingerprints, owners[, light_thr]) from assign_heavy: dcd_build_export_plan_balanced) +
     dcd_build_export_fill into torch-owned device buffers."""
     tc = np.zeros(n_owners, np.uint64)
     kc = np.zeros(n_owners, np.uint64)
     uc = np.zeros(n_owners, np.uint64)
     if isinstance(builder, Index):               # (a shard that is itself a merged index: several segments of one rank)
         return export_index(builder, n_owners, device, overrides)
-    if overrides is not None and len(overrides[0]):
+    if overrides is not None:
         ofp, oow = np.ascontiguousarray(overrides[0], np.uint64), np.ascontiguousarray(overrides[1], np.uint32)
-        check(lib().dcd_build_export_plan_balanced(builder.h, n_owners, ofp.ctypes.data, oow.ctypes.data, ofp.size, tc.ctypes.data,
-                                                   kc.ctypes.data, uc.ctypes.data))
+        thr = np.ascontiguousarray(overrides[2], np.uint32) if len(overrides) > 2 and overrides[2] is not None else None
+        check(lib().dcd_build_export_plan_balanced(builder.h, n_owners, ofp.ctypes.data if ofp.size else None, oow.ctypes.data if ofp.size else None,
+                                                   ofp.size, thr.ctypes.data if thr is not None else None, tc.ctypes.data, kc.ctypes.data, uc.ctypes.data))
     else:
         check(lib().dcd_build_export_plan(builder.h, n_owners, tc.ctypes.data, kc.ctypes.data, uc.ctypes.data))
     dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
@@ -115,10 +130,11 @@ def export_index(index, n_owners=1, device=None, overrides=None):
     tc = np.zeros(n_owners, np.uint64)
     kc = np.zeros(n_owners, np.uint64)
     uc = np.zeros(n_owners, np.uint64)
-    if overrides is not None and len(overrides[0]):
+    if overrides is not None:
         ofp, oow = np.ascontiguousarray(overrides[0], np.uint64), np.ascontiguousarray(overrides[1], np.uint32)
-        check(lib().dcd_index_export_plan_balanced(index.h, n_owners, ofp.ctypes.data, oow.ctypes.data, ofp.size, tc.ctypes.data,
-                                                   kc.ctypes.data, uc.ctypes.data))
+        thr = np.ascontiguousarray(overrides[2], np.uint32) if len(overrides) > 2 and overrides[2] is not None else None
+        check(lib().dcd_index_export_plan_balanced(index.h, n_owners, ofp.ctypes.data if ofp.size else None, oow.ctypes.data if ofp.size else None,
+                                                   ofp.size, thr.ctypes.data if thr is not None else None, tc.ctypes.data, kc.ctypes.data, uc.ctypes.data))
     else:
         check(lib().dcd_index_export_plan(index.h, n_owners, tc.ctypes.data, kc.ctypes.data, uc.ctypes.data))
     dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())

@@ -305,11 +305,13 @@ int32_t dcd_build_export_plan(dcd_build* h, uint32_t n_owners, uint64_t* term_co
  * lists the terms of this shard with at least min_units units (64-bit key fingerprint + units, sorted by fingerprint; n_out =
  * how many there are, DCD_E_OVERFLOW if more than cap); the caller all-gathers those lists, assigns the heavy terms to owners
  * (largest first, to the least loaded owner -- every rank computes the same table from the same data) and exports with
- * dcd_build_export_plan_balanced: a term whose fingerprint is in over_fp goes to over_owner, every other term to
- * hash(key) % n_owners as before.  (No reference counterpart: the reference merges on one host, Index.cs:577-752.) */
+ * dcd_build_export_plan_balanced: a term whose fingerprint is in over_fp goes to over_owner; every other (light) term goes to
+ * hash(key) % n_owners as before when light_thr == NULL, else to the first owner o with hash(key) <= light_thr[o] (n_owners
+ * ascending thresholds, the last one 2^32 - 1): the slice of the hash space an owner gets shrinks by what its heavy terms already
+ * weigh, so that every owner ends near the mean.  (No reference counterpart: the reference merges on one host, Index.cs:577-752.) */
 int32_t dcd_build_export_heavy(dcd_build* h, uint64_t min_units, uint64_t* fp, uint64_t* n_units, size_t cap, size_t* n_out);
 int32_t dcd_build_export_plan_balanced(dcd_build* h, uint32_t n_owners, const uint64_t* over_fp, const uint32_t* over_owner, size_t n_over,
-                                       uint64_t* term_count, uint64_t* key_count, uint64_t* unit_count);
+                                       const uint32_t* light_thr, uint64_t* term_count, uint64_t* key_count, uint64_t* unit_count);
 /* Fills caller-allocated DEVICE buffers: meta (dcd_term_meta per term), keys (UTF-16 units) and
  * posting units, all grouped by owner (owner 0 first) and in ordinal term order inside an owner. */
 int32_t dcd_build_export_fill(dcd_build* h, void* meta_dev, uint16_t* keys_dev, uint16_t* units_dev);
@@ -343,7 +345,7 @@ int32_t dcd_index_export_fill(dcd_index* h, void* meta_dev, uint16_t* keys_dev, 
 /* (as dcd_build_export_heavy / dcd_build_export_plan_balanced, for a shard that is itself a merged index) */
 int32_t dcd_index_export_heavy(dcd_index* h, uint64_t min_units, uint64_t* fp, uint64_t* n_units, size_t cap, size_t* n_out);
 int32_t dcd_index_export_plan_balanced(dcd_index* h, uint32_t n_owners, const uint64_t* over_fp, const uint32_t* over_owner, size_t n_over,
-                                       uint64_t* term_count, uint64_t* key_count, uint64_t* unit_count);
+                                       const uint32_t* light_thr, uint64_t* term_count, uint64_t* key_count, uint64_t* unit_count);
 int32_t dcd_index_image(dcd_index* h, uint8_t* out, size_t cap, size_t* n);
 int32_t dcd_index_list_image(dcd_index* h, uint8_t* out, size_t cap, size_t* n);
 int32_t dcd_index_set_list_image(dcd_index* h, const uint8_t* list_img, size_t n_list);
