@@ -38,6 +38,15 @@ if ROOT not in sys.path:
 import numpy as np
 import torch
 
+_T0 = time.perf_counter()
+
+
+def note(msg):
+    """progress line on stderr (a long run must show that it is alive; also the per-leg wall times of a run)"""
+    if os.environ.get("RANK", "0") == "0":
+        print("[bench %7.1f s] %s" % (time.perf_counter() - _T0, msg), file=sys.stderr, flush=True)
+
+
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB/s measured copy)
 HBM_COPY_GBS = 6290.0
 
@@ -457,6 +466,7 @@ def main():
             cal_n += np.array(list(st.n_launch))
             cal_stage += np.array([st.ms_tokenize, st.ms_vocab, st.ms_sort, st.ms_pack, st.ms_image, st.ms_total])
             cal_steps += 1
+    note("warm-up done, timing %d steps" % args.steps)
     lean = bool(args.lean_events) and cal_steps > 0
     if lean:
         docodo_amd.set_build_events(0, 1 << int(np.argmax(cal_k[:7])))
@@ -554,12 +564,15 @@ def main():
                                           if worker is not None else ""))
             out["config"]["scaling_note"] = ("the N = 1 line builds the .index image per step; shard-only steps skip it (k_img_units: ~8 % of a step) and "
                                              "add the exchange + merge instead")
+        note("timed steps done: %.3f ms per step" % ms_step)
         if world == 1 and not exchange:
             out["general_pages"] = general_pages_leg(text, D, T, local_rank, max(3, args.steps // 2))
         if world == 1 and args.inflight > 1 and not exchange:
             out["builders_in_flight"] = inflight_bench(args.inflight, args.steps, text, D, local_rank, T)
         if world == 1 and args.cpu_docs > 0 and not exchange:
+            note("cpu baseline (oracle) ...")
             out["cpu_baseline"] = cpu_baseline(min(args.cpu_docs, D), args.cpu_docs_all)
+            note("cpu baseline done")
         if world == 1 and args.queries > 0 and not exchange:
             # query leg of configs[1], outside the timed build steps
             bq = docodo_amd.Builder(coord_base=coord_base, device=local_rank)
@@ -568,6 +581,7 @@ def main():
             img, lst = (bq.index_image(), bq.list_image()) if args.cpu_docs > 0 else (None, None)
             ixq = bq.Build()
             out["queries"] = query_bench(ixq, args.queries, args.and3, 6.0 if args.cpu_docs > 0 else 0, img, lst)
+            note("configs[1] query leg done")
             ixq.close()
             bq.close()
             del img, lst
@@ -670,6 +684,7 @@ def big_index_legs(args, rank, world, device, dist, cdev):
             ddist.set_uniform_pages(ix, total, synth.DOC_BYTES)
         return ix, n_seg, dev_ms, n_post
 
+    note("configs[2]: building the %d-doc index" % total)
     ix, n_seg, dev_ms, n_post = build_once()            # warm-up (allocates)
     ix.close()
     barrier()
@@ -693,6 +708,7 @@ def big_index_legs(args, rank, world, device, dist, cdev):
                      "pipeline": ("segments (shard-only) -> dcd_merge_shards" if world == 1 else
                                   "segments -> per-rank shard index -> RCCL exchange to balanced owners + merge -> replica all-gather + merge"),
                      "note": "configs[2]: whole-job wall time from resident text to a queryable index on every GPU"}}
+    note("configs[2] index built: %.1f ms" % (dt * 1e3))
     # ---- configs[3] / configs[4] ----
     info = TermInfo(ix)
     ix.query_batch(np.array([0, 0, 258], np.int32), np.array([0, 3], np.uint64), totals=True)     # decodes the index once (auxiliary structure)
@@ -702,9 +718,11 @@ def big_index_legs(args, rank, world, device, dist, cdev):
     if args.c5_queries > 0:
         legs.append(("c5_phrase", "configs[4]: exact 2- / 3-word phrases sampled from corpus positions", phrase_queries(args.c5_queries, total, synth.SEED_QUERY), 12.0))
     oix = None
+    note("query sets ready")
     for name, label, qs, budget in legs:
         mine = qs[rank::world]                          # sharded by query id
         res, progs = run_query_leg(ix, mine, info, args.query_chunk, label)
+        note("%s: %d queries, %.1f ms device" % (name, res["queries"], res["device_ms"]))
         if dist is not None:
             v = torch.tensor([res["queries"], res["postings_in"], res["units_in"], res["positions_out"], res["pages_out"]], dtype=torch.float64, device=cdev)
             m = torch.tensor([res["device_ms"]], dtype=torch.float64, device=cdev)
@@ -723,7 +741,9 @@ def big_index_legs(args, rank, world, device, dist, cdev):
                 import oracle
                 oix = oracle.Index(stemmers=[])
                 oix.load(ix.index_image(), ix.list_image())
-            res["cpu_baseline"] = oracle_query_sample(oix, progs, budget, min_q=4)
+                note("oracle loaded the big index")
+            res["cpu_baseline"] = oracle_query_sample(oix, progs, budget, min_q=2)
+            note("%s: oracle sample done" % name)
         out[name] = res
     ix.close()
     return out

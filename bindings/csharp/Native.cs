@@ -96,6 +96,11 @@ namespace Docodo
         [DllImport(Lib)] public static extern int dcd_index_set_uniform_pages(IntPtr h, ulong nPages, uint pageChars, ulong firstDoc, char* src, UIntPtr srcLen);
         [DllImport(Lib)] public static extern int dcd_index_open([MarshalAs(UnmanagedType.LPUTF8Str)] string dir, int device, out IntPtr h);
         [DllImport(Lib)] public static extern int dcd_index_from_build(IntPtr build, out IntPtr h);
+        // out-of-core tail (Index.cs:537-689): k-way merge of the sorted ".index" runs of disjoint partitions
+        [DllImport(Lib)] public static extern int dcd_merge_index_files(IntPtr* pathsUtf8, UIntPtr n, [MarshalAs(UnmanagedType.LPUTF8Str)] string outPath);
+        // Index(path, InMemory: false), Index.cs:133-136, 346-348: postings stay in the file
+        [DllImport(Lib)] public static extern int dcd_index_open_lazy([MarshalAs(UnmanagedType.LPUTF8Str)] string dir, int device, ulong residentBytes, out IntPtr h);
+        [DllImport(Lib)] public static extern int dcd_index_lazy_stats(IntPtr h, out ulong listsRead, out ulong bytesRead, out ulong residentTerms);
         [DllImport(Lib)] public static extern int dcd_index_close_words(IntPtr h, char* word, UIntPtr len, uint n, uint* terms, out uint nOut);   // GetCloseWords
         [DllImport(Lib)] public static extern int dcd_index_suggest(IntPtr h, char* prefix, UIntPtr len, uint n, uint* terms, out uint nOut);      // GetSuggessions
         [DllImport(Lib)] public static extern int dcd_index_save(IntPtr h, [MarshalAs(UnmanagedType.LPUTF8Str)] string dir);

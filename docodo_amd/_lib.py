@@ -99,6 +99,9 @@ SIGNATURES = {
     "dcd_index_count": (_i32, [_vp, _pu64]),
     "dcd_index_max_coord": (_i32, [_vp, _pu64]),
     "dcd_index_n_units": (_i32, [_vp, _pu64]),
+    "dcd_merge_index_files": (_i32, [_vp, _sz, C.c_char_p]),
+    "dcd_index_open_lazy": (_i32, [C.c_char_p, _i32, C.c_uint64, C.POINTER(_vp)]),
+    "dcd_index_lazy_stats": (_i32, [_vp, _pu64, _pu64, _pu64]),
     "dcd_index_n_pages": (_i32, [_vp, _pu64]),
     "dcd_index_n_docs": (_i32, [_vp, _pu64]),
     "dcd_index_find": (_i32, [_vp, _vp, _sz, _pu32]),

@@ -1,6 +1,10 @@
 // dcd_host.cpp -- host-side format code: ".index.list" writer/reader (IndexPageList.Save/Load,
 // Build.cs:99-148), BinaryWriter string helpers, UTF-8 <-> UTF-16.
+#include <cstdio>
+#include <memory>
+
 #include "dcd_build_int.h"
+#include "../../include/docodo_hip.h"
 
 namespace dcd {
 
@@ -88,3 +92,104 @@ void write_list_image(const PageTable& pt, std::vector<u8>& out) {
 }
 
 }  // namespace dcd
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Out-of-core tail of a build whose index does not fit the device: every hash partition was merged on the device and saved
+// as a sorted ".index" run; the final ".index" is the k-way merge of the runs by key.  It is MergeFiles (Index.cs:577-689)
+// for inputs that never share a key -- records are copied, nothing is decoded -- streamed through bounded buffers.
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+struct RunReader {
+  FILE* f = nullptr;
+  dcd::ustr key;          // current record's key (UTF-16, the ordinal compare of String.CompareOrdinal)
+  std::string key_bytes;  // its length prefix + UTF-8 bytes, verbatim
+  uint32_t n_units = 0;
+  bool have = false;
+  ~RunReader() { if (f) fclose(f); }
+  // reads the head of the next record (key + count); the payload stays in the file
+  int32_t next() {
+    have = false;
+    int c = fgetc(f);
+    if (c == EOF) return DCD_OK;
+    key_bytes.clear();
+    uint32_t len = 0;
+    int sh = 0;
+    for (;;) {
+      if (c == EOF) return DCD_E_IO;
+      if (sh > 28) return DCD_E_IO;
+      key_bytes.push_back((char)c);
+      len |= (uint32_t)(c & 0x7F) << sh;
+      sh += 7;
+      if (!(c & 0x80)) break;
+      c = fgetc(f);
+    }
+    std::string kb(len, '\0');
+    if (len && fread(&kb[0], 1, len, f) != len) return DCD_E_IO;
+    key_bytes += kb;
+    key.clear();
+    dcd::utf8_to_utf16((const u8*)kb.data(), kb.size(), key);
+    unsigned char nb[4];
+    if (fread(nb, 1, 4, f) != 4) return DCD_E_IO;
+    n_units = (uint32_t)nb[0] | ((uint32_t)nb[1] << 8) | ((uint32_t)nb[2] << 16) | ((uint32_t)nb[3] << 24);
+    if ((int32_t)n_units < 0) return DCD_E_IO;
+    have = true;
+    return DCD_OK;
+  }
+};
+}  // namespace
+
+extern "C" int32_t dcd_merge_index_files(const char* const* paths_utf8, size_t n, const char* out_path_utf8) {
+  using namespace dcd;
+  if ((!paths_utf8 && n) || !out_path_utf8) DCD_FAIL(DCD_E_BADARG, "dcd_merge_index_files: NULL argument");
+  std::vector<std::unique_ptr<RunReader>> runs;
+  u64 max_coord = 0;
+  for (size_t q = 0; q < n; q++) {
+    std::unique_ptr<RunReader> r(new RunReader());
+    r->f = fopen(paths_utf8[q], "rb");
+    if (!r->f) DCD_FAIL(DCD_E_IO, "cannot open %s", paths_utf8[q]);
+    unsigned char h[8];
+    if (fread(h, 1, 8, r->f) != 8) DCD_FAIL(DCD_E_IO, "%s: shorter than its MaxCoord header", paths_utf8[q]);
+    u64 mc = 0;
+    for (int i = 0; i < 8; i++) mc |= (u64)h[i] << (8 * i);
+    max_coord = std::max(max_coord, mc);                       // wr.Write(maxCoords.Max()), Index.cs:596
+    if (r->next() != DCD_OK) DCD_FAIL(DCD_E_IO, "%s: malformed record", paths_utf8[q]);
+    runs.push_back(std::move(r));
+  }
+  FILE* out = fopen(out_path_utf8, "wb");
+  if (!out) DCD_FAIL(DCD_E_IO, "cannot create %s", out_path_utf8);
+  struct Closer { FILE* f; ~Closer() { if (f) fclose(f); } } closer{out};
+  unsigned char h[8];
+  for (int i = 0; i < 8; i++) h[i] = (unsigned char)(max_coord >> (8 * i));
+  if (fwrite(h, 1, 8, out) != 8) DCD_FAIL(DCD_E_IO, "write to %s failed", out_path_utf8);
+  std::vector<char> buf(1 << 20);
+  ustr prev;
+  bool first = true;
+  for (;;) {
+    int best = -1;
+    for (size_t q = 0; q < runs.size(); q++) {
+      if (!runs[q]->have) continue;
+      if (best < 0 || runs[q]->key < runs[best]->key) best = (int)q;
+      else if (runs[q]->key == runs[best]->key)
+        DCD_FAIL(DCD_E_BADARG, "dcd_merge_index_files: a key occurs in two inputs (the inputs must be disjoint partitions)");
+    }
+    if (best < 0) break;
+    RunReader& r = *runs[best];
+    if (!first && !(prev < r.key)) DCD_FAIL(DCD_E_IO, "%s: keys are not strictly ascending", paths_utf8[best]);
+    first = false;
+    prev = r.key;
+    unsigned char nb[4] = {(unsigned char)r.n_units, (unsigned char)(r.n_units >> 8), (unsigned char)(r.n_units >> 16), (unsigned char)(r.n_units >> 24)};
+    if (fwrite(r.key_bytes.data(), 1, r.key_bytes.size(), out) != r.key_bytes.size() || fwrite(nb, 1, 4, out) != 4)
+      DCD_FAIL(DCD_E_IO, "write to %s failed", out_path_utf8);
+    u64 left = 2ull * r.n_units;
+    while (left) {
+      const size_t k = (size_t)std::min<u64>(left, buf.size());
+      if (fread(buf.data(), 1, k, r.f) != k) DCD_FAIL(DCD_E_IO, "%s: truncated posting list", paths_utf8[best]);
+      if (fwrite(buf.data(), 1, k, out) != k) DCD_FAIL(DCD_E_IO, "write to %s failed", out_path_utf8);
+      left -= k;
+    }
+    if (r.next() != DCD_OK) DCD_FAIL(DCD_E_IO, "%s: malformed record", paths_utf8[best]);
+  }
+  closer.f = nullptr;
+  if (fclose(out) != 0) DCD_FAIL(DCD_E_IO, "closing %s failed", out_path_utf8);
+  return DCD_OK;
+}

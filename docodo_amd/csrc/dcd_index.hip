@@ -2,6 +2,9 @@
 // (SortedList keys, Index.cs:151, 235), this[key] (Index.cs:255-263), page table accessors
 // (IndexPageList, Build.cs:41-149).  Query evaluation lives in dcd_query.hip.
 #include <algorithm>
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 #include "dcd_index_int.h"
 #include "dcd_scan.h"
@@ -98,6 +101,81 @@ static int32_t parse_index_image(const u8* p, size_t n, DeviceIndex& ix, std::ve
   return DCD_OK;
 }
 
+LazyPostings::~LazyPostings() {
+  if (fd >= 0) close(fd);
+  if (sub) { dcd_index* p = sub.release(); dcd_index_free(p); }
+}
+
+// The key / stub scan of Index.Load with InMemory == false (Index.cs:321-354): keys, unit counts and payload positions; the
+// payloads are skipped (bin.BaseStream.Seek, :348).  Streams through the file with a bounded buffer.
+static int32_t scan_index_file(int fd, DeviceIndex& ix, LazyPostings& lz) {
+  struct stat stt;
+  if (fstat(fd, &stt) != 0) DCD_FAIL(DCD_E_IO, "cannot stat .index");
+  const u64 n = (u64)stt.st_size;
+  if (n < 8) DCD_FAIL(DCD_E_IO, ".index image shorter than its MaxCoord header");
+  auto rd = [&](u64 off, void* dst, size_t len) -> bool { return pread(fd, dst, len, (off_t)off) == (ssize_t)len; };
+  u8 hdr[8];
+  if (!rd(0, hdr, 8)) DCD_FAIL(DCD_E_IO, "short read from .index");
+  u64 mc = 0;
+  for (int i = 0; i < 8; i++) mc |= (u64)hdr[i] << (8 * i);
+  ix.max_coord = mc;
+  ix.h_term_chars.clear();
+  ix.h_term_str_off.assign(1, 0);
+  ix.h_term_unit_start.assign(1, 0);
+  u64 i = 8;
+  ustr prev;
+  bool first = true;
+  std::vector<u8> buf(1 << 16);
+  while (i < n) {
+    // record head: <= 5 length bytes + key bytes + 4 count bytes; keys are short (<= 3 * 63 UTF-8 bytes)
+    const size_t want = (size_t)std::min<u64>(buf.size(), n - i);
+    if (!rd(i, buf.data(), want)) DCD_FAIL(DCD_E_IO, "short read from .index");
+    size_t k = 0;
+    u32 len = 0;
+    int sh = 0;
+    for (;;) {
+      if (k >= want) DCD_FAIL(DCD_E_IO, "truncated key length in .index");
+      if (sh > 28) DCD_FAIL(DCD_E_IO, "malformed key length in .index (more than 5 length bytes)");
+      u8 c = buf[k++];
+      len |= (u32)(c & 0x7F) << sh;
+      sh += 7;
+      if (!(c & 0x80)) break;
+    }
+    if ((int32_t)len < 0 || k + (size_t)len + 4 > want) DCD_FAIL(DCD_E_IO, "truncated record in .index");
+    ustr key;
+    utf8_to_utf16(buf.data() + k, len, key);
+    k += len;
+    u32 nu = 0;
+    for (int b = 0; b < 4; b++) nu |= (u32)buf[k + b] << (8 * b);
+    k += 4;
+    if ((int32_t)nu < 0 || i + k + 2ull * nu > n) DCD_FAIL(DCD_E_IO, "truncated posting list in .index");
+    if (!first && !(prev < key)) DCD_FAIL(DCD_E_IO, "keys of .index are not strictly ascending (String.CompareOrdinal)");
+    first = false;
+    prev = key;
+    ix.h_term_chars.insert(ix.h_term_chars.end(), (const u16*)key.data(), (const u16*)key.data() + key.size());
+    ix.h_term_str_off.push_back((u32)ix.h_term_chars.size());
+    lz.file_off.push_back(i + k);
+    lz.n_units.push_back(nu);
+    ix.h_term_unit_start.push_back(ix.h_term_unit_start.back() + nu);
+    i += k + 2ull * nu;
+  }
+  ix.n_terms = ix.h_term_str_off.size() - 1;
+  ix.n_units = ix.h_term_unit_start.back();
+  return DCD_OK;
+}
+
+// LoadSequence, Index.cs:198-216: n_units ushorts at the list's file position
+int32_t dcd::lazy_read_units(const LazyPostings& lz, u32 term, u16* dst) {
+  const size_t bytes = 2ull * lz.n_units[term];
+  size_t done = 0;
+  while (done < bytes) {
+    ssize_t r = pread(lz.fd, (u8*)dst + done, bytes - done, (off_t)(lz.file_off[term] + done));
+    if (r <= 0) DCD_FAIL(DCD_E_IO, "short read of a posting list from .index");
+    done += (size_t)r;
+  }
+  return DCD_OK;
+}
+
 // IndexPageList.Load, Build.cs:119-148
 static int32_t parse_list_image(const u8* p, size_t n, PageTable& pt) {
   size_t i = 0;
@@ -149,7 +227,11 @@ __global__ void k_count_term_values(const u16* __restrict__ units, const u64* __
   if (lane_id() == 0) counts[t] = c;
 }
 
-static int32_t index_from_host(DeviceIndex& ix, const std::vector<u16>& units, int device) {
+namespace dcd {
+int32_t index_from_host_units(DeviceIndex& ix, const std::vector<u16>& units, int device);
+}
+static int32_t index_from_host(DeviceIndex& ix, const std::vector<u16>& units, int device) { return dcd::index_from_host_units(ix, units, device); }
+int32_t dcd::index_from_host_units(DeviceIndex& ix, const std::vector<u16>& units, int device) {
   DCD_TRY(ensure_device(device));
   ix.device = device;
   u64 V = ix.n_terms, U = ix.n_units;
@@ -229,6 +311,49 @@ int32_t dcd_index_from_images(const uint8_t* index_img, size_t n_index, const ui
   return DCD_OK;
 }
 
+int32_t dcd_index_open_lazy(const char* dir_utf8, int32_t device, uint64_t resident_bytes, dcd_index** out) {
+  if (!dir_utf8 || !out) DCD_FAIL(DCD_E_BADARG, "dcd_index_open_lazy: NULL argument");
+  std::string d(dir_utf8);
+  if (!d.empty() && d.back() != '/') d.push_back('/');
+  std::unique_ptr<dcd_index> h(new dcd_index());
+  h->lazy.reset(new LazyPostings());
+  h->lazy->resident_budget = resident_bytes ? resident_bytes : (1ull << 30);
+  h->lazy->fd = open((d + ".index").c_str(), O_RDONLY);
+  if (h->lazy->fd < 0) DCD_FAIL(DCD_E_IO, "cannot open %s.index", d.c_str());
+  DCD_TRY(scan_index_file(h->lazy->fd, h->ix, *h->lazy));
+  std::vector<u8> lst;
+  DCD_TRY(read_file(d + ".index.list", lst));
+  DCD_TRY(parse_list_image(lst.data(), lst.size(), h->ix.pages));
+  DCD_TRY(ensure_device(device));
+  // the dictionary and the page table live on the device (dictionary scans, PrepareSearchResult); no posting unit does
+  DeviceIndex& ix = h->ix;
+  ix.device = device;
+  const u64 V = ix.n_terms;
+  DCD_TRY(ix.term_chars.alloc(device, ix.h_term_chars.size() ? ix.h_term_chars.size() : 1));
+  DCD_TRY(ix.term_str_off.alloc(device, V + 1));
+  DCD_TRY(ix.term_unit_start.alloc(device, V + 1));
+  if (!ix.h_term_chars.empty()) DCD_HIP(hipMemcpy(ix.term_chars.p, ix.h_term_chars.data(), ix.h_term_chars.size() * 2, hipMemcpyHostToDevice));
+  DCD_HIP(hipMemcpy(ix.term_str_off.p, ix.h_term_str_off.data(), (V + 1) * 4, hipMemcpyHostToDevice));
+  DCD_HIP(hipMemcpy(ix.term_unit_start.p, ix.h_term_unit_start.data(), (V + 1) * 8, hipMemcpyHostToDevice));
+  if (!ix.pages.end.empty()) {
+    DCD_TRY(ix.page_end.alloc(device, ix.pages.end.size()));
+    DCD_HIP(hipMemcpy(ix.page_end.p, ix.pages.end.data(), ix.pages.end.size() * 8, hipMemcpyHostToDevice));
+  }
+  ix.h_term_item_start.clear();                // Count() of a list is known once it has been read (dcd_index_term_count)
+  DCD_TRY(stream_acquire(device, &h->st));
+  *out = h.release();
+  return DCD_OK;
+}
+
+int32_t dcd_index_lazy_stats(dcd_index* h, uint64_t* lists_read, uint64_t* bytes_read, uint64_t* resident_terms) {
+  if (!h) DCD_FAIL(DCD_E_BADARG, "dcd_index_lazy_stats: NULL handle");
+  if (!h->lazy) DCD_FAIL(DCD_E_STATE, "not an on-disk index (dcd_index_open_lazy)");
+  if (lists_read) *lists_read = h->lazy->fetches;
+  if (bytes_read) *bytes_read = h->lazy->fetched_bytes;
+  if (resident_terms) *resident_terms = h->lazy->terms.size();
+  return DCD_OK;
+}
+
 int32_t dcd_index_open(const char* dir_utf8, int32_t device, dcd_index** out) {
   if (!dir_utf8 || !out) DCD_FAIL(DCD_E_BADARG, "dcd_index_open: NULL argument");
   std::string d(dir_utf8);
@@ -294,6 +419,10 @@ int32_t dcd_index_get(dcd_index* h, uint32_t term, uint16_t* out, size_t cap, si
   u64 a = h->ix.h_term_unit_start[term], b = h->ix.h_term_unit_start[term + 1];
   *n_units = (size_t)(b - a);
   if (!out || cap < b - a) return DCD_E_OVERFLOW;
+  if (h->lazy) {                               // LoadSequence, Index.cs:198-216
+    if (b > a) { DCD_TRY(lazy_read_units(*h->lazy, term, out)); h->lazy->fetches++; h->lazy->fetched_bytes += 2 * (b - a); }
+    return DCD_OK;
+  }
   DCD_TRY(ensure_device(h->ix.device));
   if (b > a) DCD_HIP(hipMemcpy(out, h->ix.units.p + a, (b - a) * 2, hipMemcpyDeviceToHost));
   return DCD_OK;
@@ -303,6 +432,27 @@ int32_t dcd_index_term_count(dcd_index* h, uint32_t term, uint64_t* n_values) {
   if (!h || !n_values) DCD_FAIL(DCD_E_BADARG, "dcd_index_term_count: NULL argument");
   if (term >= h->ix.n_terms) DCD_FAIL(DCD_E_BADARG, "term %u out of range", term);
   DCD_TRY(index_fetch_host(h->ix));
+  if (h->lazy) {
+    // Count() enumerates the list (Search.cs:307): read it, count the terminator units on the device
+    const u32 nu = h->lazy->n_units[term];
+    *n_values = 0;
+    if (!nu) return DCD_OK;
+    std::vector<u16> u(nu);
+    DCD_TRY(lazy_read_units(*h->lazy, term, u.data()));
+    h->lazy->fetches++; h->lazy->fetched_bytes += 2ull * nu;
+    const int dev = h->ix.device;
+    DCD_TRY(ensure_device(dev));
+    StreamScope ss_(h->st);
+    DevBuf<u16> du; DevBuf<u64> us, cnt;
+    DCD_TRY(du.alloc(dev, nu)); DCD_TRY(us.alloc(dev, 2)); DCD_TRY(cnt.alloc(dev, 1));
+    const u64 se[2] = {0, nu};
+    DCD_HIP(hipMemcpyAsync(du.p, u.data(), 2ull * nu, hipMemcpyHostToDevice, h->st));
+    DCD_HIP(hipMemcpyAsync(us.p, se, 16, hipMemcpyHostToDevice, h->st));
+    hipLaunchKernelGGL(k_count_term_values, dim3(1), dim3(64), 0, h->st, du.p, us.p, (u64)1, cnt.p);
+    DCD_HIP(hipMemcpyAsync(n_values, cnt.p, 8, hipMemcpyDeviceToHost, h->st));
+    DCD_HIP(hipStreamSynchronize(h->st));
+    return DCD_OK;
+  }
   *n_values = h->ix.h_term_item_start[term + 1] - h->ix.h_term_item_start[term];
   return DCD_OK;
 }
@@ -340,6 +490,7 @@ extern "C" {
 // ".index" / ".index.list" of an index handle (an adopted build, a merged shard partition, a gathered index)
 int32_t dcd_index_image(dcd_index* h, uint8_t* out, size_t cap, size_t* n) {
   if (!h || !n) DCD_FAIL(DCD_E_BADARG, "dcd_index_image: NULL argument");
+  if (h && h->lazy) DCD_FAIL(DCD_E_STATE, "dcd_index_image: the postings of an on-disk index (dcd_index_open_lazy) are not in memory");
   std::lock_guard<std::mutex> guard(h->mu);
   if (!h->image_bytes) DCD_TRY(index_make_image(h->ix, h->st, h->image, &h->image_bytes));
   *n = (size_t)h->image_bytes;
@@ -372,6 +523,7 @@ int32_t dcd_index_set_list_image(dcd_index* h, const uint8_t* list_img, size_t n
 
 int32_t dcd_index_save(dcd_index* h, const char* dir_utf8) {
   if (!h || !dir_utf8) DCD_FAIL(DCD_E_BADARG, "dcd_index_save: NULL argument");
+  if (h && h->lazy) DCD_FAIL(DCD_E_STATE, "dcd_index_save: the postings of an on-disk index (dcd_index_open_lazy) are not in memory");
   size_t n = 0;
   (void)dcd_index_image(h, nullptr, 0, &n);
   std::vector<u8> img(n);

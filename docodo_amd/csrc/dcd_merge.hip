@@ -462,11 +462,13 @@ int32_t dcd_build_export_heavy(dcd_build* h, uint64_t min_units, uint64_t* fp, u
 }
 int32_t dcd_index_export_heavy(dcd_index* h, uint64_t min_units, uint64_t* fp, uint64_t* n_units, size_t cap, size_t* n_out) {
   if (!h || !n_out || (cap && (!fp || !n_units))) DCD_FAIL(DCD_E_BADARG, "dcd_index_export_heavy: NULL argument");
+  if (h && h->lazy) DCD_FAIL(DCD_E_STATE, "dcd_index_export_heavy: the postings of an on-disk index (dcd_index_open_lazy) are not in memory");
   return export_heavy_impl(&h->ix, h->st, min_units, fp, n_units, cap, n_out);
 }
 int32_t dcd_index_export_plan_balanced(dcd_index* h, uint32_t n_owners, const uint64_t* over_fp, const uint32_t* over_owner, size_t n_over,
                                        const uint32_t* light_thr, uint64_t* term_count, uint64_t* key_count, uint64_t* unit_count) {
   if (!h || !term_count || !key_count || !unit_count) DCD_FAIL(DCD_E_BADARG, "dcd_index_export_plan_balanced: NULL argument");
+  if (h && h->lazy) DCD_FAIL(DCD_E_STATE, "dcd_index_export_plan_balanced: the postings of an on-disk index (dcd_index_open_lazy) are not in memory");
   return export_plan_impl(h, &h->ix, h->st, n_owners, term_count, key_count, unit_count, over_fp, over_owner, n_over, light_thr);
 }
 int32_t dcd_build_export_fill(dcd_build* h, void* meta_dev, uint16_t* keys_dev, uint16_t* units_dev) {
@@ -477,6 +479,7 @@ int32_t dcd_build_export_fill(dcd_build* h, void* meta_dev, uint16_t* keys_dev, 
 }
 int32_t dcd_index_export_plan(dcd_index* h, uint32_t n_owners, uint64_t* term_count, uint64_t* key_count, uint64_t* unit_count) {
   if (!h || !term_count || !key_count || !unit_count) DCD_FAIL(DCD_E_BADARG, "dcd_index_export_plan: NULL argument");
+  if (h && h->lazy) DCD_FAIL(DCD_E_STATE, "dcd_index_export_plan: the postings of an on-disk index (dcd_index_open_lazy) are not in memory");
   return export_plan_impl(h, &h->ix, h->st, n_owners, term_count, key_count, unit_count);
 }
 int32_t dcd_index_export_fill(dcd_index* h, void* meta_dev, uint16_t* keys_dev, uint16_t* units_dev) {

@@ -55,8 +55,29 @@ struct FinalSeq {
   Seg s;
 };
 
-__device__ __forceinline__ const u64* seg_ptr(const Seg& s, const u64* idx_values, const u64* pool) {
-  return (s.kind == 0 ? idx_values : pool) + s.off;
+// Resident coordinates of the index terms.  Streaming '*' / '+' over decoded 8-byte coordinates runs at the HBM roofline of
+// THAT representation (round 3 profile: 570 G postings/s = 4.6 TB/s), so the resident form is PACKED: two planes, the low 32
+// bits and bits 32..39 of every coordinate (5 bytes per posting; any index whose MaxCoord is below 2^40 -- a terabyte of text).
+// Operator results (the work pool), external operands (dcd_seq_and / dcd_seq_or) and indexes beyond 2^40 stay plain u64.
+struct IdxVals {
+  const u64* v64;    // plain (external operands, MaxCoord >= 2^40), or nullptr
+  const u32* lo;     // packed planes (v64 == nullptr)
+  const u8* hi;
+};
+// A coordinate array seen through either representation; which one is wave-uniform (it depends on the operand only).
+struct CV {
+  const u64* v;
+  const u32* lo;
+  const u8* hi;
+  __device__ __forceinline__ u64 operator[](u64 i) const { return v ? v[i] : (((u64)hi[i] << 32) | lo[i]); }
+  __device__ __forceinline__ CV operator+(u64 d) const { CV r; r.v = v ? v + d : nullptr; r.lo = lo ? lo + d : nullptr; r.hi = hi ? hi + d : nullptr; return r; }
+};
+__device__ __forceinline__ CV seg_cv(const Seg& s, const IdxVals& iv, const u64* pool) {
+  CV r;
+  if (s.kind != 0) { r.v = pool + s.off; r.lo = nullptr; r.hi = nullptr; }
+  else if (iv.v64) { r.v = iv.v64 + s.off; r.lo = nullptr; r.hi = nullptr; }
+  else { r.v = nullptr; r.lo = iv.lo + s.off; r.hi = iv.hi + s.off; }
+  return r;
 }
 __device__ __forceinline__ u64 seg_cnt(const Seg& s, const u64* counts) { return s.cnt_ref == NONE32 ? s.cnt_imm : counts[s.cnt_ref]; }
 
@@ -64,17 +85,19 @@ __device__ __forceinline__ u64 seg_cnt(const Seg& s, const u64* counts) { return
 // whole-index decode: values[i] = absolute coordinate of posting i (term-relative prefix sum)
 // ------------------------------------------------------------------------------------------------
 __global__ void k_term_relative(const u64* __restrict__ excl, const u64* __restrict__ deltas, u64 n, const u64* __restrict__ item_start,
-                                u64 n_terms, u64* __restrict__ values) {
+                                u64 n_terms, u64* __restrict__ values, u32* __restrict__ lo, u8* __restrict__ hi) {
   u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   u64 a = 0, b = n_terms;  // last t with item_start[t] <= i
   while (a + 1 < b) { u64 m = (a + b) >> 1; if (item_start[m] <= i) a = m; else b = m; }
-  values[i] = excl[i] + deltas[i] - excl[item_start[a]];
+  const u64 v = excl[i] + deltas[i] - excl[item_start[a]];
+  if (values) values[i] = v;
+  else { lo[i] = (u32)v; hi[i] = (u8)(v >> 32); }
 }
 
 // cell directory: posting i of a term writes the directory entries of the cells between its predecessor's cell
 // (exclusive) and its own (inclusive); the last posting also fills the cells behind it with the posting count
-__global__ void k_build_dir(const u64* __restrict__ values, u64 n, const u64* __restrict__ item_start, u64 n_terms,
+__global__ void k_build_dir(CV values, u64 n, const u64* __restrict__ item_start, u64 n_terms,
                             const u64* __restrict__ dir_off, const u8* __restrict__ dir_shift, u32* __restrict__ dir) {
   u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -89,6 +112,11 @@ __global__ void k_build_dir(const u64* __restrict__ values, u64 n, const u64* __
   u64 c0 = li ? min(values[i - 1] >> sh, n_cells - 1) + 1 : 0;
   for (u64 x = c0; x <= c; x++) d[x] = (u32)li;
   if (li + 1 == cnt) for (u64 x = c + 1; x <= n_cells; x++) d[x] = (u32)cnt;
+}
+
+__global__ void k_unpack(const u32* __restrict__ lo, const u8* __restrict__ hi, u64 n, u64* __restrict__ out) {
+  u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = ((u64)hi[i] << 32) | lo[i];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -106,7 +134,7 @@ __global__ void k_build_dir(const u64* __restrict__ values, u64 n, const u64* __
 #endif
 constexpr u32 GAL_RATIO = DCD_GAL_RATIO;   // gallop when RATIO * |short| <= |long|
 
-__device__ __forceinline__ u64 lower_bound_u64(const u64* __restrict__ a, u64 n, u64 v) {
+__device__ __forceinline__ u64 lower_bound_u64(const CV& a, u64 n, u64 v) {
   u64 lo = 0, hi = n;
   while (lo < hi) { u64 m = (lo + hi) >> 1; if (a[m] < v) lo = m + 1; else hi = m; }
   return lo;
@@ -114,7 +142,7 @@ __device__ __forceinline__ u64 lower_bound_u64(const u64* __restrict__ a, u64 n,
 
 // merged, de-duplicated walk over S[si..se] and L[li..le); calls f(value) in ascending order
 template <typename F>
-__device__ __forceinline__ u32 gal_merge(const u64* __restrict__ Sv, u64 si, u64 se_incl, const u64* __restrict__ Lv, u64 li, u64 le, F f) {
+__device__ __forceinline__ u32 gal_merge(const CV& Sv, u64 si, u64 se_incl, const CV& Lv, u64 li, u64 le, F f) {
   u32 n = 0;
   u64 i = si, j = li;
   while (i <= se_incl || j < le) {
@@ -190,7 +218,7 @@ __device__ __forceinline__ u64 shfl64(u64 v, u32 src_lane) {
 
 // number of A elements among the first d elements of the union of A and B (ties: A first); all 64 lanes
 // probe one candidate each, so the search needs log64 rounds of dependent HBM accesses
-__device__ __forceinline__ u64 wave_split(const u64* __restrict__ A, u64 na, const u64* __restrict__ B, u64 nb, u64 d) {
+__device__ __forceinline__ u64 wave_split(const CV& A, u64 na, const CV& B, u64 nb, u64 d) {
   u64 lo = d > nb ? d - nb : 0, hi = d < na ? d : na;
   const u32 lane = lane_id();
   while (lo < hi) {
@@ -208,7 +236,7 @@ __device__ __forceinline__ u64 wave_split(const u64* __restrict__ A, u64 na, con
 }
 
 // ---- galloping, one slice of the short operand per work item ------------------------------------------------
-__device__ void part_gallop(const u64* __restrict__ Sv, u64 ns, const u64* __restrict__ Lv, u64 nl, bool s_is_a, u32 absR, bool ordered,
+__device__ void part_gallop(const CV& Sv, u64 ns, const CV& Lv, u64 nl, bool s_is_a, u32 absR, bool ordered,
                             u64 i_begin, u64 i_end, u64* __restrict__ tmp_op, u32* rec_lds, u64& count_out, u64& slot_out,
                             const u32* __restrict__ ldir, u32 ldir_shift, u64 ldir_last) {
   const u32 lane = threadIdx.x;
@@ -410,7 +438,7 @@ __device__ void part_gallop(const u64* __restrict__ Sv, u64 ns, const u64* __res
 #endif
 constexpr u32 GAL_PER = DCD_GAL_PER;      // short-list elements per galloping work item (256 / 512 / 1024 / 2048 -> 26.5 / 24.3 / 23.8 / 23.8 ms per 20 k C4 queries)
 constexpr u8 MODE_NONE = 0, MODE_STREAM = 1, MODE_GALLOP = 2;
-__global__ void k_pair_plan(const PairOp* __restrict__ ops, u32 n_ops, const u64* __restrict__ idx_values, const u64* __restrict__ pool,
+__global__ void k_pair_plan(const PairOp* __restrict__ ops, u32 n_ops, IdxVals idx_values, const u64* __restrict__ pool,
                             const u64* __restrict__ counts, u64 PART, u32* __restrict__ items, u8* __restrict__ mode) {
   u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i > n_ops) return;
@@ -425,7 +453,7 @@ __global__ void k_pair_plan(const PairOp* __restrict__ ops, u32 n_ops, const u64
   else if (!is_or && absR != 0) {
     const bool a_short = na <= nb;
     const u64 ns = a_short ? na : nb, nl = a_short ? nb : na;
-    const u64* Lv = seg_ptr(a_short ? op.b : op.a, idx_values, pool);
+    const CV Lv = seg_cv(a_short ? op.b : op.a, idx_values, pool);
     if (ns * GAL_RATIO <= nl && (Lv[nl - 1] - Lv[0]) / nl > 4ull * absR) { m = MODE_GALLOP; n = (ns + GAL_PER - 1) / GAL_PER; }
   }
   items[i] = (u32)n;
@@ -442,7 +470,7 @@ __device__ unsigned long long g_prof[16];
 #define PROF(i)
 #endif
 __global__ __launch_bounds__(PW_T, DCD_PW_WAVES) void k_pair_parts(const PairOp* __restrict__ ops, u32 n_ops, const u64* __restrict__ part_base,
-                                                    const u64* __restrict__ idx_values, const u64* __restrict__ pool,
+                                                    IdxVals idx_values, const u64* __restrict__ pool,
                                                     const u64* __restrict__ counts, u64* __restrict__ tmp, u64* __restrict__ part_count,
                                                     u64* __restrict__ part_src, u64 PART, const u32* __restrict__ dirs,
                                                     u64 dir_max_coord, const u8* __restrict__ op_mode) {
@@ -467,8 +495,8 @@ __global__ __launch_bounds__(PW_T, DCD_PW_WAVES) void k_pair_parts(const PairOp*
   PROF(0);   // operator lookup
   const u64 p = w - part_base[oi];
   const PairOp op = ops[oi];
-  const u64* A = seg_ptr(op.a, idx_values, pool);
-  const u64* B = seg_ptr(op.b, idx_values, pool);
+  const CV A = seg_cv(op.a, idx_values, pool);
+  const CV B = seg_cv(op.b, idx_values, pool);
   const u64 na = seg_cnt(op.a, counts), nb = seg_cnt(op.b, counts);
   u64* tmp_op = tmp + op.tmp_off;
   const u32 absR = (u32)max(abs(op.Ra), abs(op.Rb));
@@ -480,8 +508,8 @@ __global__ __launch_bounds__(PW_T, DCD_PW_WAVES) void k_pair_parts(const PairOp*
     if (gallop) {
       const bool a_short = na <= nb;
       const u64 ns = a_short ? na : nb, nl = a_short ? nb : na;
-      const u64* Sv = a_short ? A : B;
-      const u64* Lv = a_short ? B : A;
+      const CV Sv = a_short ? A : B;
+      const CV Lv = a_short ? B : A;
       const u64 i_begin = min(ns, p * (u64)GAL_PER), i_end = min(ns, i_begin + GAL_PER);
       const Seg& ls = a_short ? op.b : op.a;
       const u32* ldir = (ls.kind == 0 && ls.dir_shift != NONE32) ? dirs + ls.dir_off : nullptr;
@@ -551,13 +579,25 @@ __global__ __launch_bounds__(PW_T, DCD_PW_WAVES) void k_pair_parts(const PairOp*
         const u32 newA = nra - keepA, newB = nrb - keepB;
         // newA + newB <= PW_TILE (a tile frees ca + cb slots): ONE stream of PW_ITEMS loads per lane covers both operands
         u64 pf[PW_ITEMS];
-        const u64* srcA = A + ia + ra;
-        const u64* srcB = B + ib + rb - newA;
+        {
+          // (per lane the element comes from ONE operand: plane pointers are selected per lane, so that a packed operand costs
+          // its two plane loads and a plain one its single load -- never the loads of both operands)
+          const u64 offA = ia + ra, offB = ib + rb - newA;
 #pragma unroll
-        for (int q = 0; q < (int)PW_ITEMS; q++) {
-          const u32 xx = lane + (u32)q * PW_T;
-          const u64* sp = xx < newA ? srcA : srcB;
-          pf[q] = xx < newA + newB ? sp[xx] : 0;
+          for (int q = 0; q < (int)PW_ITEMS; q++) {
+            const u32 xx = lane + (u32)q * PW_T;
+            const bool fa = xx < newA, act = xx < newA + newB;
+            const u64 ix = (fa ? offA : offB) + xx;
+            const u64* pv = fa ? A.v : B.v;
+            const u32* pl = fa ? A.lo : B.lo;
+            const u8* ph = fa ? A.hi : B.hi;
+            u64 val = 0;
+            if (act) {
+              if (pv) val = pv[ix];
+              else val = ((u64)ph[ix] << 32) | pl[ix];
+            }
+            pf[q] = val;
+          }
         }
         PROF(3);   // half-cleaner, refill request
 #pragma unroll
@@ -895,7 +935,7 @@ __device__ __forceinline__ u64 page_of(const ResParams& P, u64 c) {  // first pa
 // validity is a prefix property, so one scan (page starts) + one min-reduction (first coordinate past
 // the cap) + one scan (document starts among the valid ones) per iteration is enough.
 template <bool FILL>
-__global__ __launch_bounds__(RS_T) void k_result(const FinalSeq* __restrict__ fin, u32 nq, const u64* __restrict__ idx_values,
+__global__ __launch_bounds__(RS_T) void k_result(const FinalSeq* __restrict__ fin, u32 nq, IdxVals idx_values,
                                                 const u64* __restrict__ pool, const u64* __restrict__ counts, ResParams P,
                                                 QCounts* __restrict__ qc, const u64* __restrict__ page_base, const u64* __restrict__ pos_base,
                                                 const u64* __restrict__ doc_base, u32* __restrict__ o_page_index, u64* __restrict__ o_pos_off,
@@ -909,7 +949,7 @@ __global__ __launch_bounds__(RS_T) void k_result(const FinalSeq* __restrict__ fi
   const u32 q = blockIdx.x, tid = threadIdx.x;
   if (q >= nq) return;
   const Seg sg = fin[q].s;
-  const u64* V = seg_ptr(sg, idx_values, pool);
+  const CV V = seg_cv(sg, idx_values, pool);
   const u64 n = seg_cnt(sg, counts);
   if (FILL && qc[q].status != DCD_OK) return;   // the count pass found a coordinate beyond the last page: no output
   if (tid == 0) { c_prev_page = ~0ull; c_pages = 0; c_docs = 0; c_err = 0; c_done = 0; c_pos = 0; }
@@ -1122,7 +1162,13 @@ static int32_t ensure_values(dcd_index* h) {
   hipStream_t st = h->st;
   StreamScope ss_(st);
   const u64 U = ix.n_units, N = ix.n_postings, V = ix.n_terms;
-  DCD_TRY(h->values.alloc(dev, N ? N : 1));
+  // packed planes (5 bytes per posting) whenever every coordinate fits 40 bits; DOCODO_QUERY_PACKED=0: plain u64 (A/B runs)
+  static const bool env_packed = !(getenv("DOCODO_QUERY_PACKED") && atoi(getenv("DOCODO_QUERY_PACKED")) == 0);
+  h->values_packed = env_packed && ix.max_coord < (1ull << 40);
+  if (h->values_packed) { DCD_TRY(h->val_lo.alloc(dev, N ? N : 1)); DCD_TRY(h->val_hi.alloc(dev, N ? N : 1)); }
+  else DCD_TRY(h->values.alloc(dev, N ? N : 1));
+  CV all;
+  all.v = h->values_packed ? nullptr : h->values.p; all.lo = h->values_packed ? h->val_lo.p : nullptr; all.hi = h->values_packed ? h->val_hi.p : nullptr;
   if (N) {
     DevBuf<u64> part, deltas, excl, sscr;
     u64 nb = div_up(U, CODEC_TILE);
@@ -1140,7 +1186,8 @@ static int32_t ensure_values(dcd_index* h) {
     }
     hipLaunchKernelGGL(k_dec_deltas, dim3((u32)nb), dim3(CODEC_THREADS), 0, st, ix.units.p, U, part.p, deltas.p);
     scan_exclusive<u64, u64>(deltas.p, excl.p, N, sscr.p, st);
-    hipLaunchKernelGGL(k_term_relative, dim3((u32)div_up(N, 256)), dim3(256), 0, st, excl.p, deltas.p, N, ix.term_item_start.p, V, h->values.p);
+    hipLaunchKernelGGL(k_term_relative, dim3((u32)div_up(N, 256)), dim3(256), 0, st, excl.p, deltas.p, N, ix.term_item_start.p, V,
+                       (u64*)all.v, (u32*)all.lo, (u8*)all.hi);
     // cell directories for the longer lists: about one cell per posting (cell width 2^shift)
     constexpr u64 DIR_MIN = 1024;
     const u32 coord_bits = log2_ceil(ix.max_coord + 2);
@@ -1168,7 +1215,7 @@ static int32_t ensure_values(dcd_index* h) {
       DCD_TRY(d_sh.alloc(dev, V));
       DCD_HIP(hipMemcpyAsync(d_off.p, h->h_dir_off.data(), (V + 1) * 8, hipMemcpyHostToDevice, st));
       DCD_HIP(hipMemcpyAsync(d_sh.p, h->h_dir_shift.data(), V, hipMemcpyHostToDevice, st));
-      hipLaunchKernelGGL(k_build_dir, dim3((u32)div_up(N, 256)), dim3(256), 0, st, h->values.p, N, ix.term_item_start.p, V, d_off.p, d_sh.p,
+      hipLaunchKernelGGL(k_build_dir, dim3((u32)div_up(N, 256)), dim3(256), 0, st, all, N, ix.term_item_start.p, V, d_off.p, d_sh.p,
                          h->dir.p);
     }
     DCD_HIP(hipStreamSynchronize(st));
@@ -1242,7 +1289,10 @@ static int32_t run_batch(dcd_index* h, const int32_t* prog, const u64* prog_off,
   StreamScope ss_(st);
   DCD_TRY(ensure_device(dev));
   if (!ext_values) DCD_TRY(ensure_values(h));
-  const u64* idx_values = ext_values ? ext_values : h->values.p;
+  IdxVals idx_values;
+  idx_values.v64 = ext_values ? ext_values : (h->values_packed ? nullptr : h->values.p);
+  idx_values.lo = (!ext_values && h->values_packed) ? h->val_lo.p : nullptr;
+  idx_values.hi = (!ext_values && h->values_packed) ? h->val_hi.p : nullptr;
 
   // ---- plan --------------------------------------------------------------------------------------
   std::vector<std::vector<PairOp>> rounds;
@@ -1471,12 +1521,19 @@ static int32_t run_batch(dcd_index* h, const int32_t* prog, const u64* prog_off,
     for (size_t q = 0; q < nq; q++) {
       const Seg& s = finals[q].s;
       u64 n = s.cnt_ref == NONE32 ? s.cnt_imm : cnt[s.cnt_ref];
-      const u64* src = (s.kind == 0 ? idx_values : pool.p) + s.off;
       size_t base = R->seq_units.size();
       if (n) {
         if (inj_late) DCD_FAIL(DCD_E_NOMEM, "injected late out-of-memory (DOCODO_QUERY_TEST_NOMEM_LATE)");
-        DevBuf<u64> part;
+        DevBuf<u64> part, plain;
         DevBuf<u16> du;
+        const u64* src;
+        if (s.kind != 0) src = pool.p + s.off;
+        else if (idx_values.v64) src = idx_values.v64 + s.off;
+        else {                                   // a final sequence that is an index term itself (single-term query): unpack it
+          DCD_TRY(plain.alloc(dev, n));
+          hipLaunchKernelGGL(k_unpack, dim3((u32)div_up(n, 256)), dim3(256), 0, st, idx_values.lo + s.off, idx_values.hi + s.off, n, plain.p);
+          src = plain.p;
+        }
         u64 nb = encode_nblocks(n);
         DCD_TRY(part.alloc(dev, nb + 1));
         DCD_TRY(du.alloc(dev, 5 * n));
@@ -1575,12 +1632,96 @@ static void append_results(dcd_results& dst, const dcd_results& src) {
   dst.ms_device += src.ms_device;
 }
 
+// On-disk postings (dcd_index_open_lazy; Index.cs:198-216, 346-348): a batch reads the lists of the terms its programs name,
+// builds a small RESIDENT index over them (same device layout as a loaded index; it borrows the page table of the handle) and
+// evaluates the programs there with the term ids translated.  The subset of the previous batches is kept while the union fits
+// the handle's resident budget, so that a working set of hot terms is read from the file once.
+static int32_t lazy_query_batch(dcd_index* h, const int32_t* prog, const uint64_t* prog_off, size_t n_queries, const dcd_query_opts* opts,
+                                dcd_results** out) {
+  LazyPostings& lz = *h->lazy;
+  const u64 V = h->ix.n_terms;
+  std::vector<u32> need;
+  const u64 end = n_queries ? prog_off[n_queries] : 0;
+  for (size_t q = 0; q < n_queries; q++) {
+    for (u64 i = prog_off[q]; i < prog_off[q + 1];) {
+      const int32_t opc = prog[i];
+      if (opc == DCD_OP_TERM) {
+        if (i + 3 > prog_off[q + 1]) DCD_FAIL(DCD_E_BADARG, "query %zu: truncated TERM", q);
+        if (prog[i + 1] < 0 || (u64)prog[i + 1] >= V) DCD_FAIL(DCD_E_BADARG, "query %zu: term %d out of range", q, prog[i + 1]);
+        need.push_back((u32)prog[i + 1]);
+        i += 3;
+      } else if (opc == DCD_OP_SETR) i += 2;
+      else i += 1;
+    }
+  }
+  std::sort(need.begin(), need.end());
+  need.erase(std::unique(need.begin(), need.end()), need.end());
+  if (!std::includes(lz.terms.begin(), lz.terms.end(), need.begin(), need.end()) || !lz.sub) {
+    // new subset: the union with what is resident if that fits the budget, else the batch's own terms
+    std::vector<u32> uni;
+    std::set_union(lz.terms.begin(), lz.terms.end(), need.begin(), need.end(), std::back_inserter(uni));
+    auto bytes_of = [&](const std::vector<u32>& ts) { u64 b = 0; for (u32 t : ts) b += 2ull * lz.n_units[t]; return b; };
+    // resident cost of a term: its units (2 B) + the decoded coordinates the operators stream (5 B per posting, <= per unit)
+    const std::vector<u32>& pick = (7 * bytes_of(uni) / 2 <= lz.resident_budget) ? uni : need;
+    std::unique_ptr<dcd_index> sub(new dcd_index());
+    DeviceIndex& sx = sub->ix;
+    sx.max_coord = h->ix.max_coord;
+    sx.n_terms = pick.size();
+    sx.h_term_str_off.assign(pick.size() + 1, 0);          // (the subset is addressed by ordinal only: no keys)
+    sx.h_term_unit_start.assign(1, 0);
+    std::vector<u16> units;
+    {
+      u64 tot = 0;
+      for (u32 t : pick) tot += lz.n_units[t];
+      units.resize(tot);
+    }
+    u64 at = 0;
+    for (u32 t : pick) {
+      // a list that is resident already is read again only if the subset is rebuilt (the file cache of the OS holds it)
+      if (lz.n_units[t]) DCD_TRY(lazy_read_units(lz, t, units.data() + at));
+      lz.fetches++; lz.fetched_bytes += 2ull * lz.n_units[t];
+      at += lz.n_units[t];
+      sx.h_term_unit_start.push_back(at);
+    }
+    sx.n_units = at;
+    DCD_TRY(index_from_host_units(sx, units, h->ix.device));
+    DCD_TRY(stream_acquire(h->ix.device, &sub->st));
+    if (lz.sub) { dcd_index* old = lz.sub.release(); dcd_index_free(old); }
+    lz.sub = std::move(sub);
+    lz.terms = pick;
+  }
+  // translate the programs
+  std::vector<int32_t> p2(prog, prog + end);
+  for (size_t q = 0; q < n_queries; q++) {
+    for (u64 i = prog_off[q]; i < prog_off[q + 1];) {
+      const int32_t opc = p2[i];
+      if (opc == DCD_OP_TERM) {
+        p2[i + 1] = (int32_t)(std::lower_bound(lz.terms.begin(), lz.terms.end(), (u32)p2[i + 1]) - lz.terms.begin());
+        i += 3;
+      } else if (opc == DCD_OP_SETR) i += 2;
+      else i += 1;
+    }
+  }
+  // the subset borrows the page table (host side and device copy) for the call
+  dcd_index* sub = lz.sub.get();
+  std::swap(sub->ix.pages, h->ix.pages);
+  std::swap(sub->ix.page_end, h->ix.page_end);
+  const int32_t st = dcd_query_batch(sub, p2.data(), prog_off, n_queries, opts, out);
+  std::swap(sub->ix.pages, h->ix.pages);
+  std::swap(sub->ix.page_end, h->ix.page_end);
+  return st;
+}
+
 int32_t dcd_query_batch(dcd_index* h, const int32_t* prog, const uint64_t* prog_off, size_t n_queries, const dcd_query_opts* opts,
                         dcd_results** out) {
   if (!h || !prog_off || !out || (!prog && n_queries && prog_off[n_queries] != 0)) DCD_FAIL(DCD_E_BADARG, "dcd_query_batch: NULL argument");
   dcd_query_opts o;
   if (opts) o = *opts; else dcd_query_default_opts(&o);
   std::lock_guard<std::mutex> guard(h->mu);
+  if (h->lazy) {
+    DCD_TRY(ensure_device(h->ix.device));
+    return lazy_query_batch(h, prog, prog_off, n_queries, opts, out);
+  }
   DCD_TRY(ensure_device(h->ix.device));
   DCD_TRY(index_fetch_host(h->ix));     // (host mirrors of a merged index are fetched on first use)
   // The work pool and the scratch arena are sized for the worst case of every operator; a batch whose worst case exceeds

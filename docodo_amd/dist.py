@@ -431,3 +431,100 @@ class SegmentedBuilder:
         owned = distributed_merge(part, group, self.device, balanced)
         part.close()
         return owned
+
+
+class OutOfCoreBuilder:
+    """A corpus whose INDEX does not fit the device: the reference's temp-index flush (Build.cs:335-340: a temp index goes to disk
+    whenever MaxTmpIndexItems postings have accumulated) and MergeAll (Index.cs:537-573) with the device as the merge engine and
+    host memory or files as the tier below it.
+
+      add_pages_dev   every segment (a doc-range shard with global coordinates, shard-only) is built on the device, exported into
+                      `partitions` hash partitions and SPILLED -- spill="host": pinned host memory, spill="disk": files
+                      <work_dir>/seg<S>.<kind>.npy (the N.tmpind of this path) -- and its device memory released;
+      finish(out)     partition by partition: the segments' slices come back to the device, dcd_merge_shards merges them (first
+                      delta of every appended segment re-coded), the partition is saved as a sorted run; the runs have disjoint
+                      keys and are merged into <out>/.index by a streaming k-way merge of records (dcd_merge_index_files).
+                      Peak device memory = one segment build, or one partition of the index -- never the whole index.
+                      Returns the index opened ON DISK (Index.LoadOnDisk): its postings stay in the file.
+
+    Uniform device-resident pages (the synthetic corpora); one document per page."""
+
+    def __init__(self, page_chars, work_dir, partitions=8, max_segment_chars=3_584_000_000, device=0, source="syn", spill="disk"):
+        import os
+        assert spill in ("disk", "host")
+        self.page_chars, self.work_dir, self.K, self.device, self.source, self.spill = page_chars, work_dir, partitions, device, source, spill
+        self.max_pages = max(1, max_segment_chars // page_chars)
+        os.makedirs(work_dir, exist_ok=True)
+        self.segments = []                    # per segment: counts [3][K], max_coord, and the three buffers (arrays or file paths)
+        self.n_pages, self.n_postings, self.spilled_bytes = 0, 0, 0
+
+    def add_pages_dev(self, text_dev_ptr, n_pages):
+        import os
+        from .index import Builder
+        done = 0
+        while done < n_pages:
+            k = min(self.max_pages, n_pages - done)
+            first = self.n_pages + done
+            b = Builder(coord_base=first * self.page_chars, device=self.device, shard_only=True)
+            b.AddUniformPagesDev(text_dev_ptr + done * self.page_chars, k, self.page_chars, first_doc=first, source=self.source)
+            st = b.Finish()
+            self.n_postings += st.n_postings
+            e = export_shard(b, self.K)
+            b.close()
+            seg = {"tc": e.term_count.copy(), "kc": e.key_count.copy(), "uc": e.unit_count.copy(), "max_coord": int(e.max_coord)}
+            for kind, t in (("meta", e.meta), ("keys", e.keys), ("units", e.units)):
+                if self.spill == "host":
+                    h = torch.empty(t.numel(), dtype=torch.uint8, pin_memory=True)
+                    h.copy_(t)
+                    seg[kind] = h
+                else:
+                    path = os.path.join(self.work_dir, "seg%d.%s.npy" % (len(self.segments), kind))
+                    np.save(path, t.cpu().numpy())
+                    seg[kind] = path
+                self.spilled_bytes += t.numel()
+            del e
+            self.segments.append(seg)
+            _lib.pool_trim(self.device)       # (the point of the exercise: the device keeps nothing of a finished segment)
+            done += k
+        self.n_pages += n_pages
+
+    def _slice(self, seg, kind, counts, width, owner):
+        off = _split_offsets((counts * width).tolist())
+        a, b = int(off[owner]), int(off[owner + 1])
+        src = seg[kind]
+        if isinstance(src, str):
+            arr = np.load(src, mmap_mode="r")[a:b]          # only the partition's bytes are read from the file
+            return torch.from_numpy(np.ascontiguousarray(arr))
+        return src[a:b]
+
+    def finish(self, out_dir, resident_bytes=0):
+        import ctypes as C
+        import os
+        os.makedirs(out_dir, exist_ok=True)
+        dev = torch.device("cuda", self.device)
+        runs = []
+        S = len(self.segments)
+        mx = max([s["max_coord"] for s in self.segments] or [0])
+        for k in range(self.K):
+            tc = np.array([s["tc"][k] for s in self.segments], np.uint64)
+            kc = np.array([s["kc"][k] for s in self.segments], np.uint64)
+            uc = np.array([s["uc"][k] for s in self.segments], np.uint64)
+            bufs = []
+            for kind, name, width in (("meta", "tc", META_BYTES), ("keys", "kc", 2), ("units", "uc", 2)):
+                parts = [self._slice(s, kind, s[name], width, k) for s in self.segments]
+                bufs.append(torch.cat(parts).to(dev) if parts else torch.empty(0, dtype=torch.uint8, device=dev))
+            ix = merge_received(tc, kc, uc, bufs[0], bufs[1], bufs[2], mx, self.device)
+            del bufs
+            set_uniform_pages(ix, self.n_pages, self.page_chars, 0, self.source)
+            run_dir = os.path.join(self.work_dir, "run%d" % k)
+            os.makedirs(run_dir, exist_ok=True)
+            ix.Save(run_dir)                                  # sorted run of this partition (+ the page list, the same for every run)
+            ix.close()
+            _lib.pool_trim(self.device)
+            runs.append(os.path.join(run_dir, ".index").encode("utf-8"))
+        arr = (C.c_char_p * len(runs))(*runs)
+        check(lib().dcd_merge_index_files(arr, len(runs), os.path.join(out_dir, ".index").encode("utf-8")))
+        import shutil
+        shutil.copyfile(os.path.join(self.work_dir, "run0", ".index.list"), os.path.join(out_dir, ".index.list"))
+        self.segments = []
+        return Index.LoadOnDisk(out_dir, self.device, resident_bytes)

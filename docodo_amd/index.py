@@ -227,6 +227,20 @@ class Index:
         return cls(h, device)
 
     @classmethod
+    def LoadOnDisk(cls, dirpath, device=0, resident_bytes=0):
+        """new Index(path, InMemory: false) (Index.cs:124-136, 346-348): dictionary + page table loaded, posting lists read from
+        ".index" when a key / a query batch asks for them (LoadSequence, Index.cs:198-216)."""
+        h = C.c_void_p()
+        check(lib().dcd_index_open_lazy(dirpath.encode("utf-8"), device, int(resident_bytes), C.byref(h)))
+        return cls(h, device)
+
+    def lazy_stats(self):
+        """(lists read, bytes read, terms resident now) of an on-disk index."""
+        a, b, c = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+        check(lib().dcd_index_lazy_stats(self.h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
+    @classmethod
     def from_images(cls, index_bytes, list_bytes, device=0):
         ib = np.frombuffer(index_bytes, np.uint8)
         lb = np.frombuffer(list_bytes, np.uint8)

@@ -213,6 +213,16 @@ int32_t dcd_index_from_build(dcd_build* b, dcd_index** out);          /* adopt t
 int32_t dcd_index_open(const char* dir_utf8, int32_t device, dcd_index** out);   /* Index.Load */
 int32_t dcd_index_from_images(const uint8_t* index_img, size_t n_index, const uint8_t* list_img, size_t n_list,
                               int32_t device, dcd_index** out);
+/* Index.Load with InMemory == false (Index.cs:133-136, 346-348): the term dictionary and the page table are loaded (host +
+ * device), the posting lists STAY in "<dir>/.index" -- one stub per key {n_units, file position}.  dcd_index_get reads a list
+ * when it is asked for (LoadSequence, Index.cs:198-216); dcd_query_batch reads the lists its programs name, keeps them as a
+ * small resident index on the device (at most ~resident_bytes of device memory, 0 = 1 GiB; the union with the previous
+ * batches' lists while it fits) and evaluates there -- same results as the in-memory handle.  Dictionary calls (find, key,
+ * close_words, suggest), the page calls and dcd_index_term_count work as on any handle; export / image / save need the
+ * postings in memory and fail with DCD_E_STATE.  dcd_index_lazy_stats: lists and bytes read from the file so far, terms
+ * resident now. */
+int32_t dcd_index_open_lazy(const char* dir_utf8, int32_t device, uint64_t resident_bytes, dcd_index** out);
+int32_t dcd_index_lazy_stats(dcd_index* h, uint64_t* lists_read, uint64_t* bytes_read, uint64_t* resident_terms);
 void dcd_index_free(dcd_index* h);
 int32_t dcd_index_count(dcd_index* h, uint64_t* n_terms);              /* Index.Count */
 int32_t dcd_index_max_coord(dcd_index* h, uint64_t* v);                /* Index.MaxCoord */
@@ -352,6 +362,14 @@ int32_t dcd_index_set_list_image(dcd_index* h, const uint8_t* list_img, size_t n
 int32_t dcd_index_save(dcd_index* h, const char* dir_utf8);
 int32_t dcd_index_set_uniform_pages(dcd_index* h, uint64_t n_pages, uint32_t page_chars, uint64_t first_doc,
                                     const uint16_t* source, size_t source_len);
+/* Out-of-core tail of a build whose index does not fit the device (the reference's temp-index flush + MergeAll, Build.cs:335-340,
+ * Index.cs:537-573): the doc-range segments are exported to K hash partitions and spilled (host memory or files), every
+ * partition is merged on the device by itself (dcd_merge_shards) and saved as a sorted run (dcd_index_save), and this call
+ * merges the runs -- ".index" files whose key sets are DISJOINT -- into one ".index" in ordinal key order: a streaming k-way
+ * merge of records on the host (MergeFiles, Index.cs:577-689, for inputs that never share a key: nothing is decoded).
+ * MaxCoord = max of the inputs (Index.cs:596).  A key in two inputs is DCD_E_BADARG.  The result is opened with
+ * dcd_index_open or, when it does not fit, dcd_index_open_lazy. */
+int32_t dcd_merge_index_files(const char* const* paths_utf8, size_t n, const char* out_path_utf8);
 
 /* ------------------------------------------------------------------------------------------
  * Measurement support (bench.py / tests): the synthetic corpus of SURVEY.md Appendix F.
