@@ -721,7 +721,8 @@ def big_index_legs(args, rank, world, device, dist, cdev):
     note("query sets ready")
     for name, label, qs, budget in legs:
         mine = qs[rank::world]                          # sharded by query id
-        res, progs = run_query_leg(ix, mine, info, args.query_chunk, label)
+        # (a phrase of two head terms yields up to 30 001 pages with their positions: smaller calls bound the device-side result arrays)
+        res, progs = run_query_leg(ix, mine, info, args.query_chunk if name == "c4_and3" else max(1, args.query_chunk // 4), label)
         note("%s: %d queries, %.1f ms device" % (name, res["queries"], res["device_ms"]))
         if dist is not None:
             v = torch.tensor([res["queries"], res["postings_in"], res["units_in"], res["positions_out"], res["pages_out"]], dtype=torch.float64, device=cdev)

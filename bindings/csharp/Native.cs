@@ -14,12 +14,13 @@ namespace Docodo
                                   public ulong coord_base; public uint vocab_capacity_log2, flags; }   // flags: 1 = DCD_BUILD_SHARD_ONLY
         [StructLayout(LayoutKind.Sequential)]
         public struct QueryOpts { public int max_found_pages, max_found_docs; public float doc_rank_multiply; public int want_sequences;
-                                  public byte* doc_match; public ulong n_doc_match; }   // -filter: one byte per document, null = none
+                                  public byte* doc_match; public ulong n_doc_match; public int no_download, reserved; }   // -filter: one byte per document, null = none
         [StructLayout(LayoutKind.Sequential)]
         public struct ResultsView { public ulong n_queries; public int* status; public ulong* page_off; public uint* page_index;
                                     public float* page_rank; public ulong* pos_off; public int* pos; public ulong* doc_off;
                                     public uint* doc_index; public float* doc_rank; public uint* doc_n_pages;
-                                    public ulong* seq_off; public ushort* seq_units; public int* seq_R; public float ms_device; }
+                                    public ulong* seq_off; public ushort* seq_units; public int* seq_R; public float ms_device;
+                                    public ulong n_pages_total, n_pos_total, n_docs_total; }
 
         [DllImport(Lib)] public static extern int dcd_last_error(byte* buf, UIntPtr cap);
         [DllImport(Lib)] public static extern int dcd_version();
@@ -102,6 +103,7 @@ namespace Docodo
         [DllImport(Lib)] public static extern int dcd_index_open_lazy([MarshalAs(UnmanagedType.LPUTF8Str)] string dir, int device, ulong residentBytes, out IntPtr h);
         [DllImport(Lib)] public static extern int dcd_index_lazy_stats(IntPtr h, out ulong listsRead, out ulong bytesRead, out ulong residentTerms);
         [DllImport(Lib)] public static extern int dcd_index_close_words(IntPtr h, char* word, UIntPtr len, uint n, uint* terms, out uint nOut);   // GetCloseWords
+        [DllImport(Lib)] public static extern int dcd_index_like_words(IntPtr h, char* pattern, UIntPtr len, uint n, uint* terms, out uint nOut);   // GetLikeWords
         [DllImport(Lib)] public static extern int dcd_index_suggest(IntPtr h, char* prefix, UIntPtr len, uint n, uint* terms, out uint nOut);      // GetSuggessions
         [DllImport(Lib)] public static extern int dcd_index_save(IntPtr h, [MarshalAs(UnmanagedType.LPUTF8Str)] string dir);
         [DllImport(Lib)] public static extern void dcd_index_free(IntPtr h);

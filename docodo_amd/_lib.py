@@ -46,7 +46,8 @@ KERNEL_NAMES = ["k_tok_count", "k_tok_emit", "k_rs_hist", "k_rs_scatter", "k_enc
 
 class QueryOpts(C.Structure):
     _fields_ = [("max_found_pages", C.c_int32), ("max_found_docs", C.c_int32), ("doc_rank_multiply", C.c_float),
-                ("want_sequences", C.c_int32), ("doc_match", C.c_void_p), ("n_doc_match", C.c_uint64)]
+                ("want_sequences", C.c_int32), ("doc_match", C.c_void_p), ("n_doc_match", C.c_uint64),
+                ("no_download", C.c_int32), ("reserved", C.c_int32)]
 
 
 class ResultsView(C.Structure):
@@ -55,7 +56,8 @@ class ResultsView(C.Structure):
                 ("pos_off", C.POINTER(C.c_uint64)), ("pos", C.POINTER(C.c_int32)), ("doc_off", C.POINTER(C.c_uint64)),
                 ("doc_index", C.POINTER(C.c_uint32)), ("doc_rank", C.POINTER(C.c_float)),
                 ("doc_n_pages", C.POINTER(C.c_uint32)), ("seq_off", C.POINTER(C.c_uint64)),
-                ("seq_units", C.POINTER(C.c_uint16)), ("seq_R", C.POINTER(C.c_int32)), ("ms_device", C.c_float)]
+                ("seq_units", C.POINTER(C.c_uint16)), ("seq_R", C.POINTER(C.c_int32)), ("ms_device", C.c_float),
+                ("n_pages_total", C.c_uint64), ("n_pos_total", C.c_uint64), ("n_docs_total", C.c_uint64)]
 
 
 # name -> (restype, argtypes); mirrors include/docodo_hip.h one to one
@@ -123,6 +125,7 @@ SIGNATURES = {
     "dcd_merge_finish": (_i32, [_vp, _vp, C.POINTER(_vp)]),
     "dcd_merge_free": (None, [_vp]),
     "dcd_index_close_words": (_i32, [_vp, _vp, _sz, C.c_uint32, _vp, _vp]),
+    "dcd_index_like_words": (_i32, [_vp, _vp, _sz, C.c_uint32, _vp, _vp]),
     "dcd_index_suggest": (_i32, [_vp, _vp, _sz, C.c_uint32, _vp, _vp]),
     "dcd_index_export_plan": (_i32, [_vp, C.c_uint32, _vp, _vp, _vp]),
     "dcd_index_export_fill": (_i32, [_vp, _vp, _vp, _vp]),

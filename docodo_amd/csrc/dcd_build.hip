@@ -220,6 +220,13 @@ __global__ void k_explicit(const u32* __restrict__ xoff, const u32* __restrict__
 }
 
 __global__ void k_set_u64(u64* p, u64 v) { *p = v; }
+// explicit page offsets -> one bit per character of the text: bit i = a page starts at i (TokParams::page_bits)
+__global__ void k_page_bits(const u64* __restrict__ page_off, u64 n, u32* __restrict__ bits) {
+  u64 p = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  const u64 o = page_off[p];
+  atomicOr(&bits[o >> 5], 1u << (o & 31));
+}
 // coordinate of the last tuple of a tile-strided buffer (the last non-empty tile is almost always the last one)
 __global__ void k_last_strided_coord(const uint2* __restrict__ tuples, const u32* __restrict__ cnt, u64 n_tiles, u32 stride, u32* out) {
   for (u64 t = n_tiles; t-- > 0;) {
@@ -1267,8 +1274,18 @@ static int32_t build_phase1(dcd_build* h, bool codes_mode) {
   t_tok.start_at_start_of(t_all);
   TokParams P;
   P.n_chars = n_chars;
-  P.page_off = d_page_off.p;
   P.n_pages = n_pages_dev;
+  // explicit page offsets: the bitmap of page starts the tokeniser reads (inside the timed region: it is device work the
+  // uniform-pages entry point does not have -- a memset of n_chars / 8 bytes and one atomic per page)
+  DevBuf<u32> d_page_bits;
+  P.page_bits = nullptr;
+  if (!uniform) {
+    const u64 words = (n_chars + TK_SPAN + 128) / 32 + 4;
+    DCD_TRY(d_page_bits.alloc(dev, words));
+    DCD_HIP(hipMemsetAsync(d_page_bits.p, 0, words * 4, st));
+    hipLaunchKernelGGL(k_page_bits, dim3((u32)div_up(n_pages_dev + 1, 256)), dim3(256), 0, st, d_page_off.p, n_pages_dev + 1, d_page_bits.p);
+    P.page_bits = d_page_bits.p;
+  }
   P.min_len = (u32)h->opts.min_word_length;
   P.max_len = (u32)h->opts.max_word_length;
   P.uniform_page_chars = uniform ? (u32)h->pages.uni_chars : 0u;

@@ -9,6 +9,7 @@
 #include "dcd_index_int.h"
 #include "dcd_scan.h"
 #include "dcd_sort.h"
+#include "dcd_tokenize.h"
 
 namespace dcd {
 DeviceIndex* build_take_index(dcd_build* b);
@@ -47,7 +48,63 @@ __global__ void k_levenshtein(const u16* __restrict__ chars, const u32* __restri
   }
   out[t] = make_uint2(d, (u32)t);
 }
+// dictionary scan of GetLikeWords (Search.cs:160-167): keys whose first unit is a letter and that match the pattern as an
+// UNANCHORED regex in which every '_' stands for ".*" -- i.e. the pattern's literal segments occur in the key in order, anywhere.
+// One thread per key, earliest-match scan (sufficient for an existence test); the pattern sits in constant kernel arguments.
+struct LikePat { u16 c[64]; u32 len; };
+__global__ void k_like_words(const u16* __restrict__ chars, const u32* __restrict__ str_off, u64 n_terms, LikePat pat, const u8* __restrict__ cls,
+                             u32* __restrict__ flag) {
+  u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_terms) return;
+  const u16* s = chars + str_off[t];
+  const u32 n = str_off[t + 1] - str_off[t];
+  bool ok = n > 0 && (cls[s[0]] & 1u) != 0;                    // IsLetter(key[0]): \p{L}
+  u32 at = 0;                                                  // the next segment may start at or behind `at`
+  for (u32 i = 0; ok && i <= pat.len;) {
+    u32 j = i;
+    while (j < pat.len && pat.c[j] != u'_') j++;               // segment [i, j)
+    const u32 m = j - i;
+    if (m) {
+      bool found = false;
+      for (u32 p = at; p + m <= n; p++) {
+        u32 q = 0;
+        while (q < m && s[p + q] == pat.c[i + q]) q++;
+        if (q == m) { found = true; at = p + m; break; }
+      }
+      ok = found;
+    }
+    i = j + 1;
+  }
+  flag[t] = ok ? 1u : 0u;
+}
+// the first `cap` flagged terms, in dictionary order (Take(MAX_LIKE_WORDS)): one workgroup walks the flags
+__global__ __launch_bounds__(1024) void k_take_flagged(const u32* __restrict__ flag, u64 n_terms, u32 cap, u32* __restrict__ out, u32* __restrict__ n_out) {
+  __shared__ u32 s_w[16];
+  __shared__ u32 s_base;
+  if (threadIdx.x == 0) s_base = 0;
+  __syncthreads();
+  for (u64 t0 = 0; t0 < n_terms && s_base < cap; t0 += 1024) {
+    const u64 t = t0 + threadIdx.x;
+    const u32 f = t < n_terms ? flag[t] : 0u;
+    const u64 m = ballot64(f != 0);
+    const u32 w = threadIdx.x >> 6;
+    if (lane_id() == 0) s_w[w] = popc64(m);
+    __syncthreads();
+    u32 before = s_base;
+    for (u32 k = 0; k < w; k++) before += s_w[k];
+    const u32 pos = before + mbcnt(m);
+    if (f && pos < cap) out[pos] = (u32)t;
+    __syncthreads();
+    if (threadIdx.x == 0) { u32 tot = 0; for (u32 k = 0; k < 16; k++) tot += s_w[k]; s_base += tot; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *n_out = s_base < cap ? s_base : cap;
+}
 }  // namespace dcd
+
+namespace dcd {
+int32_t get_char_tables16(int device, CharTables16* out);
+}
 
 using namespace dcd;
 
@@ -578,6 +635,40 @@ int32_t dcd_index_close_words(dcd_index* h, const uint16_t* word, size_t len, ui
   DCD_HIP(hipStreamSynchronize(st));
   DCD_HIP(hipGetLastError());
   for (u32 i = 0; i < k; i++) out_terms[i] = top[i].y;
+  return DCD_OK;
+}
+
+// GetLikeWords, Search.cs:158-167: the first n keys (dictionary order) that begin with a letter and match `pattern`, where '_'
+// (what the request rewriter makes of '?', Search.cs:340) stands for ".*" and the match is unanchored.  The host keeps the
+// trivial branches (no '_' or !bKeepForms: the word itself; fewer than 2 characters: nothing).
+int32_t dcd_index_like_words(dcd_index* h, const uint16_t* pattern, size_t len, uint32_t n, uint32_t* out_terms, uint32_t* n_out) {
+  if (!h || (!pattern && len) || !out_terms || !n_out) DCD_FAIL(DCD_E_BADARG, "dcd_index_like_words: NULL argument");
+  if (len > 64) DCD_FAIL(DCD_E_UNSUPPORTED, "patterns longer than 64 UTF-16 units are not supported");
+  std::lock_guard<std::mutex> guard(h->mu);
+  DeviceIndex& ix = h->ix;
+  const u64 V = ix.n_terms;
+  *n_out = 0;
+  if (!V || !n) return DCD_OK;
+  const int dev = ix.device;
+  DCD_TRY(ensure_device(dev));
+  hipStream_t st = h->st;
+  StreamScope ss_(st);
+  CharTables16 tab{nullptr, nullptr};
+  DCD_TRY(get_char_tables16(dev, &tab));
+  LikePat pat;
+  memset(&pat, 0, sizeof pat);
+  for (size_t i = 0; i < len; i++) pat.c[i] = pattern[i];
+  pat.len = (u32)len;
+  DevBuf<u32> flag, out, cnt;
+  DCD_TRY(flag.alloc(dev, V)); DCD_TRY(out.alloc(dev, n)); DCD_TRY(cnt.alloc(dev, 1));
+  hipLaunchKernelGGL(k_like_words, dim3((u32)div_up(V, 256)), dim3(256), 0, st, ix.term_chars.p, ix.term_str_off.p, V, pat, tab.cls, flag.p);
+  hipLaunchKernelGGL(k_take_flagged, dim3(1), dim3(1024), 0, st, flag.p, V, n, out.p, cnt.p);
+  u32 k = 0;
+  DCD_HIP(hipMemcpyAsync(&k, cnt.p, 4, hipMemcpyDeviceToHost, st));
+  DCD_HIP(hipStreamSynchronize(st));
+  DCD_HIP(hipGetLastError());
+  if (k) DCD_HIP(hipMemcpy(out_terms, out.p, (size_t)k * 4, hipMemcpyDeviceToHost));
+  *n_out = k;
   return DCD_OK;
 }
 

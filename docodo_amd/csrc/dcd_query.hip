@@ -1153,6 +1153,8 @@ struct dcd_results {
   std::vector<u16> seq_units;
   float ms_device = 0;
   bool have_seq = false;
+  bool downloaded = true;        // false: dcd_query_opts.no_download -- only status / page_off / doc_off and the totals are here
+  u64 n_pages_total = 0, n_pos_total = 0, n_docs_total = 0;
 };
 
 static int32_t ensure_values(dcd_index* h) {
@@ -1474,10 +1476,10 @@ static int32_t run_batch(dcd_index* h, const int32_t* prog, const u64* prog_off,
   DCD_TRY(o_doc_index_tmp.alloc(dev, tot_docs + 1)); DCD_TRY(o_doc_index.alloc(dev, tot_docs + 1));
   DCD_TRY(o_doc_first.alloc(dev, tot_docs + nq + 1));  // n_docs + 1 entries per query
   DCD_TRY(o_doc_rank.alloc(dev, tot_docs + 1)); DCD_TRY(o_doc_np.alloc(dev, tot_docs + 1));
+  DCD_HIP(hipMemcpyAsync(o_pos_off.p + tot_pages, &tot_pos, 8, hipMemcpyHostToDevice, st));   // (also for an empty batch: pos_off = [0])
   if (nq) {
     hipLaunchKernelGGL((k_result<true>), dim3((u32)nq), dim3(RS_T), 0, st, d_fin.p, (u32)nq, idx_values, pool.p, counts.p, P, d_qc.p,
                        d_pbase.p, d_sbase.p, d_dbase.p, o_page_index.p, o_pos_off.p, o_pos.p, o_doc_index_tmp.p, o_doc_first.p);
-    DCD_HIP(hipMemcpyAsync(o_pos_off.p + tot_pages, &tot_pos, 8, hipMemcpyHostToDevice, st));
     if (tot_pages) hipLaunchKernelGGL(k_page_rank, dim3((u32)div_up(tot_pages, 256)), dim3(256), 0, st, o_pos_off.p, o_pos.p, tot_pages, o_page_rank.p);
     hipLaunchKernelGGL(k_doc_rank, dim3((u32)nq), dim3(256), 0, st, (u32)nq, d_qc.p, d_pbase.p, d_dbase.p, o_doc_first.p, o_page_index.p,
                        o_page_rank.p, P.page_hdr, P.doc_mult, o_doc_index_tmp.p, o_doc_index.p, o_doc_rank.p, o_doc_np.p, P.page_doc);
@@ -1495,6 +1497,12 @@ static int32_t run_batch(dcd_index* h, const int32_t* prog, const u64* prog_off,
   R->page_off.resize(nq + 1); R->doc_off.resize(nq + 1);
   DCD_HIP(hipMemcpy(R->page_off.data(), d_pbase.p, (nq + 1) * 8, hipMemcpyDeviceToHost));
   DCD_HIP(hipMemcpy(R->doc_off.data(), d_dbase.p, (nq + 1) * 8, hipMemcpyDeviceToHost));
+  R->n_pages_total = tot_pages; R->n_pos_total = tot_pos; R->n_docs_total = tot_docs;
+  if (o.no_download) {
+    // every result array was produced on the device; only the per-query counts travel (throughput measurements)
+    R->downloaded = false;
+    return DCD_OK;
+  }
   R->page_index.resize(tot_pages); R->page_rank.resize(tot_pages); R->pos_off.resize(tot_pages + 1); R->pos.resize(tot_pos);
   R->doc_index.resize(tot_docs); R->doc_rank.resize(tot_docs); R->doc_n_pages.resize(tot_docs);
   if (tot_pages) {
@@ -1568,6 +1576,8 @@ void dcd_query_default_opts(dcd_query_opts* o) {
   o->want_sequences = 0;
   o->doc_match = nullptr;
   o->n_doc_match = 0;
+  o->no_download = 0;
+  o->reserved = 0;
 }
 
 // Worst-case device elements a query needs: every operator result can be as long as both operands (work pool), plus
@@ -1604,7 +1614,9 @@ static u64 query_pool_need(const DeviceIndex& ix, const int32_t* prog, u64 a, u6
 }
 
 static void append_results(dcd_results& dst, const dcd_results& src) {
-  const u64 p0 = dst.page_index.size(), s0 = dst.pos.size(), d0 = dst.doc_index.size(), u0 = dst.seq_units.size();
+  const u64 p0 = dst.n_pages_total, s0 = dst.n_pos_total, d0 = dst.n_docs_total, u0 = dst.seq_units.size();
+  dst.n_pages_total += src.n_pages_total; dst.n_pos_total += src.n_pos_total; dst.n_docs_total += src.n_docs_total;
+  dst.downloaded = src.downloaded;
   const bool first = dst.page_off.empty();
   dst.status.insert(dst.status.end(), src.status.begin(), src.status.end());
   auto app_off = [&](std::vector<u64>& d, const std::vector<u64>& sv, u64 base) {
@@ -1615,8 +1627,10 @@ static void append_results(dcd_results& dst, const dcd_results& src) {
   app_off(dst.page_off, src.page_off, p0);
   app_off(dst.doc_off, src.doc_off, d0);
   // pos_off has one entry per page plus a final total: keep a single running terminator
-  if (!dst.pos_off.empty()) dst.pos_off.pop_back();
-  for (size_t k = 0; k < src.pos_off.size(); k++) dst.pos_off.push_back(src.pos_off[k] + s0);
+  if (src.downloaded) {
+    if (!dst.pos_off.empty()) dst.pos_off.pop_back();
+    for (size_t k = 0; k < src.pos_off.size(); k++) dst.pos_off.push_back(src.pos_off[k] + s0);
+  }
   dst.page_index.insert(dst.page_index.end(), src.page_index.begin(), src.page_index.end());
   dst.page_rank.insert(dst.page_rank.end(), src.page_rank.begin(), src.page_rank.end());
   dst.pos.insert(dst.pos.end(), src.pos.begin(), src.pos.end());
@@ -1791,6 +1805,11 @@ int32_t dcd_results_get(dcd_results* r, dcd_results_view* v) {
   v->doc_n_pages = r->doc_n_pages.data();
   if (r->have_seq) { v->seq_off = r->seq_off.data(); v->seq_units = r->seq_units.data(); v->seq_R = r->seq_R.data(); }
   v->ms_device = r->ms_device;
+  v->n_pages_total = r->n_pages_total; v->n_pos_total = r->n_pos_total; v->n_docs_total = r->n_docs_total;
+  if (!r->downloaded) {          // (no_download: the CSR arrays stayed on the device and are gone; the offsets and totals are valid)
+    v->page_index = nullptr; v->page_rank = nullptr; v->pos_off = nullptr; v->pos = nullptr;
+    v->doc_index = nullptr; v->doc_rank = nullptr; v->doc_n_pages = nullptr;
+  }
   return DCD_OK;
 }
 

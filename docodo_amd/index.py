@@ -360,6 +360,11 @@ class Index:
         """GetCloseWords (Search.cs:168-174): terms of the n keys closest to `word` by Levenshtein distance."""
         return self._term_list(lib().dcd_index_close_words, word, n)
 
+    def like_words(self, pattern, n=100):
+        """GetLikeWords (Search.cs:158-167): terms of the first n keys that start with a letter and match `pattern` ('_' = ".*",
+        unanchored) -- a dictionary scan on the device."""
+        return self._term_list(lib().dcd_index_like_words, pattern, n)
+
     def suggest(self, prefix, n=10):
         """Term selection of GetSuggessions (Search.cs:176-188)."""
         return self._term_list(lib().dcd_index_suggest, prefix, n)
@@ -405,6 +410,8 @@ class Index:
         if doc_match is not None:
             dm = np.ascontiguousarray(doc_match, np.uint8)
             o.doc_match, o.n_doc_match = dm.ctypes.data, dm.size
+        if totals:
+            o.no_download = 1          # (the result arrays are produced on the device; only the counts come back)
         r = C.c_void_p()
         check(lib().dcd_query_batch(self.h, prog.ctypes.data if prog.size else None, off.ctypes.data, off.size - 1,
                                     C.byref(o), C.byref(r)))
@@ -412,10 +419,7 @@ class Index:
             v = ResultsView()
             check(lib().dcd_results_get(r, C.byref(v)))
             if totals:
-                nq = int(v.n_queries)
-                n_pages = int(v.page_off[nq]) if nq else 0
-                return {"ms": float(v.ms_device), "n_pages": n_pages, "n_pos": int(v.pos_off[n_pages]) if nq else 0,
-                        "n_docs": int(v.doc_off[nq]) if nq else 0}
+                return {"ms": float(v.ms_device), "n_pages": int(v.n_pages_total), "n_pos": int(v.n_pos_total), "n_docs": int(v.n_docs_total)}
             if keep_handle:
                 return v.ms_device
             return QueryBatchResult(v)

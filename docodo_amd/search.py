@@ -77,13 +77,8 @@ class Search:
                 return [], False, 0
             exact = True
             words = []
-            if len(word) >= 2:                                             # GetLikeWords, Search.cs:160-167
-                pat = regex.compile(word.replace("_", ".*"))
-                for k in self._keys_list():
-                    if k and regex.match(r"\p{L}", k[0]) and pat.search(k):
-                        words.append(k)
-                        if len(words) >= MAX_LIKE_WORDS:
-                            break
+            if len(word) >= 2:                                             # GetLikeWords, Search.cs:160-167: dictionary scan on the device
+                words = [self.ix.key(t) for t in self.ix.like_words(word, MAX_LIKE_WORDS)]
         prog, n, nfound = [], 0, 0
         for w in words:
             codes = self.get_word_codes(w)

@@ -238,6 +238,9 @@ int32_t dcd_index_term_count(dcd_index* h, uint32_t term, uint64_t* n_values);  
 /* GetCloseWords, Search.cs:168-174 (Levenshtein, Index.cs:46-95): the n keys closest to `word`, ties in dictionary
  * order -- a dictionary scan on the device (one thread per key, stable radix sort by distance) */
 int32_t dcd_index_close_words(dcd_index* h, const uint16_t* word, size_t len, uint32_t n, uint32_t* out_terms, uint32_t* n_out);
+/* GetLikeWords, Search.cs:158-167 (wildcard expansion of SearchWord): the first n keys, in dictionary order, whose first unit is a
+ * letter and that match `pattern` as an unanchored regex in which '_' stands for ".*" -- a dictionary scan on the device */
+int32_t dcd_index_like_words(dcd_index* h, const uint16_t* pattern, size_t len, uint32_t n, uint32_t* out_terms, uint32_t* n_out);
 /* term selection of GetSuggessions, Search.cs:176-188: keys starting with `prefix`, longer than it, first unit >= 'A',
  * by descending IndexSequence.Count (ushort units), the first n */
 int32_t dcd_index_suggest(dcd_index* h, const uint16_t* prefix, size_t len, uint32_t n, uint32_t* out_terms, uint32_t* n_out);
@@ -266,6 +269,12 @@ typedef struct dcd_query_opts {
    * 0 is never added to foundDocs (its pages stay in foundPages), PrepareSearchResult Search.cs:386-396.  NULL = no filter. */
   const uint8_t* doc_match;
   uint64_t n_doc_match;      /* must equal the number of documents when doc_match != NULL */
+  /* 1: the batch is evaluated and every result array (pages, positions, ranks, documents) is PRODUCED on the device as
+   * always, but only the per-query counts (status, page_off, doc_off) and the totals are copied back: the page / pos / doc
+   * arrays of the view are NULL.  For throughput measurements and for callers that only need counts (WordInfo.nFound-style
+   * statistics): the D2H copy of the CSR arrays of 100 k phrase queries is tens of gigabytes. */
+  int32_t no_download;
+  int32_t reserved;          /* 0 */
 } dcd_query_opts;
 void dcd_query_default_opts(dcd_query_opts* o);
 int32_t dcd_query_batch(dcd_index* h, const int32_t* prog, const uint64_t* prog_off, size_t n_queries,
@@ -289,6 +298,7 @@ typedef struct dcd_results_view {
   const uint16_t* seq_units;
   const int32_t* seq_R;
   float ms_device;              /* device time of the batch (HIP events) */
+  uint64_t n_pages_total, n_pos_total, n_docs_total;   /* sizes of the page / position / document arrays (also with no_download) */
 } dcd_results_view;
 int32_t dcd_results_get(dcd_results* r, dcd_results_view* out);
 void dcd_results_free(dcd_results* r);
