@@ -216,6 +216,7 @@ def run_query_leg(ix, queries, info, chunk, label, reps=1):
                 best = r
         tot_ms += best["ms"]
         nq += len(off) - 1
+        note("  %s: call %d: %d queries, %.1f ms device" % (label[:12], len(per) + 1, len(off) - 1, best["ms"]))
         n_pages += best["n_pages"]
         n_pos += best["n_pos"]
         per.append(round(best["ms"], 2))

@@ -962,6 +962,34 @@ static int32_t add_pages_impl(dcd_build* h, const void* text, u64 n_chars, const
     return DCD_OK;
   };
   u64 staged = h->n_chars;   // text index the next body character will get
+  h->page_off.reserve(h->page_off.size() + n_pages);
+  h->pages.end.reserve(h->pages.end.size() + n_pages);
+  if (!uniform) h->pages.ids.reserve(h->pages.ids.size() + n_pages);
+  if (!docs_per_page) h->pages.page_doc.reserve(h->pages.page_doc.size() + n_pages);
+  if (uniform && docs_per_page && device_text) {
+    // the bulk case (one document per page, id "1", text already on the device): page bookkeeping only -- two appends per page
+    // in one tight loop (a million pages took 14 ms through the general loop below; the text itself is not touched)
+    const size_t e0 = h->pages.end.size();
+    h->page_off.resize(h->page_off.size() + n_pages);
+    h->pages.end.resize(e0 + n_pages);
+    u64* po = h->page_off.data() + (h->page_off.size() - n_pages);
+    u64* pe = h->pages.end.data() + e0;
+    const u64 c0 = h->coord_cursor, s0 = staged;
+    u64 bad = 0;
+    for (size_t p = 0; p < n_pages; p++) {
+      bad |= (u64)(page_off[p + 1] <= page_off[p]);
+      po[p] = s0 + page_off[p + 1];
+      pe[p] = c0 + page_off[p + 1];
+    }
+    if (bad) {
+      h->page_off.resize(h->page_off.size() - n_pages);
+      h->pages.end.resize(e0);
+      DCD_FAIL(DCD_E_BADARG, "page_off must be strictly ascending (docs_per_page requires non-empty pages)");
+    }
+    h->coord_cursor = c0 + n_chars;
+    h->last_is_explicit = false;
+    return DCD_OK;
+  }
   for (size_t p = 0; p < n_pages; p++) {
     if (page_off[p + 1] < page_off[p]) DCD_FAIL(DCD_E_BADARG, "page_off must be ascending");
     const u64 len = page_off[p + 1] - page_off[p];

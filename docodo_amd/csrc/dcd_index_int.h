@@ -31,8 +31,7 @@ struct dcd_index {
   std::mutex mu;
   // decoded postings (built lazily on the first query): segment-relative values per term
   dcd::DevBuf<u64> values;   // [n_postings], term t at [term_item_start[t], term_item_start[t+1]) -- only when not packed
-  // ... packed (MaxCoord < 2^40, the default): two planes, 5 bytes per posting instead of 8 -- the streaming operators are
-  // bound by the bytes of this array (dcd_query.hip, IdxVals)
+  // ... packed (DOCODO_QUERY_PACKED=1 and MaxCoord < 2^40): two planes, 5 bytes per posting instead of 8 (dcd_query.hip, IdxVals)
   dcd::DevBuf<u32> val_lo;   // low 32 bits
   dcd::DevBuf<u8> val_hi;    // bits 32..39
   bool values_packed = false;
@@ -43,6 +42,9 @@ struct dcd_index {
   dcd::DevBuf<u32> dir;
   std::vector<u64> h_dir_off;    // [n_terms + 1]
   std::vector<u8> h_dir_shift;   // [n_terms]; 255 = no directory
+  // work pool + scratch arena of the query batches (dcd_query.hip run_batch): grown on demand, kept until the handle is freed
+  dcd::DevBuf<u64> work_pool, work_tmp;
+  u64 work_pool_elems = 0, work_tmp_elems = 0;
   // ".index" bytes of this index, generated on demand (dcd_index_image / dcd_index_save)
   dcd::DevBuf<u8> image;
   u64 image_bytes = 0;

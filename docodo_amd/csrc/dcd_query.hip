@@ -55,10 +55,9 @@ struct FinalSeq {
   Seg s;
 };
 
-// Resident coordinates of the index terms.  Streaming '*' / '+' over decoded 8-byte coordinates runs at the HBM roofline of
-// THAT representation (round 3 profile: 570 G postings/s = 4.6 TB/s), so the resident form is PACKED: two planes, the low 32
-// bits and bits 32..39 of every coordinate (5 bytes per posting; any index whose MaxCoord is below 2^40 -- a terabyte of text).
-// Operator results (the work pool), external operands (dcd_seq_and / dcd_seq_or) and indexes beyond 2^40 stay plain u64.
+// Resident coordinates of the index terms: plain u64 (default), or PACKED into two planes -- the low 32 bits and bits 32..39 of
+// every coordinate, 5 bytes per posting, for any index whose MaxCoord is below 2^40 (DOCODO_QUERY_PACKED=1; see ensure_values
+// for the measurement that keeps it optional).  Operator results (the work pool) and external operands are always plain u64.
 struct IdxVals {
   const u64* v64;    // plain (external operands, MaxCoord >= 2^40), or nullptr
   const u32* lo;     // packed planes (v64 == nullptr)
@@ -1164,8 +1163,11 @@ static int32_t ensure_values(dcd_index* h) {
   hipStream_t st = h->st;
   StreamScope ss_(st);
   const u64 U = ix.n_units, N = ix.n_postings, V = ix.n_terms;
-  // packed planes (5 bytes per posting) whenever every coordinate fits 40 bits; DOCODO_QUERY_PACKED=0: plain u64 (A/B runs)
-  static const bool env_packed = !(getenv("DOCODO_QUERY_PACKED") && atoi(getenv("DOCODO_QUERY_PACKED")) == 0);
+  // DOCODO_QUERY_PACKED=1: packed planes (5 bytes per posting instead of 8) when every coordinate fits 40 bits -- for hosts that
+  // are short of device memory.  NOT the default: measured on the 10 M-doc index (20 k three-term AND queries), packed 25.0 ms
+  // against 20.4 ms plain -- the operators are bound by instruction issue and load latency, not by the bytes of this array
+  // (two loads + a shift / or per access instead of one load), so the smaller footprint buys nothing in time.
+  static const bool env_packed = getenv("DOCODO_QUERY_PACKED") && atoi(getenv("DOCODO_QUERY_PACKED")) != 0;
   h->values_packed = env_packed && ix.max_coord < (1ull << 40);
   if (h->values_packed) { DCD_TRY(h->val_lo.alloc(dev, N ? N : 1)); DCD_TRY(h->val_hi.alloc(dev, N ? N : 1)); }
   else DCD_TRY(h->values.alloc(dev, N ? N : 1));
@@ -1389,11 +1391,28 @@ static int32_t run_batch(dcd_index* h, const int32_t* prog, const u64* prog_off,
   if (max_items >= (1ull << 31)) DCD_FAIL(DCD_E_OVERFLOW, "query batch too large: %llu work items in one round", (unsigned long long)max_items);
 
   // ---- device buffers -------------------------------------------------------------------------------
-  DevBuf<u64> pool, counts, tmp, d_part_count, d_part_src, d_part_excl, d_part_scr;
-  DCD_TRY(pool.alloc(dev, pool_elems ? pool_elems : 1));
+  // The work pool and the scratch arena are the two big buffers of a batch (tens of gigabytes for a sub-batch of phrase
+  // queries over head terms).  They belong to the INDEX HANDLE and only ever grow: allocating them per call meant a hipMalloc /
+  // hipFree of up to 100 GB each per sub-batch -- round 3 measured 87 s of wall time around 0.76 s of device time for 2 500
+  // phrase queries on the 10 M-doc index -- and blocks of that size do not survive in the library's device cache (its cap is
+  // half of the device memory).  dcd_query_batch bounds a sub-batch by DOCODO_QUERY_ARENA_BYTES (default: a quarter of the device
+  // memory), so the arena settles at that size after the first large batch.
+  DevBuf<u64> counts, d_part_count, d_part_src, d_part_excl, d_part_scr;
+  struct ArenaView { u64* p; } pool{nullptr}, tmp{nullptr};
+  auto reserve = [&](DevBuf<u64>& buf, u64& have, u64 want) -> int32_t {
+    if (want <= have && buf.p) return DCD_OK;
+    buf.reset();
+    have = 0;
+    DCD_TRY(buf.alloc(dev, want ? want : 1));
+    have = want ? want : 1;
+    return DCD_OK;
+  };
+  DCD_TRY(reserve(h->work_pool, h->work_pool_elems, pool_elems));
+  pool.p = h->work_pool.p;
   DCD_TRY(counts.alloc(dev, n_counts ? n_counts : 1));
   {
-    DCD_TRY(tmp.alloc(dev, tmp_elems ? tmp_elems : 1));
+    DCD_TRY(reserve(h->work_tmp, h->work_tmp_elems, tmp_elems));
+    tmp.p = h->work_tmp.p;
     DCD_TRY(d_part_count.alloc(dev, max_items + 1));
     DCD_TRY(d_part_src.alloc(dev, max_items + 1));
     DCD_TRY(d_part_excl.alloc(dev, max_items + 1));
@@ -1744,8 +1763,15 @@ int32_t dcd_query_batch(dcd_index* h, const int32_t* prog, const uint64_t* prog_
   // and if a sub-batch still runs out of memory (result arrays, fragmentation) it is retried with half the budget.
   size_t free_b = 0, total_b = 0;
   DCD_HIP(hipMemGetInfo(&free_b, &total_b));
-  const u64 avail_b = (u64)free_b + (u64)dev_pool_cached_bytes(h->ix.device);
+  // (what the handle's arena holds already is available to the batch)
+  const u64 avail_b = (u64)free_b + (u64)dev_pool_cached_bytes(h->ix.device) + 8 * (h->work_pool_elems + h->work_tmp_elems);
   u64 budget = std::max<u64>(avail_b / 4 * 3 / 8, 1ull << 24);   // elements of 8 bytes
+  {
+    // ... and no more than the arena bound: a sub-batch beyond it would only buy a larger hipMalloc (see run_batch)
+    static const u64 env_arena = getenv("DOCODO_QUERY_ARENA_BYTES") ? strtoull(getenv("DOCODO_QUERY_ARENA_BYTES"), nullptr, 10) : 0;
+    const u64 arena_b = env_arena ? env_arena : (u64)total_b / 4;
+    budget = std::max<u64>(std::min<u64>(budget, arena_b / 8), 1ull << 24);
+  }
   if (const char* e = getenv("DOCODO_QUERY_POOL_ELEMS")) budget = std::max<u64>(strtoull(e, nullptr, 10), 1);   // tests
   std::unique_ptr<dcd_results> R(new dcd_results());
   size_t q0 = 0;
@@ -1780,7 +1806,9 @@ int32_t dcd_query_batch(dcd_index* h, const int32_t* prog, const uint64_t* prog_
       if (st == DCD_OK) { append_results(*R, part); q0 = q1; continue; }
     }
     if (st != DCD_E_NOMEM || q1 - q0 <= 1) return st;
-    dev_pool_trim(h->ix.device);                           // out of memory: release the cache, halve the sub-batch, try again
+    h->work_pool.reset(); h->work_tmp.reset();              // out of memory: give the arena back, release the cache,
+    h->work_pool_elems = h->work_tmp_elems = 0;
+    dev_pool_trim(h->ix.device);                           // halve the sub-batch, try again
     budget = std::max<u64>(1, std::min(budget, acc) / 2);
     if (single) R.reset(new dcd_results());                // nothing of a failed single attempt survives
     single = false;

@@ -93,7 +93,11 @@ def test_synthetic_index_on_disk_batches(tmp_path, oracle_mod):
         return prog, off
 
     def same(a, c):
-        for name in ("status", "page_off", "page_index", "pos_off", "pos", "doc_off", "doc_index", "doc_n_pages", "seq_off", "seq_units", "seq_R"):
+        names = ["status", "page_off", "page_index", "pos_off", "pos", "doc_off", "doc_index", "doc_n_pages"]
+        assert (a.seq_off is None) == (c.seq_off is None)
+        if a.seq_off is not None:
+            names += ["seq_off", "seq_units", "seq_R"]
+        for name in names:
             assert np.array_equal(getattr(a, name), getattr(c, name)), name
         assert np.allclose(a.page_rank, c.page_rank, rtol=1e-6) and np.allclose(a.doc_rank, c.doc_rank, rtol=1e-6)
 
