@@ -1395,7 +1395,7 @@ static int32_t run_batch(dcd_index* h, const int32_t* prog, const u64* prog_off,
   // queries over head terms).  They belong to the INDEX HANDLE and only ever grow: allocating them per call meant a hipMalloc /
   // hipFree of up to 100 GB each per sub-batch -- round 3 measured 87 s of wall time around 0.76 s of device time for 2 500
   // phrase queries on the 10 M-doc index -- and blocks of that size do not survive in the library's device cache (its cap is
-  // half of the device memory).  dcd_query_batch bounds a sub-batch by DOCODO_QUERY_ARENA_BYTES (default: a quarter of the device
+  // half of the device memory).  dcd_query_batch bounds a sub-batch by DOCODO_QUERY_ARENA_BYTES (default: three eighths of the device
   // memory), so the arena settles at that size after the first large batch.
   DevBuf<u64> counts, d_part_count, d_part_src, d_part_excl, d_part_scr;
   struct ArenaView { u64* p; } pool{nullptr}, tmp{nullptr};
@@ -1769,7 +1769,7 @@ int32_t dcd_query_batch(dcd_index* h, const int32_t* prog, const uint64_t* prog_
   {
     // ... and no more than the arena bound: a sub-batch beyond it would only buy a larger hipMalloc (see run_batch)
     static const u64 env_arena = getenv("DOCODO_QUERY_ARENA_BYTES") ? strtoull(getenv("DOCODO_QUERY_ARENA_BYTES"), nullptr, 10) : 0;
-    const u64 arena_b = env_arena ? env_arena : (u64)total_b / 4;
+    const u64 arena_b = env_arena ? env_arena : (u64)total_b / 8 * 3;
     budget = std::max<u64>(std::min<u64>(budget, arena_b / 8), 1ull << 24);
   }
   if (const char* e = getenv("DOCODO_QUERY_POOL_ELEMS")) budget = std::max<u64>(strtoull(e, nullptr, 10), 1);   // tests
