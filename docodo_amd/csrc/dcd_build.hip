@@ -777,6 +777,16 @@ int32_t index_fetch_host(DeviceIndex& ix) {
   total_chars = ix.h_term_str_off[V];
   ix.h_term_chars.resize(total_chars);
   if (total_chars) DCD_HIP(hipMemcpy(ix.h_term_chars.data(), ix.term_chars.p, (size_t)total_chars * 2, hipMemcpyDeviceToHost));
+  // The key pool was sized for V * (longest key) units so that no host round trip sat inside the build / the merge; now that
+  // the real total is known, an index that lives on (adopted by a handle, queried) keeps only what it uses -- one 63-unit code
+  // would otherwise hold 4-8 x the real size for the lifetime of the index (640 MB instead of ~100 MB at 10 M terms).
+  if (ix.term_chars.n > (size_t)total_chars + (size_t)total_chars / 4 + 4096) {
+    DevBuf<u16> exact;
+    if (exact.alloc(ix.device, total_chars ? total_chars : 1) == DCD_OK) {
+      if (total_chars) DCD_HIP(hipMemcpy(exact.p, ix.term_chars.p, (size_t)total_chars * 2, hipMemcpyDeviceToDevice));
+      ix.term_chars = std::move(exact);
+    }
+  }
   DCD_HIP(hipMemcpy(ix.h_term_unit_start.data(), ix.term_unit_start.p, (V + 1) * 8, hipMemcpyDeviceToHost));
   DCD_HIP(hipMemcpy(ix.h_term_item_start.data(), ix.term_item_start.p, (V + 1) * 8, hipMemcpyDeviceToHost));
   ix.host_ready = true;

@@ -263,9 +263,29 @@ int32_t stream_acquire(int device, hipStream_t* out) {
   DCD_HIP(hipStreamCreateWithFlags(out, hipStreamNonBlocking));
   return DCD_OK;
 }
+// A stream that is destroyed (its synchronisation failed) leaves release tickets behind in the device cache: blocks released on
+// it would be passed over for ever (hipStreamQuery on a dead handle fails) and held until dcd_pool_trim.  After a device-wide
+// synchronisation everything released on the stream has finished: its state is dropped and its blocks lose their tickets.
+static void pool_forget_stream(int device, hipStream_t st) {
+  (void)hipDeviceSynchronize();
+  (void)hipGetLastError();
+  Pool& P = pool(device);
+  std::lock_guard<std::mutex> g(P.mu);
+  auto it = P.streams.find(st);
+  if (it != P.streams.end()) {
+    if (it->second.ev) event_release(device, it->second.ev);
+    P.streams.erase(it);
+  }
+  for (auto& kv : P.free_) if (kv.second.stream == st) { kv.second.ticket = 0; kv.second.stream = nullptr; }
+}
 void stream_release(int device, hipStream_t st) {
   if (!st) return;
-  if (hipStreamSynchronize(st) != hipSuccess) { (void)hipGetLastError(); (void)hipStreamDestroy(st); return; }   // never recycle a broken stream
+  if (hipStreamSynchronize(st) != hipSuccess) {          // never recycle a broken stream
+    (void)hipGetLastError();
+    pool_forget_stream(device, st);
+    (void)hipStreamDestroy(st);
+    return;
+  }
   HandlePool& H = handles();
   std::lock_guard<std::mutex> g(H.mu);
   H.streams[device].push_back(st);
@@ -314,7 +334,7 @@ int32_t stream_acquire_high(int device, hipStream_t* out) {
 }
 void stream_release_high(int device, hipStream_t st) {
   if (!st) return;
-  if (hipStreamSynchronize(st) != hipSuccess) { (void)hipGetLastError(); (void)hipStreamDestroy(st); return; }
+  if (hipStreamSynchronize(st) != hipSuccess) { (void)hipGetLastError(); pool_forget_stream(device, st); (void)hipStreamDestroy(st); return; }
   HandlePool& H = handles();
   std::lock_guard<std::mutex> g(H.mu);
   H.streams_high[device].push_back(st);
