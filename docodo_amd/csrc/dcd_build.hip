@@ -1271,11 +1271,22 @@ static int32_t build_phase1(dcd_build* h, bool codes_mode) {
   CharTables16 tab{nullptr, nullptr};
   if (sizeof(CharT) == 2) DCD_TRY(get_char_tables16(dev, &tab));
 
+  tr.mark("timers");
   // ---- uploads (not part of the timed device pipeline: the text is already resident) ----------
   DevBuf<u64> d_page_off;
+  // (host -> device through pinned staging, see pinned_stage_acquire: a pageable upload of these megabytes made the runtime lock
+  //  the vectors' pages, and freeing the vectors with the handle then stalled the next build by 20 ms)
+  struct Staged { void* p[2] = {nullptr, nullptr}; ~Staged() { pinned_stage_release(p[0]); pinned_stage_release(p[1]); } } staged;
+  auto upload = [&](int slot, void* dst, const void* src, size_t bytes) -> int32_t {
+    staged.p[slot] = pinned_stage_acquire(bytes);
+    if (!staged.p[slot]) DCD_FAIL(DCD_E_NOMEM, "hipHostMalloc failed");
+    memcpy(staged.p[slot], src, bytes);
+    DCD_HIP(hipMemcpyAsync(dst, staged.p[slot], bytes, hipMemcpyHostToDevice, st));
+    return DCD_OK;
+  };
   if (!uniform) {
     DCD_TRY(d_page_off.alloc(dev, n_pages_dev + 1));
-    DCD_HIP(hipMemcpyAsync(d_page_off.p, h->page_off.data(), (n_pages_dev + 1) * 8, hipMemcpyHostToDevice, st));
+    DCD_TRY(upload(0, d_page_off.p, h->page_off.data(), (n_pages_dev + 1) * 8));
   }
   // explicit postings that enter the device vocabulary: all of them, or (codes mode) only the WORDS
   std::vector<u32> xo, xl, xc;
@@ -1296,14 +1307,17 @@ static int32_t build_phase1(dcd_build* h, bool codes_mode) {
     DCD_HIP(hipMemcpyAsync(d_xcoord.p, xc.data(), n_x * 4, hipMemcpyHostToDevice, st));
     DCD_HIP(hipStreamSynchronize(st));
   }
+  tr.mark("page-off");
   if (uniform) {
     DCD_TRY(M.d_page_end.alloc(dev, h->pages.uni_n));
+    tr.mark("page-end-alloc");
     hipLaunchKernelGGL(k_uniform_page_end, dim3((u32)div_up(h->pages.uni_n, 256)), dim3(256), 0, st, M.d_page_end.p, h->pages.uni_n,
                        h->pages.uni_base, h->pages.uni_chars);
   } else if (!h->pages.end.empty()) {
     DCD_TRY(M.d_page_end.alloc(dev, h->pages.end.size()));
-    DCD_HIP(hipMemcpyAsync(M.d_page_end.p, h->pages.end.data(), h->pages.end.size() * 8, hipMemcpyHostToDevice, st));
+    DCD_TRY(upload(1, M.d_page_end.p, h->pages.end.data(), h->pages.end.size() * 8));
   }
+  tr.mark("page-end");
   DCD_HIP(hipStreamSynchronize(st));
 
   tr.mark("setup");

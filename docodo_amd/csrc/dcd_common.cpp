@@ -309,6 +309,50 @@ void event_cfg_set_global(int level, uint32_t mask) {
 }
 // A few pinned host words per thread: read-backs into pinned memory are truly asynchronous (a D2H copy into pageable memory
 // holds the calling thread until the data has arrived, i.e. until everything queued before it has run).
+namespace {
+struct PinnedCache {
+  std::mutex mu;
+  std::multimap<size_t, void*> free_;      // size -> block
+  std::map<void*, size_t> live;
+  size_t cached = 0;
+};
+PinnedCache& pinned_cache() { static PinnedCache c; return c; }
+}  // namespace
+void* pinned_stage_acquire(size_t bytes) {
+  size_t r = 1 << 16;
+  while (r < bytes) r <<= 1;
+  PinnedCache& C = pinned_cache();
+  {
+    std::lock_guard<std::mutex> g(C.mu);
+    auto it = C.free_.lower_bound(r);
+    if (it != C.free_.end() && it->first <= 2 * r) {
+      void* p = it->second;
+      C.live[p] = it->first;
+      C.cached -= it->first;
+      C.free_.erase(it);
+      return p;
+    }
+  }
+  void* q = nullptr;
+  if (hipHostMalloc(&q, r, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  std::lock_guard<std::mutex> g(C.mu);
+  C.live[q] = r;
+  return q;
+}
+void pinned_stage_release(void* p) {
+  if (!p) return;
+  PinnedCache& C = pinned_cache();
+  size_t sz = 0;
+  {
+    std::lock_guard<std::mutex> g(C.mu);
+    auto it = C.live.find(p);
+    if (it == C.live.end()) return;
+    sz = it->second;
+    C.live.erase(it);
+    if (C.cached + sz <= ((size_t)256 << 20)) { C.free_.emplace(sz, p); C.cached += sz; return; }   // keep at most 256 MB pinned
+  }
+  (void)hipHostFree(p);
+}
 u64* pinned_words() {
   static thread_local u64* p = nullptr;
   if (!p) {

@@ -1418,6 +1418,7 @@ static int32_t run_batch(dcd_index* h, const int32_t* prog, const u64* prog_off,
     DCD_TRY(d_part_excl.alloc(dev, max_items + 1));
     DCD_TRY(d_part_scr.alloc(dev, scan_scratch_elems(max_items + 1)));
   }
+  StagedUploads up;               // (plans travel through pinned staging: see pinned_stage_acquire)
   std::vector<DevBuf<PairOp>> d_rounds(rounds.size());
   std::vector<DevBuf<u64>> d_part_base(rounds.size());
   DevBuf<u32> d_items;
@@ -1430,12 +1431,12 @@ static int32_t run_batch(dcd_index* h, const int32_t* prog, const u64* prog_off,
   }
   for (size_t r = 0; r < rounds.size(); r++) {
     DCD_TRY(d_rounds[r].alloc(dev, rounds[r].size()));
-    DCD_HIP(hipMemcpyAsync(d_rounds[r].p, rounds[r].data(), rounds[r].size() * sizeof(PairOp), hipMemcpyHostToDevice, st));
+    DCD_TRY(up.copy(d_rounds[r].p, rounds[r].data(), rounds[r].size() * sizeof(PairOp), st));
     DCD_TRY(d_part_base[r].alloc(dev, part_base[r].size()));
   }
   DevBuf<FinalSeq> d_fin;
   DCD_TRY(d_fin.alloc(dev, nq ? nq : 1));
-  if (nq) DCD_HIP(hipMemcpyAsync(d_fin.p, finals.data(), nq * sizeof(FinalSeq), hipMemcpyHostToDevice, st));
+  if (nq) DCD_TRY(up.copy(d_fin.p, finals.data(), nq * sizeof(FinalSeq), st));
   PageDev pd;
   ResParams P;
   DCD_TRY(make_res_params(h, o, pd, &P));
