@@ -350,7 +350,8 @@ def main():
                     help="N > 1: 1 = the exchange + merge of step i runs on a second host thread beside the build of step i + 1 "
                     "(every merge completes inside the timed region); 0 = one after the other")
     ap.add_argument("--lean-events", type=int, default=0, help="1: the timed steps record HIP events around the dominant kernel only "
-                    "(chosen in the fully instrumented warm-up steps: +1-2 %% value); 0 (default): every event in the timed steps")
+                    "(chosen in the fully instrumented warm-up steps: +1-2 %% value); 0 (default): every event in the timed steps -- the "
+                    "default keeps the per-kernel and per-stage figures of the line measured in the timed region itself")
     ap.add_argument("--force-exchange", action="store_true", help="rehearsal: run the N > 1 step (exchange + merge) with one rank")
     args = ap.parse_args()
 

@@ -67,6 +67,15 @@ __global__ __launch_bounds__(TK_THREADS, DCD_TK_WPE) void k_tok_emit(const CharT
   // seed launch in build_phase1).
   __shared__ TokLds<CharT, true> SW[TK_WAVES];
   __shared__ u32 s_wtot[TK_WAVES];
+  // FAST (round 3): the digit histogram of the FIRST RADIX PASS as a by-product.  With a hot set the first pass scatters by
+  // min(id, n_hot) -- one bucket per hot term, one for all cold ones -- and its histogram kernel read all 1.1 GB of tuples
+  // again only to count them.  The group's counts are collected here in LDS (1 KB: what the page-start mask used to take) and
+  // added to row (digit, radix block of this group) of the pass's histogram with one atomic per non-empty bin; in FAST builds
+  // `sample_cnt` is that histogram and sample_mask / sample_step are the radix plan {tiles per block, blocks} (the kernel's
+  // scalar-register budget has no room for three more arguments).  Keys that are still unresolved are counted by the epilogue.
+  __shared__ u32 s_h[FAST ? 256 : 1];
+  const bool do_hist = FAST && !SAMPLE && sample_cnt != nullptr;
+  if (do_hist) s_h[threadIdx.x] = 0;
   const u32 w = threadIdx.x >> 6, lane = lane_id();
   // SAMPLE: a SAMPLING launch (builds with early ids, in front of the real one): workgroup b takes group b *
   // sample_step, looks its tokens up / inserts them WITHOUT numbering them and counts them in their records (word 3); it
@@ -103,6 +112,7 @@ __global__ __launch_bounds__(TK_THREADS, DCD_TK_WPE) void k_tok_emit(const CharT
   // every (sample_mask + 1)-th group counts its tokens per vocabulary slot: the frequency sample behind the hot / cold
   // split of the tuple sort (build_phase2)
   const bool sampled = !FAST && sample_cnt != nullptr && ((u32)group & sample_mask) == 0u;
+  const u32 n_hot_h = do_hist ? *vt.id_base : 0u;
   const u64 obase = SAMPLE ? 0 : (FAST || stride) ? group * stride : tile_off[group * TK_WAVES];
   if (!SAMPLE && (FAST || stride) && threadIdx.x == 0) tile_cnt[group] = gtotal;
   constexpr u32 CS = sizeof(CharT);
@@ -181,6 +191,7 @@ __global__ __launch_bounds__(TK_THREADS, DCD_TK_WPE) void k_tok_emit(const CharT
                : vt.pool ? vocab_lookup_insert_pooled<CharT>(vt, tv, hs.fin(), len, gpos, wv, word)
                          : vocab_lookup_insert<CharT>(vt, tv, hs.fin(), len, gpos, word);
     any_unres |= (FAST || vt.id_ctr != nullptr) && slot != 0xFFFFFFFFu && (slot & VOC_UNRESOLVED) != 0u;
+    if (do_hist && (slot & VOC_UNRESOLVED) == 0u) atomicAdd(&s_h[slot < n_hot_h ? slot : n_hot_h], 1u);   // (overflow = 0xFFFFFFFF has the bit too)
 #endif
 #if DCD_TOK_NT
     {
@@ -192,6 +203,11 @@ __global__ __launch_bounds__(TK_THREADS, DCD_TK_WPE) void k_tok_emit(const CharT
     tuples[obase + k] = make_uint2(slot, coord_of(gpos));
 #endif
     if (sampled && slot != 0xFFFFFFFFu) atomicAdd(&sample_cnt[slot], 1u);
+  }
+  if (do_hist) {
+    __syncthreads();
+    const u32 c = s_h[threadIdx.x];
+    if (c) atomicAdd(&sample_cnt[(u64)threadIdx.x * sample_step + (u32)(group / sample_mask)], c);   // hist[digit * nblk + block]
   }
   // groups that hold unresolved keys go on the fix-up list: unres[0] = their number, unres[1 ..] = the first UNRES_CAP of them
   // (a wave reports its group; the list may name a group more than once -- the fix-up is idempotent)
@@ -257,7 +273,8 @@ __global__ __launch_bounds__(256) void k_id_dense_table(IdCounts n, u32 n_hot, u
 //  * the coordinate of the last posting (maxCoord, Build.cs:326).
 __global__ __launch_bounds__(256) void k_emit_epilogue(uint2* __restrict__ tuples, const u32* __restrict__ tile_cnt, u64 n_tiles, u32 stride,
                                                        const u32* __restrict__ unres, const u64* __restrict__ slots, u32 slot_stride,
-                                                       u64* __restrict__ n_tok, u32* __restrict__ last_coord) {
+                                                       u64* __restrict__ n_tok, u32* __restrict__ last_coord,
+                                                       u32* __restrict__ hist_a, u32 hist_tpb, u32 hist_nblk, const u32* __restrict__ n_hot_p) {
   __shared__ u64 s_sum[4];
   const u32 n = unres[0];
   if (n) {
@@ -271,7 +288,11 @@ __global__ __launch_bounds__(256) void k_emit_epilogue(uint2* __restrict__ tuple
         const u32 x = tuples[t * stride + j].x;
         if (x != 0xFFFFFFFFu && (x & VOC_UNRESOLVED)) {
           const u32 slot = x & ~VOC_UNRESOLVED;
-          tuples[t * stride + j].x = reinterpret_cast<const u32*>(slots + (u64)slot * slot_stride)[2] - 1u;
+          const u32 id = reinterpret_cast<const u32*>(slots + (u64)slot * slot_stride)[2] - 1u;
+          // (the list may name a group twice, see k_tok_emit: the visit that REPLACES the key -- one compare-and-swap wins --
+          //  is the one that counts it in the first radix pass's histogram)
+          const u32 was = atomicCAS(&tuples[t * stride + j].x, x, id);
+          if (hist_a && was == x) { const u32 nh = *n_hot_p; atomicAdd(&hist_a[(u64)(id < nh ? id : nh) * hist_nblk + (u32)(t / hist_tpb)], 1u); }
         }
       }
     }
@@ -1152,6 +1173,8 @@ struct BuildMid {
   DevBuf<u64> slots;
   u32 slot_stride = 1;              // u64 units per slot: 1, or VocPool::W when the string pool is interleaved (VocabTable)
   DevBuf<u32> d_flags, slot_excl, scan_scr32, d_hist;
+  DevBuf<u32> d_histA;              // first radix pass's histogram, filled by the emit kernel (early ids + hot set); see k_tok_emit
+  bool histA_ready = false;
   VocabRanks vr;
   VocabPrep vprep;                  // id-keyed builds: first half of the vocabulary finalisation, run at the end of phase 1
   bool vprep_done = false;
@@ -1508,10 +1531,20 @@ static int32_t build_phase1(dcd_build* h, bool codes_mode) {
         vt.id_base = R + EI_NHOT;
       }
       if (early_ids && n_sample) {
+        // the emit kernel also fills the histogram of the first radix pass (digit = min(id, n_hot)): zeroed per round
+        static const bool env_emit_hist = !(getenv("DOCODO_EMIT_HIST") && atoi(getenv("DOCODO_EMIT_HIST")) == 0);
+        const RsTilePlan tpa = rs_tile_plan(n_st);
+        M.histA_ready = false;
+        if (P.n_runs == 0 && env_emit_hist && env_hot > 0) {
+          DCD_TRY(M.d_histA.alloc(dev, (u64)tpa.nblk << 8));
+          DCD_HIP(hipMemsetAsync(M.d_histA.p, 0, ((u64)tpa.nblk << 8) * 4, st));
+          M.histA_ready = true;
+        }
         probes.begin(DCD_K_TOK_EMIT);
         if (P.n_runs == 0)      // (early ids imply strided output and no per-slot sample counts)
           hipLaunchKernelGGL((k_tok_emit<CharT, false, true>), dim3((u32)div_up(n_tiles, TK_WAVES)), dim3(TK_THREADS), 0, st, text, P, tab, tv, vt,
-                             M.tile_off.p, M.tupA.p, n_tiles, M.stride, M.tile_cnt.p, (u64)0, (u32*)nullptr, 0u, unres, 0u);
+                             M.tile_off.p, M.tupA.p, n_tiles, M.stride, M.tile_cnt.p, (u64)0, M.histA_ready ? M.d_histA.p : (u32*)nullptr,
+                             M.histA_ready ? tpa.tpb : 0u, unres, M.histA_ready ? tpa.nblk : 0u);
         else
           hipLaunchKernelGGL((k_tok_emit<CharT>), dim3((u32)div_up(n_tiles, TK_WAVES)), dim3(TK_THREADS), 0, st, text, P, tab, tv, vt,
                              M.tile_off.p, M.tupA.p, n_tiles, M.stride, M.tile_cnt.p, (u64)0, sample_cnt.p, sample_mask, unres, 0u);
@@ -1549,8 +1582,10 @@ static int32_t build_phase1(dcd_build* h, bool codes_mode) {
       u32* R = early_ids ? id_ctr.p + ID_CTR_WORDS : nullptr;
       if (early_ids) {
         // keys whose id was not visible when the token was looked up -> ids; the number of postings; maxCoord
+        const RsTilePlan tpe = rs_tile_plan(n_st);
         hipLaunchKernelGGL(k_emit_epilogue, dim3(256), dim3(256), 0, st, M.tupA.p, (const u32*)M.tile_cnt.p, n_st, M.stride, (const u32*)unres,
-                           (const u64*)M.slots.p, M.slot_stride, (u64*)(R + EI_NTOK), R + EI_LASTC);
+                           (const u64*)M.slots.p, M.slot_stride, (u64*)(R + EI_NTOK), R + EI_LASTC,
+                           M.histA_ready ? M.d_histA.p : (u32*)nullptr, tpe.tpb, tpe.nblk, (const u32*)(R + EI_NHOT));
       } else if (strided) {
         // the tiles' dense offsets and the number of postings, now that the emit kernel has counted
         scan_exclusive<u32, u64>(M.tile_cnt.p, M.tile_off.p, n_st, scan_scr64.p, st);
@@ -1931,7 +1966,11 @@ static int32_t build_phase2(dcd_build* h) {
       const RsTilePlan tp = rs_tile_plan(M.n_tiles);
       u64* pin = pinned_words();
       if (!pin) DCD_FAIL(DCD_E_NOMEM, "hipHostMalloc failed");
-      nh.src = M.d_hist.p + (u64)hot_n * tp.nblk; nh.dst = (u32*)pin; nh.ev = event_acquire(dev); nh.status = DCD_OK;
+      // (early ids: the emit kernel has counted the digits of this pass already -- no histogram kernel)
+      const bool have_hist = early && M.histA_ready && hot_n == M.id_hot && bits_a <= 8;
+      u32* const histA = have_hist ? M.d_histA.p : M.d_hist.p;
+      sd.hist_ready = have_hist;
+      nh.src = histA + (u64)hot_n * tp.nblk; nh.dst = (u32*)pin; nh.ev = event_acquire(dev); nh.status = DCD_OK;
       if (!nh.ev) DCD_FAIL(DCD_E_HIP, "hipEventCreate failed");
       // ... and the vocabulary chain is queued right there, behind the histogram kernel it is to run beside, and the main
       // stream ordered behind it (see queue_vocab_side)
@@ -1944,7 +1983,7 @@ static int32_t build_phase2(dcd_build* h) {
         if (hipMemcpyAsync(r->dst, r->src, 4, hipMemcpyDeviceToHost, s) != hipSuccess || hipEventRecord(r->ev, s) != hipSuccess) r->status = DCD_E_HIP;
         if (r->side) r->side_status = (*r->side)();
       };
-      rs_pass_dyn(bits_a, a, b, remap, N, (int)hot_s, M.d_hist.p, M.scan_scr32.p, st, rpa, cache_ok, &sd);
+      rs_pass_dyn(bits_a, a, b, remap, N, (int)hot_s, histA, M.scan_scr32.p, st, rpa, cache_ok, &sd);
       passes++;
       if (early) nh.side_status = queue_vocab_side();
       int32_t vst = nh.side_status;

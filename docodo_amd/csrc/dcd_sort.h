@@ -156,6 +156,9 @@ struct RsStrided {
   // key becomes d << hot_s for a hot term and (hot_n << hot_s) + (d - hot_n) for a cold one (d - hot_n < 2^hot_s), so that
   // the digit (key >> hot_s) gives every hot term a bucket of its own and all cold terms the bucket hot_n
   u32 hot_n = 0, hot_s = 0;
+  // host side only: the caller has filled the pass's histogram (hist[digit * nblk + block], digit = key >> shift) itself -- the
+  // tokeniser counts the digits of the first pass while it writes the tuples -- so the histogram kernel is not launched
+  bool hist_ready = false;
 };
 __host__ __device__ __forceinline__ u32 rs_hot_key(u32 d, u32 hot_n, u32 hot_s) { return d < hot_n ? d << hot_s : (hot_n << hot_s) + (d - hot_n); }
 // the key has to fit 32 bits: digits 0 .. hot_n above hot_s bits of cold id (the host gives up the split otherwise)
@@ -514,7 +517,8 @@ inline void rs_pass(const uint2* in, uint2* out, const u32* remap, u64 n, int sh
   if (sd) {
     // tile-strided input: blocks own tiles, not tuples
     const RsTilePlan tp = rs_tile_plan(sd->n_tiles);
-    if (remap && remap_cache)
+    if (sd->hist_ready) {}
+    else if (remap && remap_cache)
       hipLaunchKernelGGL((k_rs_hist_strided<BITS, true>), dim3(tp.nblk), dim3(RS_THREADS), 0, st, in, *sd, remap, tp.tpb, tp.nblk, shift, hist);
     else
       hipLaunchKernelGGL((k_rs_hist_strided<BITS, false>), dim3(tp.nblk), dim3(RS_THREADS), 0, st, in, *sd, remap, tp.tpb, tp.nblk, shift, hist);

@@ -190,3 +190,37 @@ def test_malformed_list_images_end_the_load_like_the_reference():
     ix = docodo_amd.Index.from_images(idx, good + more)
     assert ix.n_pages == 3
     ix.close()
+
+
+def test_merge_index_files_is_host_side(tmp_path):
+    """dcd_merge_index_files: streaming k-way merge of ".index" runs with disjoint keys (the out-of-core tail, MergeFiles
+    Index.cs:577-689 for inputs that never share a key) -- host-only, runs without a GPU.  Header = max MaxCoord (Index.cs:596)."""
+    import struct
+    import docodo_amd
+    from docodo_amd import _lib
+
+    def rec(k, units):
+        b = k.encode("utf-8")
+        return bytes([len(b)]) + b + struct.pack("<i", len(units)) + np.array(units, np.uint16).tobytes()
+
+    runs = [struct.pack("<Q", 50) + rec("abc", [1, 2]) + rec("zed", [9]) + rec("\u00e9t\u00e9", [5]),
+            struct.pack("<Q", 70) + rec("abd", [3] * 70000) + rec("b", []),
+            struct.pack("<Q", 10)]
+    paths = []
+    for i, x in enumerate(runs):
+        p = tmp_path / ("run%d" % i)
+        p.write_bytes(x)
+        paths.append(str(p).encode())
+    out = str(tmp_path / "out.index")
+    arr = (C.c_char_p * len(paths))(*paths)
+    _lib.check(docodo_amd.lib().dcd_merge_index_files(arr, len(paths), out.encode()))
+    want = struct.pack("<Q", 70) + rec("abc", [1, 2]) + rec("abd", [3] * 70000) + rec("b", []) + rec("zed", [9]) + rec("\u00e9t\u00e9", [5])
+    assert open(out, "rb").read() == want                       # ordinal (UTF-16 code unit) key order
+    twice = (C.c_char_p * 2)(paths[0], paths[0])
+    assert docodo_amd.lib().dcd_merge_index_files(twice, 2, out.encode()) == _lib.DCD_E_BADARG     # a key in two inputs
+    missing = (C.c_char_p * 1)(str(tmp_path / "nope").encode())
+    assert docodo_amd.lib().dcd_merge_index_files(missing, 1, out.encode()) == _lib.DCD_E_IO
+    # the merged file is a loadable index image as far as the host-side format checks go
+    with pytest.raises(docodo_amd.DocodoError) as e:
+        docodo_amd.Index.from_images(open(out, "rb").read()[:-1], b"")
+    assert e.value.code == _lib.DCD_E_IO

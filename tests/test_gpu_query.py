@@ -355,3 +355,26 @@ def test_sub_batching_matches_single_batch(synth_index, monkeypatch):
     for name in ("status", "page_off", "page_index", "page_rank", "pos_off", "pos", "doc_off", "doc_index", "doc_rank",
                  "doc_n_pages", "seq_off", "seq_units", "seq_R"):
         assert np.array_equal(getattr(a, name), getattr(b, name)), name
+
+
+def test_no_download_returns_the_same_counts(synth_index):
+    """dcd_query_opts.no_download: the batch is evaluated and every result array produced on the device as always, only the
+    per-query counts and the totals come back (bench.py's query legs; statistics-only callers)."""
+    import docodo_amd
+    from docodo_amd import synth
+    ix, oix, _, _ = synth_index
+    prog, off = [], [0]
+    for row in synth.query_ranks(50, 3, lo_rank=5):
+        ts = [ix.find(synth.term(int(k))) for k in row]
+        if any(t is None for t in ts):
+            continue
+        for k, (r, t) in enumerate(zip(row, ts)):
+            prog += [docodo_amd.DCD_OP_TERM, t, 255 + len(synth.term(int(r)))]
+            if k:
+                prog.append(docodo_amd.DCD_OP_AND)
+        off.append(len(prog))
+    full = ix.query_batch(prog, off)
+    tot = ix.query_batch(prog, off, totals=True)
+    assert tot["n_pages"] == full.page_index.size and tot["n_pos"] == full.pos.size and tot["n_docs"] == full.doc_index.size
+    assert tot["ms"] > 0
+    assert ix.query_batch([], [0], totals=True) == {"ms": ix.query_batch([], [0], totals=True)["ms"], "n_pages": 0, "n_pos": 0, "n_docs": 0}
