@@ -70,9 +70,11 @@ __global__ __launch_bounds__(TK_THREADS, DCD_TK_WPE) void k_tok_emit(const CharT
   // FAST (round 3): the digit histogram of the FIRST RADIX PASS as a by-product.  With a hot set the first pass scatters by
   // min(id, n_hot) -- one bucket per hot term, one for all cold ones -- and its histogram kernel read all 1.1 GB of tuples
   // again only to count them.  The group's counts are collected here in LDS (1 KB: what the page-start mask used to take) and
-  // added to row (digit, radix block of this group) of the pass's histogram with one atomic per non-empty bin; in FAST builds
-  // `sample_cnt` is that histogram and sample_mask / sample_step are the radix plan {tiles per block, blocks} (the kernel's
-  // scalar-register budget has no room for three more arguments).  Keys that are still unresolved are counted by the epilogue.
+  // leave as ONE ROW of 256 u16 counts per group (a coalesced 512-byte store; `sample_cnt` is the row array in FAST builds --
+  // the kernel's scalar-register budget has no room for another argument); k_hist_rows adds the rows of every radix block up
+  // behind the launch.  (First attempt: one global atomic per non-empty bin straight into the pass's histogram -- 35 M
+  // device-scope atomics per build, executed at the memory side: the emit kernel went from 1.10 to 2.54 ms.)  Keys that are
+  // still unresolved are counted by the epilogue.
   __shared__ u32 s_h[FAST ? 256 : 1];
   const bool do_hist = FAST && !SAMPLE && sample_cnt != nullptr;
   if (do_hist) s_h[threadIdx.x] = 0;
@@ -191,6 +193,8 @@ __global__ __launch_bounds__(TK_THREADS, DCD_TK_WPE) void k_tok_emit(const CharT
                : vt.pool ? vocab_lookup_insert_pooled<CharT>(vt, tv, hs.fin(), len, gpos, wv, word)
                          : vocab_lookup_insert<CharT>(vt, tv, hs.fin(), len, gpos, word);
     any_unres |= (FAST || vt.id_ctr != nullptr) && slot != 0xFFFFFFFFu && (slot & VOC_UNRESOLVED) != 0u;
+    // (one LDS atomic per token; gathering the cold bucket's third of the tokens with a ballot first measured slower: the kernel
+    //  is bound by instruction issue, not by the same-address atomics)
     if (do_hist && (slot & VOC_UNRESOLVED) == 0u) atomicAdd(&s_h[slot < n_hot_h ? slot : n_hot_h], 1u);   // (overflow = 0xFFFFFFFF has the bit too)
 #endif
 #if DCD_TOK_NT
@@ -206,8 +210,7 @@ __global__ __launch_bounds__(TK_THREADS, DCD_TK_WPE) void k_tok_emit(const CharT
   }
   if (do_hist) {
     __syncthreads();
-    const u32 c = s_h[threadIdx.x];
-    if (c) atomicAdd(&sample_cnt[(u64)threadIdx.x * sample_step + (u32)(group / sample_mask)], c);   // hist[digit * nblk + block]
+    reinterpret_cast<u16*>(sample_cnt)[group * 256u + threadIdx.x] = (u16)s_h[threadIdx.x];   // (a group holds <= 4 * 318 tokens)
   }
   // groups that hold unresolved keys go on the fix-up list: unres[0] = their number, unres[1 ..] = the first UNRES_CAP of them
   // (a wave reports its group; the list may name a group more than once -- the fix-up is idempotent)
@@ -236,6 +239,19 @@ __global__ void k_explicit(const u32* __restrict__ xoff, const u32* __restrict__
 }
 
 __global__ void k_set_u64(u64* p, u64 v) { *p = v; }
+// rows[g][d] (u16: tokens of digit d in group g, written by k_tok_emit) -> hist[d * nblk + b] += sum over the groups of radix
+// block b (the epilogue has already added the keys it resolved: plain read-modify-write, every element has one owner)
+__global__ __launch_bounds__(256) void k_hist_rows(const u16* __restrict__ rows, u64 n_groups, u32 tpb, u32 nblk, u32* __restrict__ hist) {
+  const u32 b = blockIdx.x, d = threadIdx.x;
+  const u64 g0 = (u64)b * tpb, g1 = g0 + tpb < n_groups ? g0 + tpb : n_groups;
+  u32 s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+  u64 g = g0;
+  for (; g + 4 <= g1; g += 4) {
+    s0 += rows[(g + 0) * 256 + d]; s1 += rows[(g + 1) * 256 + d]; s2 += rows[(g + 2) * 256 + d]; s3 += rows[(g + 3) * 256 + d];
+  }
+  for (; g < g1; g++) s0 += rows[g * 256 + d];
+  hist[(u64)d * nblk + b] += s0 + s1 + s2 + s3;
+}
 // explicit page offsets -> one bit per character of the text: bit i = a page starts at i (TokParams::page_bits)
 __global__ void k_page_bits(const u64* __restrict__ page_off, u64 n, u32* __restrict__ bits) {
   u64 p = (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1173,7 +1189,8 @@ struct BuildMid {
   DevBuf<u64> slots;
   u32 slot_stride = 1;              // u64 units per slot: 1, or VocPool::W when the string pool is interleaved (VocabTable)
   DevBuf<u32> d_flags, slot_excl, scan_scr32, d_hist;
-  DevBuf<u32> d_histA;              // first radix pass's histogram, filled by the emit kernel (early ids + hot set); see k_tok_emit
+  DevBuf<u32> d_histA;              // first radix pass's histogram, from the emit kernel's per-group rows (early ids + hot set); see k_tok_emit
+  DevBuf<u16> d_hist_rows;          // [groups][256]
   bool histA_ready = false;
   VocabRanks vr;
   VocabPrep vprep;                  // id-keyed builds: first half of the vocabulary finalisation, run at the end of phase 1
@@ -1537,14 +1554,15 @@ static int32_t build_phase1(dcd_build* h, bool codes_mode) {
         M.histA_ready = false;
         if (P.n_runs == 0 && env_emit_hist && env_hot > 0) {
           DCD_TRY(M.d_histA.alloc(dev, (u64)tpa.nblk << 8));
+          DCD_TRY(M.d_hist_rows.alloc(dev, n_st * 256));
           DCD_HIP(hipMemsetAsync(M.d_histA.p, 0, ((u64)tpa.nblk << 8) * 4, st));
           M.histA_ready = true;
         }
         probes.begin(DCD_K_TOK_EMIT);
         if (P.n_runs == 0)      // (early ids imply strided output and no per-slot sample counts)
           hipLaunchKernelGGL((k_tok_emit<CharT, false, true>), dim3((u32)div_up(n_tiles, TK_WAVES)), dim3(TK_THREADS), 0, st, text, P, tab, tv, vt,
-                             M.tile_off.p, M.tupA.p, n_tiles, M.stride, M.tile_cnt.p, (u64)0, M.histA_ready ? M.d_histA.p : (u32*)nullptr,
-                             M.histA_ready ? tpa.tpb : 0u, unres, M.histA_ready ? tpa.nblk : 0u);
+                             M.tile_off.p, M.tupA.p, n_tiles, M.stride, M.tile_cnt.p, (u64)0, M.histA_ready ? (u32*)M.d_hist_rows.p : (u32*)nullptr,
+                             0u, unres, 0u);
         else
           hipLaunchKernelGGL((k_tok_emit<CharT>), dim3((u32)div_up(n_tiles, TK_WAVES)), dim3(TK_THREADS), 0, st, text, P, tab, tv, vt,
                              M.tile_off.p, M.tupA.p, n_tiles, M.stride, M.tile_cnt.p, (u64)0, sample_cnt.p, sample_mask, unres, 0u);
@@ -1586,6 +1604,8 @@ static int32_t build_phase1(dcd_build* h, bool codes_mode) {
         hipLaunchKernelGGL(k_emit_epilogue, dim3(256), dim3(256), 0, st, M.tupA.p, (const u32*)M.tile_cnt.p, n_st, M.stride, (const u32*)unres,
                            (const u64*)M.slots.p, M.slot_stride, (u64*)(R + EI_NTOK), R + EI_LASTC,
                            M.histA_ready ? M.d_histA.p : (u32*)nullptr, tpe.tpb, tpe.nblk, (const u32*)(R + EI_NHOT));
+        if (M.histA_ready)
+          hipLaunchKernelGGL(k_hist_rows, dim3(tpe.nblk), dim3(256), 0, st, (const u16*)M.d_hist_rows.p, n_st, tpe.tpb, tpe.nblk, M.d_histA.p);
       } else if (strided) {
         // the tiles' dense offsets and the number of postings, now that the emit kernel has counted
         scan_exclusive<u32, u64>(M.tile_cnt.p, M.tile_off.p, n_st, scan_scr64.p, st);
