@@ -1191,6 +1191,7 @@ struct BuildMid {
   DevBuf<u32> d_flags, slot_excl, scan_scr32, d_hist;
   DevBuf<u32> d_histA;              // first radix pass's histogram, from the emit kernel's per-group rows (early ids + hot set); see k_tok_emit
   DevBuf<u16> d_hist_rows;          // [groups][256]
+  DevBuf<u32> d_hist1;              // first cold pass's histogram, counted by pass A's scatter kernel (RsStrided::next_hist)
   bool histA_ready = false;
   VocabRanks vr;
   VocabPrep vprep;                  // id-keyed builds: first half of the vocabulary finalisation, run at the end of phase 1
@@ -1990,6 +1991,15 @@ static int32_t build_phase2(dcd_build* h) {
       const bool have_hist = early && M.histA_ready && hot_n == M.id_hot && bits_a <= 8;
       u32* const histA = have_hist ? M.d_histA.p : M.d_hist.p;
       sd.hist_ready = have_hist;
+      // ... and its scatter kernel counts the first COLD pass's digit per block (see RsStrided::next_hist): that pass then needs
+      // no histogram kernel either.  (The cold passes sort by the low hot_s bits, narrow digit first.)
+      static const bool env_next = !(getenv("DOCODO_SORT_NEXT_HIST") && atoi(getenv("DOCODO_SORT_NEXT_HIST")) == 0);
+      const int w0 = rs_schedule((int)hot_s, 9).width[0];
+      const bool next_ok = env_next && w0 <= 8 && ((u64)tp.nblk << w0) <= ((u64)RS_MAX_BLOCKS << 10);
+      if (next_ok) {
+        DCD_TRY(M.d_hist1.alloc(dev, (u64)tp.nblk << w0));      // (every block of pass A writes its row: no memset)
+        sd.next_hist = M.d_hist1.p; sd.next_bits = (u32)w0;
+      }
       nh.src = histA + (u64)hot_n * tp.nblk; nh.dst = (u32*)pin; nh.ev = event_acquire(dev); nh.status = DCD_OK;
       if (!nh.ev) DCD_FAIL(DCD_E_HIP, "hipEventCreate failed");
       // ... and the vocabulary chain is queued right there, behind the histogram kernel it is to run beside, and the main
@@ -2013,7 +2023,25 @@ static int32_t build_phase2(dcd_build* h) {
       if (nh.status != DCD_OK) { (void)hipGetLastError(); DCD_FAIL(DCD_E_HIP, "reading the hot / cold boundary failed"); }
       const u64 Nh = *nh.dst, Nc = N - Nh;
       n_hot_postings = Nh;
-      if (Nc) {
+      if (Nc && next_ok) {
+        // first cold pass without a histogram kernel: pass A's scatter kernel counted its digit per block (sd.next_hist), and
+        // block k of this pass sorts exactly the cold tuples block k of pass A wrote -- the range [off_k, off_k+1) of pass A's
+        // scanned offsets of the cold digit (histA is scanned in place)
+        const RsSchedule sc = rs_schedule((int)hot_s, 9);
+        RsStrided s1;
+        s1.cnt = nullptr; s1.stride = 0; s1.n_tiles = 0;
+        s1.range = histA + (u64)hot_n * tp.nblk; s1.range_nblk = tp.nblk; s1.range_end = N;
+        rs_pass_dyn(sc.width[0], b, a + Nh, nullptr, N, 0, M.d_hist1.p, M.scan_scr32.p, st, rp, false, &s1);
+        uint2 *in2 = a + Nh, *out2 = b + Nh;
+        int shift2 = sc.width[0];
+        for (int i = 1; i < sc.npass; i++) {
+          rs_pass_dyn(sc.width[i], in2, out2, nullptr, Nc, shift2, M.d_hist.p, M.scan_scr32.p, st, rp, false, nullptr);
+          shift2 += sc.width[i];
+          uint2* t2 = in2; in2 = out2; out2 = t2;
+        }
+        passes += sc.npass;
+        if (in2 != b + Nh) DCD_HIP(hipMemcpyAsync(b + Nh, in2, Nc * sizeof(uint2), hipMemcpyDeviceToDevice, st));   // (odd number of cold passes)
+      } else if (Nc) {
         int pc = 0;
         uint2* r = rs_sort(b + Nh, a + Nh, nullptr, Nc, (int)hot_s, M.d_hist.p, M.scan_scr32.p, st, &pc, rp, 9);
         passes += pc;

@@ -159,6 +159,17 @@ struct RsStrided {
   // host side only: the caller has filled the pass's histogram (hist[digit * nblk + block], digit = key >> shift) itself -- the
   // tokeniser counts the digits of the first pass while it writes the tuples -- so the histogram kernel is not launched
   bool hist_ready = false;
+  // ---- the pass BEHIND a hot / cold first pass without a histogram kernel of its own (round 3) -------------------------------
+  // first pass (cnt != nullptr, hot_s != 0): next_hist != nullptr = the scatter kernel also counts, per block, the digit
+  // (key & ((1 << next_bits) - 1)) of its COLD tuples and leaves them as next_hist[digit * nblk + block] -- exactly the histogram
+  // of a following pass whose block b sorts the cold tuples block b of this pass wrote (contiguous, in order).
+  u32* next_hist = nullptr;
+  u32 next_bits = 0;
+  // following pass (cnt == nullptr, range != nullptr): dense input, but block b owns the tuples [range[b], range[b + 1]) of `in`
+  // (the last block ends at range_end) instead of a fixed number: range = the first pass's scanned offsets of the cold digit.
+  const u32* range = nullptr;
+  u32 range_nblk = 0;
+  u64 range_end = 0;
 };
 __host__ __device__ __forceinline__ u32 rs_hot_key(u32 d, u32 hot_n, u32 hot_s) { return d < hot_n ? d << hot_s : (hot_n << hot_s) + (d - hot_n); }
 // the key has to fit 32 bits: digits 0 .. hot_n above hot_s bits of cold id (the host gives up the split otherwise)
@@ -291,6 +302,14 @@ __global__ __launch_bounds__(RSS_THREADS) __attribute__((amdgpu_waves_per_eu(DCD
   // dense layout, but a row is one contiguous load; rows packed across tile borders cost more than they save --
   // measured).  s_rowpre[t] = number of rows before tile t (block-local), rows_b = all of them.
   u64 beg = (u64)blockIdx.x * ipb, end = beg + ipb < n ? beg + ipb : n;
+  if (!STRIDED && sd.range) {                      // variable block ranges (see RsStrided::range)
+    beg = sd.range[blockIdx.x];
+    end = blockIdx.x + 1 < nblk ? (u64)sd.range[blockIdx.x + 1] : sd.range_end;
+  }
+  // counts of the NEXT pass's digit among this block's cold tuples (first pass of a hot / cold sort only)
+  __shared__ u32 s_nx[STRIDED ? 256 : 1];
+  const bool count_next = STRIDED && sd.next_hist != nullptr;
+  if (count_next) { for (int i = threadIdx.x; i < 256; i += RSS_THREADS) s_nx[i] = 0; }
   __shared__ u16 s_tcnt[STRIDED ? RS_TPB_MAX : 1];
   __shared__ u16 s_rowpre[STRIDED ? RS_TPB_MAX + 1 : 1];
   const u64 ta = (u64)blockIdx.x * tpb;
@@ -472,6 +491,7 @@ __global__ __launch_bounds__(RSS_THREADS) __attribute__((amdgpu_waves_per_eu(DCD
     for (u32 j = threadIdx.x; j < tile_n; j += RSS_THREADS) {
       uint2 it = s_tile[j];
       u32 d = (it.x >> shift) & (NB - 1);
+      if (count_next && d == sd.hot_n) atomicAdd(&s_nx[it.x & ((1u << sd.next_bits) - 1u)], 1u);
 #if DCD_RS_NT >= 2
       if (STRIDED) {
         typedef u32 u32x2_t __attribute__((ext_vector_type(2)));
@@ -483,6 +503,10 @@ __global__ __launch_bounds__(RSS_THREADS) __attribute__((amdgpu_waves_per_eu(DCD
     }
     // no barrier here: phase A of the next tile touches only the wave's own s_cnt row, and everything that phase D
     // reads is rewritten behind the next tile's first barrier at the earliest
+  }
+  if (count_next) {
+    lds_barrier();
+    for (u32 dd = threadIdx.x; dd < (1u << sd.next_bits); dd += RSS_THREADS) sd.next_hist[(u64)dd * nblk + blockIdx.x] = s_nx[dd];
   }
 }
 
@@ -514,6 +538,17 @@ inline void rs_pass(const uint2* in, uint2* out, const u32* remap, u64 n, int sh
                     hipStream_t st, const RsProbe& pr, bool remap_cache, const RsStrided* sd = nullptr) {
   RsPlan p = rs_plan(n);
   pr.rec(st, false);
+  if (sd && !sd->cnt && sd->range) {
+    // dense input in variable block ranges, histogram supplied by the pass before (RsStrided::range / next_hist)
+    const u32 nblk = sd->range_nblk;
+    pr.rec(st, false);
+    u64 ne = (u64)nblk << BITS;
+    scan_exclusive<u32, u32>(hist, hist, ne, scan_scratch, st);
+    pr.rec(st, true);
+    hipLaunchKernelGGL((k_rs_scatter<BITS, false, false>), dim3(nblk), dim3(RSS_THREADS), 0, st, in, remap, n, (u64)0, nblk, shift, hist, out, *sd, 0u);
+    pr.rec(st, true);
+    return;
+  }
   if (sd) {
     // tile-strided input: blocks own tiles, not tuples
     const RsTilePlan tp = rs_tile_plan(sd->n_tiles);
