@@ -51,12 +51,16 @@ HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 
 HBM_COPY_GBS = 6290.0
 
 
-def algorithmic_bytes(kernel, T, N, U, n_launch=1, n_hot=0, id_keys=False):
+def algorithmic_bytes(kernel, T, N, U, n_launch=1, n_hot=0, id_keys=False, passes=0):
     """Algorithmic HBM bytes of ONE launch, averaged over the kernel's launches of a step.
     With the hot / cold split the radix kernels run once over all N tuples and (n_launch - 1) times over the N - n_hot
-    cold ones; an id-keyed build's k_img_units also writes the units in term order (one read, two writes)."""
+    cold ones; an id-keyed build's k_img_units also writes the units in term order (one read, two writes).  Round 3: the
+    histogram kernel no longer runs for the first pass (the tokeniser counts its digits) nor for the first cold pass (the first
+    pass's scatter kernel counts them): fewer histogram launches than passes = every one of them reads cold tuples only."""
     n_launch = max(1, int(round(n_launch)))
     tuples = (N + (n_launch - 1) * (N - n_hot)) / n_launch if n_hot else N
+    if kernel == "k_rs_hist" and n_hot and passes and n_launch < passes:
+        tuples = N - n_hot
     return {
         "k_tok_count": T,                 # reads the text once
         "k_tok_emit": T + 8 * N,          # reads the text, writes one (term, coord) tuple per posting
@@ -75,6 +79,9 @@ LIMITER = {"k_tok_emit": "VALU issue + the latency of one table gather per token
            "k_tok_count": "VALU issue (PMC: ~100 % busy; 280 wave-instructions per wave tile)",
            "k_rs_scatter": "VALU issue (match-any ballot ranking, ~50 % busy) + hbm (first pass: partial lines of short digit runs)",
            "k_rs_hist": "LDS atomics + hbm"}
+LIMITER["k_tok_emit"] = ("VALU issue + the latency of one table gather per token (profiles/r02_pmc_build.txt: SQ_ACTIVE_INST_VALU ~87 % of the busy cycles; "
+                         "scripts/diag_tok.py: front half -- classification, boundaries, token list -- 0.53 ms, hashing + tuple stores +0.30 ms, table "
+                         "lookup +0.35 ms; round 3 adds the first radix pass's digit counts, +0.04 ms, which removes a 0.19 ms histogram kernel)")
 
 
 TRAFFIC_FILES = ("r03_final_traffic.json", "r02_final_traffic.json")
@@ -510,7 +517,7 @@ def main():
         lps = kcnt / args.steps            # launches per step of every kernel
 
         def abytes_of(k):
-            return algorithmic_bytes(KERNEL_NAMES[k], T, N, U, lps[k], hot_post, bool(id_keys))
+            return algorithmic_bytes(KERNEL_NAMES[k], T, N, U, lps[k], hot_post, bool(id_keys), passes)
         ms_step = dt / args.steps * 1e3
         value = world * T / 1e9 / (dt / args.steps)
         # dominant kernel = largest total device time per step (HIP events on the build stream)

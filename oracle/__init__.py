@@ -72,6 +72,9 @@ def lib():
         sig("orc_index_page_doc", C.c_int, vp, sz)
         sig("orc_get_word_codes", sz, vp, vp, sz, vp, sz)
         sig("orc_search_word", sz, vp, vp, sz, vp, sz, i32p)
+        sig("orc_close_words", sz, vp, vp, sz, sz, vp, sz, C.POINTER(sz))
+        sig("orc_suggest", sz, vp, vp, sz, sz, vp, sz, C.POINTER(sz))
+        sig("orc_like_words", sz, vp, vp, sz, vp, sz, C.POINTER(sz))
         sig("orc_builder_new", vp, vp)
         sig("orc_builder_free", None, vp)
         sig("orc_builder_add_doc", None, vp, vp, sz, vp, sz)
@@ -387,6 +390,28 @@ class Index:
         if m == 0:
             return []
         return _from_u16(out, m).split("\0")
+
+    def _scan(self, fn, word, *take):
+        a, p, n = _u16(word)
+        cnt = C.c_size_t(0)
+        m = fn(self.h, p, n, *take, None, 0, C.byref(cnt))
+        out = np.empty(max(1, m), np.uint16)
+        fn(self.h, p, n, *take, out.ctypes.data, out.size, C.byref(cnt))
+        if cnt.value == 0:
+            return []
+        return _from_u16(out, m).split("\0")
+
+    def close_words(self, word, n=10):
+        """GetCloseWords, Search.cs:168-174 (Levenshtein, Index.cs:46-89)."""
+        return self._scan(self.L.orc_close_words, word, n)
+
+    def suggest_tails(self, lastword, n=10):
+        """Term selection of GetSuggessions, Search.cs:176-188: the completions of `lastword` (already lower-cased)."""
+        return self._scan(self.L.orc_suggest, lastword, n)
+
+    def like_words(self, pattern):
+        """GetLikeWords, Search.cs:158-167, non-trivial branch ('_' = ".*", unanchored, first 100 keys that start with a letter)."""
+        return self._scan(self.L.orc_like_words, pattern)
 
     def search_word(self, word):
         """SearchWord (Search.cs:192-260) -> (units, R)."""

@@ -663,6 +663,56 @@ bool like_match(const ustr& key, const ustr& pat) {
   return true;
 }
 
+// Utils.Levenshtein, Index.cs:46-89 -- literal (full matrix)
+int levenshtein(const ustr& s, const ustr& t) {
+  const int n = (int)s.size(), m = (int)t.size();
+  if (n == 0) return m;
+  if (m == 0) return n;
+  std::vector<std::vector<int>> d(n + 1, std::vector<int>(m + 1, 0));
+  for (int i = 0; i <= n; i++) d[i][0] = i;
+  for (int j = 0; j <= m; j++) d[0][j] = j;
+  for (int i = 1; i <= n; i++)
+    for (int j = 1; j <= m; j++) {
+      int cost = (t[j - 1] == s[i - 1]) ? 0 : 1;
+      d[i][j] = std::min(std::min(d[i - 1][j] + 1, d[i][j - 1] + 1), d[i - 1][j - 1] + cost);
+    }
+  return d[n][m];
+}
+// GetCloseWords, Search.cs:168-174: self.Keys.OrderBy(Levenshtein).Take(10) -- OrderBy is a STABLE sort over the dictionary order
+std::vector<ustr> GetCloseWords(const Index& ix, const ustr& word, size_t n) {
+  std::vector<std::pair<int, const ustr*>> v;
+  for (const auto& kv : ix.self) v.emplace_back(levenshtein(kv.first, word), &kv.first);
+  std::stable_sort(v.begin(), v.end(), [](const std::pair<int, const ustr*>& a, const std::pair<int, const ustr*>& b) { return a.first < b.first; });
+  std::vector<ustr> r;
+  for (size_t i = 0; i < v.size() && i < n; i++) r.push_back(*v[i].second);
+  return r;
+}
+// the term selection of GetSuggessions, Search.cs:176-188: keys with Key[0] >= 'A' that start with lastword (ordinal) and are
+// longer than it, OrderBy(-Value.Count) (stable; Count = ushort units), Select(Key.Substring(lastword.Length)), Take(n)
+std::vector<ustr> SuggestTails(const Index& ix, const ustr& lastword, size_t n) {
+  std::vector<std::pair<long long, const ustr*>> v;
+  for (const auto& kv : ix.self) {
+    const ustr& k = kv.first;
+    if (k.empty() || k[0] < u'A') continue;
+    if (k.size() <= lastword.size() || k.compare(0, lastword.size(), lastword) != 0) continue;
+    v.emplace_back(-(long long)kv.second.self.size(), &k);
+  }
+  std::stable_sort(v.begin(), v.end(), [](const std::pair<long long, const ustr*>& a, const std::pair<long long, const ustr*>& b) { return a.first < b.first; });
+  std::vector<ustr> r;
+  for (size_t i = 0; i < v.size() && i < n; i++) r.push_back(v[i].second->substr(lastword.size()));
+  return r;
+}
+// GetLikeWords, Search.cs:158-167 (the non-trivial branch: word contains '_', bKeepForms, Length >= 2)
+std::vector<ustr> GetLikeWords(const Index& ix, const ustr& word) {
+  std::vector<ustr> r;
+  for (const auto& kv : ix.self)
+    if (!kv.first.empty() && is_L(kv.first[0]) && like_match(kv.first, word)) {
+      r.push_back(kv.first);
+      if (r.size() >= 100) break;                              // MAX_LIKE_WORDS
+    }
+  return r;
+}
+
 // SearchWord, Search.cs:192-260
 Seq SearchWord(Index& ix, ustr word) {
   bool bExact = false;
@@ -874,6 +924,23 @@ size_t orc_get_word_codes(void* h, const u16* w, size_t n, u16* out, size_t cap)
 size_t orc_search_word(void* h, const u16* w, size_t n, u16* out, size_t cap, int* R) {
   Seq s = SearchWord(*(Index*)h, mk(w, n));
   return emit(s, out, cap, R);
+}
+
+// dictionary scans: results joined by U+0000; returns the total length (call with out == NULL for the size)
+static size_t join0(const std::vector<ustr>& v, u16* out, size_t cap) {
+  ustr j;
+  for (size_t i = 0; i < v.size(); i++) { if (i) j.push_back(u'\0'); j += v[i]; }
+  if (out && cap >= j.size()) memcpy(out, j.data(), j.size() * 2);
+  return j.size() + (v.empty() ? 0 : 0);
+}
+size_t orc_close_words(void* h, const u16* w, size_t n, size_t take, u16* out, size_t cap, size_t* count) {
+  auto v = GetCloseWords(*(Index*)h, mk(w, n), take); *count = v.size(); return join0(v, out, cap);
+}
+size_t orc_suggest(void* h, const u16* w, size_t n, size_t take, u16* out, size_t cap, size_t* count) {
+  auto v = SuggestTails(*(Index*)h, mk(w, n), take); *count = v.size(); return join0(v, out, cap);
+}
+size_t orc_like_words(void* h, const u16* w, size_t n, u16* out, size_t cap, size_t* count) {
+  auto v = GetLikeWords(*(Index*)h, mk(w, n)); *count = v.size(); return join0(v, out, cap);
 }
 
 // ---- Builder ---------------------------------------------------------------------------------

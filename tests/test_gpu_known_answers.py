@@ -299,14 +299,21 @@ def test_close_words_and_suggestions(gpu_nostem):
                 diag, row[j] = row[j], v
         return row[len(t)]
 
+    oix = gpu_nostem[3]           # the oracle over the same index bytes
     for w in ("pikwick", "tupmann", "ld", "", "winkle", "&nam", "zzzzzzzzzzzzzzzzzzzzzzzzzzzzzzzz"):
         want = [k for _, _, k in sorted((lev(k, w), i, k) for i, k in enumerate(keys))[:10]]
-        assert S.GetCloseWords(w) == want, w
+        assert S.GetCloseWords(w) == want == oix.close_words(w, 10), w
     for req in ("mr pi", "the tu", "x", "snod", "and wi", "&n", "12"):
         last = [p for p in __import__("regex").split(r"\b", req) if p][-1].lower()
         cand = [(-(len(ix.get(t).units)), t) for t, k in enumerate(keys) if len(last) >= 2 and k[0] >= "A" and k.startswith(last) and len(k) > len(last)]
         want = [keys[t][len(last):] for _, t in sorted(cand)[:10]] if len(req) >= 2 else []
         assert S.GetSuggessions(req) == want, req
+        if len(req) >= 2 and len(last) >= 2:
+            assert want == oix.suggest_tails(last, 10), req
+    # GetLikeWords (Search.cs:158-167) as a dictionary kernel == the oracle's scan
+    for pat in ("_an_", "t_p", "pick_", "_ick_ic_", "__", "a_", "_", "zz_", "wel_er", "&n_"):
+        got = [ix.key(t) for t in ix.like_words(pat, 100)]
+        assert got == oix.like_words(pat), pat
 
 
 def test_search_many_and_micro_batcher(gpu_nostem, known, oracle_mod):
