@@ -191,7 +191,7 @@ class TermInfo:
         return r
 
 
-def run_query_leg(ix, queries, info, chunk, label, reps=1):
+def run_query_leg(ix, queries, info, chunk, label, reps=1, warm=True):
     """queries: list of [(word, R), ...] joined by AND.  Evaluated in calls of `chunk` queries (bounds the host-side result
     arrays); device time of dcd_query_batch (HIP events), results produced on the device, D2H of the result arrays excluded.
     Roofline on the SURVEY 8(d) bytes: 2 * units of every operand list + 4 * positions + 8 * pages, exact counts."""
@@ -216,6 +216,12 @@ def run_query_leg(ix, queries, info, chunk, label, reps=1):
             continue
         pa, oa = np.array(prog, np.int32), np.array(off, np.uint64)
         progs.append((pa, oa))
+        if not progs[1:] and warm:
+            # the first call of a leg also sizes the handle's work arena (one hipMalloc of up to half the device memory: seconds):
+            # run it once untimed, as a serving process would have done long before
+            tw = time.perf_counter()
+            ix.query_batch(pa, oa, totals=True)
+            note("  %s: warm-up call (work arena): %.1f s" % (label[:12], time.perf_counter() - tw))
         best = None
         for _ in range(reps):
             tw = time.perf_counter()

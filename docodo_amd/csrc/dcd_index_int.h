@@ -43,8 +43,8 @@ struct dcd_index {
   std::vector<u64> h_dir_off;    // [n_terms + 1]
   std::vector<u8> h_dir_shift;   // [n_terms]; 255 = no directory
   // work pool + scratch arena of the query batches (dcd_query.hip run_batch): grown on demand, kept until the handle is freed
-  dcd::DevBuf<u64> work_pool, work_tmp;
-  u64 work_pool_elems = 0, work_tmp_elems = 0;
+  dcd::DevBuf<u64> work_pool;       // (pool first, scratch behind it)
+  u64 work_pool_elems = 0;
   // ".index" bytes of this index, generated on demand (dcd_index_image / dcd_index_save)
   dcd::DevBuf<u8> image;
   u64 image_bytes = 0;

@@ -1395,24 +1395,34 @@ static int32_t run_batch(dcd_index* h, const int32_t* prog, const u64* prog_off,
   // queries over head terms).  They belong to the INDEX HANDLE and only ever grow: allocating them per call meant a hipMalloc /
   // hipFree of up to 100 GB each per sub-batch -- round 3 measured 87 s of wall time around 0.76 s of device time for 2 500
   // phrase queries on the 10 M-doc index -- and blocks of that size do not survive in the library's device cache (its cap is
-  // half of the device memory).  dcd_query_batch bounds a sub-batch by DOCODO_QUERY_ARENA_BYTES (default: three eighths of the device
+  // half of the device memory).  dcd_query_batch bounds a sub-batch by DOCODO_QUERY_ARENA_BYTES (default: half of the device
   // memory), so the arena settles at that size after the first large batch.
   DevBuf<u64> counts, d_part_count, d_part_src, d_part_excl, d_part_scr;
   struct ArenaView { u64* p; } pool{nullptr}, tmp{nullptr};
-  auto reserve = [&](DevBuf<u64>& buf, u64& have, u64 want) -> int32_t {
-    if (want <= have && buf.p) return DCD_OK;
-    buf.reset();
-    have = 0;
-    DCD_TRY(buf.alloc(dev, want ? want : 1));
-    have = want ? want : 1;
-    return DCD_OK;
-  };
-  DCD_TRY(reserve(h->work_pool, h->work_pool_elems, pool_elems));
-  pool.p = h->work_pool.p;
+  {
+    // ONE arena for both (pool first, scratch behind it).  It grows in big steps -- twice what is needed, and straight to the
+    // sub-batch bound once a batch needs more than an eighth of it -- because every growth is a hipMalloc + hipFree of tens of
+    // gigabytes (2.8-4 s each on MI355X): with exact sizes ten C4 calls of 10 k queries grew it three times.
+    const u64 want = (pool_elems ? pool_elems : 1) + (tmp_elems ? tmp_elems : 1);
+    if (want > h->work_pool_elems || !h->work_pool.p) {
+      size_t fb = 0, tb = 0;
+      DCD_HIP(hipMemGetInfo(&fb, &tb));
+      static const u64 env_arena = getenv("DOCODO_QUERY_ARENA_BYTES") ? strtoull(getenv("DOCODO_QUERY_ARENA_BYTES"), nullptr, 10) : 0;
+      const u64 bound = (env_arena ? env_arena : (u64)tb / 2) / 8;
+      u64 size = want > bound / 8 ? std::max(want, bound) : 2 * want;
+      h->work_pool.reset();
+      h->work_pool_elems = 0;
+      if (h->work_pool.alloc(dev, size) != DCD_OK) {          // (not that much memory left: exactly what this batch needs)
+        size = want;
+        DCD_TRY(h->work_pool.alloc(dev, size));
+      }
+      h->work_pool_elems = size;
+    }
+    pool.p = h->work_pool.p;
+    tmp.p = h->work_pool.p + (pool_elems ? pool_elems : 1);
+  }
   DCD_TRY(counts.alloc(dev, n_counts ? n_counts : 1));
   {
-    DCD_TRY(reserve(h->work_tmp, h->work_tmp_elems, tmp_elems));
-    tmp.p = h->work_tmp.p;
     DCD_TRY(d_part_count.alloc(dev, max_items + 1));
     DCD_TRY(d_part_src.alloc(dev, max_items + 1));
     DCD_TRY(d_part_excl.alloc(dev, max_items + 1));
@@ -1765,12 +1775,12 @@ int32_t dcd_query_batch(dcd_index* h, const int32_t* prog, const uint64_t* prog_
   size_t free_b = 0, total_b = 0;
   DCD_HIP(hipMemGetInfo(&free_b, &total_b));
   // (what the handle's arena holds already is available to the batch)
-  const u64 avail_b = (u64)free_b + (u64)dev_pool_cached_bytes(h->ix.device) + 8 * (h->work_pool_elems + h->work_tmp_elems);
+  const u64 avail_b = (u64)free_b + (u64)dev_pool_cached_bytes(h->ix.device) + 8 * h->work_pool_elems;
   u64 budget = std::max<u64>(avail_b / 4 * 3 / 8, 1ull << 24);   // elements of 8 bytes
   {
     // ... and no more than the arena bound: a sub-batch beyond it would only buy a larger hipMalloc (see run_batch)
     static const u64 env_arena = getenv("DOCODO_QUERY_ARENA_BYTES") ? strtoull(getenv("DOCODO_QUERY_ARENA_BYTES"), nullptr, 10) : 0;
-    const u64 arena_b = env_arena ? env_arena : (u64)total_b / 8 * 3;
+    const u64 arena_b = env_arena ? env_arena : (u64)total_b / 2;
     budget = std::max<u64>(std::min<u64>(budget, arena_b / 8), 1ull << 24);
   }
   if (const char* e = getenv("DOCODO_QUERY_POOL_ELEMS")) budget = std::max<u64>(strtoull(e, nullptr, 10), 1);   // tests
@@ -1807,8 +1817,8 @@ int32_t dcd_query_batch(dcd_index* h, const int32_t* prog, const uint64_t* prog_
       if (st == DCD_OK) { append_results(*R, part); q0 = q1; continue; }
     }
     if (st != DCD_E_NOMEM || q1 - q0 <= 1) return st;
-    h->work_pool.reset(); h->work_tmp.reset();              // out of memory: give the arena back, release the cache,
-    h->work_pool_elems = h->work_tmp_elems = 0;
+    h->work_pool.reset();                                   // out of memory: give the arena back, release the cache,
+    h->work_pool_elems = 0;
     dev_pool_trim(h->ix.device);                           // halve the sub-batch, try again
     budget = std::max<u64>(1, std::min(budget, acc) / 2);
     if (single) R.reset(new dcd_results());                // nothing of a failed single attempt survives
