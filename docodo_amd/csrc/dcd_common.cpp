@@ -152,9 +152,11 @@ int32_t dev_alloc(int device, size_t bytes, void** out) {
   const bool have_want = t_have_stream;
   {
     std::lock_guard<std::mutex> g(P.mu);
-    // accept a cached block up to 25 % larger than needed
-    for (auto it = P.free_.lower_bound(r); it != P.free_.end() && it->first <= r + r / 4; ++it) {
-      if (!make_usable(device, P, it->second, want, have_want, false)) continue;
+    // accept a cached block up to 25 % larger than needed.  The pool's mutex is held while candidates are probed (an event /
+    // stream query for a block whose releasing stream may still be busy): after four busy ones the allocation goes to hipMalloc
+    int failed = 0;
+    for (auto it = P.free_.lower_bound(r); it != P.free_.end() && it->first <= r + r / 4 && failed < 4; ++it) {
+      if (!make_usable(device, P, it->second, want, have_want, false)) { failed++; continue; }
       *out = it->second.p;
       P.live[it->second.p] = LiveBlock{it->first, want, have_want};
       P.cached -= it->first;
