@@ -68,7 +68,8 @@ def algorithmic_bytes(kernel, T, N, U, n_launch=1, n_hot=0, id_keys=False, passe
         "k_rs_scatter": 16 * tuples,      # reads and writes every 8-byte tuple
         "k_enc_reduce": 8 * N,            # reads the sorted tuples
         "k_enc_write": 8 * N + 2 * U,     # reads the tuples, writes the ushort units
-        "k_img_units": (6 if id_keys else 4) * U,   # copies the units into the .index image (+ into term order)
+        "k_img_units": 4 * U,             # copies the units into the .index image (round 3: the term-ordered posting array of a
+                                          # queryable index is made when a handle adopts the build, not in every build)
     }.get(kernel, 0)
 
 

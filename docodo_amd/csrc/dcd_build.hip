@@ -656,16 +656,22 @@ __device__ __forceinline__ void img_copy8(const u16* __restrict__ units, u64 u0,
 // PERM: the source holds the terms in another order (src_start[t] = first unit of term t in `units`); the units also go,
 // in term order, to units_out (the index's posting array): one read, two writes.  The source run of a term starts at an
 // arbitrary 2-byte boundary (dword loads at that alignment), units_out[u0] is 16-byte aligned.
+template <bool W_IMG, bool W_OUT>
 __device__ __forceinline__ void img_copy8_perm(const u16* __restrict__ units, u64 s0, u8* __restrict__ img, u64 dst, u16* __restrict__ units_out,
                                                u64 u0) {
   const u32_a1* s = reinterpret_cast<const u32_a1*>(units + s0);
   uint4 v;
   v.x = s[0]; v.y = s[1]; v.z = s[2]; v.w = s[3];
-  u32_a1* d = reinterpret_cast<u32_a1*>(img + dst);
-  d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-  *reinterpret_cast<uint4*>(units_out + u0) = v;
+  if (W_IMG) {
+    u32_a1* d = reinterpret_cast<u32_a1*>(img + dst);
+    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+  }
+  if (W_OUT) *reinterpret_cast<uint4*>(units_out + u0) = v;
 }
-template <bool PERM>
+// W_IMG / W_OUT (PERM only): which of the two destinations is written.  Round 3: the BUILD writes the image only (the units stay
+// where the pack kernel left them, in sort-key order); the term-ordered posting array is an auxiliary structure of a QUERYABLE
+// index and is made when a handle adopts the build (index_materialize_units: the same kernel with W_IMG = false).
+template <bool PERM, bool W_IMG = true, bool W_OUT = true>
 __global__ __launch_bounds__(IMG_THREADS) void k_img_units(const u16* __restrict__ units, u64 n_units, const u64* __restrict__ unit_start,
                                                           u64 n_terms, const u64* __restrict__ pay_off, u8* __restrict__ img,
                                                           const u64* __restrict__ src_start, u16* __restrict__ units_out) {
@@ -679,13 +685,13 @@ __global__ __launch_bounds__(IMG_THREADS) void k_img_units(const u16* __restrict
   if (span >= n_units) return;
   const u64 t0 = img_term_of(unit_start, s_t[0], s_t[1] + 1, span);          // wave-uniform
   if (span + IMG_SPAN <= unit_start[t0 + 1]) {                               // the whole span inside one term
-    const u64 dst0 = pay_off[t0] + 2 * (span - unit_start[t0]);
+    const u64 dst0 = W_IMG ? pay_off[t0] + 2 * (span - unit_start[t0]) : 0;
     if (PERM) {
       const u64 s0 = src_start[t0] + (span - unit_start[t0]);
 #pragma unroll
       for (int c = 0; c < IMG_CPL; c++) {
         const u64 o = (u64)(c * 64 + lane) * IMG_UPT;
-        img_copy8_perm(units, s0 + o, img, dst0 + o * 2, units_out, span + o);
+        img_copy8_perm<W_IMG, W_OUT>(units, s0 + o, img, dst0 + o * 2, units_out, span + o);
       }
       return;
     }
@@ -698,20 +704,19 @@ __global__ __launch_bounds__(IMG_THREADS) void k_img_units(const u16* __restrict
     if (u0 >= n_units) break;
     u64 t = img_term_of(unit_start, t0, s_t[1] + 1, u0);
     u64 next = unit_start[t + 1];
-    u64 dst = pay_off[t] + 2 * (u0 - unit_start[t]);
+    u64 dst = W_IMG ? pay_off[t] + 2 * (u0 - unit_start[t]) : 0;
     u64 sp = PERM ? src_start[t] + (u0 - unit_start[t]) : u0;       // source position of unit u0
     if (u0 + IMG_UPT <= next) {
-      if (PERM) img_copy8_perm(units, sp, img, dst, units_out, u0); else img_copy8(units, u0, img, dst);
+      if (PERM) img_copy8_perm<W_IMG, W_OUT>(units, sp, img, dst, units_out, u0); else img_copy8(units, u0, img, dst);
       continue;
     }
     for (int k = 0; k < IMG_UPT; k++) {
       u64 u = u0 + k;
       if (u >= n_units) break;
-      while (u >= next) { t++; next = unit_start[t + 1]; dst = pay_off[t]; if (PERM) sp = src_start[t]; }
+      while (u >= next) { t++; next = unit_start[t + 1]; if (W_IMG) dst = pay_off[t]; if (PERM) sp = src_start[t]; }
       u16 v = units[PERM ? sp : u];
-      if (PERM) { units_out[u] = v; sp++; }
-      img[dst] = (u8)v;
-      img[dst + 1] = (u8)(v >> 8);
+      if (PERM) { if (W_OUT) units_out[u] = v; sp++; }
+      if (W_IMG) { img[dst] = (u8)v; img[dst + 1] = (u8)(v >> 8); }
       dst += 2;
     }
   }
@@ -767,7 +772,7 @@ namespace dcd {
 int32_t get_char_tables16(int device, CharTables16* out);
 void host_char_tables16(const u8** cls, const u16** lower);
 DeviceIndex* build_take_index(dcd_build* b) {
-  if (!b->finished || b->adopted || b->ix.units_by_key.p) return nullptr;      // (a shard-only build has no index to hand over)
+  if (!b->finished || b->adopted || b->ix.shard_only || b->ix.units_by_key.p) return nullptr;   // (shard-only: nothing to hand over; else the caller materialises the units first)
   b->adopted = true;
   return &b->ix;
 }
@@ -827,6 +832,27 @@ int32_t index_fetch_host(DeviceIndex& ix) {
   DCD_HIP(hipMemcpy(ix.h_term_unit_start.data(), ix.term_unit_start.p, (V + 1) * 8, hipMemcpyDeviceToHost));
   DCD_HIP(hipMemcpy(ix.h_term_item_start.data(), ix.term_item_start.p, (V + 1) * 8, hipMemcpyDeviceToHost));
   ix.host_ready = true;
+  return DCD_OK;
+}
+}  // namespace dcd
+
+namespace dcd {
+// The term-ordered posting array of an id-keyed build (DeviceIndex::units), made from the sort-key-ordered units the pack kernel
+// left -- when an index handle adopts the build (the query path and dcd_index_get address postings by ordinal term).
+int32_t index_materialize_units(DeviceIndex& ix, hipStream_t st) {
+  if (!ix.units_by_key.p || ix.units.p) return DCD_OK;
+  if (ix.shard_only) DCD_FAIL(DCD_E_STATE, "a DCD_BUILD_SHARD_ONLY build can only be exported");
+  DCD_TRY(ensure_device(ix.device));
+  StreamScope ss_(st);
+  const u64 U = ix.n_units, V = ix.n_terms;
+  DCD_TRY(ix.units.alloc(ix.device, U ? U : 1));
+  if (U && V)
+    hipLaunchKernelGGL((k_img_units<true, false, true>), dim3((u32)div_up(U, IMG_TILE)), dim3(IMG_THREADS), 0, st, (const u16*)ix.units_by_key.p, U,
+                       (const u64*)ix.term_unit_start.p, V, (const u64*)nullptr, (u8*)nullptr, (const u64*)ix.unit_src_start.p, ix.units.p);
+  DCD_HIP(hipStreamSynchronize(st));
+  DCD_HIP(hipGetLastError());
+  ix.units_by_key.reset();
+  ix.unit_src_start.reset();
   return DCD_OK;
 }
 }  // namespace dcd
@@ -2188,7 +2214,9 @@ static int32_t build_phase2(dcd_build* h) {
   // DCD_BUILD_SHARD_ONLY (id-keyed builds): the shard is exported, not serialised or queried -- no image, no copy of the units
   // into term order; the export reads them where the pack kernel left them (units_by_key + unit_src_start)
   const bool shard_only = idk && (h->opts.flags & DCD_BUILD_SHARD_ONLY) != 0;
-  if (idk && !shard_only) DCD_TRY(ix.units.alloc(dev, U ? U : 1));
+  // (id-keyed builds: the term-ordered posting array is not made here any more -- index_materialize_units, when a handle adopts
+  //  the build; the build's own product is the image)
+  ix.shard_only = shard_only;
   u64 max_coord = 0;
   {
     // coordinate of the last Add call: the later of (last explicit posting, last text token)
@@ -2199,10 +2227,7 @@ static int32_t build_phase2(dcd_build* h) {
     else if (any_x) max_coord = h->last_explicit_coord;
   }
   h->image_bytes = shard_only ? 0 : 8 + rec_total;
-  if (shard_only) {
-    ix.units_by_key = std::move(units_id);
-    ix.unit_src_start = std::move(src_start);
-  } else {
+  if (!shard_only) {
   DCD_TRY(h->image.alloc(dev, h->image_bytes));
   hipLaunchKernelGGL(k_put_u64_bytes, dim3(1), dim3(1), 0, st, h->image.p, max_coord);
   }
@@ -2212,8 +2237,8 @@ static int32_t build_phase2(dcd_build* h) {
     if (U) {
       probes.begin(DCD_K_IMG_UNITS);
       if (idk)
-        hipLaunchKernelGGL(k_img_units<true>, dim3((u32)div_up(U, IMG_TILE)), dim3(IMG_THREADS), 0, st, (const u16*)units_id.p, U,
-                           (const u64*)ix.term_unit_start.p, V, (const u64*)pay_off.p, h->image.p, (const u64*)src_start.p, ix.units.p);
+        hipLaunchKernelGGL((k_img_units<true, true, false>), dim3((u32)div_up(U, IMG_TILE)), dim3(IMG_THREADS), 0, st, (const u16*)units_id.p, U,
+                           (const u64*)ix.term_unit_start.p, V, (const u64*)pay_off.p, h->image.p, (const u64*)src_start.p, (u16*)nullptr);
       else
         hipLaunchKernelGGL(k_img_units<false>, dim3((u32)div_up(U, IMG_TILE)), dim3(IMG_THREADS), 0, st, (const u16*)ix.units.p, U,
                            (const u64*)ix.term_unit_start.p, V, (const u64*)pay_off.p, h->image.p, (const u64*)nullptr, (u16*)nullptr);
@@ -2224,6 +2249,10 @@ static int32_t build_phase2(dcd_build* h) {
   t_all.stop_at_stop_of(t_img);
   DCD_HIP(hipStreamSynchronize(st));
   DCD_HIP(hipGetLastError());
+  if (idk) {                      // the units stay in sort-key order: term r's run starts at units_by_key[unit_src_start[r]]
+    ix.units_by_key = std::move(units_id);
+    ix.unit_src_start = std::move(src_start);
+  }
   tr.mark("image");
 
   // ---- host mirrors + stats ----------------------------------------------------------------------
@@ -2327,7 +2356,7 @@ int32_t dcd_build_get_stats(dcd_build* h, dcd_build_stats* out) {
 int32_t dcd_build_index_image(dcd_build* h, uint8_t* out, size_t cap, size_t* n) {
   if (!h || !n) DCD_FAIL(DCD_E_BADARG, "dcd_build_index_image: NULL argument");
   if (!h->finished) DCD_FAIL(DCD_E_STATE, "dcd_build_finish has not run");
-  if (h->ix.units_by_key.p) DCD_FAIL(DCD_E_STATE, "a DCD_BUILD_SHARD_ONLY build has no .index image");
+  if (h->ix.shard_only) DCD_FAIL(DCD_E_STATE, "a DCD_BUILD_SHARD_ONLY build has no .index image");
   *n = (size_t)h->image_bytes;
   if (!out || cap < h->image_bytes) return DCD_E_OVERFLOW;
   DCD_TRY(ensure_device(h->device));
@@ -2348,7 +2377,7 @@ int32_t dcd_build_list_image(dcd_build* h, uint8_t* out, size_t cap, size_t* n) 
 int32_t dcd_build_save(dcd_build* h, const char* dir_utf8) {
   if (!h || !dir_utf8) DCD_FAIL(DCD_E_BADARG, "dcd_build_save: NULL argument");
   if (!h->finished) DCD_FAIL(DCD_E_STATE, "dcd_build_finish has not run");
-  if (h->ix.units_by_key.p) DCD_FAIL(DCD_E_STATE, "a DCD_BUILD_SHARD_ONLY build cannot be saved");
+  if (h->ix.shard_only) DCD_FAIL(DCD_E_STATE, "a DCD_BUILD_SHARD_ONLY build cannot be saved");
   std::vector<u8> img(h->image_bytes);
   size_t n = 0;
   DCD_TRY(dcd_build_index_image(h, img.data(), img.size(), &n));

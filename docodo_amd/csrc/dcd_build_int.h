@@ -53,6 +53,10 @@ struct DeviceIndex {
   // and term r's run starts at units_by_key[unit_src_start[r]]
   DevBuf<u16> units_by_key;
   DevBuf<u64> unit_src_start;    // [n_terms]
+  // ... round 3: EVERY id-keyed build leaves its units like that (the build's product is the ".index" image); `units` is made
+  // from them when an index handle adopts the build (index_materialize_units).  shard_only: there is no image either, the
+  // build can only be exported.
+  bool shard_only = false;
   // host mirrors (small): keys for dcd_index_find, offsets
   std::vector<u16> h_term_chars;
   std::vector<u32> h_term_str_off;
@@ -64,6 +68,7 @@ struct DeviceIndex {
 // downloads the host mirrors of an index a build left on the device (done on demand: a build that is only saved
 // or exported never needs them)
 int32_t index_fetch_host(DeviceIndex& ix);
+int32_t index_materialize_units(DeviceIndex& ix, hipStream_t st);
 // exact ".index" bytes (Build.cs:375-386 / Appendix A.3) of a device-resident index, generated on the device
 int32_t index_make_image(const DeviceIndex& ix, hipStream_t st, DevBuf<u8>& image, u64* image_bytes);
 

@@ -15,6 +15,7 @@ namespace dcd {
 DeviceIndex* build_take_index(dcd_build* b);
 DeviceIndex* build_peek_index(dcd_build* b);
 int build_device(dcd_build* b);
+hipStream_t build_stream(dcd_build* b);
 }  // namespace dcd
 
 namespace dcd {
@@ -342,7 +343,8 @@ int32_t dcd_index_from_build(dcd_build* b, dcd_index** out) {
   // everything that can fail happens while the build still owns its index: a failed call leaves the builder usable
   DeviceIndex* peek = build_peek_index(b);
   if (!peek) DCD_FAIL(DCD_E_STATE, "build is not finished or its index was already adopted");
-  if (peek->units_by_key.p) DCD_FAIL(DCD_E_STATE, "a DCD_BUILD_SHARD_ONLY build can only be exported");
+  if (peek->shard_only) DCD_FAIL(DCD_E_STATE, "a DCD_BUILD_SHARD_ONLY build can only be exported");
+  DCD_TRY(index_materialize_units(*peek, build_stream(b)));   // (the build left its units in sort-key order)
   DCD_TRY(index_fetch_host(*peek));
   hipStream_t st = nullptr;
   DCD_TRY(stream_acquire(peek->device, &st));

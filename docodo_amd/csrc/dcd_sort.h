@@ -537,11 +537,10 @@ template <int BITS>
 inline void rs_pass(const uint2* in, uint2* out, const u32* remap, u64 n, int shift, u32* hist, u32* scan_scratch,
                     hipStream_t st, const RsProbe& pr, bool remap_cache, const RsStrided* sd = nullptr) {
   RsPlan p = rs_plan(n);
-  pr.rec(st, false);
   if (sd && !sd->cnt && sd->range) {
     // dense input in variable block ranges, histogram supplied by the pass before (RsStrided::range / next_hist)
+    // (no histogram kernel: no histogram probe either)
     const u32 nblk = sd->range_nblk;
-    pr.rec(st, false);
     u64 ne = (u64)nblk << BITS;
     scan_exclusive<u32, u32>(hist, hist, ne, scan_scratch, st);
     pr.rec(st, true);
@@ -552,12 +551,14 @@ inline void rs_pass(const uint2* in, uint2* out, const u32* remap, u64 n, int sh
   if (sd) {
     // tile-strided input: blocks own tiles, not tuples
     const RsTilePlan tp = rs_tile_plan(sd->n_tiles);
-    if (sd->hist_ready) {}
-    else if (remap && remap_cache)
-      hipLaunchKernelGGL((k_rs_hist_strided<BITS, true>), dim3(tp.nblk), dim3(RS_THREADS), 0, st, in, *sd, remap, tp.tpb, tp.nblk, shift, hist);
-    else
-      hipLaunchKernelGGL((k_rs_hist_strided<BITS, false>), dim3(tp.nblk), dim3(RS_THREADS), 0, st, in, *sd, remap, tp.tpb, tp.nblk, shift, hist);
-    pr.rec(st, false);
+    if (!sd->hist_ready) {
+      pr.rec(st, false);
+      if (remap && remap_cache)
+        hipLaunchKernelGGL((k_rs_hist_strided<BITS, true>), dim3(tp.nblk), dim3(RS_THREADS), 0, st, in, *sd, remap, tp.tpb, tp.nblk, shift, hist);
+      else
+        hipLaunchKernelGGL((k_rs_hist_strided<BITS, false>), dim3(tp.nblk), dim3(RS_THREADS), 0, st, in, *sd, remap, tp.tpb, tp.nblk, shift, hist);
+      pr.rec(st, false);
+    }
     u64 ne = (u64)tp.nblk << BITS;
     scan_exclusive<u32, u32>(hist, hist, ne, scan_scratch, st);
     if (pr.after_scan) pr.after_scan(pr.after_scan_arg, st);
@@ -571,6 +572,7 @@ inline void rs_pass(const uint2* in, uint2* out, const u32* remap, u64 n, int sh
     pr.rec(st, true);
     return;
   }
+  pr.rec(st, false);
   if (remap && remap_cache)
     hipLaunchKernelGGL((k_rs_hist<BITS, true>), dim3(p.nblk), dim3(RS_THREADS), 0, st, in, remap, n, p.ipb, p.nblk, shift, hist);
   else
