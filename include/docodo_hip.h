@@ -209,7 +209,9 @@ int32_t dcd_build_save(dcd_build* h, const char* dir_utf8);
  * (Search.cs:307), PrepareSearchResult (Search.cs:365-420) and the ranks (Search.cs:99-111,
  * 552-557, 599).
  * ------------------------------------------------------------------------------------------ */
-int32_t dcd_index_from_build(dcd_build* b, dcd_index** out);          /* adopt the HBM-resident index */
+/* adopt the HBM-resident index of a finished build.  (The build itself leaves the ".index" image and the posting units in its
+ * sort order; the term-ordered posting array a queryable index needs is made here, once, on the device.) */
+int32_t dcd_index_from_build(dcd_build* b, dcd_index** out);
 int32_t dcd_index_open(const char* dir_utf8, int32_t device, dcd_index** out);   /* Index.Load */
 int32_t dcd_index_from_images(const uint8_t* index_img, size_t n_index, const uint8_t* list_img, size_t n_list,
                               int32_t device, dcd_index** out);
