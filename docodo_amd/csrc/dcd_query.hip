@@ -234,76 +234,141 @@ __device__ __forceinline__ u64 wave_split(const CV& A, u64 na, const CV& B, u64 
   return lo;
 }
 
+#ifdef DCD_PROF
+// debug build only: wave-residency cycles per phase of k_pair_parts (s_memtime deltas, summed over all waves)
+__device__ unsigned long long g_prof[16];
+#define PROF_T() unsigned long long _pt = __builtin_readcyclecounter()
+#define PROF(i) do { unsigned long long _n = __builtin_readcyclecounter(); if (threadIdx.x == 0) atomicAdd(&g_prof[i], _n - _pt); _pt = _n; } while (0)
+#else
+#define PROF_T()
+#define PROF(i)
+#endif
 // ---- galloping, one slice of the short operand per work item ------------------------------------------------
 __device__ void part_gallop(const CV& Sv, u64 ns, const CV& Lv, u64 nl, bool s_is_a, u32 absR, bool ordered,
                             u64 i_begin, u64 i_end, u64* __restrict__ tmp_op, u32* rec_lds, u64& count_out, u64& slot_out,
                             const u32* __restrict__ ldir, u32 ldir_shift, u64 ldir_last) {
   const u32 lane = threadIdx.x;
+  // records of the elements that WALK their chain, by position in the walk list (an element without a neighbour within absR
+  // emits nothing and needs no record)
   u64* r_b = reinterpret_cast<u64*>(rec_lds);                 // [PW_TILE] first L index of the emitted part
   u32* r_d = rec_lds + 2 * PW_TILE;                           // [PW_TILE] number of L elements emitted from r_b
-  u32* r_s0 = rec_lds + 3 * PW_TILE;                          // [PW_TILE] first S index emitted (relative to i0)
-  u32* r_s1 = rec_lds + 4 * PW_TILE;                          // [PW_TILE] last S index emitted (inclusive, relative to i0)
+  u32* r_s0 = rec_lds + 3 * PW_TILE;                          // [PW_TILE] first S index emitted (relative to i_begin)
+  u32* r_s1 = rec_lds + 4 * PW_TILE;                          // [PW_TILE] last S index emitted (inclusive, relative to i_begin)
   u32* r_n = rec_lds + 5 * PW_TILE;                           // [PW_TILE] emitted values (0 = not a leader / nothing)
-  u16* g_list = reinterpret_cast<u16*>(rec_lds + 6 * PW_TILE);  // [PW_TILE] element slots of the elements that walk their chain
+  u16* g_list = reinterpret_cast<u16*>(rec_lds + 6 * PW_TILE);  // [PW_TILE] the walk list: element index relative to i_begin (< GAL_PER)
   u64 cursor = 0, slot = 0;
   bool have_slot = false;
+  u32 n_list = 0;                                             // (wave-uniform)
+  auto general = [&](u64 i, u32 k, u64 il) {
+    const u64 s = Sv[i];
+    u64 a = i, b = il, cur = s;                              // left walk over the union
+    for (;;) {
+      bool hs = a > 0, hl = b > 0;
+      if (!hs && !hl) break;
+      u64 cs = hs ? Sv[a - 1] : 0, cl = hl ? Lv[b - 1] : 0;
+      bool takeS = hs && (!hl || cs >= cl);
+      u64 cand = takeS ? cs : cl;
+      if (cur - cand > (u64)absR) break;
+      if (takeS) a--; else b--;
+      cur = cand;
+      if (a < i) break;   // an earlier short-list element is in this chain: not the leader
+    }
+    u32 n = 0;
+    u64 eb = 0, es0 = i, es1 = i;
+    u32 ed = 0;
+    if (a == i) {
+      u64 c = i, d = il;                                     // right walk
+      cur = s;
+      for (;;) {
+        bool hs = c + 1 < ns, hl = d < nl;
+        if (!hs && !hl) break;
+        u64 cs = hs ? Sv[c + 1] : 0, cl = hl ? Lv[d] : 0;
+        bool takeS = hs && (!hl || cs <= cl);
+        u64 cand = takeS ? cs : cl;
+        if (cand - cur > (u64)absR) break;
+        if (takeS) c++; else d++;
+        cur = cand;
+      }
+      // chain = S[i..c] u L[b..d)
+      u64 lb = b, ld = d, sb = i;
+      bool ok = d > b;                                      // needs an element of the long operand
+      if (ok && ordered) {
+        if (s_is_a) {                                       // first A element = s: drop L elements before it
+          lb = il;
+          ok = d > il;                                      // a B element at or after the first A
+        } else {                                            // A is the long operand: first A = L[b]
+          u64 fa = Lv[b];
+          while (sb <= c && Sv[sb] < fa) sb++;             // drop B-only prefix
+          ok = sb <= c;
+        }
+      }
+      if (ok) {
+        eb = lb; ed = (u32)(ld - lb); es0 = sb; es1 = c;
+        n = gal_merge(Sv, sb, c, Lv, lb, ld, [](u64) {});
+      }
+    }
+    r_b[k] = eb; r_d[k] = ed; r_s0[k] = (u32)(es0 - i_begin); r_s1[k] = (u32)(es1 - i_begin); r_n[k] = n;
+  };
+  // Round 3: the chain walks and the emission are BATCHED over the whole work item.  They are serial, latency-bound code -- a
+  // lane follows its chain load by load, three traversals per emitting chain (walk, count, emit) -- and used to run once per
+  // round of 256 short-list elements with the two or three elements of that round that had a neighbour: 56 % of the wave
+  // residency of configs[3] (in-kernel phase profile) with a handful of lanes active.  Now the rounds only APPEND to the walk
+  // list; one walk + emit phase serves the item's 1024 elements (or runs earlier when the list is about to overflow).
+  auto flush = [&]() {
+    wsync();
+    for (u32 b0 = 0; b0 < n_list; b0 += PW_T) {
+      if (b0 + lane < n_list) {
+        const u32 p = b0 + lane;
+        const u64 i = i_begin + g_list[p];
+        const u64 s = Sv[i];
+        u64 il;                                                // first L >= s, located again (cheaper than keeping it in LDS)
+        if (ldir) {
+          const u64 c = min(s >> ldir_shift, ldir_last);
+          u64 lo = ldir[c], hi = ldir[c + 1];
+          while (lo < hi) { u64 m = (lo + hi) >> 1; if (Lv[m] < s) lo = m + 1; else hi = m; }
+          il = lo;
+        } else il = lower_bound_u64(Lv, nl, s);
+        general(i, p, il);
+      }
+    }
+    wsync();
+    u32 mine = 0;
+    for (u32 q = 0; q < PW_ITEMS; q++) { u32 p = lane * PW_ITEMS + q; if (p < n_list) mine += r_n[p]; }
+    const u32 incl = wave_scan_incl(mine);
+    const u32 total = rdl(incl, 63);
+    u32 ex = incl - mine;
+    if (!have_slot && total) {
+      // scratch slot of this work item = union index (S index + L index) of its first emitted element
+      const u64 m = ballot64(mine != 0);
+      const u32 fl = (u32)__builtin_ctzll(m);
+      u64 cand = 0;
+      if (lane == fl) {
+        for (u32 q = 0; q < PW_ITEMS; q++) { u32 p = lane * PW_ITEMS + q; if (p < n_list && r_n[p]) { cand = r_b[p] + i_begin + r_s0[p]; break; } }
+      }
+      slot = rdl64(cand, fl);
+      have_slot = true;
+    }
+    u64* out = tmp_op + slot;
+    for (u32 q = 0; q < PW_ITEMS; q++) {
+      u32 p = lane * PW_ITEMS + q;
+      if (p < n_list && r_n[p]) {
+        u64 o = cursor + ex;
+        gal_merge(Sv, i_begin + r_s0[p], i_begin + r_s1[p], Lv, r_b[p], r_b[p] + r_d[p], [&](u64 v) { out[o++] = v; });
+        ex += r_n[p];
+      }
+    }
+    cursor += total;
+    wsync();                                                   // (the records are free again; the stores stay in flight)
+    n_list = 0;
+  };
   for (u64 i0 = i_begin; i0 < i_end; i0 += PW_TILE) {
+    PROF_T();
     const u32 cn = (u32)min((u64)PW_TILE, i_end - i0);
     // Every lane looks after PW_ITEMS short-list elements.  Their loads are issued together, phase by phase (the
     // chain of dependent accesses -- directory cell, long-list position, neighbours -- is latency bound, so the
     // elements of a lane overlap each other): position in the long list, then the four union neighbours.  An
     // element without a neighbour within absR on either side is a chain of its own and emits nothing; only the
-    // others walk their chain.
-    auto general = [&](u64 i, u32 k, u64 il) {
-      const u64 s = Sv[i];
-      u64 a = i, b = il, cur = s;                              // left walk over the union
-      for (;;) {
-        bool hs = a > 0, hl = b > 0;
-        if (!hs && !hl) break;
-        u64 cs = hs ? Sv[a - 1] : 0, cl = hl ? Lv[b - 1] : 0;
-        bool takeS = hs && (!hl || cs >= cl);
-        u64 cand = takeS ? cs : cl;
-        if (cur - cand > (u64)absR) break;
-        if (takeS) a--; else b--;
-        cur = cand;
-        if (a < i) break;   // an earlier short-list element is in this chain: not the leader
-      }
-      u32 n = 0;
-      u64 eb = 0, es0 = i, es1 = i;
-      u32 ed = 0;
-      if (a == i) {
-        u64 c = i, d = il;                                     // right walk
-        cur = s;
-        for (;;) {
-          bool hs = c + 1 < ns, hl = d < nl;
-          if (!hs && !hl) break;
-          u64 cs = hs ? Sv[c + 1] : 0, cl = hl ? Lv[d] : 0;
-          bool takeS = hs && (!hl || cs <= cl);
-          u64 cand = takeS ? cs : cl;
-          if (cand - cur > (u64)absR) break;
-          if (takeS) c++; else d++;
-          cur = cand;
-        }
-        // chain = S[i..c] u L[b..d)
-        u64 lb = b, ld = d, sb = i;
-        bool ok = d > b;                                      // needs an element of the long operand
-        if (ok && ordered) {
-          if (s_is_a) {                                       // first A element = s: drop L elements before it
-            lb = il;
-            ok = d > il;                                      // a B element at or after the first A
-          } else {                                            // A is the long operand: first A = L[b]
-            u64 fa = Lv[b];
-            while (sb <= c && Sv[sb] < fa) sb++;             // drop B-only prefix
-            ok = sb <= c;
-          }
-        }
-        if (ok) {
-          eb = lb; ed = (u32)(ld - lb); es0 = sb; es1 = c;
-          n = gal_merge(Sv, sb, c, Lv, lb, ld, [](u64) {});
-        }
-      }
-      r_b[k] = eb; r_d[k] = ed; r_s0[k] = (u32)(es0 - i0); r_s1[k] = (u32)(es1 - i0); r_n[k] = n;
-    };
+    // others go on the walk list.
     {
       // (all loads below are unconditional on clamped, always-valid indices: a load under a lane predicate would put
       // a branch and a wait between the loads of the PW_ITEMS elements)
@@ -343,6 +408,7 @@ __device__ void part_gallop(const CV& Sv, u64 ns, const CV& Lv, u64 nl, bool s_i
 #pragma unroll
         for (int q = 0; q < (int)PW_ITEMS; q++) ilv[q] = act[q] ? lower_bound_u64(Lv, nl, sv[q]) : 0;
       }
+      PROF(11);  // gallop: short elements, directory cells, position in the long list
       u64 lft[PW_ITEMS], rgt[PW_ITEMS];                        // nearest union neighbours (~0: none)
       {
         u64 sp[PW_ITEMS], lp[PW_ITEMS], sn[PW_ITEMS], ln[PW_ITEMS];
@@ -362,65 +428,28 @@ __device__ void part_gallop(const CV& Sv, u64 ns, const CV& Lv, u64 nl, bool s_i
           rgt[q] = min(hsn ? sn[q] : ~0ull, hln ? ln[q] : ~0ull);
         }
       }
-      // The few elements that do have a neighbour are compacted into a list and walked with one lane each: walking them
-      // where they stand would run the (long, divergent) chain code once per element slot with a single active lane.
-      u32 n_list = 0;
+      // the few elements that do have a neighbour go on the walk list (in element order: the emission below relies on it)
+      u64 wm[PW_ITEMS];
+      u32 n_new = 0;
+#pragma unroll
+      for (int q = 0; q < (int)PW_ITEMS; q++) {
+        const bool left_far = lft[q] == ~0ull || sv[q] - lft[q] > (u64)absR;
+        const bool right_far = rgt[q] == ~0ull || rgt[q] - sv[q] > (u64)absR;
+        wm[q] = ballot64(act[q] && !(left_far && right_far));
+        n_new += popc64(wm[q]);
+      }
+      PROF(12);  // gallop: neighbours, walk list
+      if (n_list + n_new > PW_TILE) flush();                   // (a round adds at most PW_TILE entries)
 #pragma unroll
       for (int q = 0; q < (int)PW_ITEMS; q++) {
         const u32 k = lane + (u32)q * PW_T;
-        const bool left_far = lft[q] == ~0ull || sv[q] - lft[q] > (u64)absR;
-        const bool right_far = rgt[q] == ~0ull || rgt[q] - sv[q] > (u64)absR;
-        const bool walk = act[q] && !(left_far && right_far);
-        if (act[q] && !walk) { r_b[k] = 0; r_d[k] = 0; r_s0[k] = k; r_s1[k] = k; r_n[k] = 0; }
-        const u64 m = ballot64(walk);
-        if (walk) g_list[n_list + mbcnt(m)] = (u16)k;
-        n_list += popc64(m);
-      }
-      wsync();
-      for (u32 b0 = 0; b0 < n_list; b0 += PW_T) {
-        if (b0 + lane < n_list) {
-          const u32 k = g_list[b0 + lane];
-          const u64 s = Sv[i0 + k];
-          u64 il;                                              // first L >= s, located again (cheaper than keeping it in LDS)
-          if (ldir) {
-            const u64 c = min(s >> ldir_shift, ldir_last);
-            u64 lo = ldir[c], hi = ldir[c + 1];
-            while (lo < hi) { u64 m = (lo + hi) >> 1; if (Lv[m] < s) lo = m + 1; else hi = m; }
-            il = lo;
-          } else il = lower_bound_u64(Lv, nl, s);
-          general(i0 + k, k, il);
-        }
+        if ((wm[q] >> lane) & 1ull) g_list[n_list + mbcnt(wm[q])] = (u16)((u32)(i0 - i_begin) + k);
+        n_list += popc64(wm[q]);
       }
     }
-    __syncthreads();
-    u32 mine = 0;
-    for (u32 q = 0; q < PW_ITEMS; q++) { u32 k = lane * PW_ITEMS + q; if (k < cn) mine += r_n[k]; }
-    const u32 incl = wave_scan_incl(mine);
-    const u32 total = rdl(incl, 63);
-    u32 ex = incl - mine;
-    if (!have_slot && total) {
-      // scratch slot of this work item = union index (S index + L index) of its first emitted element
-      const u64 m = ballot64(mine != 0);
-      const u32 fl = (u32)__builtin_ctzll(m);
-      u64 cand = 0;
-      if (lane == fl) {
-        for (u32 q = 0; q < PW_ITEMS; q++) { u32 k = lane * PW_ITEMS + q; if (k < cn && r_n[k]) { cand = r_b[k] + i0 + r_s0[k]; break; } }
-      }
-      slot = rdl64(cand, fl);
-      have_slot = true;
-    }
-    u64* out = tmp_op + slot;
-    for (u32 q = 0; q < PW_ITEMS; q++) {
-      u32 k = lane * PW_ITEMS + q;
-      if (k < cn && r_n[k]) {
-        u64 o = cursor + ex;
-        gal_merge(Sv, i0 + r_s0[k], i0 + r_s1[k], Lv, r_b[k], r_b[k] + r_d[k], [&](u64 v) { out[o++] = v; });
-        ex += r_n[k];
-      }
-    }
-    cursor += total;
-    __syncthreads();
+    PROF(13);
   }
+  if (n_list) flush();
   count_out = cursor;
   slot_out = slot;
 }
@@ -435,7 +464,8 @@ __device__ void part_gallop(const CV& Sv, u64 ns, const CV& Lv, u64 nl, bool s_i
 #ifndef DCD_GAL_PER
 #define DCD_GAL_PER 1024
 #endif
-constexpr u32 GAL_PER = DCD_GAL_PER;      // short-list elements per galloping work item (256 / 512 / 1024 / 2048 -> 26.5 / 24.3 / 23.8 / 23.8 ms per 20 k C4 queries)
+constexpr u32 GAL_PER = DCD_GAL_PER;
+static_assert(DCD_GAL_PER <= 65536, "part_gallop's walk-list entries are 16-bit element indices");      // short-list elements per galloping work item (256 / 512 / 1024 / 2048 -> 26.5 / 24.3 / 23.8 / 23.8 ms per 20 k C4 queries)
 constexpr u8 MODE_NONE = 0, MODE_STREAM = 1, MODE_GALLOP = 2;
 __global__ void k_pair_plan(const PairOp* __restrict__ ops, u32 n_ops, IdxVals idx_values, const u64* __restrict__ pool,
                             const u64* __restrict__ counts, u64 PART, u32* __restrict__ items, u8* __restrict__ mode) {
@@ -459,15 +489,6 @@ __global__ void k_pair_plan(const PairOp* __restrict__ ops, u32 n_ops, IdxVals i
   mode[i] = m;
 }
 
-#ifdef DCD_PROF
-// debug build only: wave-residency cycles per phase of k_pair_parts (s_memtime deltas, summed over all waves)
-__device__ unsigned long long g_prof[16];
-#define PROF_T() unsigned long long _pt = __builtin_readcyclecounter()
-#define PROF(i) do { unsigned long long _n = __builtin_readcyclecounter(); if (threadIdx.x == 0) atomicAdd(&g_prof[i], _n - _pt); _pt = _n; } while (0)
-#else
-#define PROF_T()
-#define PROF(i)
-#endif
 __global__ __launch_bounds__(PW_T, DCD_PW_WAVES) void k_pair_parts(const PairOp* __restrict__ ops, u32 n_ops, const u64* __restrict__ part_base,
                                                     IdxVals idx_values, const u64* __restrict__ pool,
                                                     const u64* __restrict__ counts, u64* __restrict__ tmp, u64* __restrict__ part_count,

@@ -50,7 +50,8 @@ L.dcd_debug_prof(z.ctypes.data, 1)
 r = ix.query_batch(pa, oa, totals=True)
 L.dcd_debug_prof(z.ctypes.data, 0)
 names = ["operator lookup", "gallop (everything)", "stream: split search + first fill", "half-cleaner + refill request", "bitonic sort", "merge flags",
-         "refill store (waits for HBM)", "ownership", "fast path", "general path", "epilogue"]
+         "refill store (waits for HBM)", "ownership", "fast path", "general path", "epilogue",
+         "  gallop: short elems + directory + search", "  gallop: neighbours + walk list", "  gallop: chain walks", "  gallop: scan + emit"]
 tot = float(z[:11].sum())
 print("device %.2f ms for %d queries" % (r["ms"], oa.size - 1))
 for i, n in enumerate(names):
