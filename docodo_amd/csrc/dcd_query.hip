@@ -238,10 +238,17 @@ __device__ __forceinline__ u64 wave_split(const CV& A, u64 na, const CV& B, u64 
 // debug build only: wave-residency cycles per phase of k_pair_parts (s_memtime deltas, summed over all waves)
 __device__ unsigned long long g_prof[16];
 #define PROF_T() unsigned long long _pt = __builtin_readcyclecounter()
-#define PROF(i) do { unsigned long long _n = __builtin_readcyclecounter(); if (threadIdx.x == 0) atomicAdd(&g_prof[i], _n - _pt); _pt = _n; } while (0)
+// (accumulated per wavefront in LDS and added to g_prof once, at the end of the work item: one global atomic per probe made the
+// profiled kernel 17x slower and charged the atomics' latency to whichever phase waited for memory next)
+__shared__ unsigned long long s_prof[16];
+#define PROF(i) do { unsigned long long _n = __builtin_readcyclecounter(); if (threadIdx.x == 0) s_prof[i] += _n - _pt; _pt = __builtin_readcyclecounter(); } while (0)
+#define PROF_BEGIN() do { if (threadIdx.x < 16) s_prof[threadIdx.x] = 0; } while (0)
+#define PROF_END() do { __builtin_amdgcn_s_waitcnt(0xc07f); if (threadIdx.x < 16 && s_prof[threadIdx.x]) atomicAdd(&g_prof[threadIdx.x], s_prof[threadIdx.x]); } while (0)
 #else
 #define PROF_T()
 #define PROF(i)
+#define PROF_BEGIN()
+#define PROF_END()
 #endif
 // ---- galloping, one slice of the short operand per work item ------------------------------------------------
 __device__ void part_gallop(const CV& Sv, u64 ns, const CV& Lv, u64 nl, bool s_is_a, u32 absR, bool ordered,
@@ -317,7 +324,7 @@ __device__ void part_gallop(const CV& Sv, u64 ns, const CV& Lv, u64 nl, bool s_i
   auto flush = [&]() {
     wsync();
     for (u32 b0 = 0; b0 < n_list; b0 += PW_T) {
-      if (b0 + lane < n_list) {
+      if (b0 + lane < n_list && r_n[b0 + lane] == NONE32) {       // (the others were resolved by the round that listed them)
         const u32 p = b0 + lane;
         const u64 i = i_begin + g_list[p];
         const u64 s = Sv[i];
@@ -409,41 +416,131 @@ __device__ void part_gallop(const CV& Sv, u64 ns, const CV& Lv, u64 nl, bool s_i
         for (int q = 0; q < (int)PW_ITEMS; q++) ilv[q] = act[q] ? lower_bound_u64(Lv, nl, sv[q]) : 0;
       }
       PROF(11);  // gallop: short elements, directory cells, position in the long list
-      u64 lft[PW_ITEMS], rgt[PW_ITEMS];                        // nearest union neighbours (~0: none)
+      // Round 3: the chain of an element is RESOLVED IN REGISTERS from a window of both lists around it -- S[i-1 .. i+2] and
+      // L[il-2 .. il+1], fetched together in one round trip -- whenever it closes inside the window: the same decisions as the
+      // walk (general()), without its dependent loads.  Phrases and Dist-sized windows over sparse lists give chains of two or
+      // three elements, so nearly every element with a neighbour within absR ends here: as "emits nothing" (not the leader of its
+      // chain, no element of the long operand, the ordered rule fails: dropped -- two thirds of them on configs[4]) or as a
+      // finished record on the list (only its emission is left for flush()).  The rare longer chain goes on the list unresolved
+      // (r_n = NONE32) and walks.
+      u64 wm[PW_ITEMS];
+      u32 n_new = 0;
+      u64 e_b[PW_ITEMS];
+      u32 e_d[PW_ITEMS], e_s0[PW_ITEMS], e_s1[PW_ITEMS], e_n[PW_ITEMS];
       {
-        u64 sp[PW_ITEMS], lp[PW_ITEMS], sn[PW_ITEMS], ln[PW_ITEMS];
+        u64 sp[PW_ITEMS], sn[PW_ITEMS], snn[PW_ITEMS], lpp[PW_ITEMS], lp[PW_ITEMS], ln[PW_ITEMS], lnn[PW_ITEMS];
 #pragma unroll
         for (int q = 0; q < (int)PW_ITEMS; q++) {
           const u64 i = min(i0 + lane + (u64)q * PW_T, s_last);
+          const u64 il = ilv[q];
           sp[q] = Sv[i > 0 ? i - 1 : 0];
           sn[q] = Sv[min(i + 1, s_last)];
-          lp[q] = Lv[ilv[q] > 0 ? min(ilv[q] - 1, l_last) : 0];
-          ln[q] = Lv[min(ilv[q], l_last)];
+          snn[q] = Sv[min(i + 2, s_last)];
+          lpp[q] = Lv[il > 1 ? min(il - 2, l_last) : 0];
+          lp[q] = Lv[il > 0 ? min(il - 1, l_last) : 0];
+          ln[q] = Lv[min(il, l_last)];
+          lnn[q] = Lv[min(il + 1, l_last)];
         }
 #pragma unroll
         for (int q = 0; q < (int)PW_ITEMS; q++) {
-          const u64 i = i0 + lane + (u64)q * PW_T;
-          const bool hsp = i > 0, hlp = ilv[q] > 0, hsn = i + 1 < ns, hln = ilv[q] < nl;
-          lft[q] = (hsp || hlp) ? max(hsp ? sp[q] : 0ull, hlp ? lp[q] : 0ull) : ~0ull;
-          rgt[q] = min(hsn ? sn[q] : ~0ull, hln ? ln[q] : ~0ull);
+          const u64 i = i0 + lane + (u64)q * PW_T, il = ilv[q], s = sv[q];
+          const bool hsp = i > 0, hlp = il > 0, hlpp = il > 1, hsn = i + 1 < ns, hln = il < nl;
+          const u64 lft = (hsp || hlp) ? max(hsp ? sp[q] : 0ull, hlp ? lp[q] : 0ull) : ~0ull;   // nearest union neighbours (~0: none)
+          const u64 rgt = min(hsn ? sn[q] : ~0ull, hln ? ln[q] : ~0ull);
+          const bool left_far = lft == ~0ull || s - lft > (u64)absR;
+          const bool right_far = rgt == ~0ull || rgt - s > (u64)absR;
+          // an element without a neighbour within absR on either side is a chain of its own and emits nothing
+          bool listed = false;
+          e_b[q] = 0; e_d[q] = 0; e_s0[q] = 0; e_s1[q] = 0; e_n[q] = NONE32;
+          if (act[q] && !(left_far && right_far)) {
+            bool leader = true, unres = false;
+            u32 bl = 0;                                          // left walk: long-list elements taken (b = il - bl)
+            if (!left_far) {
+              bool takeS = hsp && (!hlp || sp[q] >= lp[q]);
+              if (takeS) leader = false;                         // (the nearest left neighbour is within absR: !left_far)
+              else {
+                bl = 1;
+                u64 cur = lp[q];
+                if (hsp || hlpp) {
+                  takeS = hsp && (!hlpp || sp[q] >= lpp[q]);
+                  const u64 cv = takeS ? sp[q] : lpp[q];
+                  if (cur - cv <= (u64)absR) {
+                    if (takeS) leader = false;
+                    else {
+                      bl = 2;
+                      cur = lpp[q];
+                      if (il > 2) unres = true;                  // L[il - 3] is outside the window
+                      else if (hsp && cur - sp[q] <= (u64)absR) leader = false;
+                    }
+                  }
+                }
+              }
+            }
+            if (unres) listed = true;
+            else if (leader) {
+              u32 cr = 0, dr = 0;                                // right walk: elements taken (c = i + cr, d = il + dr)
+              u64 cur = s;
+              bool open = true;
+#pragma unroll
+              for (int it = 0; it < 5; it++) {
+                if (open) {
+                  const bool hs = i + cr + 1 < ns, hl = il + dr < nl;
+                  if ((hs && cr >= 2u) || (hl && dr >= 2u)) { unres = true; open = false; }   // S[i + 3] / L[il + 2]: outside the window
+                  else if (!hs && !hl) open = false;
+                  else {
+                    const u64 cs = cr == 0u ? sn[q] : snn[q], cl = dr == 0u ? ln[q] : lnn[q];
+                    const bool takeS = hs && (!hl || cs <= cl);
+                    const u64 cv = takeS ? cs : cl;
+                    if (cv - cur > (u64)absR) open = false;
+                    else { if (takeS) cr++; else dr++; cur = cv; }
+                  }
+                }
+              }
+              if (unres) listed = true;
+              else {
+                // chain = S[i .. i + cr] u L[il - bl .. il + dr): the rules of general()
+                u32 lb_back = bl, k0 = 0;
+                bool ok = bl + dr > 0u;                          // needs an element of the long operand
+                if (ok && ordered) {
+                  if (s_is_a) { lb_back = 0; ok = dr > 0u; }     // first A = s: long-list elements before it are dropped
+                  else {                                        // first A = L[il - bl]: the B-only prefix is dropped
+                    const u64 fa = bl == 2u ? lpp[q] : (bl == 1u ? lp[q] : ln[q]);
+                    k0 = (s < fa ? 1u : 0u) + ((cr >= 1u && sn[q] < fa) ? 1u : 0u) + ((cr >= 2u && snn[q] < fa) ? 1u : 0u);
+                    ok = k0 <= cr;
+                  }
+                }
+                if (ok) {
+                  // a coordinate held by both operands is emitted once (gal_merge): only L[il], L[il + 1] can equal a short-list member
+                  const bool m0 = dr >= 1u, m1 = dr >= 2u;
+                  u32 dups = 0;
+                  if (k0 == 0u) dups += ((m0 && s == ln[q]) ? 1u : 0u) + ((m1 && s == lnn[q]) ? 1u : 0u);
+                  if (k0 <= 1u && cr >= 1u) dups += ((m0 && sn[q] == ln[q]) ? 1u : 0u) + ((m1 && sn[q] == lnn[q]) ? 1u : 0u);
+                  if (cr >= 2u) dups += ((m0 && snn[q] == ln[q]) ? 1u : 0u) + ((m1 && snn[q] == lnn[q]) ? 1u : 0u);
+                  e_b[q] = il - lb_back;
+                  e_d[q] = lb_back + dr;
+                  e_s0[q] = (u32)(i - i_begin) + k0;
+                  e_s1[q] = (u32)(i - i_begin) + cr;
+                  e_n[q] = (cr + 1u - k0) + lb_back + dr - dups;
+                  listed = true;
+                }
+              }
+            }
+          }
+          wm[q] = ballot64(listed);
+          n_new += popc64(wm[q]);
         }
       }
-      // the few elements that do have a neighbour go on the walk list (in element order: the emission below relies on it)
-      u64 wm[PW_ITEMS];
-      u32 n_new = 0;
-#pragma unroll
-      for (int q = 0; q < (int)PW_ITEMS; q++) {
-        const bool left_far = lft[q] == ~0ull || sv[q] - lft[q] > (u64)absR;
-        const bool right_far = rgt[q] == ~0ull || rgt[q] - sv[q] > (u64)absR;
-        wm[q] = ballot64(act[q] && !(left_far && right_far));
-        n_new += popc64(wm[q]);
-      }
-      PROF(12);  // gallop: neighbours, walk list
+      PROF(12);  // gallop: window, chains resolved in registers
       if (n_list + n_new > PW_TILE) flush();                   // (a round adds at most PW_TILE entries)
+      // (entries in element order: the emission relies on it)
 #pragma unroll
       for (int q = 0; q < (int)PW_ITEMS; q++) {
         const u32 k = lane + (u32)q * PW_T;
-        if ((wm[q] >> lane) & 1ull) g_list[n_list + mbcnt(wm[q])] = (u16)((u32)(i0 - i_begin) + k);
+        if ((wm[q] >> lane) & 1ull) {
+          const u32 p = n_list + mbcnt(wm[q]);
+          g_list[p] = (u16)((u32)(i0 - i_begin) + k);
+          r_b[p] = e_b[q]; r_d[p] = e_d[q]; r_s0[p] = e_s0[q]; r_s1[p] = e_s1[q]; r_n[p] = e_n[q];
+        }
         n_list += popc64(wm[q]);
       }
     }
@@ -468,7 +565,7 @@ constexpr u32 GAL_PER = DCD_GAL_PER;
 static_assert(DCD_GAL_PER <= 65536, "part_gallop's walk-list entries are 16-bit element indices");      // short-list elements per galloping work item (256 / 512 / 1024 / 2048 -> 26.5 / 24.3 / 23.8 / 23.8 ms per 20 k C4 queries)
 constexpr u8 MODE_NONE = 0, MODE_STREAM = 1, MODE_GALLOP = 2;
 __global__ void k_pair_plan(const PairOp* __restrict__ ops, u32 n_ops, IdxVals idx_values, const u64* __restrict__ pool,
-                            const u64* __restrict__ counts, u64 PART, u32* __restrict__ items, u8* __restrict__ mode) {
+                            const u64* __restrict__ counts, u64 PART, u32* __restrict__ items, u8* __restrict__ mode, u32 gal_ratio) {
   u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i > n_ops) return;
   if (i == n_ops) { items[i] = 0; return; }
@@ -483,7 +580,7 @@ __global__ void k_pair_plan(const PairOp* __restrict__ ops, u32 n_ops, IdxVals i
     const bool a_short = na <= nb;
     const u64 ns = a_short ? na : nb, nl = a_short ? nb : na;
     const CV Lv = seg_cv(a_short ? op.b : op.a, idx_values, pool);
-    if (ns * GAL_RATIO <= nl && (Lv[nl - 1] - Lv[0]) / nl > 4ull * absR) { m = MODE_GALLOP; n = (ns + GAL_PER - 1) / GAL_PER; }
+    if (ns * gal_ratio <= nl && (Lv[nl - 1] - Lv[0]) / nl > 4ull * absR) { m = MODE_GALLOP; n = (ns + GAL_PER - 1) / GAL_PER; }
   }
   items[i] = (u32)n;
   mode[i] = m;
@@ -493,19 +590,26 @@ __global__ __launch_bounds__(PW_T, DCD_PW_WAVES) void k_pair_parts(const PairOp*
                                                     IdxVals idx_values, const u64* __restrict__ pool,
                                                     const u64* __restrict__ counts, u64* __restrict__ tmp, u64* __restrict__ part_count,
                                                     u64* __restrict__ part_src, u64 PART, const u32* __restrict__ dirs,
-                                                    u64 dir_max_coord, const u8* __restrict__ op_mode) {
+                                                    u64 dir_max_coord, const u8* __restrict__ op_mode, u64 W_cap, unsigned long long* __restrict__ work_ctr) {
   constexpr u32 RAW_WORDS = 6u * PW_TILE + PW_TILE / 2u + 16u;   // rings + chain flags, or the gallop records + walk list
   __shared__ __attribute__((aligned(16))) u32 s_raw[RAW_WORDS];
   u64* sA = reinterpret_cast<u64*>(s_raw);
   u64* sB = sA + PW_TILE;
   u32* s_cm = s_raw + 4 * PW_TILE;                 // [PW_TILE + 1] chain flags of the general path
-  PROF_T();
+  PROF_BEGIN();
   const u32 lane = threadIdx.x;
-  const u64 w = blockIdx.x;
-  if (w >= part_base[n_ops]) {                               // surplus wavefront (the grid is sized for the capacities)
-    if (lane == 0) { part_count[w] = 0; part_src[w] = 0; }
-    return;
-  }
+  // Round 3: a FIXED grid of wavefronts works through the items the device plan really made (part_base[n_ops]), each taking
+  // its next item from a counter.  One wavefront per item of the host's capacity bound meant up to 1.5 M wavefronts that left at
+  // once in the second round of a configs[3] batch (the bound of an intermediate result is the sum of its operands): 0.7 ns
+  // each, 1 - 2 ms of a 20 ms batch.  (A static stride over the items instead of the counter was 10 % slower on configs[3]:
+  // the items differ too much.)  The counter is read one item ahead, so its round trip hides behind the item's work.
+  const u64 n_items = part_base[n_ops];
+  for (u64 x = n_items + (u64)blockIdx.x * PW_T + lane; x < W_cap; x += (u64)gridDim.x * PW_T) { part_count[x] = 0; part_src[x] = 0; }   // (the scans run over the capacity)
+  u64 w = blockIdx.x;
+  while (w < n_items) {
+  unsigned long long w_next = 0;
+  if (lane == 0) w_next = atomicAdd(work_ctr, 1ull) + gridDim.x;
+  PROF_T();
   u32 oi;
   {   // operator of this work item: last op with part_base[op] <= w
     u32 lo = 0, hi = n_ops;
@@ -868,6 +972,10 @@ __global__ __launch_bounds__(PW_T, DCD_PW_WAVES) void k_pair_parts(const PairOp*
   }
   if (lane == 0) { part_count[w] = count; part_src[w] = slot; }
   PROF(10);
+  wsync();                                                     // (the next item reuses the rings / records)
+  w = rfl64(w_next);
+  }
+  PROF_END();
 }
 
 // out[...] <- scratch: every wave looks at 64 work items at a time; each lane resolves its own item (operator by
@@ -1389,6 +1497,19 @@ static int32_t run_batch(dcd_index* h, const int32_t* prog, const u64* prog_off,
   // work items of every round: operator i owns part_base[i+1] - part_base[i] partitions of PART union elements
   // (sized for the operands' capacities; the device knows the real counts) and a scratch region of the
   // same capacity as its result
+  // Round 3: the operators of a round run in the order of their LONGER index-term operand, so that the queries of a batch that
+  // probe the same posting list (the head terms of a Zipf query load) do so at about the same time and share its cache lines:
+  // galloping over configs[3] fetched 42 GB per 20 k queries, several times the whole index, at a 51 % L2 hit rate.  (Results,
+  // scratch regions and work items are addressed through the operator, so the order is free.)
+  static const bool sort_ops = !(getenv("DOCODO_QUERY_SORT_OPS") && atoi(getenv("DOCODO_QUERY_SORT_OPS")) == 0);
+  if (sort_ops) {
+    auto key = [](const PairOp& p) -> u64 {
+      const bool ta = p.a.kind == 0 && p.a.cnt_ref == NONE32, tb = p.b.kind == 0 && p.b.cnt_ref == NONE32;
+      if (ta && tb) return p.a.cnt_imm >= p.b.cnt_imm ? p.a.off : p.b.off;
+      return ta ? p.a.off : (tb ? p.b.off : ~0ull);
+    };
+    for (auto& rd : rounds) std::stable_sort(rd.begin(), rd.end(), [&](const PairOp& x, const PairOp& y) { return key(x) < key(y); });
+  }
   u64 PART = PART_DEFAULT;
   if (const char* e = getenv("DOCODO_QUERY_PART")) PART = std::max<u64>(strtoull(e, nullptr, 10), 1);   // tests: tiny partitions
   std::vector<std::vector<u64>> part_base(rounds.size());
@@ -1481,15 +1602,29 @@ static int32_t run_batch(dcd_index* h, const int32_t* prog, const u64* prog_off,
   EvTimer tm;
   DCD_TRY(tm.init(st));
   DCD_TRY(tm.start());
+  // wavefronts of k_pair_parts: a few per wavefront slot of the device (256 CUs x 4 SIMDs x DCD_PW_WAVES), so that the hardware
+  // still balances the tail
+  static const u64 pw_grid = [&]() -> u64 {
+    const char* e = getenv("DOCODO_QUERY_PW_GRID");
+    if (e && atoll(e) > 0) return (u64)atoll(e);
+    hipDeviceProp_t pr;
+    const int cus = hipGetDeviceProperties(&pr, dev) == hipSuccess ? pr.multiProcessorCount : 256;
+    return (u64)cus * 4u * DCD_PW_WAVES * 4u;
+  }();
+  DevBuf<u64> d_work_ctr;
+  DCD_TRY(d_work_ctr.alloc(dev, std::max<size_t>(1, rounds.size())));
+  DCD_HIP(hipMemsetAsync(d_work_ctr.p, 0, std::max<size_t>(1, rounds.size()) * sizeof(u64), st));
+  static const u32 gal_ratio = getenv("DOCODO_QUERY_GAL_RATIO") ? (u32)atoi(getenv("DOCODO_QUERY_GAL_RATIO")) : GAL_RATIO;   // (A/B knob)
   for (size_t r = 0; r < rounds.size(); r++) {
     u32 n = (u32)rounds[r].size();
     const u64 W = part_base[r][n];
     // device plan: item count + mode per operator, exclusive scan -> first work item of every operator
     hipLaunchKernelGGL(k_pair_plan, dim3(div_up(n + 1, 256)), dim3(256), 0, st, d_rounds[r].p, n, idx_values, pool.p, counts.p, PART,
-                       d_items.p, d_mode.p);
+                       d_items.p, d_mode.p, gal_ratio);
     scan_exclusive<u32, u64>(d_items.p, d_part_base[r].p, (u64)n + 1, d_part_scr.p, st);
-    hipLaunchKernelGGL(k_pair_parts, dim3((u32)W), dim3(PW_T), 0, st, d_rounds[r].p, n, d_part_base[r].p, idx_values, pool.p, counts.p,
-                       tmp.p, d_part_count.p, d_part_src.p, PART, ext_values ? nullptr : h->dir.p, ix.max_coord, d_mode.p);
+    hipLaunchKernelGGL(k_pair_parts, dim3((u32)std::min<u64>(W, pw_grid)), dim3(PW_T), 0, st, d_rounds[r].p, n, d_part_base[r].p, idx_values, pool.p,
+                       counts.p, tmp.p, d_part_count.p, d_part_src.p, PART, ext_values ? nullptr : h->dir.p, ix.max_coord, d_mode.p, W,
+                       reinterpret_cast<unsigned long long*>(d_work_ctr.p + r));
     DCD_HIP(hipMemsetAsync(d_part_count.p + W, 0, 8, st));
     scan_exclusive<u64, u64>(d_part_count.p, d_part_excl.p, W + 1, d_part_scr.p, st);
     const u32 gg = (u32)std::min<u64>(div_up(div_up(W, 64), 4), 4096);
