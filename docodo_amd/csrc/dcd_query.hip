@@ -1042,8 +1042,11 @@ struct ResParams {
 struct QCounts { u64 n_pages, n_pos, n_docs; int32_t status; u32 pad; };
 
 constexpr int RS_T = 256;
-constexpr int RS_I = 4;                 // coordinates per thread
-constexpr int RS_TILE = RS_T * RS_I;    // 1024 coordinates per workgroup iteration
+#ifndef DCD_RS_I
+#define DCD_RS_I 8
+#endif
+constexpr int RS_I = DCD_RS_I;          // coordinates per thread
+constexpr int RS_TILE = RS_T * RS_I;    // coordinates per workgroup iteration (round 3: 8 per thread, 4 / 8 / 16 -> 707 / 692 / 690 ms per 2.5 k configs[4] queries)
 
 __device__ __forceinline__ u64 page_of(const ResParams& P, u64 c) {  // first page with end > c
   if (P.uniform_chars) {
