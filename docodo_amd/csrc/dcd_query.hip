@@ -978,8 +978,9 @@ __global__ __launch_bounds__(PW_T, DCD_PW_WAVES) void k_pair_parts(const PairOp*
   PROF_END();
 }
 
-// out[...] <- scratch: every wave looks at 64 work items at a time; each lane resolves its own item (operator by
-// binary search, source and destination), then the wave copies the non-empty items one after the other
+// out[...] <- scratch: one group of EIGHT LANES per work item (64 bytes per step), eight items per wavefront at a time.
+// (Round 3.  It used to be 64 items per wavefront, copied eight at a time one group after the other: with ~100 values per item
+// -- phrases over head terms -- that was ~100 dependent load -> store round trips per wavefront, 190 us for a 64 MB copy.)
 __global__ __launch_bounds__(256) void k_pair_gather(const PairOp* __restrict__ ops, u32 n_ops, const u64* __restrict__ part_base, u64 W,
                                                     const u64* __restrict__ part_count, const u64* __restrict__ part_src,
                                                     const u64* __restrict__ excl, const u64* __restrict__ tmp, u64* __restrict__ pool) {
@@ -987,35 +988,20 @@ __global__ __launch_bounds__(256) void k_pair_gather(const PairOp* __restrict__ 
   const u64 gw = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = ((u64)gridDim.x * blockDim.x) >> 6;
   const u64 W_act = min(W, part_base[n_ops]);              // work items the device plan really used
   const u32 grp = lane >> 3, sub = lane & 7u;
-  for (u64 base = gw * 64; base < W_act; base += nw * 64) {
-    const u64 w = base + lane;
+  for (u64 base = gw * 8; base < W_act; base += nw * 8) {
+    const u64 w = base + grp;
     const u64 c = w < W_act ? part_count[w] : 0;
-    u64 so = 0, dof = 0;
-    if (c) {
-      u32 lo = 0, hi = n_ops;
-      while (lo + 1 < hi) { u32 mid = (lo + hi) >> 1; if (part_base[mid] <= w) lo = mid; else hi = mid; }
-      so = ops[lo].tmp_off + part_src[w];
-      dof = ops[lo].out_off + (excl[w] - excl[part_base[lo]]);
+    if (!c) continue;
+    u32 lo = 0, hi = n_ops;                                  // operator of the item (the eight lanes read the same words)
+    while (lo + 1 < hi) { u32 mid = (lo + hi) >> 1; if (part_base[mid] <= w) lo = mid; else hi = mid; }
+    const u64* sp = tmp + ops[lo].tmp_off + part_src[w];
+    u64* dp = pool + ops[lo].out_off + (excl[w] - excl[part_base[lo]]);
+    u64 k = sub;
+    for (; k + 24 < c; k += 32) {                            // four steps in flight
+      const u64 v0 = sp[k], v1 = sp[k + 8], v2 = sp[k + 16], v3 = sp[k + 24];
+      dp[k] = v0; dp[k + 8] = v1; dp[k + 16] = v2; dp[k + 24] = v3;
     }
-    // non-empty items are copied eight at a time, eight lanes (64 bytes per step) each
-    const u64 m = ballot64(c != 0);
-    const u32 rank = mbcnt(m), nnz = popc64(m);
-    for (u32 b0 = 0; b0 < nnz; b0 += 8) {
-      u32 src = 64;
-#pragma unroll
-      for (u32 gi = 0; gi < 8; gi++) {
-        const u64 mg = ballot64(c != 0 && rank == b0 + gi);
-        const u32 l = mg ? (u32)__builtin_ctzll(mg) : 64u;
-        if (grp == gi) src = l;
-      }
-      const bool have = src < 64;
-      const u64 cc = shfl64(c, have ? src : 0), so_ = shfl64(so, have ? src : 0), dof_ = shfl64(dof, have ? src : 0);
-      if (have) {
-        const u64* sp = tmp + so_;
-        u64* dp = pool + dof_;
-        for (u64 k = sub; k < cc; k += 8) dp[k] = sp[k];
-      }
-    }
+    for (; k < c; k += 8) dp[k] = sp[k];
   }
 }
 
@@ -1630,7 +1616,7 @@ static int32_t run_batch(dcd_index* h, const int32_t* prog, const u64* prog_off,
                        reinterpret_cast<unsigned long long*>(d_work_ctr.p + r));
     DCD_HIP(hipMemsetAsync(d_part_count.p + W, 0, 8, st));
     scan_exclusive<u64, u64>(d_part_count.p, d_part_excl.p, W + 1, d_part_scr.p, st);
-    const u32 gg = (u32)std::min<u64>(div_up(div_up(W, 64), 4), 4096);
+    const u32 gg = (u32)std::min<u64>(div_up(div_up(W, 8), 4), 16384);
     hipLaunchKernelGGL(k_pair_gather, dim3(gg), dim3(256), 0, st, d_rounds[r].p, n, d_part_base[r].p, W, d_part_count.p, d_part_src.p,
                        d_part_excl.p, tmp.p, pool.p);
     hipLaunchKernelGGL(k_pair_totals, dim3(div_up(n, 256)), dim3(256), 0, st, d_rounds[r].p, n, d_part_base[r].p, d_part_excl.p, counts.p);
