@@ -236,19 +236,21 @@ __device__ __forceinline__ u64 wave_split(const CV& A, u64 na, const CV& B, u64 
 
 #ifdef DCD_PROF
 // debug build only: wave-residency cycles per phase of k_pair_parts (s_memtime deltas, summed over all waves)
-__device__ unsigned long long g_prof[16];
+__device__ unsigned long long g_prof[24];   // [0, 16): cycles per phase; [16, 24): event counts
 #define PROF_T() unsigned long long _pt = __builtin_readcyclecounter()
 // (accumulated per wavefront in LDS and added to g_prof once, at the end of the work item: one global atomic per probe made the
 // profiled kernel 17x slower and charged the atomics' latency to whichever phase waited for memory next)
-__shared__ unsigned long long s_prof[16];
+__shared__ unsigned long long s_prof[24];
 #define PROF(i) do { unsigned long long _n = __builtin_readcyclecounter(); if (threadIdx.x == 0) s_prof[i] += _n - _pt; _pt = __builtin_readcyclecounter(); } while (0)
-#define PROF_BEGIN() do { if (threadIdx.x < 16) s_prof[threadIdx.x] = 0; } while (0)
-#define PROF_END() do { __builtin_amdgcn_s_waitcnt(0xc07f); if (threadIdx.x < 16 && s_prof[threadIdx.x]) atomicAdd(&g_prof[threadIdx.x], s_prof[threadIdx.x]); } while (0)
+#define PROF_BEGIN() do { if (threadIdx.x < 24) s_prof[threadIdx.x] = 0; } while (0)
+#define PROF_CNT(i, n) do { const unsigned long long _c = (n); if (threadIdx.x == 0) s_prof[i] += _c; } while (0)
+#define PROF_END() do { __builtin_amdgcn_s_waitcnt(0xc07f); if (threadIdx.x < 24 && s_prof[threadIdx.x]) atomicAdd(&g_prof[threadIdx.x], s_prof[threadIdx.x]); } while (0)
 #else
 #define PROF_T()
 #define PROF(i)
 #define PROF_BEGIN()
 #define PROF_END()
+#define PROF_CNT(i, n)
 #endif
 // ---- galloping, one slice of the short operand per work item ------------------------------------------------
 __device__ void part_gallop(const CV& Sv, u64 ns, const CV& Lv, u64 nl, bool s_is_a, u32 absR, bool ordered,
@@ -266,6 +268,7 @@ __device__ void part_gallop(const CV& Sv, u64 ns, const CV& Lv, u64 nl, bool s_i
   u64 cursor = 0, slot = 0;
   bool have_slot = false;
   u32 n_list = 0;                                             // (wave-uniform)
+  PROF_T();
   auto general = [&](u64 i, u32 k, u64 il) {
     const u64 s = Sv[i];
     u64 a = i, b = il, cur = s;                              // left walk over the union
@@ -323,6 +326,7 @@ __device__ void part_gallop(const CV& Sv, u64 ns, const CV& Lv, u64 nl, bool s_i
   // list; one walk + emit phase serves the item's 1024 elements (or runs earlier when the list is about to overflow).
   auto flush = [&]() {
     wsync();
+    PROF(13);  // gallop: list append (+ the time since the last probe)
     for (u32 b0 = 0; b0 < n_list; b0 += PW_T) {
       if (b0 + lane < n_list && r_n[b0 + lane] == NONE32) {       // (the others were resolved by the round that listed them)
         const u32 p = b0 + lane;
@@ -339,6 +343,7 @@ __device__ void part_gallop(const CV& Sv, u64 ns, const CV& Lv, u64 nl, bool s_i
       }
     }
     wsync();
+    PROF(14);  // gallop: walks of the unresolved chains
     u32 mine = 0;
     for (u32 q = 0; q < PW_ITEMS; q++) { u32 p = lane * PW_ITEMS + q; if (p < n_list) mine += r_n[p]; }
     const u32 incl = wave_scan_incl(mine);
@@ -367,9 +372,9 @@ __device__ void part_gallop(const CV& Sv, u64 ns, const CV& Lv, u64 nl, bool s_i
     cursor += total;
     wsync();                                                   // (the records are free again; the stores stay in flight)
     n_list = 0;
+    PROF(15);  // gallop: scan + emission
   };
   for (u64 i0 = i_begin; i0 < i_end; i0 += PW_TILE) {
-    PROF_T();
     const u32 cn = (u32)min((u64)PW_TILE, i_end - i0);
     // Every lane looks after PW_ITEMS short-list elements.  Their loads are issued together, phase by phase (the
     // chain of dependent accesses -- directory cell, long-list position, neighbours -- is latency bound, so the
@@ -528,6 +533,10 @@ __device__ void part_gallop(const CV& Sv, u64 ns, const CV& Lv, u64 nl, bool s_i
           }
           wm[q] = ballot64(listed);
           n_new += popc64(wm[q]);
+          PROF_CNT(16, popc64(ballot64(act[q])));                                   // short-list elements
+          PROF_CNT(17, popc64(ballot64(act[q] && !(left_far && right_far))));      // ... with a neighbour within absR
+          PROF_CNT(18, popc64(ballot64(listed && e_n[q] != NONE32)));              // ... resolved, emitting
+          PROF_CNT(19, popc64(ballot64(listed && e_n[q] == NONE32)));              // ... unresolved (walk)
         }
       }
       PROF(12);  // gallop: window, chains resolved in registers
@@ -544,7 +553,6 @@ __device__ void part_gallop(const CV& Sv, u64 ns, const CV& Lv, u64 nl, bool s_i
         n_list += popc64(wm[q]);
       }
     }
-    PROF(13);
   }
   if (n_list) flush();
   count_out = cursor;
@@ -1735,9 +1743,9 @@ static int32_t run_batch(dcd_index* h, const int32_t* prog, const u64* prog_off,
 }
 
 #ifdef DCD_PROF
-extern "C" int32_t dcd_debug_prof(unsigned long long* out16, int32_t reset) {
-  if (out16) (void)hipMemcpyFromSymbol(out16, HIP_SYMBOL(dcd::g_prof), 16 * 8);
-  if (reset) { unsigned long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(dcd::g_prof), z, 16 * 8); }
+extern "C" int32_t dcd_debug_prof(unsigned long long* out24, int32_t reset) {
+  if (out24) (void)hipMemcpyFromSymbol(out24, HIP_SYMBOL(dcd::g_prof), 24 * 8);
+  if (reset) { unsigned long long z[24] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(dcd::g_prof), z, 24 * 8); }
   return 0;
 }
 #endif

@@ -44,15 +44,18 @@ else:
 pa, oa = np.array(prog, np.int32), np.array(off, np.uint64)
 L = docodo_amd.lib()
 L.dcd_debug_prof.argtypes = [C.c_void_p, C.c_int32]
-z = np.zeros(16, np.uint64)
+z = np.zeros(24, np.uint64)
 ix.query_batch(pa, oa, totals=True)
 L.dcd_debug_prof(z.ctypes.data, 1)
 r = ix.query_batch(pa, oa, totals=True)
 L.dcd_debug_prof(z.ctypes.data, 0)
 names = ["operator lookup", "gallop (everything)", "stream: split search + first fill", "half-cleaner + refill request", "bitonic sort", "merge flags",
          "refill store (waits for HBM)", "ownership", "fast path", "general path", "epilogue",
-         "  gallop: short elems + directory + search", "  gallop: neighbours + walk list", "  gallop: chain walks", "  gallop: scan + emit"]
+         "  gallop: short elems + directory + search", "  gallop: windows + chains resolved in registers", "  gallop: list append", "  gallop: walks (unresolved chains)",
+         "  gallop: scan + emission"]
 tot = float(z[:11].sum())
 print("device %.2f ms for %d queries" % (r["ms"], oa.size - 1))
 for i, n in enumerate(names):
     print("  %-36s %6.2f %%" % (n, 100.0 * float(z[i]) / tot))
+print("galloping: %d short-list elements, %.2f %% with a neighbour within absR, %.2f %% resolved + emitting, %.2f %% unresolved (walk)" %
+      (int(z[16]), 100.0 * float(z[17]) / max(1, int(z[16])), 100.0 * float(z[18]) / max(1, int(z[16])), 100.0 * float(z[19]) / max(1, int(z[16]))))

@@ -33,3 +33,9 @@ for r in range(reps):
     t0 = time.perf_counter()
     ms = ix.query_batch(pa, oa, keep_handle=True)
     print("rep %d: %d queries device %.2f ms wall %.2f ms -> %.0f q/s" % (r, oa.size - 1, ms, (time.perf_counter() - t0) * 1e3, (oa.size - 1) / ms * 1e3), flush=True)
+if os.environ.get("C4_SIZES"):
+    cnt = np.array([[ix.term_count(int(pa[int(o) + 1])), ix.term_count(int(pa[int(o) + 4])), ix.term_count(int(pa[int(o) + 8]))] for o in oa[:-1]], dtype=np.float64)
+    ns, nl = np.minimum(cnt[:, 0], cnt[:, 1]), np.maximum(cnt[:, 0], cnt[:, 1])
+    g = nl >= 2 * ns
+    print("round 0: sum short %.3e long %.3e; gallop ops %.1f %% with short %.3e long %.3e; stream ops short+long %.3e; third term sum %.3e" %
+          (ns.sum(), nl.sum(), 100 * g.mean(), ns[g].sum(), nl[g].sum(), (ns[~g] + nl[~g]).sum(), cnt[:, 2].sum()))

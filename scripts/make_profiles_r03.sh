@@ -5,6 +5,9 @@
 #    TAG_traffic.json                            FETCH_SIZE / WRITE_SIZE per kernel (separate --pmc passes) -> bench.py roofline.traffic
 #    TAG_c4_kernel_stats.csv                     rocprofv3 --kernel-trace --stats of the configs[2..4] legs (100 k AND3 + 4 k phrases)
 #    TAG_pmc_c4.txt                              SQ counters of k_pair_parts on configs[3] (issue / wait / LDS)
+#    TAG_c4_mem.txt                              L2 / HBM-side counters of k_pair_parts on one 20 k configs[3] batch (scripts/pmc_c4_mem.sh)
+#    TAG_c4_phases.txt, TAG_c5_phases.txt        in-kernel phase profile of k_pair_parts (needs variants/libdocodo_hip_prof.so:
+#                                                scripts/build_variant.sh prof "-DDCD_PROF")
 # (copy what is to be judged into profiles/ afterwards)
 set -e
 TAG=${1:-r03_final}
@@ -37,5 +40,12 @@ for grp in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU S
   timeout -k 10 300 rocprofv3 --pmc $grp --kernel-trace -d $O/raw/pmcq/g$i -o p -- python3 bench.py --steps 1 --warmup 1 --cpu-docs 0 --inflight 0 --queries 0 --c4-queries 20000 --c5-queries 0 > $O/raw/pmcq_g$i.log 2>&1
 done
 python3 scripts/pmc_summary.py $O/raw/pmcq k_pair_parts k_pair_gather k_result > $O/${TAG}_pmc_c4.txt
-rm -rf $O/raw/*trace.csv
+echo "[profiles] k_pair_parts memory counters"
+CTRS="FETCH_SIZE TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCP_TCC_READ_REQ_sum" bash scripts/pmc_c4_mem.sh gpurun_out/profiles/raw/c4mem > $O/${TAG}_c4_mem.txt 2>&1 || true
+if [ -f variants/libdocodo_hip_prof.so ]; then
+  echo "[profiles] k_pair_parts phase profiles"
+  DOCODO_HIP_LIB=variants/libdocodo_hip_prof.so timeout -k 10 300 python3 scripts/c4_phase_profile.py 10000000 20000 2>&1 | grep -v amdgpu.ids > $O/${TAG}_c4_phases.txt || true
+  DOCODO_HIP_LIB=variants/libdocodo_hip_prof.so timeout -k 10 300 python3 scripts/c4_phase_profile.py 10000000 2500 phrase 2>&1 | grep -v amdgpu.ids > $O/${TAG}_c5_phases.txt || true
+fi
+rm -rf $O/raw/*trace.csv $O/raw/c4mem
 ls -la $O
