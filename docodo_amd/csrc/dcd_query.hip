@@ -1505,7 +1505,16 @@ static int32_t run_batch(dcd_index* h, const int32_t* prog, const u64* prog_off,
       if (ta && tb) return p.a.cnt_imm >= p.b.cnt_imm ? p.a.off : p.b.off;
       return ta ? p.a.off : (tb ? p.b.off : ~0ull);
     };
-    for (auto& rd : rounds) std::stable_sort(rd.begin(), rd.end(), [&](const PairOp& x, const PairOp& y) { return key(x) < key(y); });
+    std::vector<std::pair<u64, u32>> ord;
+    std::vector<PairOp> sorted_ops;
+    for (auto& rd : rounds) {                                  // (keys + indices are sorted, not the 100-byte operators)
+      ord.resize(rd.size());
+      for (size_t k = 0; k < rd.size(); k++) ord[k] = {key(rd[k]), (u32)k};
+      std::sort(ord.begin(), ord.end());
+      sorted_ops.resize(rd.size());
+      for (size_t k = 0; k < rd.size(); k++) sorted_ops[k] = rd[ord[k].second];
+      rd.swap(sorted_ops);
+    }
   }
   u64 PART = PART_DEFAULT;
   if (const char* e = getenv("DOCODO_QUERY_PART")) PART = std::max<u64>(strtoull(e, nullptr, 10), 1);   // tests: tiny partitions
