@@ -379,3 +379,18 @@ def test_no_download_returns_the_same_counts(synth_index):
     assert tot["ms"] > 0
     empty = ix.query_batch([], [0], totals=True)
     assert (empty["n_pages"], empty["n_pos"], empty["n_docs"]) == (0, 0, 0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("script,args", [("stress_ops.py", ["80", "11"]), ("stress_queries.py", ["30000", "300", "5"])])
+def test_work_counter_loop_against_oracle(script, args):
+    """k_pair_parts takes its work items from a device counter with a fixed grid of wavefronts (round 3).  With a grid of
+    THREE wavefronts every wavefront works through many items of many operators -- galloping and streaming ones in turn --
+    and the randomised differential tests (operators through dcd_seq_and / dcd_seq_or, programs through dcd_query_batch)
+    must still match the oracle bit for bit."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DOCODO_QUERY_PW_GRID="3")
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", script)] + args, capture_output=True, text=True, env=env, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert ", 0 mismatches" in r.stdout.strip().splitlines()[-1], r.stdout[-2000:]
