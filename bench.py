@@ -291,8 +291,42 @@ def oracle_query_sample(oix, progs, budget_s, min_q=8):
         t_used += time.perf_counter() - t0
         done += k
         k *= 2
-    return {"queries_per_s": round(done / t_used, 2), "cores": 1, "kind": "port",
+    return {"queries_per_s": round(done / t_used, 2), "cores": 1, "kind": "port", "queries": done,
             "sample": "first %d queries of the leg on the same index bytes, oracle 1 thread, %.1f s" % (done, t_used)}
+
+
+def oracle_query_all_cores(img, lst, progs, n_1core, max_copies, budget_s):
+    """the reference serialises Search under ONE lock (Search.cs:448; GetPage keeps a cursor in the page list,
+    Build.cs:74-97), so queries/s of one index object is the one-thread figure.  This is the query-sharded variant: one
+    private copy of the index per thread (the oracle's page cursor is per object too), the sample's queries dealt out in
+    contiguous slices, wall time of the slowest thread.  Copies are bounded by host memory (`max_copies`)."""
+    import concurrent.futures as cf
+    import oracle
+    C = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    C = max(1, min(C, max_copies))
+    pa, oa = progs[0]
+    n = int(min(oa.size - 1, max(C, n_1core * C)))                # ~ the one-thread sample's work per thread
+    if C < 2 or n < C:
+        return None
+
+    def load(_):
+        o = oracle.Index(stemmers=[])
+        o.load(img, lst)
+        return o
+
+    with cf.ThreadPoolExecutor(C) as ex:
+        copies = list(ex.map(load, range(C)))
+        cuts = [n * k // C for k in range(C + 1)]
+
+        def run(k):
+            a, b = cuts[k], cuts[k + 1]
+            if a < b:
+                copies[k].query_batch(pa[int(oa[a]):int(oa[b])], oa[a:b + 1] - oa[a])
+        t0 = time.perf_counter()
+        list(ex.map(run, range(C)))
+        dt = time.perf_counter() - t0
+    return {"queries_per_s": round(n / dt, 2), "cores": C,
+            "sample": "first %d queries of the leg, %d threads with a private copy of the index each (query-sharded), %.1f s" % (n, C, dt)}
 
 
 def query_bench(ix, n_single, n_and3, cpu_sample, img=None, lst=None, seed_offset=0):
@@ -314,6 +348,9 @@ def query_bench(ix, n_single, n_and3, cpu_sample, img=None, lst=None, seed_offse
         out[name], progs = run_query_leg(ix, qs, info, max(nq, 1), "configs[1] index", reps=3)
         if oix is not None and progs:
             out[name]["cpu_baseline"] = oracle_query_sample(oix, progs, cpu_sample)
+            ac = oracle_query_all_cores(img, lst, progs, out[name]["cpu_baseline"]["queries"], 16, cpu_sample)
+            if ac:
+                out[name]["cpu_baseline"]["all_cores"] = ac
     return out
 
 
@@ -772,10 +809,14 @@ def big_index_legs(args, rank, world, device, dist, cdev):
             if oix is None:
                 import oracle
                 oix = oracle.Index(stemmers=[])
-                oix.load(ix.index_image(), ix.list_image())
+                big_img, big_lst = ix.index_image(), ix.list_image()
+                oix.load(big_img, big_lst)
                 note("oracle loaded the big index")
             res["cpu_baseline"] = oracle_query_sample(oix, progs, budget, min_q=2)
-            note("%s: oracle sample done" % name)
+            ac = oracle_query_all_cores(big_img, big_lst, progs, res["cpu_baseline"]["queries"], 8, budget)   # (8 copies of a 3.5 GB index)
+            if ac:
+                res["cpu_baseline"]["all_cores"] = ac
+            note("%s: oracle samples done" % name)
         out[name] = res
     ix.close()
     return out
