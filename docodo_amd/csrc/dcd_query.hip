@@ -265,6 +265,8 @@ __device__ void part_gallop(const CV& Sv, u64 ns, const CV& Lv, u64 nl, bool s_i
   u32* r_s1 = rec_lds + 4 * PW_TILE;                          // [PW_TILE] last S index emitted (inclusive, relative to i_begin)
   u32* r_n = rec_lds + 5 * PW_TILE;                           // [PW_TILE] emitted values (0 = not a leader / nothing)
   u16* g_list = reinterpret_cast<u16*>(rec_lds + 6 * PW_TILE);  // [PW_TILE] the walk list: element index relative to i_begin (< GAL_PER)
+  u16* c_k = g_list + PW_TILE;                                  // [PW_TILE] candidates of a round: element number in the round ...
+  u32* c_il = rec_lds + 7 * PW_TILE;                            // [PW_TILE] ... and position in the long list relative to the round's first
   u64 cursor = 0, slot = 0;
   bool have_slot = false;
   u32 n_list = 0;                                             // (wave-uniform)
@@ -421,137 +423,156 @@ __device__ void part_gallop(const CV& Sv, u64 ns, const CV& Lv, u64 nl, bool s_i
         for (int q = 0; q < (int)PW_ITEMS; q++) ilv[q] = act[q] ? lower_bound_u64(Lv, nl, sv[q]) : 0;
       }
       PROF(11);  // gallop: short elements, directory cells, position in the long list
-      // Round 3: the chain of an element is RESOLVED IN REGISTERS from a window of both lists around it -- S[i-1 .. i+2] and
-      // L[il-2 .. il+1], fetched together in one round trip -- whenever it closes inside the window: the same decisions as the
-      // walk (general()), without its dependent loads.  Phrases and Dist-sized windows over sparse lists give chains of two or
-      // three elements, so nearly every element with a neighbour within absR ends here: as "emits nothing" (not the leader of its
-      // chain, no element of the long operand, the ordered rule fails: dropped -- two thirds of them on configs[4]) or as a
-      // finished record on the list (only its emission is left for flush()).  The rare longer chain goes on the list unresolved
-      // (r_n = NONE32) and walks.
-      u64 wm[PW_ITEMS];
-      u32 n_new = 0;
-      u64 e_b[PW_ITEMS];
-      u32 e_d[PW_ITEMS], e_s0[PW_ITEMS], e_s1[PW_ITEMS], e_n[PW_ITEMS];
+      // An element without a neighbour within absR on either side is a chain of its own and emits nothing: the nearest union
+      // neighbours S[i - 1], S[i + 1], L[il - 1], L[il] decide that for ALL elements of the round (four loads each).  The few that do
+      // have one -- 10 % on configs[3], a third on configs[4] -- are COMPACTED (element number + position, in element order) and
+      // looked at again below with full lanes: the window loads and the in-register resolution run once or twice per round over
+      // the candidates instead of four times over every element slot with a tenth of the lanes active.
+      u32 n_c = 0;
+      const u64 il_base = rfl64(ilv[0]);                         // (positions ascend with the elements: lane 0's first is the smallest)
       {
-        u64 sp[PW_ITEMS], sn[PW_ITEMS], snn[PW_ITEMS], lpp[PW_ITEMS], lp[PW_ITEMS], ln[PW_ITEMS], lnn[PW_ITEMS];
+        u64 sp[PW_ITEMS], sn[PW_ITEMS], lp[PW_ITEMS], ln[PW_ITEMS];
 #pragma unroll
         for (int q = 0; q < (int)PW_ITEMS; q++) {
           const u64 i = min(i0 + lane + (u64)q * PW_T, s_last);
           const u64 il = ilv[q];
           sp[q] = Sv[i > 0 ? i - 1 : 0];
           sn[q] = Sv[min(i + 1, s_last)];
-          snn[q] = Sv[min(i + 2, s_last)];
-          lpp[q] = Lv[il > 1 ? min(il - 2, l_last) : 0];
           lp[q] = Lv[il > 0 ? min(il - 1, l_last) : 0];
           ln[q] = Lv[min(il, l_last)];
-          lnn[q] = Lv[min(il + 1, l_last)];
         }
 #pragma unroll
         for (int q = 0; q < (int)PW_ITEMS; q++) {
           const u64 i = i0 + lane + (u64)q * PW_T, il = ilv[q], s = sv[q];
-          const bool hsp = i > 0, hlp = il > 0, hlpp = il > 1, hsn = i + 1 < ns, hln = il < nl;
+          const bool hsp = i > 0, hlp = il > 0, hsn = i + 1 < ns, hln = il < nl;
           const u64 lft = (hsp || hlp) ? max(hsp ? sp[q] : 0ull, hlp ? lp[q] : 0ull) : ~0ull;   // nearest union neighbours (~0: none)
           const u64 rgt = min(hsn ? sn[q] : ~0ull, hln ? ln[q] : ~0ull);
           const bool left_far = lft == ~0ull || s - lft > (u64)absR;
           const bool right_far = rgt == ~0ull || rgt - s > (u64)absR;
-          // an element without a neighbour within absR on either side is a chain of its own and emits nothing
-          bool listed = false;
-          e_b[q] = 0; e_d[q] = 0; e_s0[q] = 0; e_s1[q] = 0; e_n[q] = NONE32;
-          if (act[q] && !(left_far && right_far)) {
-            bool leader = true, unres = false;
-            u32 bl = 0;                                          // left walk: long-list elements taken (b = il - bl)
-            if (!left_far) {
-              bool takeS = hsp && (!hlp || sp[q] >= lp[q]);
-              if (takeS) leader = false;                         // (the nearest left neighbour is within absR: !left_far)
-              else {
-                bl = 1;
-                u64 cur = lp[q];
-                if (hsp || hlpp) {
-                  takeS = hsp && (!hlpp || sp[q] >= lpp[q]);
-                  const u64 cv = takeS ? sp[q] : lpp[q];
-                  if (cur - cv <= (u64)absR) {
-                    if (takeS) leader = false;
-                    else {
-                      bl = 2;
-                      cur = lpp[q];
-                      if (il > 2) unres = true;                  // L[il - 3] is outside the window
-                      else if (hsp && cur - sp[q] <= (u64)absR) leader = false;
-                    }
-                  }
-                }
-              }
-            }
-            if (unres) listed = true;
-            else if (leader) {
-              u32 cr = 0, dr = 0;                                // right walk: elements taken (c = i + cr, d = il + dr)
-              u64 cur = s;
-              bool open = true;
-#pragma unroll
-              for (int it = 0; it < 5; it++) {
-                if (open) {
-                  const bool hs = i + cr + 1 < ns, hl = il + dr < nl;
-                  if ((hs && cr >= 2u) || (hl && dr >= 2u)) { unres = true; open = false; }   // S[i + 3] / L[il + 2]: outside the window
-                  else if (!hs && !hl) open = false;
+          const bool cand = act[q] && !(left_far && right_far);
+          const u64 cm = ballot64(cand);
+          if (cand) {
+            const u32 pos = n_c + mbcnt(cm);
+            c_k[pos] = (u16)(lane + (u32)q * PW_T);
+            c_il[pos] = il - il_base < 0xFFFFFFFFull ? (u32)(il - il_base) : 0xFFFFFFFFu;
+          }
+          n_c += popc64(cm);
+          PROF_CNT(16, popc64(ballot64(act[q])));                // short-list elements
+          PROF_CNT(17, popc64(cm));                              // ... with a neighbour within absR
+        }
+      }
+      wsync();
+      PROF(12);  // gallop: neighbours, candidates
+      // Round 3: the chain of a candidate is RESOLVED IN REGISTERS from a window of both lists around it -- S[i-1 .. i+2] and
+      // L[il-2 .. il+1], fetched together in one round trip (cache hits: the round has just touched these lines) -- whenever it
+      // closes inside the window: the same decisions as the walk (general()), without its dependent loads.  Phrases and
+      // Dist-sized windows over sparse lists give chains of two or three elements, so nearly every candidate ends here: as "emits
+      // nothing" (not the leader of its chain, no element of the long operand, the ordered rule fails: dropped -- two thirds of
+      // them on configs[4]) or as a finished record on the list (only its emission is left for flush()).  The rare longer chain
+      // goes on the list unresolved (r_n = NONE32) and walks.
+      for (u32 b0 = 0; b0 < n_c; b0 += PW_T) {
+        const bool on = b0 + lane < n_c;
+        const u32 k = on ? c_k[b0 + lane] : 0u;
+        const u32 il32 = on ? c_il[b0 + lane] : 0u;
+        const u64 i = i0 + k, il = il_base + (il32 == 0xFFFFFFFFu ? 0u : il32);
+        const u64 ic = min(i, s_last);
+        const u64 s = Sv[ic];
+        const u64 sp = Sv[ic > 0 ? ic - 1 : 0], sn = Sv[min(ic + 1, s_last)], snn = Sv[min(ic + 2, s_last)];
+        const u64 lpp = Lv[il > 1 ? min(il - 2, l_last) : 0], lp = Lv[il > 0 ? min(il - 1, l_last) : 0];
+        const u64 ln = Lv[min(il, l_last)], lnn = Lv[min(il + 1, l_last)];
+        const bool hsp = i > 0, hlp = il > 0, hlpp = il > 1;
+        const u64 lft = (hsp || hlp) ? max(hsp ? sp : 0ull, hlp ? lp : 0ull) : ~0ull;
+        const bool left_far = lft == ~0ull || s - lft > (u64)absR;
+        bool listed = false;
+        u64 e_b = 0;
+        u32 e_d = 0, e_s0 = 0, e_s1 = 0, e_n = NONE32;
+        if (on) {
+          bool leader = true, unres = il32 == 0xFFFFFFFFu;       // (a round that spans 2^32 postings: the walk locates the element)
+          u32 bl = 0;                                            // left walk: long-list elements taken (b = il - bl)
+          if (!unres && !left_far) {
+            bool takeS = hsp && (!hlp || sp >= lp);
+            if (takeS) leader = false;                           // (the nearest left neighbour is within absR: !left_far)
+            else {
+              bl = 1;
+              u64 cur = lp;
+              if (hsp || hlpp) {
+                takeS = hsp && (!hlpp || sp >= lpp);
+                const u64 cv = takeS ? sp : lpp;
+                if (cur - cv <= (u64)absR) {
+                  if (takeS) leader = false;
                   else {
-                    const u64 cs = cr == 0u ? sn[q] : snn[q], cl = dr == 0u ? ln[q] : lnn[q];
-                    const bool takeS = hs && (!hl || cs <= cl);
-                    const u64 cv = takeS ? cs : cl;
-                    if (cv - cur > (u64)absR) open = false;
-                    else { if (takeS) cr++; else dr++; cur = cv; }
+                    bl = 2;
+                    cur = lpp;
+                    if (il > 2) unres = true;                    // L[il - 3] is outside the window
+                    else if (hsp && cur - sp <= (u64)absR) leader = false;
                   }
-                }
-              }
-              if (unres) listed = true;
-              else {
-                // chain = S[i .. i + cr] u L[il - bl .. il + dr): the rules of general()
-                u32 lb_back = bl, k0 = 0;
-                bool ok = bl + dr > 0u;                          // needs an element of the long operand
-                if (ok && ordered) {
-                  if (s_is_a) { lb_back = 0; ok = dr > 0u; }     // first A = s: long-list elements before it are dropped
-                  else {                                        // first A = L[il - bl]: the B-only prefix is dropped
-                    const u64 fa = bl == 2u ? lpp[q] : (bl == 1u ? lp[q] : ln[q]);
-                    k0 = (s < fa ? 1u : 0u) + ((cr >= 1u && sn[q] < fa) ? 1u : 0u) + ((cr >= 2u && snn[q] < fa) ? 1u : 0u);
-                    ok = k0 <= cr;
-                  }
-                }
-                if (ok) {
-                  // a coordinate held by both operands is emitted once (gal_merge): only L[il], L[il + 1] can equal a short-list member
-                  const bool m0 = dr >= 1u, m1 = dr >= 2u;
-                  u32 dups = 0;
-                  if (k0 == 0u) dups += ((m0 && s == ln[q]) ? 1u : 0u) + ((m1 && s == lnn[q]) ? 1u : 0u);
-                  if (k0 <= 1u && cr >= 1u) dups += ((m0 && sn[q] == ln[q]) ? 1u : 0u) + ((m1 && sn[q] == lnn[q]) ? 1u : 0u);
-                  if (cr >= 2u) dups += ((m0 && snn[q] == ln[q]) ? 1u : 0u) + ((m1 && snn[q] == lnn[q]) ? 1u : 0u);
-                  e_b[q] = il - lb_back;
-                  e_d[q] = lb_back + dr;
-                  e_s0[q] = (u32)(i - i_begin) + k0;
-                  e_s1[q] = (u32)(i - i_begin) + cr;
-                  e_n[q] = (cr + 1u - k0) + lb_back + dr - dups;
-                  listed = true;
                 }
               }
             }
           }
-          wm[q] = ballot64(listed);
-          n_new += popc64(wm[q]);
-          PROF_CNT(16, popc64(ballot64(act[q])));                                   // short-list elements
-          PROF_CNT(17, popc64(ballot64(act[q] && !(left_far && right_far))));      // ... with a neighbour within absR
-          PROF_CNT(18, popc64(ballot64(listed && e_n[q] != NONE32)));              // ... resolved, emitting
-          PROF_CNT(19, popc64(ballot64(listed && e_n[q] == NONE32)));              // ... unresolved (walk)
-        }
-      }
-      PROF(12);  // gallop: window, chains resolved in registers
-      if (n_list + n_new > PW_TILE) flush();                   // (a round adds at most PW_TILE entries)
-      // (entries in element order: the emission relies on it)
+          if (unres) listed = true;
+          else if (leader) {
+            u32 cr = 0, dr = 0;                                  // right walk: elements taken (c = i + cr, d = il + dr)
+            u64 cur = s;
+            bool open = true;
 #pragma unroll
-      for (int q = 0; q < (int)PW_ITEMS; q++) {
-        const u32 k = lane + (u32)q * PW_T;
-        if ((wm[q] >> lane) & 1ull) {
-          const u32 p = n_list + mbcnt(wm[q]);
-          g_list[p] = (u16)((u32)(i0 - i_begin) + k);
-          r_b[p] = e_b[q]; r_d[p] = e_d[q]; r_s0[p] = e_s0[q]; r_s1[p] = e_s1[q]; r_n[p] = e_n[q];
+            for (int it = 0; it < 5; it++) {
+              if (open) {
+                const bool hs = i + cr + 1 < ns, hl = il + dr < nl;
+                if ((hs && cr >= 2u) || (hl && dr >= 2u)) { unres = true; open = false; }   // S[i + 3] / L[il + 2]: outside the window
+                else if (!hs && !hl) open = false;
+                else {
+                  const u64 cs = cr == 0u ? sn : snn, cl = dr == 0u ? ln : lnn;
+                  const bool takeS = hs && (!hl || cs <= cl);
+                  const u64 cv = takeS ? cs : cl;
+                  if (cv - cur > (u64)absR) open = false;
+                  else { if (takeS) cr++; else dr++; cur = cv; }
+                }
+              }
+            }
+            if (unres) listed = true;
+            else {
+              // chain = S[i .. i + cr] u L[il - bl .. il + dr): the rules of general()
+              u32 lb_back = bl, k0 = 0;
+              bool ok = bl + dr > 0u;                            // needs an element of the long operand
+              if (ok && ordered) {
+                if (s_is_a) { lb_back = 0; ok = dr > 0u; }       // first A = s: long-list elements before it are dropped
+                else {                                          // first A = L[il - bl]: the B-only prefix is dropped
+                  const u64 fa = bl == 2u ? lpp : (bl == 1u ? lp : ln);
+                  k0 = (s < fa ? 1u : 0u) + ((cr >= 1u && sn < fa) ? 1u : 0u) + ((cr >= 2u && snn < fa) ? 1u : 0u);
+                  ok = k0 <= cr;
+                }
+              }
+              if (ok) {
+                // a coordinate held by both operands is emitted once (gal_merge): only L[il], L[il + 1] can equal a short-list member
+                const bool m0 = dr >= 1u, m1 = dr >= 2u;
+                u32 dups = 0;
+                if (k0 == 0u) dups += ((m0 && s == ln) ? 1u : 0u) + ((m1 && s == lnn) ? 1u : 0u);
+                if (k0 <= 1u && cr >= 1u) dups += ((m0 && sn == ln) ? 1u : 0u) + ((m1 && sn == lnn) ? 1u : 0u);
+                if (cr >= 2u) dups += ((m0 && snn == ln) ? 1u : 0u) + ((m1 && snn == lnn) ? 1u : 0u);
+                e_b = il - lb_back;
+                e_d = lb_back + dr;
+                e_s0 = (u32)(i - i_begin) + k0;
+                e_s1 = (u32)(i - i_begin) + cr;
+                e_n = (cr + 1u - k0) + lb_back + dr - dups;
+                listed = true;
+              }
+            }
+          }
         }
-        n_list += popc64(wm[q]);
+        const u64 wm = ballot64(listed);
+        PROF_CNT(18, popc64(ballot64(listed && e_n != NONE32)));   // ... resolved, emitting
+        PROF_CNT(19, popc64(ballot64(listed && e_n == NONE32)));   // ... unresolved (walk)
+        if (n_list + popc64(wm) > PW_TILE) flush();
+        // (entries in element order: the emission relies on it)
+        if (listed) {
+          const u32 p = n_list + mbcnt(wm);
+          g_list[p] = (u16)((u32)(i0 - i_begin) + k);
+          r_b[p] = e_b; r_d[p] = e_d; r_s0[p] = e_s0; r_s1[p] = e_s1; r_n[p] = e_n;
+        }
+        n_list += popc64(wm);
       }
+      wsync();                                                   // (the next round rewrites the candidate list)
     }
   }
   if (n_list) flush();
@@ -599,7 +620,7 @@ __global__ __launch_bounds__(PW_T, DCD_PW_WAVES) void k_pair_parts(const PairOp*
                                                     const u64* __restrict__ counts, u64* __restrict__ tmp, u64* __restrict__ part_count,
                                                     u64* __restrict__ part_src, u64 PART, const u32* __restrict__ dirs,
                                                     u64 dir_max_coord, const u8* __restrict__ op_mode, u64 W_cap, unsigned long long* __restrict__ work_ctr) {
-  constexpr u32 RAW_WORDS = 6u * PW_TILE + PW_TILE / 2u + 16u;   // rings + chain flags, or the gallop records + walk list
+  constexpr u32 RAW_WORDS = 8u * PW_TILE + 16u;                  // rings + chain flags, or the gallop records + walk list + candidate list
   __shared__ __attribute__((aligned(16))) u32 s_raw[RAW_WORDS];
   u64* sA = reinterpret_cast<u64*>(s_raw);
   u64* sB = sA + PW_TILE;
