@@ -346,29 +346,41 @@ __device__ void part_gallop(const CV& Sv, u64 ns, const CV& Lv, u64 nl, bool s_i
     }
     wsync();
     PROF(14);  // gallop: walks of the unresolved chains
-    u32 mine = 0;
-    for (u32 q = 0; q < PW_ITEMS; q++) { u32 p = lane * PW_ITEMS + q; if (p < n_list) mine += r_n[p]; }
-    const u32 incl = wave_scan_incl(mine);
-    const u32 total = rdl(incl, 63);
-    u32 ex = incl - mine;
+    // entry p = q * 64 + lane: a list of 40 entries keeps 40 lanes busy for one serial merge each (with four consecutive entries
+    // per lane it was ten lanes for four merges)
+    u32 nq_[PW_ITEMS], exq[PW_ITEMS];
+    u32 total = 0;
+#pragma unroll
+    for (int q = 0; q < (int)PW_ITEMS; q++) {
+      const u32 p = (u32)q * PW_T + lane;
+      nq_[q] = p < n_list ? r_n[p] : 0u;
+      const u32 incl = wave_scan_incl(nq_[q]);
+      exq[q] = total + incl - nq_[q];
+      total += rdl(incl, 63);
+    }
     if (!have_slot && total) {
       // scratch slot of this work item = union index (S index + L index) of its first emitted element
-      const u64 m = ballot64(mine != 0);
-      const u32 fl = (u32)__builtin_ctzll(m);
       u64 cand = 0;
-      if (lane == fl) {
-        for (u32 q = 0; q < PW_ITEMS; q++) { u32 p = lane * PW_ITEMS + q; if (p < n_list && r_n[p]) { cand = r_b[p] + i_begin + r_s0[p]; break; } }
+      bool found = false;
+#pragma unroll
+      for (int q = 0; q < (int)PW_ITEMS; q++) {
+        const u64 m = ballot64(nq_[q] != 0u);
+        if (!found && m) {
+          const u32 fl = (u32)__builtin_ctzll(m), p = (u32)q * PW_T + fl;
+          cand = r_b[p] + i_begin + r_s0[p];                   // (LDS reads of one address: every lane gets the value)
+          found = true;
+        }
       }
-      slot = rdl64(cand, fl);
+      slot = cand;
       have_slot = true;
     }
     u64* out = tmp_op + slot;
-    for (u32 q = 0; q < PW_ITEMS; q++) {
-      u32 p = lane * PW_ITEMS + q;
-      if (p < n_list && r_n[p]) {
-        u64 o = cursor + ex;
+#pragma unroll
+    for (int q = 0; q < (int)PW_ITEMS; q++) {
+      const u32 p = (u32)q * PW_T + lane;
+      if (nq_[q]) {
+        u64 o = cursor + exq[q];
         gal_merge(Sv, i_begin + r_s0[p], i_begin + r_s1[p], Lv, r_b[p], r_b[p] + r_d[p], [&](u64 v) { out[o++] = v; });
-        ex += r_n[p];
       }
     }
     cursor += total;
