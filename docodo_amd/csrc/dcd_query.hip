@@ -266,7 +266,7 @@ __device__ void part_gallop(const CV& Sv, u64 ns, const CV& Lv, u64 nl, bool s_i
   u32* r_n = rec_lds + 5 * PW_TILE;                           // [PW_TILE] emitted values (0 = not a leader / nothing)
   u16* g_list = reinterpret_cast<u16*>(rec_lds + 6 * PW_TILE);  // [PW_TILE] the walk list: element index relative to i_begin (< GAL_PER)
   u16* c_k = g_list + PW_TILE;                                  // [PW_TILE] candidates of a round: element number in the round ...
-  u32* c_il = rec_lds + 7 * PW_TILE;                            // [PW_TILE] ... and position in the long list relative to the round's first
+  u32* c_il = rec_lds + 6 * PW_TILE + PW_TILE / 2 + 160;         // [320] ... and position in the long list relative to the item's first  (c_k: [320])
   u64 cursor = 0, slot = 0;
   bool have_slot = false;
   u32 n_list = 0;                                             // (wave-uniform)
@@ -388,6 +388,120 @@ __device__ void part_gallop(const CV& Sv, u64 ns, const CV& Lv, u64 nl, bool s_i
     n_list = 0;
     PROF(15);  // gallop: scan + emission
   };
+  u32 n_c = 0;                                                // pending candidates (wave-uniform)
+  u64 il_base = 0;                                            // position of the item's first element in the long list
+  const u64 s_last = ns - 1, l_last = nl - 1;
+  auto resolve_pass = [&](u32 c0, u32 cnt) {                  // candidates c0 .. c0 + cnt (cnt <= 64), one per lane
+    // Round 3: the chain of a candidate is RESOLVED IN REGISTERS from a window of both lists around it -- S[i-1 .. i+2] and
+    // L[il-2 .. il+1], fetched together in one round trip (cache hits: the round has just touched these lines) -- whenever it
+    // closes inside the window: the same decisions as the walk (general()), without its dependent loads.  Phrases and
+    // Dist-sized windows over sparse lists give chains of two or three elements, so nearly every candidate ends here: as "emits
+    // nothing" (not the leader of its chain, no element of the long operand, the ordered rule fails: dropped -- two thirds of
+    // them on configs[4]) or as a finished record on the list (only its emission is left for flush()).  The rare longer chain
+    // goes on the list unresolved (r_n = NONE32) and walks.
+    {
+      const bool on = lane < cnt;
+      const u32 k = on ? c_k[c0 + lane] : 0u;                  // element number relative to i_begin
+      const u32 il32 = on ? c_il[c0 + lane] : 0u;
+      const u64 i = i_begin + k, il = il_base + (il32 == 0xFFFFFFFFu ? 0u : il32);
+      const u64 ic = min(i, s_last);
+      const u64 s = Sv[ic];
+      const u64 sp = Sv[ic > 0 ? ic - 1 : 0], sn = Sv[min(ic + 1, s_last)], snn = Sv[min(ic + 2, s_last)];
+      const u64 lpp = Lv[il > 1 ? min(il - 2, l_last) : 0], lp = Lv[il > 0 ? min(il - 1, l_last) : 0];
+      const u64 ln = Lv[min(il, l_last)], lnn = Lv[min(il + 1, l_last)];
+      const bool hsp = i > 0, hlp = il > 0, hlpp = il > 1;
+      const u64 lft = (hsp || hlp) ? max(hsp ? sp : 0ull, hlp ? lp : 0ull) : ~0ull;
+      const bool left_far = lft == ~0ull || s - lft > (u64)absR;
+      bool listed = false;
+      u64 e_b = 0;
+      u32 e_d = 0, e_s0 = 0, e_s1 = 0, e_n = NONE32;
+      if (on) {
+        bool leader = true, unres = il32 == 0xFFFFFFFFu;       // (a round that spans 2^32 postings: the walk locates the element)
+        u32 bl = 0;                                            // left walk: long-list elements taken (b = il - bl)
+        if (!unres && !left_far) {
+          bool takeS = hsp && (!hlp || sp >= lp);
+          if (takeS) leader = false;                           // (the nearest left neighbour is within absR: !left_far)
+          else {
+            bl = 1;
+            u64 cur = lp;
+            if (hsp || hlpp) {
+              takeS = hsp && (!hlpp || sp >= lpp);
+              const u64 cv = takeS ? sp : lpp;
+              if (cur - cv <= (u64)absR) {
+                if (takeS) leader = false;
+                else {
+                  bl = 2;
+                  cur = lpp;
+                  if (il > 2) unres = true;                    // L[il - 3] is outside the window
+                  else if (hsp && cur - sp <= (u64)absR) leader = false;
+                }
+              }
+            }
+          }
+        }
+        if (unres) listed = true;
+        else if (leader) {
+          u32 cr = 0, dr = 0;                                  // right walk: elements taken (c = i + cr, d = il + dr)
+          u64 cur = s;
+          bool open = true;
+#pragma unroll
+          for (int it = 0; it < 5; it++) {
+            if (open) {
+              const bool hs = i + cr + 1 < ns, hl = il + dr < nl;
+              if ((hs && cr >= 2u) || (hl && dr >= 2u)) { unres = true; open = false; }   // S[i + 3] / L[il + 2]: outside the window
+              else if (!hs && !hl) open = false;
+              else {
+                const u64 cs = cr == 0u ? sn : snn, cl = dr == 0u ? ln : lnn;
+                const bool takeS = hs && (!hl || cs <= cl);
+                const u64 cv = takeS ? cs : cl;
+                if (cv - cur > (u64)absR) open = false;
+                else { if (takeS) cr++; else dr++; cur = cv; }
+              }
+            }
+          }
+          if (unres) listed = true;
+          else {
+            // chain = S[i .. i + cr] u L[il - bl .. il + dr): the rules of general()
+            u32 lb_back = bl, k0 = 0;
+            bool ok = bl + dr > 0u;                            // needs an element of the long operand
+            if (ok && ordered) {
+              if (s_is_a) { lb_back = 0; ok = dr > 0u; }       // first A = s: long-list elements before it are dropped
+              else {                                          // first A = L[il - bl]: the B-only prefix is dropped
+                const u64 fa = bl == 2u ? lpp : (bl == 1u ? lp : ln);
+                k0 = (s < fa ? 1u : 0u) + ((cr >= 1u && sn < fa) ? 1u : 0u) + ((cr >= 2u && snn < fa) ? 1u : 0u);
+                ok = k0 <= cr;
+              }
+            }
+            if (ok) {
+              // a coordinate held by both operands is emitted once (gal_merge): only L[il], L[il + 1] can equal a short-list member
+              const bool m0 = dr >= 1u, m1 = dr >= 2u;
+              u32 dups = 0;
+              if (k0 == 0u) dups += ((m0 && s == ln) ? 1u : 0u) + ((m1 && s == lnn) ? 1u : 0u);
+              if (k0 <= 1u && cr >= 1u) dups += ((m0 && sn == ln) ? 1u : 0u) + ((m1 && sn == lnn) ? 1u : 0u);
+              if (cr >= 2u) dups += ((m0 && snn == ln) ? 1u : 0u) + ((m1 && snn == lnn) ? 1u : 0u);
+              e_b = il - lb_back;
+              e_d = lb_back + dr;
+              e_s0 = (u32)(i - i_begin) + k0;
+              e_s1 = (u32)(i - i_begin) + cr;
+              e_n = (cr + 1u - k0) + lb_back + dr - dups;
+              listed = true;
+            }
+          }
+        }
+      }
+      const u64 wm = ballot64(listed);
+      PROF_CNT(18, popc64(ballot64(listed && e_n != NONE32)));   // ... resolved, emitting
+      PROF_CNT(19, popc64(ballot64(listed && e_n == NONE32)));   // ... unresolved (walk)
+      if (n_list + popc64(wm) > PW_TILE) flush();
+      // (entries in element order: the emission relies on it)
+      if (listed) {
+        const u32 p = n_list + mbcnt(wm);
+        g_list[p] = (u16)k;
+        r_b[p] = e_b; r_d[p] = e_d; r_s0[p] = e_s0; r_s1[p] = e_s1; r_n[p] = e_n;
+      }
+      n_list += popc64(wm);
+    }
+  };
   for (u64 i0 = i_begin; i0 < i_end; i0 += PW_TILE) {
     const u32 cn = (u32)min((u64)PW_TILE, i_end - i0);
     // Every lane looks after PW_ITEMS short-list elements.  Their loads are issued together, phase by phase (the
@@ -400,7 +514,6 @@ __device__ void part_gallop(const CV& Sv, u64 ns, const CV& Lv, u64 nl, bool s_i
       // a branch and a wait between the loads of the PW_ITEMS elements)
       u64 sv[PW_ITEMS], ilv[PW_ITEMS], hiv[PW_ITEMS];
       bool act[PW_ITEMS];
-      const u64 s_last = ns - 1, l_last = nl - 1;
 #pragma unroll
       for (int q = 0; q < (int)PW_ITEMS; q++) {
         const u32 k = lane + (u32)q * PW_T;
@@ -440,8 +553,7 @@ __device__ void part_gallop(const CV& Sv, u64 ns, const CV& Lv, u64 nl, bool s_i
       // have one -- 10 % on configs[3], a third on configs[4] -- are COMPACTED (element number + position, in element order) and
       // looked at again below with full lanes: the window loads and the in-register resolution run once or twice per round over
       // the candidates instead of four times over every element slot with a tenth of the lanes active.
-      u32 n_c = 0;
-      const u64 il_base = rfl64(ilv[0]);                         // (positions ascend with the elements: lane 0's first is the smallest)
+      if (i0 == i_begin) il_base = rfl64(ilv[0]);                // (positions ascend with the elements: the item's first is the smallest)
       {
         u64 sp[PW_ITEMS], sn[PW_ITEMS], lp[PW_ITEMS], ln[PW_ITEMS];
 #pragma unroll
@@ -465,7 +577,7 @@ __device__ void part_gallop(const CV& Sv, u64 ns, const CV& Lv, u64 nl, bool s_i
           const u64 cm = ballot64(cand);
           if (cand) {
             const u32 pos = n_c + mbcnt(cm);
-            c_k[pos] = (u16)(lane + (u32)q * PW_T);
+            c_k[pos] = (u16)((u32)(i0 - i_begin) + lane + (u32)q * PW_T);
             c_il[pos] = il - il_base < 0xFFFFFFFFull ? (u32)(il - il_base) : 0xFFFFFFFFu;
           }
           n_c += popc64(cm);
@@ -475,118 +587,24 @@ __device__ void part_gallop(const CV& Sv, u64 ns, const CV& Lv, u64 nl, bool s_i
       }
       wsync();
       PROF(12);  // gallop: neighbours, candidates
-      // Round 3: the chain of a candidate is RESOLVED IN REGISTERS from a window of both lists around it -- S[i-1 .. i+2] and
-      // L[il-2 .. il+1], fetched together in one round trip (cache hits: the round has just touched these lines) -- whenever it
-      // closes inside the window: the same decisions as the walk (general()), without its dependent loads.  Phrases and
-      // Dist-sized windows over sparse lists give chains of two or three elements, so nearly every candidate ends here: as "emits
-      // nothing" (not the leader of its chain, no element of the long operand, the ordered rule fails: dropped -- two thirds of
-      // them on configs[4]) or as a finished record on the list (only its emission is left for flush()).  The rare longer chain
-      // goes on the list unresolved (r_n = NONE32) and walks.
-      for (u32 b0 = 0; b0 < n_c; b0 += PW_T) {
-        const bool on = b0 + lane < n_c;
-        const u32 k = on ? c_k[b0 + lane] : 0u;
-        const u32 il32 = on ? c_il[b0 + lane] : 0u;
-        const u64 i = i0 + k, il = il_base + (il32 == 0xFFFFFFFFu ? 0u : il32);
-        const u64 ic = min(i, s_last);
-        const u64 s = Sv[ic];
-        const u64 sp = Sv[ic > 0 ? ic - 1 : 0], sn = Sv[min(ic + 1, s_last)], snn = Sv[min(ic + 2, s_last)];
-        const u64 lpp = Lv[il > 1 ? min(il - 2, l_last) : 0], lp = Lv[il > 0 ? min(il - 1, l_last) : 0];
-        const u64 ln = Lv[min(il, l_last)], lnn = Lv[min(il + 1, l_last)];
-        const bool hsp = i > 0, hlp = il > 0, hlpp = il > 1;
-        const u64 lft = (hsp || hlp) ? max(hsp ? sp : 0ull, hlp ? lp : 0ull) : ~0ull;
-        const bool left_far = lft == ~0ull || s - lft > (u64)absR;
-        bool listed = false;
-        u64 e_b = 0;
-        u32 e_d = 0, e_s0 = 0, e_s1 = 0, e_n = NONE32;
-        if (on) {
-          bool leader = true, unres = il32 == 0xFFFFFFFFu;       // (a round that spans 2^32 postings: the walk locates the element)
-          u32 bl = 0;                                            // left walk: long-list elements taken (b = il - bl)
-          if (!unres && !left_far) {
-            bool takeS = hsp && (!hlp || sp >= lp);
-            if (takeS) leader = false;                           // (the nearest left neighbour is within absR: !left_far)
-            else {
-              bl = 1;
-              u64 cur = lp;
-              if (hsp || hlpp) {
-                takeS = hsp && (!hlpp || sp >= lpp);
-                const u64 cv = takeS ? sp : lpp;
-                if (cur - cv <= (u64)absR) {
-                  if (takeS) leader = false;
-                  else {
-                    bl = 2;
-                    cur = lpp;
-                    if (il > 2) unres = true;                    // L[il - 3] is outside the window
-                    else if (hsp && cur - sp <= (u64)absR) leader = false;
-                  }
-                }
-              }
-            }
-          }
-          if (unres) listed = true;
-          else if (leader) {
-            u32 cr = 0, dr = 0;                                  // right walk: elements taken (c = i + cr, d = il + dr)
-            u64 cur = s;
-            bool open = true;
-#pragma unroll
-            for (int it = 0; it < 5; it++) {
-              if (open) {
-                const bool hs = i + cr + 1 < ns, hl = il + dr < nl;
-                if ((hs && cr >= 2u) || (hl && dr >= 2u)) { unres = true; open = false; }   // S[i + 3] / L[il + 2]: outside the window
-                else if (!hs && !hl) open = false;
-                else {
-                  const u64 cs = cr == 0u ? sn : snn, cl = dr == 0u ? ln : lnn;
-                  const bool takeS = hs && (!hl || cs <= cl);
-                  const u64 cv = takeS ? cs : cl;
-                  if (cv - cur > (u64)absR) open = false;
-                  else { if (takeS) cr++; else dr++; cur = cv; }
-                }
-              }
-            }
-            if (unres) listed = true;
-            else {
-              // chain = S[i .. i + cr] u L[il - bl .. il + dr): the rules of general()
-              u32 lb_back = bl, k0 = 0;
-              bool ok = bl + dr > 0u;                            // needs an element of the long operand
-              if (ok && ordered) {
-                if (s_is_a) { lb_back = 0; ok = dr > 0u; }       // first A = s: long-list elements before it are dropped
-                else {                                          // first A = L[il - bl]: the B-only prefix is dropped
-                  const u64 fa = bl == 2u ? lpp : (bl == 1u ? lp : ln);
-                  k0 = (s < fa ? 1u : 0u) + ((cr >= 1u && sn < fa) ? 1u : 0u) + ((cr >= 2u && snn < fa) ? 1u : 0u);
-                  ok = k0 <= cr;
-                }
-              }
-              if (ok) {
-                // a coordinate held by both operands is emitted once (gal_merge): only L[il], L[il + 1] can equal a short-list member
-                const bool m0 = dr >= 1u, m1 = dr >= 2u;
-                u32 dups = 0;
-                if (k0 == 0u) dups += ((m0 && s == ln) ? 1u : 0u) + ((m1 && s == lnn) ? 1u : 0u);
-                if (k0 <= 1u && cr >= 1u) dups += ((m0 && sn == ln) ? 1u : 0u) + ((m1 && sn == lnn) ? 1u : 0u);
-                if (cr >= 2u) dups += ((m0 && snn == ln) ? 1u : 0u) + ((m1 && snn == lnn) ? 1u : 0u);
-                e_b = il - lb_back;
-                e_d = lb_back + dr;
-                e_s0 = (u32)(i - i_begin) + k0;
-                e_s1 = (u32)(i - i_begin) + cr;
-                e_n = (cr + 1u - k0) + lb_back + dr - dups;
-                listed = true;
-              }
-            }
-          }
+      // full passes of 64 candidates now; the rest waits for the next round (a round of configs[3] leaves ~25: a pass per round
+      // would run the resolution at 40 % of the lanes)
+      {
+        u32 c_head = 0;
+        while (n_c - c_head >= PW_T) { resolve_pass(c_head, PW_T); c_head += PW_T; }
+        if (c_head) {
+          const u32 rem = n_c - c_head;
+          const u16 tk = lane < rem ? c_k[c_head + lane] : (u16)0;
+          const u32 ti = lane < rem ? c_il[c_head + lane] : 0u;
+          wsync();
+          if (lane < rem) { c_k[lane] = tk; c_il[lane] = ti; }
+          n_c = rem;
+          wsync();
         }
-        const u64 wm = ballot64(listed);
-        PROF_CNT(18, popc64(ballot64(listed && e_n != NONE32)));   // ... resolved, emitting
-        PROF_CNT(19, popc64(ballot64(listed && e_n == NONE32)));   // ... unresolved (walk)
-        if (n_list + popc64(wm) > PW_TILE) flush();
-        // (entries in element order: the emission relies on it)
-        if (listed) {
-          const u32 p = n_list + mbcnt(wm);
-          g_list[p] = (u16)((u32)(i0 - i_begin) + k);
-          r_b[p] = e_b; r_d[p] = e_d; r_s0[p] = e_s0; r_s1[p] = e_s1; r_n[p] = e_n;
-        }
-        n_list += popc64(wm);
       }
-      wsync();                                                   // (the next round rewrites the candidate list)
     }
   }
+  if (n_c) resolve_pass(0, n_c);
   if (n_list) flush();
   count_out = cursor;
   slot_out = slot;
@@ -632,7 +650,7 @@ __global__ __launch_bounds__(PW_T, DCD_PW_WAVES) void k_pair_parts(const PairOp*
                                                     const u64* __restrict__ counts, u64* __restrict__ tmp, u64* __restrict__ part_count,
                                                     u64* __restrict__ part_src, u64 PART, const u32* __restrict__ dirs,
                                                     u64 dir_max_coord, const u8* __restrict__ op_mode, u64 W_cap, unsigned long long* __restrict__ work_ctr) {
-  constexpr u32 RAW_WORDS = 8u * PW_TILE + 16u;                  // rings + chain flags, or the gallop records + walk list + candidate list
+  constexpr u32 RAW_WORDS = 6u * PW_TILE + PW_TILE / 2u + 160u + 320u + 16u;   // rings + chain flags, or the gallop records + walk list + candidate list
   __shared__ __attribute__((aligned(16))) u32 s_raw[RAW_WORDS];
   u64* sA = reinterpret_cast<u64*>(s_raw);
   u64* sB = sA + PW_TILE;
