@@ -328,7 +328,7 @@ __device__ void part_gallop(const CV& Sv, u64 ns, const CV& Lv, u64 nl, bool s_i
   // list; one walk + emit phase serves the item's 1024 elements (or runs earlier when the list is about to overflow).
   auto flush = [&]() {
     wsync();
-    PROF(13);  // gallop: list append (+ the time since the last probe)
+    PROF(13);  // gallop: (a pass that ran behind the last round)
     for (u32 b0 = 0; b0 < n_list; b0 += PW_T) {
       if (b0 + lane < n_list && r_n[b0 + lane] == NONE32) {       // (the others were resolved by the round that listed them)
         const u32 p = b0 + lane;
@@ -602,6 +602,7 @@ __device__ void part_gallop(const CV& Sv, u64 ns, const CV& Lv, u64 nl, bool s_i
           wsync();
         }
       }
+      PROF(13);  // gallop: dense passes over the candidates (window loads, chains resolved in registers, list append)
     }
   }
   if (n_c) resolve_pass(0, n_c);

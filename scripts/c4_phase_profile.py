@@ -51,7 +51,7 @@ r = ix.query_batch(pa, oa, totals=True)
 L.dcd_debug_prof(z.ctypes.data, 0)
 names = ["operator lookup", "gallop (everything)", "stream: split search + first fill", "half-cleaner + refill request", "bitonic sort", "merge flags",
          "refill store (waits for HBM)", "ownership", "fast path", "general path", "epilogue",
-         "  gallop: short elems + directory + search", "  gallop: windows + chains resolved in registers", "  gallop: list append", "  gallop: walks (unresolved chains)",
+         "  gallop: short elems + directory + search", "  gallop: nearest neighbours + candidate list", "  gallop: candidates resolved in registers (dense passes)", "  gallop: walks (unresolved chains)",
          "  gallop: scan + emission"]
 tot = float(z[:11].sum())
 print("device %.2f ms for %d queries" % (r["ms"], oa.size - 1))
