@@ -533,7 +533,7 @@ __device__ void part_gallop(const CV& Sv, u64 ns, const CV& Lv, u64 nl, bool s_i
           more = false;
           u64 mv[PW_ITEMS], lv[PW_ITEMS];
 #pragma unroll
-          for (int q = 0; q < (int)PW_ITEMS; q++) { mv[q] = (ilv[q] + hiv[q]) >> 1; lv[q] = Lv[min(mv[q], l_last)]; }
+          for (int q = 0; q < (int)PW_ITEMS; q++) { mv[q] = (ilv[q] + hiv[q]) >> 1; lv[q] = ilv[q] < hiv[q] ? Lv[min(mv[q], l_last)] : 0ull; }   // (finished searches load nothing)
 #pragma unroll
           for (int q = 0; q < (int)PW_ITEMS; q++) {
             if (ilv[q] < hiv[q]) {
