@@ -524,7 +524,9 @@ __device__ void part_gallop(const CV& Sv, u64 ns, const CV& Lv, u64 nl, bool s_i
 #pragma unroll
         for (int q = 0; q < (int)PW_ITEMS; q++) {
           const u64 c = min(sv[q] >> ldir_shift, ldir_last);
-          const u32 e0 = ldir[c], e1 = ldir[c + 1];
+          struct E2 { u32 a, b; } e;                             // both ends of the cell in ONE 8-byte request
+          __builtin_memcpy(&e, ldir + c, sizeof(e));
+          const u32 e0 = e.a, e1 = e.b;
           ilv[q] = e0;
           hiv[q] = act[q] ? e1 : e0;
         }
