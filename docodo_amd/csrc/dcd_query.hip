@@ -257,16 +257,17 @@ __device__ void part_gallop(const CV& Sv, u64 ns, const CV& Lv, u64 nl, bool s_i
                             u64 i_begin, u64 i_end, u64* __restrict__ tmp_op, u32* rec_lds, u64& count_out, u64& slot_out,
                             const u32* __restrict__ ldir, u32 ldir_shift, u64 ldir_last) {
   const u32 lane = threadIdx.x;
-  // records of the elements that WALK their chain, by position in the walk list (an element without a neighbour within absR
-  // emits nothing and needs no record)
+  // records of the LISTED elements, by position in the list: the chains the dense passes resolved (finished records, only their
+  // emission is left) and the ones that have to walk (r_n = NONE32 until flush() has walked them); an element without a neighbour
+  // within absR emits nothing and needs no record
   u64* r_b = reinterpret_cast<u64*>(rec_lds);                 // [PW_TILE] first L index of the emitted part
   u32* r_d = rec_lds + 2 * PW_TILE;                           // [PW_TILE] number of L elements emitted from r_b
   u32* r_s0 = rec_lds + 3 * PW_TILE;                          // [PW_TILE] first S index emitted (relative to i_begin)
   u32* r_s1 = rec_lds + 4 * PW_TILE;                          // [PW_TILE] last S index emitted (inclusive, relative to i_begin)
   u32* r_n = rec_lds + 5 * PW_TILE;                           // [PW_TILE] emitted values (0 = not a leader / nothing)
   u16* g_list = reinterpret_cast<u16*>(rec_lds + 6 * PW_TILE);  // [PW_TILE] the walk list: element index relative to i_begin (< GAL_PER)
-  u16* c_k = g_list + PW_TILE;                                  // [PW_TILE] candidates of a round: element number in the round ...
-  u32* c_il = rec_lds + 6 * PW_TILE + PW_TILE / 2 + 160;         // [320] ... and position in the long list relative to the item's first  (c_k: [320])
+  u16* c_k = g_list + PW_TILE;                                  // [320] pending candidates (< 64 carried over + a round's 256): element index relative to i_begin ...
+  u32* c_il = rec_lds + 6 * PW_TILE + PW_TILE / 2 + 160;         // [320] ... and position in the long list relative to the item's first element's
   u64 cursor = 0, slot = 0;
   bool have_slot = false;
   u32 n_list = 0;                                             // (wave-uniform)
