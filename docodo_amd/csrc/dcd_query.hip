@@ -8,14 +8,18 @@
 //   * the posting lists are decoded once per index into absolute coordinates (HBM-resident u64,
 //     built lazily on the first query: an auxiliary structure, the .index image stays canonical);
 //   * a query is a postfix program; programs advance in rounds, one binary operator per query and
-//     round, all operators of a round in ONE launch of k_pair_parts: one WAVEFRONT per (operator,
-//     partition of 8192 union elements), see the comment above that kernel;
+//     round, all operators of a round (ordered by their longer index term, so that queries probing
+//     the same list run together) in ONE launch of k_pair_parts: a work item is one (operator,
+//     partition of 8192 union elements) or (operator, 1024 elements of the short operand when it
+//     gallops), a fixed grid of wavefronts takes items from a device counter, see that kernel;
 //   * a work item streams both operands through LDS rings in 256-element tiles: merge path -> union
 //     with source tags -> gap chains -> "contains both operands" (and the ordered-mode prefix rule)
 //     -> compaction.  A chain that is still open at a tile border is written optimistically and
 //     rolled back if it closes without the other operand (exact restatement of the group logic of
 //     IndexSequence.cs:218-284); skewed sparse pairs gallop from the
-//     short operand (GAL_RATIO = 2 measured best on MI355X);
+//     short operand (GAL_RATIO = 2 measured best on MI355X): cell directory -> position in the long
+//     list -> nearest neighbours; the few elements that have one within absR are compacted and their
+//     chains resolved in registers with full lanes, the rest of them walks (part_gallop);
 //   * k_result<false/true> walk the final sequence of each query (one workgroup per query):
 //     coordinate -> page by binary search over the page END table (IndexPageList.GetPage,
 //     Build.cs:74-97), page-relative positions, the 30000-page / 500-document caps, ranks.
