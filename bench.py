@@ -199,6 +199,7 @@ def run_query_leg(ix, queries, info, chunk, label, reps=1, warm=True):
     import docodo_amd
     T, A = docodo_amd.DCD_OP_TERM, docodo_amd.DCD_OP_AND
     tot_ms, nq, npost, nunits, n_pages, n_pos, per, wall_ms = 0.0, 0, 0, 0, 0, 0, [], 0.0
+    ops_named, ops_eval, un_named, un_eval = 0, 0, 0, 0
     progs = []
     for c0 in range(0, len(queries), chunk):
         prog, off = [], [0]
@@ -236,8 +237,13 @@ def run_query_leg(ix, queries, info, chunk, label, reps=1, warm=True):
         note("  %s: call %d: %d queries, %.1f ms device" % (label[:12], len(per) + 1, len(off) - 1, best["ms"]))
         n_pages += best["n_pages"]
         n_pos += best["n_pos"]
+        ops_named += best.get("ops_named", 0)
+        ops_eval += best.get("ops_evaluated", 0)
+        un_named += best.get("units_named", 0)
+        un_eval += best.get("units_evaluated", 0)
         per.append(round(best["ms"], 2))
     a_query = 2 * nunits + 4 * n_pos + 8 * n_pages
+    a_cse = a_query - 2 * (un_named - un_eval)        # every distinct operator's index-term operands once
     out = {"queries": nq, "postings_in": int(npost), "units_in": int(nunits), "positions_out": int(n_pos), "pages_out": int(n_pages),
            "device_ms": round(tot_ms, 3), "queries_per_s": round(nq / (tot_ms / 1e3), 0) if tot_ms else 0.0,
            # wall time of the dcd_query_batch calls themselves (host planning + device + the per-query counts coming back; the
@@ -246,7 +252,12 @@ def run_query_leg(ix, queries, info, chunk, label, reps=1, warm=True):
            "gpostings_per_s": round(npost / 1e9 / (tot_ms / 1e3), 2) if tot_ms else 0.0,
            "roofline": {"bound": "hbm", "algorithmic_bytes": int(a_query), "achieved": round(a_query / 1e9 / (tot_ms / 1e3), 1) if tot_ms else 0.0,
                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(a_query / 1e9 / (tot_ms / 1e3) / HBM_PEAK_GBS, 4) if tot_ms else 0.0,
-                        "bytes": "2 * units of every operand list + 4 * positions + 8 * pages (SURVEY 8d), exact counts"},
+                        "bytes": "2 * units of every operand list + 4 * positions + 8 * pages (SURVEY 8d), exact counts",
+                        # throughput, not kernel credit: an operator that several queries of the batch name is evaluated once
+                        "bytes_after_cse": int(a_cse),
+                        "frac_after_cse": round(a_cse / 1e9 / (tot_ms / 1e3) / HBM_PEAK_GBS, 4) if tot_ms else 0.0},
+           "common_subexpressions": {"operators_named": int(ops_named), "operators_evaluated": int(ops_eval),
+                                     "operand_units_named": int(un_named), "operand_units_evaluated": int(un_eval)},
            "calls": len(per), "call_ms": per[:6], "label": label}
     return out, progs
 
@@ -394,7 +405,7 @@ def main():
                     "per rank); 0 = skip those legs")
     ap.add_argument("--c4-queries", type=int, default=100_000, help="configs[3]: 3-term AND queries over the big index")
     ap.add_argument("--c5-queries", type=int, default=100_000, help="configs[4]: exact-phrase queries over the big index")
-    ap.add_argument("--query-chunk", type=int, default=10_000, help="queries per dcd_query_batch call in the configs[3] / [4] legs")
+    ap.add_argument("--query-chunk", type=int, default=0, help="queries per dcd_query_batch call in the configs[3] / [4] legs (0 = the whole leg in ONE call)")
     ap.add_argument("--inflight", type=int, default=2, help="extra (untimed for `value`) leg: this many builders at once, as the "
                     "reference's MaxDegreeOfParallelism index tasks (Index.cs:127, 464-465); 0/1 = skip")
     ap.add_argument("--pipeline", type=int, default=int(os.environ.get("DOCODO_BENCH_PIPELINE", "1")),
@@ -780,8 +791,9 @@ def big_index_legs(args, rank, world, device, dist, cdev):
     note("query sets ready")
     for name, label, qs, budget in legs:
         mine = qs[rank::world]                          # sharded by query id
-        # (a phrase of two head terms yields up to 30 001 pages with their positions: smaller calls bound the device-side result arrays)
-        res, progs = run_query_leg(ix, mine, info, args.query_chunk if name == "c4_and3" else max(1, args.query_chunk // 4), label)
+        # ONE dcd_query_batch call per leg (round 4): the library cuts it into chunks itself, plans chunk k + 1 on the host while
+        # chunk k runs, and shares the operators that several queries name
+        res, progs = run_query_leg(ix, mine, info, args.query_chunk if args.query_chunk > 0 else max(1, len(mine)), label)
         note("%s: %d queries, %.1f ms device" % (name, res["queries"], res["device_ms"]))
         if dist is not None:
             v = torch.tensor([res["queries"], res["postings_in"], res["units_in"], res["positions_out"], res["pages_out"]], dtype=torch.float64, device=cdev)

@@ -57,7 +57,8 @@ class ResultsView(C.Structure):
                 ("doc_index", C.POINTER(C.c_uint32)), ("doc_rank", C.POINTER(C.c_float)),
                 ("doc_n_pages", C.POINTER(C.c_uint32)), ("seq_off", C.POINTER(C.c_uint64)),
                 ("seq_units", C.POINTER(C.c_uint16)), ("seq_R", C.POINTER(C.c_int32)), ("ms_device", C.c_float),
-                ("n_pages_total", C.c_uint64), ("n_pos_total", C.c_uint64), ("n_docs_total", C.c_uint64)]
+                ("n_pages_total", C.c_uint64), ("n_pos_total", C.c_uint64), ("n_docs_total", C.c_uint64),
+                ("ops_named", C.c_uint64), ("ops_evaluated", C.c_uint64), ("units_named", C.c_uint64), ("units_evaluated", C.c_uint64)]
 
 
 # name -> (restype, argtypes); mirrors include/docodo_hip.h one to one
@@ -65,6 +66,7 @@ _vp, _sz, _i32, _u64, _u32 = C.c_void_p, C.c_size_t, C.c_int32, C.c_uint64, C.c_
 _pz, _pi32, _pu64, _pu32 = C.POINTER(C.c_size_t), C.POINTER(C.c_int32), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)
 SIGNATURES = {
     "dcd_version": (_i32, []),
+    "dcd_struct_size": (_u64, [_i32]),
     "dcd_last_error": (_i32, [C.c_char_p, _sz]),
     "dcd_device_count": (_i32, [_pi32]),
     "dcd_pool_trim": (_i32, [_i32]),
@@ -98,6 +100,7 @@ SIGNATURES = {
     "dcd_index_open": (_i32, [C.c_char_p, _i32, C.POINTER(_vp)]),
     "dcd_index_from_images": (_i32, [_vp, _sz, _vp, _sz, _i32, C.POINTER(_vp)]),
     "dcd_index_free": (None, [_vp]),
+    "dcd_index_trim": (_i32, [_vp]),
     "dcd_index_count": (_i32, [_vp, _pu64]),
     "dcd_index_max_coord": (_i32, [_vp, _pu64]),
     "dcd_index_n_units": (_i32, [_vp, _pu64]),

@@ -406,7 +406,17 @@ void event_release(int device, hipEvent_t e) {
 }  // namespace dcd
 
 extern "C" {
-int32_t dcd_version(void) { return 1; }
+int32_t dcd_version(void) { return DCD_ABI_VERSION; }
+uint64_t dcd_struct_size(int32_t which) {
+  switch (which) {
+    case 0: return sizeof(dcd_build_opts);
+    case 1: return sizeof(dcd_build_stats);
+    case 2: return sizeof(dcd_query_opts);
+    case 3: return sizeof(dcd_results_view);
+    case 4: return sizeof(dcd_term_meta);
+    default: return 0;
+  }
+}
 int32_t dcd_last_error(char* buf, size_t cap) {
   const std::string& e = dcd::last_error();
   if (buf && cap) {

@@ -28,7 +28,11 @@
 // result); equal values in both operands are merged as the reference does.
 #include <algorithm>
 #include <cmath>
+#include <cstdarg>
+#include <functional>
 #include <memory>
+#include <mutex>
+#include <thread>
 
 #include "dcd_codec.h"
 #include "dcd_index_int.h"
@@ -39,10 +43,10 @@ namespace dcd {
 constexpr u32 NONE32 = 0xFFFFFFFFu;
 
 struct Seg {       // a sequence of absolute coordinates somewhere on the device
-  u64 off;         // element offset into index values (kind 0) or the work pool (kind 1)
+  u64 off;         // kind 0: element offset into the index values (kind 1: unused -- the pool offset of a result is assigned on the device)
   u64 cnt_imm;     // count when cnt_ref == NONE32
-  u32 kind;
-  u32 cnt_ref;     // index into the device `counts` array (results of earlier operators)
+  u32 kind;        // 0 = posting list of an index term, 1 = result of an earlier operator (work pool)
+  u32 cnt_ref;     // kind 1: number of the operator result -- index into the device arrays `counts` and `res_off`
   u64 dir_off;     // cell directory of an index term (see dcd_index), valid when dir_shift != NONE32
   u32 dir_shift;
   u32 pad;
@@ -51,9 +55,19 @@ struct PairOp {
   Seg a, b;
   int32_t Ra, Rb;
   u32 op;          // DCD_OP_AND / DCD_OP_OR
-  u32 out_cnt_ref;
-  u64 out_off;     // into the work pool; capacity = cap(a) + cap(b)
-  u64 tmp_off;     // into the round's scratch arena (same capacity)
+  u32 out_cnt_ref; // number of this operator's result: counts[ref] values at pool + res_off[ref], both written on the device
+  u64 cap;         // host-side bound of the result length = cap(a) + cap(b) (sizes the scratch region)
+  u64 tmp_off;     // into the slice's scratch region (cap elements)
+};
+// The work pool as the kernels see it.  Round 4: results are placed by the DEVICE, back to back in the order the slices complete
+// (res_off[ref] = pool elements used so far + exclusive scan of the slice's result counts), so the pool holds what the operators
+// really produced instead of cap(a) + cap(b) per operator -- a phrase over two head terms has a capacity of 3.7e8 elements and a
+// result of a few 1e7 -- and a sub-batch is bounded by its results, not by its worst case.
+struct Pool {
+  const u64* base;      // pool elements
+  const u64* res_off;   // [n results] offset of result `ref`
+  const u64* counts;    // [n results] length of result `ref`
+  const u32* overflow;  // != 0: the pool ran full -- nothing behind that point may be read (every kernel leaves at once)
 };
 struct FinalSeq {
   Seg s;
@@ -75,14 +89,14 @@ struct CV {
   __device__ __forceinline__ u64 operator[](u64 i) const { return v ? v[i] : (((u64)hi[i] << 32) | lo[i]); }
   __device__ __forceinline__ CV operator+(u64 d) const { CV r; r.v = v ? v + d : nullptr; r.lo = lo ? lo + d : nullptr; r.hi = hi ? hi + d : nullptr; return r; }
 };
-__device__ __forceinline__ CV seg_cv(const Seg& s, const IdxVals& iv, const u64* pool) {
+__device__ __forceinline__ CV seg_cv(const Seg& s, const IdxVals& iv, const Pool& pl) {
   CV r;
-  if (s.kind != 0) { r.v = pool + s.off; r.lo = nullptr; r.hi = nullptr; }
+  if (s.kind != 0) { r.v = pl.base + pl.res_off[s.cnt_ref]; r.lo = nullptr; r.hi = nullptr; }
   else if (iv.v64) { r.v = iv.v64 + s.off; r.lo = nullptr; r.hi = nullptr; }
   else { r.v = nullptr; r.lo = iv.lo + s.off; r.hi = iv.hi + s.off; }
   return r;
 }
-__device__ __forceinline__ u64 seg_cnt(const Seg& s, const u64* counts) { return s.cnt_ref == NONE32 ? s.cnt_imm : counts[s.cnt_ref]; }
+__device__ __forceinline__ u64 seg_cnt(const Seg& s, const Pool& pl) { return s.kind == 0 ? s.cnt_imm : pl.counts[s.cnt_ref]; }
 
 // ------------------------------------------------------------------------------------------------
 // whole-index decode: values[i] = absolute coordinate of posting i (term-relative prefix sum)
@@ -631,13 +645,14 @@ __device__ void part_gallop(const CV& Sv, u64 ns, const CV& Lv, u64 nl, bool s_i
 constexpr u32 GAL_PER = DCD_GAL_PER;
 static_assert(DCD_GAL_PER <= 65536, "part_gallop's walk-list entries are 16-bit element indices");      // short-list elements per galloping work item (256 / 512 / 1024 / 2048 -> 26.5 / 24.3 / 23.8 / 23.8 ms per 20 k C4 queries)
 constexpr u8 MODE_NONE = 0, MODE_STREAM = 1, MODE_GALLOP = 2;
-__global__ void k_pair_plan(const PairOp* __restrict__ ops, u32 n_ops, IdxVals idx_values, const u64* __restrict__ pool,
-                            const u64* __restrict__ counts, u64 PART, u32* __restrict__ items, u8* __restrict__ mode, u32 gal_ratio) {
+__global__ void k_pair_plan(const PairOp* __restrict__ ops, u32 n_ops, IdxVals idx_values, Pool pool,
+                            u64 PART, u32* __restrict__ items, u8* __restrict__ mode, u32 gal_ratio) {
   u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i > n_ops) return;
   if (i == n_ops) { items[i] = 0; return; }
+  if (*pool.overflow) { items[i] = 0; mode[i] = MODE_NONE; return; }     // the pool ran full: the sub-batch is abandoned
   const PairOp op = ops[i];
-  const u64 na = seg_cnt(op.a, counts), nb = seg_cnt(op.b, counts);
+  const u64 na = seg_cnt(op.a, pool), nb = seg_cnt(op.b, pool);
   const bool is_or = op.op == DCD_OP_OR;
   const u32 absR = (u32)max(abs(op.Ra), abs(op.Rb));
   u8 m = MODE_STREAM;
@@ -647,15 +662,14 @@ __global__ void k_pair_plan(const PairOp* __restrict__ ops, u32 n_ops, IdxVals i
     const bool a_short = na <= nb;
     const u64 ns = a_short ? na : nb, nl = a_short ? nb : na;
     const CV Lv = seg_cv(a_short ? op.b : op.a, idx_values, pool);
-    if (ns * gal_ratio <= nl && (Lv[nl - 1] - Lv[0]) / nl > 4ull * absR) { m = MODE_GALLOP; n = (ns + GAL_PER - 1) / GAL_PER; }
+    if (ns * (u64)gal_ratio <= nl && (Lv[nl - 1] - Lv[0]) / nl > 4ull * absR) { m = MODE_GALLOP; n = (ns + GAL_PER - 1) / GAL_PER; }
   }
   items[i] = (u32)n;
   mode[i] = m;
 }
 
 __global__ __launch_bounds__(PW_T, DCD_PW_WAVES) void k_pair_parts(const PairOp* __restrict__ ops, u32 n_ops, const u64* __restrict__ part_base,
-                                                    IdxVals idx_values, const u64* __restrict__ pool,
-                                                    const u64* __restrict__ counts, u64* __restrict__ tmp, u64* __restrict__ part_count,
+                                                    IdxVals idx_values, Pool pool, u64* __restrict__ tmp, u64* __restrict__ part_count,
                                                     u64* __restrict__ part_src, u64 PART, const u32* __restrict__ dirs,
                                                     u64 dir_max_coord, const u8* __restrict__ op_mode, u64 W_cap, unsigned long long* __restrict__ work_ctr) {
   constexpr u32 RAW_WORDS = 6u * PW_TILE + PW_TILE / 2u + 160u + 320u + 16u;   // rings + chain flags, or the gallop records + walk list + candidate list
@@ -688,7 +702,7 @@ __global__ __launch_bounds__(PW_T, DCD_PW_WAVES) void k_pair_parts(const PairOp*
   const PairOp op = ops[oi];
   const CV A = seg_cv(op.a, idx_values, pool);
   const CV B = seg_cv(op.b, idx_values, pool);
-  const u64 na = seg_cnt(op.a, counts), nb = seg_cnt(op.b, counts);
+  const u64 na = seg_cnt(op.a, pool), nb = seg_cnt(op.b, pool);
   u64* tmp_op = tmp + op.tmp_off;
   const u32 absR = (u32)max(abs(op.Ra), abs(op.Rb));
   const bool ordered = op.Ra < 0 && op.Rb < 0 && absR != 0;   // R = -absR < 0  (IndexSequence.cs:221-222)
@@ -1050,7 +1064,9 @@ __global__ __launch_bounds__(PW_T, DCD_PW_WAVES) void k_pair_parts(const PairOp*
 // -- phrases over head terms -- that was ~100 dependent load -> store round trips per wavefront, 190 us for a 64 MB copy.)
 __global__ __launch_bounds__(256) void k_pair_gather(const PairOp* __restrict__ ops, u32 n_ops, const u64* __restrict__ part_base, u64 W,
                                                     const u64* __restrict__ part_count, const u64* __restrict__ part_src,
-                                                    const u64* __restrict__ excl, const u64* __restrict__ tmp, u64* __restrict__ pool) {
+                                                    const u64* __restrict__ excl, const u64* __restrict__ tmp, u64* __restrict__ pool,
+                                                    const u64* __restrict__ res_off, const u32* __restrict__ overflow) {
+  if (*overflow) return;                                   // (the slice's results do not fit the pool: nothing is copied, the host retries)
   const u32 lane = lane_id();
   const u64 gw = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = ((u64)gridDim.x * blockDim.x) >> 6;
   const u64 W_act = min(W, part_base[n_ops]);              // work items the device plan really used
@@ -1062,7 +1078,7 @@ __global__ __launch_bounds__(256) void k_pair_gather(const PairOp* __restrict__ 
     u32 lo = 0, hi = n_ops;                                  // operator of the item (the eight lanes read the same words)
     while (lo + 1 < hi) { u32 mid = (lo + hi) >> 1; if (part_base[mid] <= w) lo = mid; else hi = mid; }
     const u64* sp = tmp + ops[lo].tmp_off + part_src[w];
-    u64* dp = pool + ops[lo].out_off + (excl[w] - excl[part_base[lo]]);
+    u64* dp = pool + res_off[ops[lo].out_cnt_ref] + (excl[w] - excl[part_base[lo]]);
     u64 k = sub;
     for (; k + 24 < c; k += 32) {                            // four steps in flight
       const u64 v0 = sp[k], v1 = sp[k + 8], v2 = sp[k + 16], v3 = sp[k + 24];
@@ -1073,9 +1089,23 @@ __global__ __launch_bounds__(256) void k_pair_gather(const PairOp* __restrict__ 
 }
 
 __global__ void k_pair_totals(const PairOp* __restrict__ ops, u32 n_ops, const u64* __restrict__ part_base, const u64* __restrict__ excl,
-                              u64* __restrict__ counts) {
+                              u64* __restrict__ counts, u64* __restrict__ slice_cnt) {
   u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n_ops) counts[ops[i].out_cnt_ref] = excl[part_base[i + 1]] - excl[part_base[i]];
+  if (i < n_ops) { const u64 c = excl[part_base[i + 1]] - excl[part_base[i]]; counts[ops[i].out_cnt_ref] = c; slice_cnt[i] = c; }
+}
+// places the results of a slice in the pool: res_off[ref] = elements used before the slice + exclusive scan of the slice's counts.
+// `used` is a pair of words used alternately by consecutive slices (this launch reads used[seq & 1] and writes the other one: the
+// launches of a stream run one after the other, so no thread of this launch can read what another has written).
+__global__ void k_pair_assign(const PairOp* __restrict__ ops, u32 n_ops, const u64* __restrict__ slice_off, const u64* __restrict__ slice_total,
+                              u64* __restrict__ used, u32 seq, u64 pool_cap, u64* __restrict__ res_off, u32* __restrict__ overflow) {
+  u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  const u64 u0 = used[seq & 1u];
+  if (i < n_ops) res_off[ops[i].out_cnt_ref] = u0 + slice_off[i];
+  if (i == 0) {
+    const u64 u1 = u0 + *slice_total;
+    used[(seq + 1u) & 1u] = u1;
+    if (u1 > pool_cap) *overflow = 1u;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1119,8 +1149,7 @@ __device__ __forceinline__ u64 page_of(const ResParams& P, u64 c) {  // first pa
 // validity is a prefix property, so one scan (page starts) + one min-reduction (first coordinate past
 // the cap) + one scan (document starts among the valid ones) per iteration is enough.
 template <bool FILL>
-__global__ __launch_bounds__(RS_T) void k_result(const FinalSeq* __restrict__ fin, u32 nq, IdxVals idx_values,
-                                                const u64* __restrict__ pool, const u64* __restrict__ counts, ResParams P,
+__global__ __launch_bounds__(RS_T) void k_result(const FinalSeq* __restrict__ fin, u32 nq, IdxVals idx_values, Pool pool, ResParams P,
                                                 QCounts* __restrict__ qc, const u64* __restrict__ page_base, const u64* __restrict__ pos_base,
                                                 const u64* __restrict__ doc_base, u32* __restrict__ o_page_index, u64* __restrict__ o_pos_off,
                                                 int32_t* __restrict__ o_pos, u32* __restrict__ o_doc_index, u32* __restrict__ o_doc_first_page) {
@@ -1133,8 +1162,12 @@ __global__ __launch_bounds__(RS_T) void k_result(const FinalSeq* __restrict__ fi
   const u32 q = blockIdx.x, tid = threadIdx.x;
   if (q >= nq) return;
   const Seg sg = fin[q].s;
+  if (*pool.overflow) {                                    // abandoned sub-batch: no result is read
+    if (!FILL && tid == 0) { QCounts r; r.status = DCD_E_NOMEM; r.n_pages = 0; r.n_pos = 0; r.n_docs = 0; r.pad = 0; qc[q] = r; }
+    return;
+  }
   const CV V = seg_cv(sg, idx_values, pool);
-  const u64 n = seg_cnt(sg, counts);
+  const u64 n = seg_cnt(sg, pool);
   if (FILL && qc[q].status != DCD_OK) return;   // the count pass found a coordinate beyond the last page: no output
   if (tid == 0) { c_prev_page = ~0ull; c_pages = 0; c_docs = 0; c_err = 0; c_done = 0; c_pos = 0; }
   __syncthreads();
@@ -1339,6 +1372,7 @@ struct dcd_results {
   bool have_seq = false;
   bool downloaded = true;        // false: dcd_query_opts.no_download -- only status / page_off / doc_off and the totals are here
   u64 n_pages_total = 0, n_pos_total = 0, n_docs_total = 0;
+  u64 ops_named = 0, ops_evaluated = 0, units_named = 0, units_evaluated = 0;   // common sub-expressions, see SubBatch
 };
 
 static int32_t ensure_values(dcd_index* h) {
@@ -1414,12 +1448,224 @@ static int32_t ensure_values(dcd_index* h) {
   return DCD_OK;
 }
 
-// page metadata on the device (doc of page, header flag), built on demand
+// ================================================================================================
+// planning (host only, no HIP call: a chunk is planned on a helper thread while the previous one runs on the device)
+// ================================================================================================
+// Symbolic value on a query's evaluation stack.
+struct SymVal { Seg s; int32_t R; u64 cap; u32 round; u64 key; };
+
+// Round 4: cross-query COMMON SUB-EXPRESSIONS.  Two operators with the same operands, the same R on both sides and the same
+// opcode compute the same sequence (IndexSequence.cs:218-322 is a pure function of those), so a sub-batch evaluates every distinct
+// operator ONCE and every query that contains it refers to the one result.  Under a Zipf query load this is most of the work: 100 k
+// phrases sampled from corpus positions name the pair of the two most frequent terms 1 800 times (p1 * p1 * 100 k), each
+// evaluation a streaming merge of 3.7e8 postings.  Key of an operand: the term ordinal, or the number of the operator result.
+struct CseTable {
+  struct Ent { u64 ka, kb; int32_t Ra, Rb; u32 op, ref; };
+  std::vector<Ent> t;
+  u64 mask = 0;
+  void init(u64 n_ops) {
+    u64 c = 64;
+    while (c < 2 * n_ops + 16) c <<= 1;
+    t.assign(c, Ent{0, 0, 0, 0, 0, NONE32});
+    mask = c - 1;
+  }
+  static u64 mix(u64 x) { x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33; return x; }
+  // the entry of the key; ref == NONE32: new (the caller sets ref)
+  Ent& slot(u64 ka, u64 kb, int32_t Ra, int32_t Rb, u32 op) {
+    const u64 h = mix(mix(ka) + 0x9E3779B97F4A7C15ULL * mix(kb ^ 0x632BE59BD9B4E019ULL) + ((((u64)(u32)Ra) << 32) | (u32)Rb) * 0xD1B54A32D192ED03ULL + op);
+    for (u64 i = h & mask;; i = (i + 1) & mask) {
+      Ent& e = t[i];
+      if (e.ref == NONE32) { e.ka = ka; e.kb = kb; e.Ra = Ra; e.Rb = Rb; e.op = op; return e; }
+      if (e.ka == ka && e.kb == kb && e.Ra == Ra && e.Rb == Rb && e.op == op) return e;
+    }
+  }
+};
+
+// State of a SUB-BATCH: the scope of the work pool and of the common sub-expressions.  Its queries are planned and run in CHUNKS
+// (a chunk's plan is made while the previous chunk runs); operator results stay in the pool until the sub-batch ends, so a later
+// chunk refers to the results of an earlier one.
+struct SubBatch {
+  CseTable cse;
+  bool use_cse = true;
+  std::vector<u64> ref_cap;      // [n_refs] bound of the result length
+  std::vector<u32> ref_chunk;    // [n_refs] chunk that evaluates it
+  std::vector<u32> ref_round;    // [n_refs] round inside that chunk
+  u32 n_refs = 0;
+  // statistics: operators named by the programs / of those found in the table; ushort units of their index-term operands
+  // as named (every query's operands: the SURVEY 8(d) bytes) and as evaluated (every distinct operator once)
+  u64 ops_total = 0, ops_shared = 0, units_named = 0, units_evaluated = 0;
+};
+
+// A SLICE = consecutive operators of one round whose scratch regions (cap elements each) fit the scratch arena together.
+struct SliceInfo { u32 first, n; u64 W, tmp_elems; };
+struct ChunkPlan {
+  size_t q0 = 0, q1 = 0;
+  u32 chunk = 0;
+  PairOp* ops = nullptr;         // pinned staging owned by the executor: [ops_cap]
+  FinalSeq* finals = nullptr;    // pinned staging: [q1 - q0]
+  size_t ops_cap = 0, n_ops = 0;
+  std::vector<int32_t> finalR;
+  std::vector<SliceInfo> slices;
+  u64 max_W = 0;
+  u32 max_slice_ops = 0;
+  int32_t status = DCD_OK;
+  std::string err;
+};
+
+static void plan_fail(ChunkPlan& P, int32_t code, const char* fmt, ...) {
+  char buf[256];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  P.status = code;
+  P.err = buf;
+}
+
+// queries [P.q0, P.q1) -> the operators that are new to the sub-batch (in execution order, cut into slices) + the final sequences
+static void plan_chunk(const dcd_index* h, const std::vector<SymVal>* ext_leaves, SubBatch& sb, const int32_t* prog, const u64* prog_off,
+                       u64 PART, u64 slice_elems, ChunkPlan& P) {
+  const DeviceIndex& ix = h->ix;
+  struct Ord { u32 round; u32 idx; u64 key; };
+  std::vector<PairOp> ops;
+  std::vector<Ord> ord;
+  std::vector<SymVal> stk;
+  P.finalR.assign(P.q1 - P.q0, 0);
+  P.slices.clear();
+  P.n_ops = 0; P.max_W = 0; P.max_slice_ops = 0;
+  const bool have_dir = !h->h_dir_off.empty();
+  for (size_t q = P.q0; q < P.q1; q++) {
+    stk.clear();
+    for (u64 i = prog_off[q]; i < prog_off[q + 1];) {
+      const int32_t opc = prog[i];
+      if (opc == DCD_OP_TERM) {
+        if (i + 3 > prog_off[q + 1]) return plan_fail(P, DCD_E_BADARG, "query %zu: truncated TERM", q);
+        const int64_t t = prog[i + 1];
+        SymVal v;
+        if (ext_leaves) {
+          if (t < 0 || (size_t)t >= ext_leaves->size()) return plan_fail(P, DCD_E_BADARG, "query %zu: leaf %lld out of range", q, (long long)t);
+          v = (*ext_leaves)[(size_t)t];
+        } else {
+          if (t < 0 || (u64)t >= ix.n_terms) return plan_fail(P, DCD_E_BADARG, "query %zu: term %lld out of range", q, (long long)t);
+          v.s.kind = 0; v.s.off = ix.h_term_item_start[t]; v.s.cnt_ref = NONE32;
+          v.s.dir_off = have_dir ? h->h_dir_off[t] : 0;
+          v.s.dir_shift = (!have_dir || h->h_dir_shift[t] == 255) ? NONE32 : (u32)h->h_dir_shift[t];
+          v.s.pad = 0;
+          v.s.cnt_imm = ix.h_term_item_start[t + 1] - ix.h_term_item_start[t];
+          v.cap = v.s.cnt_imm;
+        }
+        v.round = 0;
+        v.key = (u64)t;
+        v.R = prog[i + 2];
+        stk.push_back(v);
+        i += 3;
+      } else if (opc == DCD_OP_AND || opc == DCD_OP_OR) {
+        if (stk.size() < 2) return plan_fail(P, DCD_E_BADARG, "query %zu: operator without two operands", q);
+        const SymVal b = stk.back(); stk.pop_back();
+        const SymVal a = stk.back(); stk.pop_back();
+        sb.ops_total++;
+        u64 op_units = 0;
+        if (a.s.kind == 0) op_units += ext_leaves ? a.cap : ix.h_term_unit_start[a.key + 1] - ix.h_term_unit_start[a.key];
+        if (b.s.kind == 0) op_units += ext_leaves ? b.cap : ix.h_term_unit_start[b.key + 1] - ix.h_term_unit_start[b.key];
+        sb.units_named += op_units;
+        CseTable::Ent* e = sb.use_cse ? &sb.cse.slot(a.key, b.key, a.R, b.R, (u32)opc) : nullptr;
+        SymVal r;
+        u32 ref;
+        if (e && e->ref != NONE32) {                       // evaluated already (this chunk or an earlier one of the sub-batch)
+          ref = e->ref;
+          r.round = sb.ref_chunk[ref] == P.chunk ? sb.ref_round[ref] : 0u;
+          sb.ops_shared++;
+        } else {
+          ref = sb.n_refs++;
+          if (e) e->ref = ref;
+          sb.units_evaluated += op_units;
+          r.round = std::max(a.round, b.round) + 1;
+          sb.ref_cap.push_back(a.cap + b.cap);
+          sb.ref_chunk.push_back(P.chunk);
+          sb.ref_round.push_back(r.round);
+          PairOp p;
+          p.a = a.s; p.b = b.s; p.Ra = a.R; p.Rb = b.R; p.op = (u32)opc;
+          p.out_cnt_ref = ref; p.cap = a.cap + b.cap; p.tmp_off = 0;
+          // operators of a round run in the order of their LONGER index-term operand, so that the queries of a batch that probe the
+          // same posting list (the head terms of a Zipf query load) do so at about the same time and share its cache lines
+          const bool ta = a.s.kind == 0, tb = b.s.kind == 0;
+          u64 key;
+          if (ta && tb) key = a.s.cnt_imm >= b.s.cnt_imm ? a.s.off : b.s.off;
+          else key = ta ? a.s.off : (tb ? b.s.off : ~0ull);
+          ord.push_back(Ord{r.round, (u32)ops.size(), key});
+          ops.push_back(p);
+        }
+        r.cap = sb.ref_cap[ref];
+        r.s.kind = 1; r.s.off = 0; r.s.cnt_ref = ref; r.s.cnt_imm = 0;
+        r.s.dir_off = 0; r.s.dir_shift = NONE32; r.s.pad = 0;
+        const int absR = std::max(std::abs(a.R), std::abs(b.R));
+        r.R = (a.R < 0 && b.R < 0) ? -absR : absR;                       // IndexSequence.cs:221-222, 288-289
+        r.key = (1ull << 63) | ref;
+        stk.push_back(r);
+        i += 1;
+      } else if (opc == DCD_OP_SETR) {
+        if (i + 2 > prog_off[q + 1] || stk.empty()) return plan_fail(P, DCD_E_BADARG, "query %zu: bad SETR", q);
+        stk.back().R = prog[i + 1];
+        i += 2;
+      } else {
+        return plan_fail(P, DCD_E_BADARG, "query %zu: unknown opcode %d", q, opc);
+      }
+    }
+    if (stk.size() != 1) return plan_fail(P, DCD_E_BADARG, "query %zu: program leaves %zu values on the stack", q, stk.size());
+    P.finals[q - P.q0].s = stk[0].s;
+    P.finalR[q - P.q0] = stk[0].R;
+  }
+  if (ops.size() > P.ops_cap) return plan_fail(P, DCD_E_BADARG, "query plan: %zu operators, %zu expected", ops.size(), P.ops_cap);
+  static const bool sort_ops = !(getenv("DOCODO_QUERY_SORT_OPS") && atoi(getenv("DOCODO_QUERY_SORT_OPS")) == 0);
+  if (sort_ops) std::sort(ord.begin(), ord.end(), [](const Ord& x, const Ord& y) {
+    return x.round != y.round ? x.round < y.round : (x.key != y.key ? x.key < y.key : x.idx < y.idx); });
+  else std::stable_sort(ord.begin(), ord.end(), [](const Ord& x, const Ord& y) { return x.round < y.round; });
+  // slices: work items of an operator = ceil(cap / PART) partitions of the union, or ceil(|short| / GAL_PER) when it gallops
+  // (upper bound of the device's plan); scratch region = cap elements
+  SliceInfo cur{0, 0, 0, 0};
+  u32 cur_round = 0;
+  auto close = [&]() {
+    if (!cur.n) return;
+    P.slices.push_back(cur);
+    P.max_W = std::max(P.max_W, cur.W);
+    P.max_slice_ops = std::max(P.max_slice_ops, cur.n);
+  };
+  for (size_t k = 0; k < ord.size(); k++) {
+    PairOp p = ops[ord[k].idx];
+    if (cur.n && (ord[k].round != cur_round || cur.tmp_elems + p.cap > slice_elems)) { close(); cur = SliceInfo{(u32)k, 0, 0, 0}; }
+    if (!cur.n) { cur.first = (u32)k; cur_round = ord[k].round; }
+    const u64 ca = p.a.kind == 0 ? p.a.cnt_imm : sb.ref_cap[p.a.cnt_ref];
+    const u64 cb = p.b.kind == 0 ? p.b.cnt_imm : sb.ref_cap[p.b.cnt_ref];
+    p.tmp_off = cur.tmp_elems;
+    cur.tmp_elems += p.cap;
+    cur.W += std::max<u64>(std::max<u64>(1, div_up(ca + cb, PART)), div_up(std::min(ca, cb), GAL_PER));
+    cur.n++;
+    P.ops[k] = p;
+    if (cur.W >= (1ull << 31)) return plan_fail(P, DCD_E_OVERFLOW, "query batch too large: %llu work items in one slice", (unsigned long long)cur.W);
+  }
+  close();
+  P.n_ops = ord.size();
+}
+
+// ================================================================================================
+// execution of a planned chunk
+// ================================================================================================
+// Device state of a sub-batch: the pool's bump pointer, the result directory, the page metadata.
 struct PageDev {
   DevBuf<u32> page_doc;
   DevBuf<u8> page_hdr;
   DevBuf<u8> doc_match;
-  DevBuf<u64> page_end;  // only when the index did not bring one (loaded from images)
+};
+struct SubBatchDev {
+  DevBuf<u64> counts, res_off;     // [ops of the sub-batch]
+  DevBuf<u64> used;                // [2] pool elements in use (alternating, see k_pair_assign) + [1] scratch
+  DevBuf<u32> overflow;            // [1]
+  u64* pool = nullptr;             // pool_cap elements
+  u64* tmp = nullptr;              // scratch_cap elements
+  u64 pool_cap = 0, scratch_cap = 0;
+  u32 seq = 0;                     // slices executed so far
+  PageDev pd;
+  ResParams P;
 };
 
 static int32_t make_res_params(dcd_index* h, const dcd_query_opts& o, PageDev& pd, ResParams* P) {
@@ -1467,239 +1713,113 @@ static int32_t make_res_params(dcd_index* h, const dcd_query_opts& o, PageDev& p
   return DCD_OK;
 }
 
-// Symbolic evaluation of one query's program: emits PairOps (grouped into rounds) and the final Seg.
-struct SymVal { Seg s; int32_t R; u64 cap; int round; };
+// wavefronts of k_pair_parts: a few per wavefront slot of the device (CUs x 4 SIMDs x DCD_PW_WAVES), so that the hardware still
+// balances the tail (per device: a process may drive several)
+static u64 pw_grid_of(int dev) {
+  static const u64 env = [] { const char* e = getenv("DOCODO_QUERY_PW_GRID"); return (e && atoll(e) > 0) ? (u64)atoll(e) : 0ull; }();
+  if (env) return env;
+  static std::mutex mu;
+  static std::vector<u64> per_dev;
+  std::lock_guard<std::mutex> g(mu);
+  if ((size_t)dev >= per_dev.size()) per_dev.resize(dev + 1, 0);
+  if (!per_dev[dev]) {
+    hipDeviceProp_t pr;
+    const int cus = hipGetDeviceProperties(&pr, dev) == hipSuccess ? pr.multiProcessorCount : 256;
+    per_dev[dev] = (u64)cus * 4u * DCD_PW_WAVES * 4u;
+  }
+  return per_dev[dev];
+}
 
-static int32_t run_batch(dcd_index* h, const int32_t* prog, const u64* prog_off, size_t nq, const dcd_query_opts& o, dcd_results* R,
-                         const u64* ext_values, const std::vector<SymVal>* ext_leaves) {
+struct PinnedBlock {     // pinned staging returned to the cache when the scope ends
+  void* p = nullptr;
+  PinnedBlock() {}
+  PinnedBlock(const PinnedBlock&) = delete;
+  PinnedBlock& operator=(const PinnedBlock&) = delete;
+  ~PinnedBlock() { if (p) pinned_stage_release(p); }
+  int32_t get(size_t bytes) {
+    if (p) pinned_stage_release(p);
+    p = pinned_stage_acquire(bytes ? bytes : 1);
+    return p ? DCD_OK : DCD_E_NOMEM;
+  }
+};
+
+static int32_t exec_chunk(dcd_index* h, const dcd_query_opts& o, SubBatchDev& D, const ChunkPlan& C, u64 PART,
+                          dcd_results* R, const u64* ext_values, u32 n_refs_after) {
   DeviceIndex& ix = h->ix;
   const int dev = ix.device;
   hipStream_t st = h->st;
-  StreamScope ss_(st);
-  DCD_TRY(ensure_device(dev));
-  if (!ext_values) DCD_TRY(ensure_values(h));
+  const size_t nq = C.q1 - C.q0;
   IdxVals idx_values;
   idx_values.v64 = ext_values ? ext_values : (h->values_packed ? nullptr : h->values.p);
   idx_values.lo = (!ext_values && h->values_packed) ? h->val_lo.p : nullptr;
   idx_values.hi = (!ext_values && h->values_packed) ? h->val_hi.p : nullptr;
+  const Pool pool{D.pool, D.res_off.p, D.counts.p, D.overflow.p};
 
-  // ---- plan --------------------------------------------------------------------------------------
-  std::vector<std::vector<PairOp>> rounds;
-  std::vector<FinalSeq> finals(nq);
-  std::vector<int32_t> finalR(nq, 0);
-  std::vector<u64> final_cap(nq, 0);
-  u64 pool_elems = 0;
-  u32 n_counts = 0;
-  std::vector<u64> op_cap;          // capacity of every operator result, by count reference
-  for (size_t q = 0; q < nq; q++) {
-    std::vector<SymVal> stk;
-    for (u64 i = prog_off[q]; i < prog_off[q + 1];) {
-      int32_t opc = prog[i];
-      if (opc == DCD_OP_TERM) {
-        if (i + 3 > prog_off[q + 1]) DCD_FAIL(DCD_E_BADARG, "query %zu: truncated TERM", q);
-        int64_t t = prog[i + 1];
-        SymVal v;
-        if (ext_leaves) {
-          if (t < 0 || (size_t)t >= ext_leaves->size()) DCD_FAIL(DCD_E_BADARG, "query %zu: leaf %lld out of range", q, (long long)t);
-          v = (*ext_leaves)[(size_t)t];
-        } else {
-          if (t < 0 || (u64)t >= ix.n_terms) DCD_FAIL(DCD_E_BADARG, "query %zu: term %lld out of range", q, (long long)t);
-          v.s.kind = 0; v.s.off = ix.h_term_item_start[t]; v.s.cnt_ref = NONE32;
-          v.s.dir_off = h->h_dir_off.empty() ? 0 : h->h_dir_off[t];
-          v.s.dir_shift = (h->h_dir_shift.empty() || h->h_dir_shift[t] == 255) ? NONE32 : (u32)h->h_dir_shift[t];
-          v.s.pad = 0;
-          v.s.cnt_imm = ix.h_term_item_start[t + 1] - ix.h_term_item_start[t];
-          v.cap = v.s.cnt_imm; v.round = 0;
-        }
-        v.R = prog[i + 2];
-        stk.push_back(v);
-        i += 3;
-      } else if (opc == DCD_OP_AND || opc == DCD_OP_OR) {
-        if (stk.size() < 2) DCD_FAIL(DCD_E_BADARG, "query %zu: operator without two operands", q);
-        SymVal b = stk.back(); stk.pop_back();
-        SymVal a = stk.back(); stk.pop_back();
-        PairOp p;
-        p.a = a.s; p.b = b.s; p.Ra = a.R; p.Rb = b.R; p.op = (u32)opc;
-        p.out_off = pool_elems; p.out_cnt_ref = n_counts++;
-        p.tmp_off = 0;                                                   // assigned per round below
-        SymVal r;
-        r.cap = a.cap + b.cap;
-        op_cap.push_back(r.cap);
-        pool_elems += r.cap;
-        r.s.kind = 1; r.s.off = p.out_off; r.s.cnt_ref = p.out_cnt_ref; r.s.cnt_imm = 0;
-        r.s.dir_off = 0; r.s.dir_shift = NONE32; r.s.pad = 0;
-        int absR = std::max(std::abs(a.R), std::abs(b.R));
-        r.R = (a.R < 0 && b.R < 0) ? -absR : absR;                       // IndexSequence.cs:221-222, 288-289
-        r.round = std::max(a.round, b.round) + 1;
-        if ((int)rounds.size() < r.round) rounds.resize(r.round);
-        rounds[r.round - 1].push_back(p);
-        stk.push_back(r);
-        i += 1;
-      } else if (opc == DCD_OP_SETR) {
-        if (i + 2 > prog_off[q + 1] || stk.empty()) DCD_FAIL(DCD_E_BADARG, "query %zu: bad SETR", q);
-        stk.back().R = prog[i + 1];
-        i += 2;
-      } else {
-        DCD_FAIL(DCD_E_BADARG, "query %zu: unknown opcode %d", q, opc);
-      }
-    }
-    if (stk.size() != 1) DCD_FAIL(DCD_E_BADARG, "query %zu: program leaves %zu values on the stack", q, stk.size());
-    finals[q].s = stk[0].s;
-    finalR[q] = stk[0].R;
-    final_cap[q] = stk[0].cap;
-  }
-  if (o.max_found_docs > 512 || o.max_found_docs < 0 || o.max_found_pages < 0) DCD_FAIL(DCD_E_BADARG, "max_found_docs must be in [0, 512]");
-
-  // work items of every round: operator i owns part_base[i+1] - part_base[i] partitions of PART union elements
-  // (sized for the operands' capacities; the device knows the real counts) and a scratch region of the
-  // same capacity as its result
-  // Round 3: the operators of a round run in the order of their LONGER index-term operand, so that the queries of a batch that
-  // probe the same posting list (the head terms of a Zipf query load) do so at about the same time and share its cache lines:
-  // galloping over configs[3] fetched 42 GB per 20 k queries, several times the whole index, at a 51 % L2 hit rate.  (Results,
-  // scratch regions and work items are addressed through the operator, so the order is free.)
-  static const bool sort_ops = !(getenv("DOCODO_QUERY_SORT_OPS") && atoi(getenv("DOCODO_QUERY_SORT_OPS")) == 0);
-  if (sort_ops) {
-    auto key = [](const PairOp& p) -> u64 {
-      const bool ta = p.a.kind == 0 && p.a.cnt_ref == NONE32, tb = p.b.kind == 0 && p.b.cnt_ref == NONE32;
-      if (ta && tb) return p.a.cnt_imm >= p.b.cnt_imm ? p.a.off : p.b.off;
-      return ta ? p.a.off : (tb ? p.b.off : ~0ull);
-    };
-    std::vector<std::pair<u64, u32>> ord;
-    std::vector<PairOp> sorted_ops;
-    for (auto& rd : rounds) {                                  // (keys + indices are sorted, not the 100-byte operators)
-      ord.resize(rd.size());
-      for (size_t k = 0; k < rd.size(); k++) ord[k] = {key(rd[k]), (u32)k};
-      std::sort(ord.begin(), ord.end());
-      sorted_ops.resize(rd.size());
-      for (size_t k = 0; k < rd.size(); k++) sorted_ops[k] = rd[ord[k].second];
-      rd.swap(sorted_ops);
-    }
-  }
-  u64 PART = PART_DEFAULT;
-  if (const char* e = getenv("DOCODO_QUERY_PART")) PART = std::max<u64>(strtoull(e, nullptr, 10), 1);   // tests: tiny partitions
-  std::vector<std::vector<u64>> part_base(rounds.size());
-  u64 tmp_elems = 0, max_items = 0;
-  for (size_t r = 0; r < rounds.size(); r++) {
-    u64 t = 0, wsum = 0;
-    part_base[r].resize(rounds[r].size() + 1);
-    for (size_t k = 0; k < rounds[r].size(); k++) {
-      PairOp& p = rounds[r][k];
-      p.tmp_off = t;
-      part_base[r][k] = wsum;
-      u64 ca = p.a.cnt_ref == NONE32 ? p.a.cnt_imm : op_cap[p.a.cnt_ref];
-      u64 cb = p.b.cnt_ref == NONE32 ? p.b.cnt_imm : op_cap[p.b.cnt_ref];
-      t += ca + cb;
-      wsum += std::max<u64>(std::max<u64>(1, div_up(ca + cb, PART)), div_up(std::min(ca, cb), GAL_PER));   // upper bound of the device's plan
-    }
-    part_base[r][rounds[r].size()] = wsum;
-    tmp_elems = std::max(tmp_elems, t);
-    max_items = std::max(max_items, wsum);
-  }
-  if (max_items >= (1ull << 31)) DCD_FAIL(DCD_E_OVERFLOW, "query batch too large: %llu work items in one round", (unsigned long long)max_items);
-
-  // ---- device buffers -------------------------------------------------------------------------------
-  // The work pool and the scratch arena are the two big buffers of a batch (tens of gigabytes for a sub-batch of phrase
-  // queries over head terms).  They belong to the INDEX HANDLE and only ever grow: allocating them per call meant a hipMalloc /
-  // hipFree of up to 100 GB each per sub-batch -- round 3 measured 87 s of wall time around 0.76 s of device time for 2 500
-  // phrase queries on the 10 M-doc index -- and blocks of that size do not survive in the library's device cache (its cap is
-  // half of the device memory).  dcd_query_batch bounds a sub-batch by DOCODO_QUERY_ARENA_BYTES (default: half of the device
-  // memory), so the arena settles at that size after the first large batch.
-  DevBuf<u64> counts, d_part_count, d_part_src, d_part_excl, d_part_scr;
-  struct ArenaView { u64* p; } pool{nullptr}, tmp{nullptr};
-  {
-    // ONE arena for both (pool first, scratch behind it).  It grows in big steps -- twice what is needed, and straight to the
-    // sub-batch bound once a batch needs more than an eighth of it -- because every growth is a hipMalloc + hipFree of tens of
-    // gigabytes (2.8-4 s each on MI355X): with exact sizes ten C4 calls of 10 k queries grew it three times.
-    const u64 want = (pool_elems ? pool_elems : 1) + (tmp_elems ? tmp_elems : 1);
-    if (want > h->work_pool_elems || !h->work_pool.p) {
-      size_t fb = 0, tb = 0;
-      DCD_HIP(hipMemGetInfo(&fb, &tb));
-      static const u64 env_arena = getenv("DOCODO_QUERY_ARENA_BYTES") ? strtoull(getenv("DOCODO_QUERY_ARENA_BYTES"), nullptr, 10) : 0;
-      const u64 bound = (env_arena ? env_arena : (u64)tb / 2) / 8;
-      u64 size = want > bound / 8 ? std::max(want, bound) : 2 * want;
-      h->work_pool.reset();
-      h->work_pool_elems = 0;
-      if (h->work_pool.alloc(dev, size) != DCD_OK) {          // (not that much memory left: exactly what this batch needs)
-        size = want;
-        DCD_TRY(h->work_pool.alloc(dev, size));
-      }
-      h->work_pool_elems = size;
-    }
-    pool.p = h->work_pool.p;
-    tmp.p = h->work_pool.p + (pool_elems ? pool_elems : 1);
-  }
-  DCD_TRY(counts.alloc(dev, n_counts ? n_counts : 1));
-  {
-    DCD_TRY(d_part_count.alloc(dev, max_items + 1));
-    DCD_TRY(d_part_src.alloc(dev, max_items + 1));
-    DCD_TRY(d_part_excl.alloc(dev, max_items + 1));
-    DCD_TRY(d_part_scr.alloc(dev, scan_scratch_elems(max_items + 1)));
-  }
-  StagedUploads up;               // (plans travel through pinned staging: see pinned_stage_acquire)
-  std::vector<DevBuf<PairOp>> d_rounds(rounds.size());
-  std::vector<DevBuf<u64>> d_part_base(rounds.size());
+  // ---- device buffers of the chunk (from the library's device cache) --------------------------------
+  DevBuf<PairOp> d_ops;
+  DevBuf<u64> d_part_base, d_part_count, d_part_src, d_part_excl, d_part_scr, d_slice_cnt, d_slice_off, d_slice_scr, d_work_ctr;
   DevBuf<u32> d_items;
   DevBuf<u8> d_mode;
-  {
-    size_t mx = 1;
-    for (auto& rr : rounds) mx = std::max(mx, rr.size());
-    DCD_TRY(d_items.alloc(dev, mx + 1));
-    DCD_TRY(d_mode.alloc(dev, mx + 1));
-  }
-  for (size_t r = 0; r < rounds.size(); r++) {
-    DCD_TRY(d_rounds[r].alloc(dev, rounds[r].size()));
-    DCD_TRY(up.copy(d_rounds[r].p, rounds[r].data(), rounds[r].size() * sizeof(PairOp), st));
-    DCD_TRY(d_part_base[r].alloc(dev, part_base[r].size()));
-  }
+  DCD_TRY(d_ops.alloc(dev, C.n_ops ? C.n_ops : 1));
+  DCD_TRY(d_items.alloc(dev, (size_t)C.max_slice_ops + 1));
+  DCD_TRY(d_mode.alloc(dev, (size_t)C.max_slice_ops + 1));
+  DCD_TRY(d_part_base.alloc(dev, (size_t)C.max_slice_ops + 1));
+  DCD_TRY(d_slice_cnt.alloc(dev, (size_t)C.max_slice_ops + 1));
+  DCD_TRY(d_slice_off.alloc(dev, (size_t)C.max_slice_ops + 1));
+  DCD_TRY(d_slice_scr.alloc(dev, scan_scratch_elems((u64)C.max_slice_ops + 1)));
+  DCD_TRY(d_part_count.alloc(dev, C.max_W + 1));
+  DCD_TRY(d_part_src.alloc(dev, C.max_W + 1));
+  DCD_TRY(d_part_excl.alloc(dev, C.max_W + 1));
+  DCD_TRY(d_part_scr.alloc(dev, scan_scratch_elems(C.max_W + 1)));
+  DCD_TRY(d_work_ctr.alloc(dev, std::max<size_t>(1, C.slices.size())));
   DevBuf<FinalSeq> d_fin;
   DCD_TRY(d_fin.alloc(dev, nq ? nq : 1));
-  if (nq) DCD_TRY(up.copy(d_fin.p, finals.data(), nq * sizeof(FinalSeq), st));
-  PageDev pd;
-  ResParams P;
-  DCD_TRY(make_res_params(h, o, pd, &P));
   DevBuf<QCounts> d_qc;
   DevBuf<u64> d_pbase, d_sbase, d_dbase, sscr;
   DCD_TRY(d_qc.alloc(dev, nq ? nq : 1));
   DCD_TRY(d_pbase.alloc(dev, nq + 1)); DCD_TRY(d_sbase.alloc(dev, nq + 1)); DCD_TRY(d_dbase.alloc(dev, nq + 1));
   DCD_TRY(sscr.alloc(dev, 3 * scan_scratch_elems(nq ? nq : 1)));
-  DCD_HIP(hipStreamSynchronize(st));
+  // the plan was written into pinned staging by the planner: two asynchronous uploads
+  if (C.n_ops) DCD_HIP(hipMemcpyAsync(d_ops.p, C.ops, C.n_ops * sizeof(PairOp), hipMemcpyHostToDevice, st));
+  if (nq) DCD_HIP(hipMemcpyAsync(d_fin.p, C.finals, nq * sizeof(FinalSeq), hipMemcpyHostToDevice, st));
+  DCD_HIP(hipMemsetAsync(d_work_ctr.p, 0, std::max<size_t>(1, C.slices.size()) * sizeof(u64), st));
 
   EvTimer tm;
-  DCD_TRY(tm.init(st));
+  DCD_TRY(tm.init(st, dev));
   DCD_TRY(tm.start());
-  // wavefronts of k_pair_parts: a few per wavefront slot of the device (256 CUs x 4 SIMDs x DCD_PW_WAVES), so that the hardware
-  // still balances the tail
-  static const u64 pw_grid = [&]() -> u64 {
-    const char* e = getenv("DOCODO_QUERY_PW_GRID");
-    if (e && atoll(e) > 0) return (u64)atoll(e);
-    hipDeviceProp_t pr;
-    const int cus = hipGetDeviceProperties(&pr, dev) == hipSuccess ? pr.multiProcessorCount : 256;
-    return (u64)cus * 4u * DCD_PW_WAVES * 4u;
-  }();
-  DevBuf<u64> d_work_ctr;
-  DCD_TRY(d_work_ctr.alloc(dev, std::max<size_t>(1, rounds.size())));
-  DCD_HIP(hipMemsetAsync(d_work_ctr.p, 0, std::max<size_t>(1, rounds.size()) * sizeof(u64), st));
+  const u64 pw_grid = pw_grid_of(dev);
   static const u32 gal_ratio = getenv("DOCODO_QUERY_GAL_RATIO") ? (u32)atoi(getenv("DOCODO_QUERY_GAL_RATIO")) : GAL_RATIO;   // (A/B knob)
-  for (size_t r = 0; r < rounds.size(); r++) {
-    u32 n = (u32)rounds[r].size();
-    const u64 W = part_base[r][n];
+  for (size_t s = 0; s < C.slices.size(); s++) {
+    const SliceInfo& sl = C.slices[s];
+    const u32 n = sl.n;
+    const u64 W = sl.W;
+    const PairOp* ops = d_ops.p + sl.first;
+    if (sl.tmp_elems > D.scratch_cap) DCD_FAIL(DCD_E_NOMEM, "query slice needs %llu scratch elements, the arena has %llu",
+                                               (unsigned long long)sl.tmp_elems, (unsigned long long)D.scratch_cap);
     // device plan: item count + mode per operator, exclusive scan -> first work item of every operator
-    hipLaunchKernelGGL(k_pair_plan, dim3(div_up(n + 1, 256)), dim3(256), 0, st, d_rounds[r].p, n, idx_values, pool.p, counts.p, PART,
-                       d_items.p, d_mode.p, gal_ratio);
-    scan_exclusive<u32, u64>(d_items.p, d_part_base[r].p, (u64)n + 1, d_part_scr.p, st);
-    hipLaunchKernelGGL(k_pair_parts, dim3((u32)std::min<u64>(W, pw_grid)), dim3(PW_T), 0, st, d_rounds[r].p, n, d_part_base[r].p, idx_values, pool.p,
-                       counts.p, tmp.p, d_part_count.p, d_part_src.p, PART, ext_values ? nullptr : h->dir.p, ix.max_coord, d_mode.p, W,
-                       reinterpret_cast<unsigned long long*>(d_work_ctr.p + r));
+    hipLaunchKernelGGL(k_pair_plan, dim3(div_up(n + 1, 256)), dim3(256), 0, st, ops, n, idx_values, pool, PART, d_items.p, d_mode.p, gal_ratio);
+    scan_exclusive<u32, u64>(d_items.p, d_part_base.p, (u64)n + 1, d_part_scr.p, st);
+    hipLaunchKernelGGL(k_pair_parts, dim3((u32)std::min<u64>(W, pw_grid)), dim3(PW_T), 0, st, ops, n, d_part_base.p, idx_values, pool,
+                       D.tmp, d_part_count.p, d_part_src.p, PART, ext_values ? nullptr : h->dir.p, ix.max_coord, d_mode.p, W,
+                       reinterpret_cast<unsigned long long*>(d_work_ctr.p + s));
     DCD_HIP(hipMemsetAsync(d_part_count.p + W, 0, 8, st));
     scan_exclusive<u64, u64>(d_part_count.p, d_part_excl.p, W + 1, d_part_scr.p, st);
+    // result lengths -> their places in the pool (device-side bump allocation) -> copy out of the scratch
+    hipLaunchKernelGGL(k_pair_totals, dim3(div_up(n, 256)), dim3(256), 0, st, ops, n, d_part_base.p, d_part_excl.p, D.counts.p, d_slice_cnt.p);
+    scan_exclusive<u64, u64>(d_slice_cnt.p, d_slice_off.p, (u64)n, d_slice_scr.p, st);
+    hipLaunchKernelGGL(k_pair_assign, dim3(div_up(n, 256)), dim3(256), 0, st, ops, n, d_slice_off.p, d_slice_scr.p + scan_nblocks(n), D.used.p,
+                       D.seq, D.pool_cap, D.res_off.p, D.overflow.p);
+    D.seq++;
     const u32 gg = (u32)std::min<u64>(div_up(div_up(W, 8), 4), 16384);
-    hipLaunchKernelGGL(k_pair_gather, dim3(gg), dim3(256), 0, st, d_rounds[r].p, n, d_part_base[r].p, W, d_part_count.p, d_part_src.p,
-                       d_part_excl.p, tmp.p, pool.p);
-    hipLaunchKernelGGL(k_pair_totals, dim3(div_up(n, 256)), dim3(256), 0, st, d_rounds[r].p, n, d_part_base[r].p, d_part_excl.p, counts.p);
+    hipLaunchKernelGGL(k_pair_gather, dim3(gg), dim3(256), 0, st, ops, n, d_part_base.p, W, d_part_count.p, d_part_src.p, d_part_excl.p, D.tmp,
+                       D.pool, D.res_off.p, D.overflow.p);
   }
-  u64 tot_pages = 0, tot_pos = 0, tot_docs = 0;
+  u64* pw = pinned_words();
+  if (!pw) DCD_FAIL(DCD_E_NOMEM, "no pinned host memory");
+  pw[0] = pw[1] = pw[2] = 0; pw[3] = 0;
+  const ResParams& P = D.P;
   if (nq) {
-    hipLaunchKernelGGL((k_result<false>), dim3((u32)nq), dim3(RS_T), 0, st, d_fin.p, (u32)nq, idx_values, pool.p, counts.p, P, d_qc.p,
+    hipLaunchKernelGGL((k_result<false>), dim3((u32)nq), dim3(RS_T), 0, st, d_fin.p, (u32)nq, idx_values, pool, P, d_qc.p,
                        nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
     // three scans on separate scratch, totals copied to the host together: one round trip instead of three
     const u64 se = scan_scratch_elems(nq), sn = scan_nblocks(nq);
@@ -1709,15 +1829,18 @@ static int32_t run_batch(dcd_index* h, const int32_t* prog, const u64* prog_off,
     DCD_HIP(hipMemcpyAsync(d_pbase.p + nq, sscr.p + sn, 8, hipMemcpyDeviceToDevice, st));
     DCD_HIP(hipMemcpyAsync(d_sbase.p + nq, sscr.p + se + sn, 8, hipMemcpyDeviceToDevice, st));
     DCD_HIP(hipMemcpyAsync(d_dbase.p + nq, sscr.p + 2 * se + sn, 8, hipMemcpyDeviceToDevice, st));
-    DCD_HIP(hipMemcpyAsync(&tot_pages, sscr.p + sn, 8, hipMemcpyDeviceToHost, st));
-    DCD_HIP(hipMemcpyAsync(&tot_pos, sscr.p + se + sn, 8, hipMemcpyDeviceToHost, st));
-    DCD_HIP(hipMemcpyAsync(&tot_docs, sscr.p + 2 * se + sn, 8, hipMemcpyDeviceToHost, st));
-    DCD_HIP(hipStreamSynchronize(st));
+    DCD_HIP(hipMemcpyAsync(&pw[0], sscr.p + sn, 8, hipMemcpyDeviceToHost, st));
+    DCD_HIP(hipMemcpyAsync(&pw[1], sscr.p + se + sn, 8, hipMemcpyDeviceToHost, st));
+    DCD_HIP(hipMemcpyAsync(&pw[2], sscr.p + 2 * se + sn, 8, hipMemcpyDeviceToHost, st));
   } else {
     DCD_HIP(hipMemsetAsync(d_pbase.p, 0, 8, st));
     DCD_HIP(hipMemsetAsync(d_sbase.p, 0, 8, st));
     DCD_HIP(hipMemsetAsync(d_dbase.p, 0, 8, st));
   }
+  DCD_HIP(hipMemcpyAsync(&pw[3], D.overflow.p, 4, hipMemcpyDeviceToHost, st));
+  DCD_HIP(hipStreamSynchronize(st));
+  if ((u32)pw[3] != 0) DCD_FAIL(DCD_E_NOMEM, "query work pool full (%llu elements)", (unsigned long long)D.pool_cap);
+  const u64 tot_pages = pw[0], tot_pos = pw[1], tot_docs = pw[2];
   DevBuf<u32> o_page_index, o_doc_index_tmp, o_doc_first, o_doc_index, o_doc_np;
   DevBuf<u64> o_pos_off;
   DevBuf<int32_t> o_pos;
@@ -1727,33 +1850,42 @@ static int32_t run_batch(dcd_index* h, const int32_t* prog, const u64* prog_off,
   DCD_TRY(o_doc_index_tmp.alloc(dev, tot_docs + 1)); DCD_TRY(o_doc_index.alloc(dev, tot_docs + 1));
   DCD_TRY(o_doc_first.alloc(dev, tot_docs + nq + 1));  // n_docs + 1 entries per query
   DCD_TRY(o_doc_rank.alloc(dev, tot_docs + 1)); DCD_TRY(o_doc_np.alloc(dev, tot_docs + 1));
-  DCD_HIP(hipMemcpyAsync(o_pos_off.p + tot_pages, &tot_pos, 8, hipMemcpyHostToDevice, st));   // (also for an empty batch: pos_off = [0])
+  pw[4] = tot_pos;
+  DCD_HIP(hipMemcpyAsync(o_pos_off.p + tot_pages, &pw[4], 8, hipMemcpyHostToDevice, st));   // (also for an empty batch: pos_off = [0])
   if (nq) {
-    hipLaunchKernelGGL((k_result<true>), dim3((u32)nq), dim3(RS_T), 0, st, d_fin.p, (u32)nq, idx_values, pool.p, counts.p, P, d_qc.p,
+    hipLaunchKernelGGL((k_result<true>), dim3((u32)nq), dim3(RS_T), 0, st, d_fin.p, (u32)nq, idx_values, pool, P, d_qc.p,
                        d_pbase.p, d_sbase.p, d_dbase.p, o_page_index.p, o_pos_off.p, o_pos.p, o_doc_index_tmp.p, o_doc_first.p);
     if (tot_pages) hipLaunchKernelGGL(k_page_rank, dim3((u32)div_up(tot_pages, 256)), dim3(256), 0, st, o_pos_off.p, o_pos.p, tot_pages, o_page_rank.p);
     hipLaunchKernelGGL(k_doc_rank, dim3((u32)nq), dim3(256), 0, st, (u32)nq, d_qc.p, d_pbase.p, d_dbase.p, o_doc_first.p, o_page_index.p,
                        o_page_rank.p, P.page_hdr, P.doc_mult, o_doc_index_tmp.p, o_doc_index.p, o_doc_rank.p, o_doc_np.p, P.page_doc);
   }
   DCD_TRY(tm.stop());
+  // ---- the per-query counts come back through ONE pinned block, behind ONE synchronisation --------------
+  PinnedBlock back;
+  const size_t qc_bytes = nq * sizeof(QCounts), off_bytes = (nq + 1) * 8;
+  DCD_TRY(back.get(qc_bytes + 2 * off_bytes));
+  u8* bp = static_cast<u8*>(back.p);
+  if (nq) DCD_HIP(hipMemcpyAsync(bp, d_qc.p, qc_bytes, hipMemcpyDeviceToHost, st));
+  DCD_HIP(hipMemcpyAsync(bp + qc_bytes, d_pbase.p, off_bytes, hipMemcpyDeviceToHost, st));
+  DCD_HIP(hipMemcpyAsync(bp + qc_bytes + off_bytes, d_dbase.p, off_bytes, hipMemcpyDeviceToHost, st));
   DCD_HIP(hipStreamSynchronize(st));
   DCD_HIP(hipGetLastError());
   R->ms_device = tm.ms();
-
-  // ---- download ------------------------------------------------------------------------------------
-  std::vector<QCounts> qc(nq);
-  if (nq) DCD_HIP(hipMemcpy(qc.data(), d_qc.p, nq * sizeof(QCounts), hipMemcpyDeviceToHost));
-  R->status.resize(nq);
-  for (size_t q = 0; q < nq; q++) R->status[q] = qc[q].status;
-  R->page_off.resize(nq + 1); R->doc_off.resize(nq + 1);
-  DCD_HIP(hipMemcpy(R->page_off.data(), d_pbase.p, (nq + 1) * 8, hipMemcpyDeviceToHost));
-  DCD_HIP(hipMemcpy(R->doc_off.data(), d_dbase.p, (nq + 1) * 8, hipMemcpyDeviceToHost));
+  {
+    const QCounts* qc = reinterpret_cast<const QCounts*>(bp);
+    R->status.resize(nq);
+    for (size_t q = 0; q < nq; q++) R->status[q] = qc[q].status;
+    R->page_off.resize(nq + 1); R->doc_off.resize(nq + 1);
+    memcpy(R->page_off.data(), bp + qc_bytes, off_bytes);
+    memcpy(R->doc_off.data(), bp + qc_bytes + off_bytes, off_bytes);
+  }
   R->n_pages_total = tot_pages; R->n_pos_total = tot_pos; R->n_docs_total = tot_docs;
   if (o.no_download) {
     // every result array was produced on the device; only the per-query counts travel (throughput measurements)
     R->downloaded = false;
     return DCD_OK;
   }
+  // ---- download ------------------------------------------------------------------------------------
   R->page_index.resize(tot_pages); R->page_rank.resize(tot_pages); R->pos_off.resize(tot_pages + 1); R->pos.resize(tot_pos);
   R->doc_index.resize(tot_docs); R->doc_rank.resize(tot_docs); R->doc_n_pages.resize(tot_docs);
   if (tot_pages) {
@@ -1771,36 +1903,35 @@ static int32_t run_batch(dcd_index* h, const int32_t* prog, const u64* prog_off,
     // final IndexSequence units per query: re-encode the final coordinates from 0 (Builder.AddRange)
     R->have_seq = true;
     R->seq_off.assign(nq + 1, 0);
-    R->seq_R = finalR;
-    std::vector<u64> cnt(n_counts ? n_counts : 1);
-    if (n_counts) DCD_HIP(hipMemcpy(cnt.data(), counts.p, (size_t)n_counts * 8, hipMemcpyDeviceToHost));
-    // tests: fail AFTER the result arrays were filled (the caller must not keep anything of this attempt); read once per call
-    const char* inj_env = getenv("DOCODO_QUERY_TEST_NOMEM_LATE");
-    const bool inj_late = inj_env && nq > (size_t)atoll(inj_env);
+    R->seq_R = C.finalR;
+    std::vector<u64> cnt(n_refs_after ? n_refs_after : 1), roff(n_refs_after ? n_refs_after : 1);
+    if (n_refs_after) {
+      DCD_HIP(hipMemcpy(cnt.data(), D.counts.p, (size_t)n_refs_after * 8, hipMemcpyDeviceToHost));
+      DCD_HIP(hipMemcpy(roff.data(), D.res_off.p, (size_t)n_refs_after * 8, hipMemcpyDeviceToHost));
+    }
     for (size_t q = 0; q < nq; q++) {
-      const Seg& s = finals[q].s;
-      u64 n = s.cnt_ref == NONE32 ? s.cnt_imm : cnt[s.cnt_ref];
-      size_t base = R->seq_units.size();
+      const Seg& s = C.finals[q].s;
+      const u64 n = s.kind == 0 ? s.cnt_imm : cnt[s.cnt_ref];
+      const size_t base = R->seq_units.size();
       if (n) {
-        if (inj_late) DCD_FAIL(DCD_E_NOMEM, "injected late out-of-memory (DOCODO_QUERY_TEST_NOMEM_LATE)");
         DevBuf<u64> part, plain;
         DevBuf<u16> du;
         const u64* src;
-        if (s.kind != 0) src = pool.p + s.off;
+        if (s.kind != 0) src = D.pool + roff[s.cnt_ref];
         else if (idx_values.v64) src = idx_values.v64 + s.off;
         else {                                   // a final sequence that is an index term itself (single-term query): unpack it
           DCD_TRY(plain.alloc(dev, n));
           hipLaunchKernelGGL(k_unpack, dim3((u32)div_up(n, 256)), dim3(256), 0, st, idx_values.lo + s.off, idx_values.hi + s.off, n, plain.p);
           src = plain.p;
         }
-        u64 nb = encode_nblocks(n);
+        const u64 nb = encode_nblocks(n);
         DCD_TRY(part.alloc(dev, nb + 1));
         DCD_TRY(du.alloc(dev, 5 * n));
         EncSrcValues es{src};
         encode_launch(es, n, part.p, du.p, st);
-        u64 total = 0;
-        DCD_HIP(hipMemcpyAsync(&total, part.p + nb, 8, hipMemcpyDeviceToHost, st));
+        DCD_HIP(hipMemcpyAsync(&pw[5], part.p + nb, 8, hipMemcpyDeviceToHost, st));
         DCD_HIP(hipStreamSynchronize(st));
+        const u64 total = pw[5];
         R->seq_units.resize(base + total);
         DCD_HIP(hipMemcpy(R->seq_units.data() + base, du.p, total * 2, hipMemcpyDeviceToHost));
       }
@@ -1831,37 +1962,22 @@ void dcd_query_default_opts(dcd_query_opts* o) {
   o->reserved = 0;
 }
 
-// Worst-case device elements a query needs: every operator result can be as long as both operands (work pool), plus
-// the scratch arena, which is shared by the operators of one round (the largest round counts).
-static u64 query_pool_need(const DeviceIndex& ix, const int32_t* prog, u64 a, u64 b) {
-  std::vector<std::pair<u64, int>> stk;   // (capacity, round)
-  std::vector<u64> round_cap;
-  u64 need = 0;
+// operators a query names and the postings of its leaves (= the capacity bound of its last operator)
+static void query_prepass(const DeviceIndex& ix, const std::vector<SymVal>* ext_leaves, const int32_t* prog, u64 a, u64 b, u64* n_ops, u64* leaf_sum) {
+  u64 ops = 0, sum = 0;
   for (u64 i = a; i < b;) {
-    int32_t opc = prog[i];
+    const int32_t opc = prog[i];
     if (opc == DCD_OP_TERM) {
       if (i + 3 > b) break;
-      int64_t t = prog[i + 1];
-      stk.emplace_back((t >= 0 && (u64)t < ix.n_terms) ? ix.h_term_item_start[t + 1] - ix.h_term_item_start[t] : 0, 0);
+      const int64_t t = prog[i + 1];
+      if (ext_leaves) { if (t >= 0 && (size_t)t < ext_leaves->size()) sum += (*ext_leaves)[(size_t)t].cap; }
+      else if (t >= 0 && (u64)t < ix.n_terms) sum += ix.h_term_item_start[t + 1] - ix.h_term_item_start[t];
       i += 3;
-    } else if (opc == DCD_OP_SETR) {
-      i += 2;
-    } else {
-      if (stk.size() < 2) break;
-      auto y = stk.back(); stk.pop_back();
-      auto x = stk.back(); stk.pop_back();
-      const int r = std::max(x.second, y.second) + 1;
-      const u64 cap = x.first + y.first;
-      stk.emplace_back(cap, r);
-      if ((int)round_cap.size() < r) round_cap.resize(r, 0);
-      round_cap[r - 1] += cap;
-      need += cap;
-      i += 1;
-    }
+    } else if (opc == DCD_OP_SETR) i += 2;
+    else { ops++; i += 1; }
   }
-  u64 mx = 0;
-  for (u64 c : round_cap) mx = std::max(mx, c);
-  return need + mx;
+  *n_ops = ops;
+  *leaf_sum = sum;
 }
 
 static void append_results(dcd_results& dst, const dcd_results& src) {
@@ -1871,8 +1987,7 @@ static void append_results(dcd_results& dst, const dcd_results& src) {
   const bool first = dst.page_off.empty();
   dst.status.insert(dst.status.end(), src.status.begin(), src.status.end());
   auto app_off = [&](std::vector<u64>& d, const std::vector<u64>& sv, u64 base) {
-    size_t k0 = first ? 0 : 1;                         // later chunks drop their leading 0
-    if (!first && !d.empty()) {}
+    const size_t k0 = first ? 0 : 1;                   // later chunks drop their leading 0
     for (size_t k = k0; k < sv.size(); k++) d.push_back(sv[k] + base);
   };
   app_off(dst.page_off, src.page_off, p0);
@@ -1895,6 +2010,163 @@ static void append_results(dcd_results& dst, const dcd_results& src) {
     dst.seq_R.insert(dst.seq_R.end(), src.seq_R.begin(), src.seq_R.end());
   }
   dst.ms_device += src.ms_device;
+  dst.ops_named += src.ops_named; dst.ops_evaluated += src.ops_evaluated;
+  dst.units_named += src.units_named; dst.units_evaluated += src.units_evaluated;
+}
+
+// The handle's work arena = [pool | scratch].  Round 4: its DEFAULT size is an eighth of the device memory (round 3: half of
+// it, because every operator reserved cap(a) + cap(b) pool elements and as much scratch): results are placed by the device where
+// the previous one ended, and the scratch is reused slice by slice.  It grows only when one operator's capacity does not fit the
+// scratch half; dcd_index_trim gives it back.
+static int32_t arena_ensure(dcd_index* h, u64 pool_elems, u64 scratch_elems, u64 bound_elems) {
+  const u64 want = pool_elems + scratch_elems;
+  if (h->work_pool.p && h->work_pool_elems >= want) return DCD_OK;
+  // (a growth is a hipMalloc of gigabytes: in steps of at least twice the old size, up to the bound)
+  const u64 size = std::max(want, std::min(2 * h->work_pool_elems, bound_elems));
+  h->work_pool.reset();
+  h->work_pool_elems = 0;
+  if (h->work_pool.alloc(h->ix.device, size) == DCD_OK) { h->work_pool_elems = size; return DCD_OK; }
+  dev_pool_trim(h->ix.device);                             // (the cache may hold what is missing)
+  DCD_TRY(h->work_pool.alloc(h->ix.device, want));
+  h->work_pool_elems = want;
+  return DCD_OK;
+}
+
+// one sub-batch: queries [q0, q1) with one pool and one table of common sub-expressions, run in pipelined chunks
+static int32_t run_sub_batch(dcd_index* h, const int32_t* prog, const u64* prog_off, size_t q0, size_t q1, const dcd_query_opts& o,
+                             dcd_results* R, const u64* ext_values, const std::vector<SymVal>* ext_leaves, u64 pool_bound, u64 scratch_bound,
+                             bool exact_pool) {
+  DeviceIndex& ix = h->ix;
+  const int dev = ix.device;
+  hipStream_t st = h->st;
+  StreamScope ss_(st);
+  if (o.max_found_docs > 512 || o.max_found_docs < 0 || o.max_found_pages < 0) DCD_FAIL(DCD_E_BADARG, "max_found_docs must be in [0, 512]");
+  if (!ext_values) DCD_TRY(ensure_values(h));
+  u64 PART = PART_DEFAULT;
+  if (const char* e = getenv("DOCODO_QUERY_PART")) PART = std::max<u64>(strtoull(e, nullptr, 10), 1);   // tests: tiny partitions
+  size_t chunk_q = 16384;                                   // queries per chunk (plan of chunk k + 1 is made while chunk k runs)
+  if (const char* e = getenv("DOCODO_QUERY_CHUNK")) chunk_q = std::max<size_t>(strtoull(e, nullptr, 10), 1);
+  // pre-pass: operators per chunk (sizes of the staging blocks and of the result directory), largest operator capacity
+  const size_t nq = q1 - q0;
+  const size_t n_chunks = std::max<size_t>(1, div_up(nq, chunk_q));
+  std::vector<u64> chunk_ops(n_chunks, 0);
+  u64 ops_total = 0, max_cap = 0, cap_sum = 0;
+  for (size_t q = q0; q < q1; q++) {
+    u64 no = 0, ls = 0;
+    query_prepass(ix, ext_leaves, prog, prog_off[q], prog_off[q + 1], &no, &ls);
+    chunk_ops[(q - q0) / chunk_q] += no;
+    ops_total += no;
+    if (no) max_cap = std::max(max_cap, ls);
+    cap_sum += no * ls;                                     // (bound of the results of the query's operators together)
+  }
+  if (ops_total >= 0xFFFFFFF0ull) DCD_FAIL(DCD_E_OVERFLOW, "query batch too large: %llu operators", (unsigned long long)ops_total);
+  // the arena is as large as this sub-batch can need, up to the bounds: a small index never reserves gigabytes
+  const u64 scratch_elems = std::max<u64>(std::max(std::min(scratch_bound, cap_sum), max_cap), 1);
+  const u64 pool_elems = std::max<u64>(std::min(pool_bound, cap_sum), 1);
+  DCD_TRY(arena_ensure(h, pool_elems, scratch_elems, pool_bound + std::max(scratch_bound, scratch_elems)));
+  SubBatch sb;
+  static const bool env_cse = !(getenv("DOCODO_QUERY_CSE") && atoi(getenv("DOCODO_QUERY_CSE")) == 0);   // (A/B knob)
+  sb.use_cse = env_cse;
+  if (sb.use_cse) sb.cse.init(ops_total);
+  sb.ref_cap.reserve(ops_total); sb.ref_chunk.reserve(ops_total); sb.ref_round.reserve(ops_total);
+  SubBatchDev D;
+  DCD_TRY(D.counts.alloc(dev, ops_total ? ops_total : 1));
+  DCD_TRY(D.res_off.alloc(dev, ops_total ? ops_total : 1));
+  DCD_TRY(D.used.alloc(dev, 2));
+  DCD_TRY(D.overflow.alloc(dev, 1));
+  DCD_HIP(hipMemsetAsync(D.used.p, 0, 16, st));
+  DCD_HIP(hipMemsetAsync(D.overflow.p, 0, 4, st));
+  // [pool | scratch]: everything the arena holds beyond the scratch belongs to the pool
+  D.scratch_cap = scratch_elems;
+  D.pool_cap = exact_pool ? pool_elems : h->work_pool_elems - scratch_elems;
+  D.pool = h->work_pool.p;
+  D.tmp = h->work_pool.p + D.pool_cap;
+  DCD_TRY(make_res_params(h, o, D.pd, &D.P));
+
+  ChunkPlan plans[2];
+  PinnedBlock pin_ops[2], pin_fin[2];
+  auto prepare = [&](size_t c) -> int32_t {                // staging of chunk c (the executor owns every HIP object)
+    ChunkPlan& P = plans[c & 1];
+    P.chunk = (u32)c;
+    P.q0 = q0 + c * chunk_q;
+    P.q1 = std::min(q1, P.q0 + chunk_q);
+    P.status = DCD_OK;
+    P.err.clear();
+    P.ops_cap = chunk_ops[c];
+    DCD_TRY(pin_ops[c & 1].get(std::max<size_t>(1, P.ops_cap) * sizeof(PairOp)));
+    DCD_TRY(pin_fin[c & 1].get(std::max<size_t>(1, P.q1 - P.q0) * sizeof(FinalSeq)));
+    P.ops = static_cast<PairOp*>(pin_ops[c & 1].p);
+    P.finals = static_cast<FinalSeq*>(pin_fin[c & 1].p);
+    return DCD_OK;
+  };
+  DCD_TRY(prepare(0));
+  plan_chunk(h, ext_leaves, sb, prog, prog_off, PART, scratch_elems, plans[0]);
+  int32_t status = DCD_OK;
+  for (size_t c = 0; c < n_chunks && status == DCD_OK; c++) {
+    ChunkPlan& P = plans[c & 1];
+    if (P.status != DCD_OK) { set_error("%s", P.err.c_str()); status = P.status; break; }
+    const u32 refs_after = sb.n_refs;                      // (results this chunk's final sequences can name)
+    std::thread planner;
+    if (c + 1 < n_chunks) {
+      status = prepare(c + 1);
+      if (status != DCD_OK) break;
+      planner = std::thread(plan_chunk, h, ext_leaves, std::ref(sb), prog, prog_off, PART, scratch_elems, std::ref(plans[(c + 1) & 1]));
+    }
+    if (n_chunks == 1) status = exec_chunk(h, o, D, P, PART, R, ext_values, refs_after);
+    else {
+      dcd_results part;
+      status = exec_chunk(h, o, D, P, PART, &part, ext_values, refs_after);
+      if (status == DCD_OK) append_results(*R, part);
+    }
+    if (planner.joinable()) planner.join();
+  }
+  if (status != DCD_OK) { (void)hipStreamSynchronize(st); return status; }
+  R->ops_named += sb.ops_total;
+  R->ops_evaluated += sb.n_refs;
+  R->units_named += sb.units_named;
+  R->units_evaluated += sb.units_evaluated;
+  return DCD_OK;
+}
+
+// queries of one call: one sub-batch if the pool holds its results, otherwise halves (quarters, ...) of it
+static int32_t run_queries(dcd_index* h, const int32_t* prog, const u64* prog_off, size_t n_queries, const dcd_query_opts& o,
+                           std::unique_ptr<dcd_results>& out, const u64* ext_values, const std::vector<SymVal>* ext_leaves) {
+  size_t free_b = 0, total_b = 0;
+  DCD_HIP(hipMemGetInfo(&free_b, &total_b));
+  static const u64 env_arena = getenv("DOCODO_QUERY_ARENA_BYTES") ? strtoull(getenv("DOCODO_QUERY_ARENA_BYTES"), nullptr, 10) : 0;
+  const u64 arena_b = env_arena ? env_arena : (u64)total_b / 8;
+  u64 pool_bound = std::max<u64>(arena_b / 16, 1ull << 16), scratch_bound = pool_bound;   // elements: half of the arena each
+  bool env_pool = false;
+  if (const char* e = getenv("DOCODO_QUERY_POOL_ELEMS")) {   // tests / hosts short of memory: pool and scratch of this many elements
+    pool_bound = scratch_bound = std::max<u64>(strtoull(e, nullptr, 10), 1);
+    env_pool = true;
+  }
+  std::unique_ptr<dcd_results> R(new dcd_results());
+  size_t q0 = 0, span = std::max<size_t>(n_queries, 1);
+  bool first = true;
+  while (q0 < n_queries || first) {
+    const size_t q1 = std::min(n_queries, q0 + span);
+    // (an attempt works on an object of its own that is adopted only on success: a failed one may have filled arrays already)
+    std::unique_ptr<dcd_results> part(new dcd_results());
+    const int32_t st = run_sub_batch(h, prog, prog_off, q0, q1, o, part.get(), ext_values, ext_leaves, pool_bound, scratch_bound, env_pool);
+    if (st == DCD_OK) {
+      if (first && q1 == n_queries) { R = std::move(part); break; }       // the common case: one sub-batch, no copies
+      append_results(*R, *part);
+      q0 = q1;
+      first = false;
+      continue;
+    }
+    if (st != DCD_E_NOMEM) return st;
+    if (q1 - q0 > 1) { span = (q1 - q0 + 1) / 2; first = false; continue; }   // the pool ran full: half as many queries share it
+    // a single query does not fit: a larger pool if the device has the memory
+    (void)hipMemGetInfo(&free_b, &total_b);
+    const u64 avail = ((u64)free_b + (u64)dev_pool_cached_bytes(h->ix.device) + 8 * h->work_pool_elems) / 8;
+    if (env_pool || 2 * pool_bound + scratch_bound > avail / 4 * 3) return st;
+    pool_bound *= 2;
+    first = false;
+  }
+  out = std::move(R);
+  return DCD_OK;
 }
 
 // On-disk postings (dcd_index_open_lazy; Index.cs:198-216, 346-348): a batch reads the lists of the terms its programs name,
@@ -1989,63 +2261,22 @@ int32_t dcd_query_batch(dcd_index* h, const int32_t* prog, const uint64_t* prog_
   }
   DCD_TRY(ensure_device(h->ix.device));
   DCD_TRY(index_fetch_host(h->ix));     // (host mirrors of a merged index are fetched on first use)
-  // The work pool and the scratch arena are sized for the worst case of every operator; a batch whose worst case exceeds
-  // three quarters of the free HBM (incl. the library's device cache) is evaluated in consecutive sub-batches (results are
-  // concatenated).  Fewer, larger sub-batches are better -- every one costs ~0.7 ms of launches and host round trips --
-  // and if a sub-batch still runs out of memory (result arrays, fragmentation) it is retried with half the budget.
-  size_t free_b = 0, total_b = 0;
-  DCD_HIP(hipMemGetInfo(&free_b, &total_b));
-  // (what the handle's arena holds already is available to the batch)
-  const u64 avail_b = (u64)free_b + (u64)dev_pool_cached_bytes(h->ix.device) + 8 * h->work_pool_elems;
-  u64 budget = std::max<u64>(avail_b / 4 * 3 / 8, 1ull << 24);   // elements of 8 bytes
-  {
-    // ... and no more than the arena bound: a sub-batch beyond it would only buy a larger hipMalloc (see run_batch)
-    static const u64 env_arena = getenv("DOCODO_QUERY_ARENA_BYTES") ? strtoull(getenv("DOCODO_QUERY_ARENA_BYTES"), nullptr, 10) : 0;
-    const u64 arena_b = env_arena ? env_arena : (u64)total_b / 2;
-    budget = std::max<u64>(std::min<u64>(budget, arena_b / 8), 1ull << 24);
-  }
-  if (const char* e = getenv("DOCODO_QUERY_POOL_ELEMS")) budget = std::max<u64>(strtoull(e, nullptr, 10), 1);   // tests
-  std::unique_ptr<dcd_results> R(new dcd_results());
-  size_t q0 = 0;
-  bool single = true;
-  while (q0 < n_queries || (n_queries == 0 && single)) {
-    size_t q1 = q0;
-    u64 acc = 0;
-    while (q1 < n_queries) {
-      u64 need = query_pool_need(h->ix, prog, prog_off[q1], prog_off[q1 + 1]);
-      if (q1 > q0 && acc + need > budget) break;
-      acc += need;
-      q1++;
-    }
-    int32_t st;
-    const char* inj = getenv("DOCODO_QUERY_TEST_NOMEM");   // tests: pretend that sub-batches of more than n queries do not fit
-    if (inj && q1 - q0 > (size_t)atoll(inj)) {
-      set_error("injected out-of-memory (DOCODO_QUERY_TEST_NOMEM)");
-      st = DCD_E_NOMEM;
-    } else
-    if (q0 == 0 && q1 == n_queries) {                      // the common case: one sub-batch, no copies
-      // a failed attempt may already have filled its result arrays (run_batch can run out of memory after the
-      // download, in the want_sequences loop): it works on an object of its own that is adopted only on success
-      std::unique_ptr<dcd_results> one(new dcd_results());
-      st = run_batch(h, prog, prog_off, n_queries, o, one.get(), nullptr, nullptr);
-      if (st == DCD_OK) { R = std::move(one); break; }
-    } else {
-      single = false;
-      std::vector<u64> off(q1 - q0 + 1);
-      for (size_t k = 0; k <= q1 - q0; k++) off[k] = prog_off[q0 + k] - prog_off[q0];
-      dcd_results part;
-      st = run_batch(h, prog + prog_off[q0], off.data(), q1 - q0, o, &part, nullptr, nullptr);
-      if (st == DCD_OK) { append_results(*R, part); q0 = q1; continue; }
-    }
-    if (st != DCD_E_NOMEM || q1 - q0 <= 1) return st;
-    h->work_pool.reset();                                   // out of memory: give the arena back, release the cache,
-    h->work_pool_elems = 0;
-    dev_pool_trim(h->ix.device);                           // halve the sub-batch, try again
-    budget = std::max<u64>(1, std::min(budget, acc) / 2);
-    if (single) R.reset(new dcd_results());                // nothing of a failed single attempt survives
-    single = false;
-  }
+  std::unique_ptr<dcd_results> R;
+  DCD_TRY(run_queries(h, prog, prog_off, n_queries, o, R, nullptr, nullptr));
   *out = R.release();
+  return DCD_OK;
+}
+
+// gives the handle's work arena (and, for an on-disk index, the resident subset) back to the device
+int32_t dcd_index_trim(dcd_index* h) {
+  if (!h) DCD_FAIL(DCD_E_BADARG, "dcd_index_trim: NULL argument");
+  std::lock_guard<std::mutex> guard(h->mu);
+  DCD_TRY(ensure_device(h->ix.device));
+  if (h->st) DCD_HIP(hipStreamSynchronize(h->st));
+  h->work_pool.reset();
+  h->work_pool_elems = 0;
+  if (h->lazy && h->lazy->sub) { dcd_index* old = h->lazy->sub.release(); dcd_index_free(old); h->lazy->terms.clear(); }
+  dev_pool_trim(h->ix.device);
   return DCD_OK;
 }
 
@@ -2066,6 +2297,8 @@ int32_t dcd_results_get(dcd_results* r, dcd_results_view* v) {
   if (r->have_seq) { v->seq_off = r->seq_off.data(); v->seq_units = r->seq_units.data(); v->seq_R = r->seq_R.data(); }
   v->ms_device = r->ms_device;
   v->n_pages_total = r->n_pages_total; v->n_pos_total = r->n_pos_total; v->n_docs_total = r->n_docs_total;
+  v->ops_named = r->ops_named; v->ops_evaluated = r->ops_evaluated;
+  v->units_named = r->units_named; v->units_evaluated = r->units_evaluated;
   if (!r->downloaded) {          // (no_download: the CSR arrays stayed on the device and are gone; the offsets and totals are valid)
     v->page_index = nullptr; v->page_rank = nullptr; v->pos_off = nullptr; v->pos = nullptr;
     v->doc_index = nullptr; v->doc_rank = nullptr; v->doc_n_pages = nullptr;
@@ -2116,7 +2349,7 @@ static int32_t seq_binop(int opc, const u16* a, size_t na, int32_t Ra, const u16
     DCD_HIP(hipStreamSynchronize(st));
     leaves[k].s.kind = 0; leaves[k].s.off = off; leaves[k].s.cnt_ref = NONE32; leaves[k].s.cnt_imm = nv[k];
     leaves[k].s.dir_off = 0; leaves[k].s.dir_shift = NONE32; leaves[k].s.pad = 0;
-    leaves[k].cap = nv[k]; leaves[k].round = 0; leaves[k].R = 0;
+    leaves[k].cap = nv[k]; leaves[k].round = 0; leaves[k].R = 0; leaves[k].key = (u64)k;
     off += nv[k];
   }
   int32_t prog[7] = {DCD_OP_TERM, 0, Ra, DCD_OP_TERM, 1, Rb, opc};
@@ -2125,9 +2358,10 @@ static int32_t seq_binop(int opc, const u16* a, size_t na, int32_t Ra, const u16
   dcd_query_default_opts(&o);
   o.want_sequences = 1;
   o.max_found_pages = 0;  // no page table here: results are not wanted
-  dcd_results R;
+  std::unique_ptr<dcd_results> Rp;
   tmp.ix.pages = PageTable();
-  DCD_TRY(run_batch(&tmp, prog, poff, 1, o, &R, vals.p, &leaves));
+  DCD_TRY(run_queries(&tmp, prog, poff, 1, o, Rp, vals.p, &leaves));
+  const dcd_results& R = *Rp;
   *n_out = R.seq_units.size();
   if (R_out) *R_out = R.seq_R[0];
   if (R.seq_units.size() > cap || (!out && !R.seq_units.empty())) return DCD_E_OVERFLOW;

@@ -196,6 +196,9 @@ class QueryBatchResult:
             self.seq_units = arr(view.seq_units, int(self.seq_off[-1]), np.uint16)
             self.seq_R = arr(view.seq_R, nq, np.int32)
         self.ms_device = view.ms_device
+        # common sub-expressions (dcd_results_view, ABI 2): operators named by the programs / evaluated, units of their index terms
+        self.ops_named, self.ops_evaluated = int(view.ops_named), int(view.ops_evaluated)
+        self.units_named, self.units_evaluated = int(view.units_named), int(view.units_evaluated)
 
     def pages(self, q):
         a, b = int(self.page_off[q]), int(self.page_off[q + 1])
@@ -258,6 +261,10 @@ class Index:
             self.close()
         except Exception:
             pass
+
+    def trim(self):
+        """Releases the work arena of the query batches (and the resident lists of an on-disk index)."""
+        check(lib().dcd_index_trim(self.h))
 
     def _u64(self, fn):
         v = C.c_uint64(0)
@@ -419,7 +426,9 @@ class Index:
             v = ResultsView()
             check(lib().dcd_results_get(r, C.byref(v)))
             if totals:
-                return {"ms": float(v.ms_device), "n_pages": int(v.n_pages_total), "n_pos": int(v.n_pos_total), "n_docs": int(v.n_docs_total)}
+                return {"ms": float(v.ms_device), "n_pages": int(v.n_pages_total), "n_pos": int(v.n_pos_total), "n_docs": int(v.n_docs_total),
+                        "ops_named": int(v.ops_named), "ops_evaluated": int(v.ops_evaluated),
+                        "units_named": int(v.units_named), "units_evaluated": int(v.units_evaluated)}
             if keep_handle:
                 return v.ms_device
             return QueryBatchResult(v)

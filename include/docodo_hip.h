@@ -47,7 +47,13 @@ typedef struct dcd_build dcd_build;
 typedef struct dcd_index dcd_index;
 typedef struct dcd_results dcd_results;
 
+/* ABI version.  2 (round 4): dcd_results_view ends with ops_named .. units_evaluated; dcd_index_trim, dcd_struct_size.
+ * A host compiled against version 1 must be rebuilt (dcd_results_get writes sizeof(dcd_results_view) bytes). */
+#define DCD_ABI_VERSION 2
 int32_t dcd_version(void);
+/* sizeof of the ABI's structs as this library was built, for hosts that declare them by hand (P/Invoke, ctypes):
+ * which = 0 dcd_build_opts, 1 dcd_build_stats, 2 dcd_query_opts, 3 dcd_results_view, 4 dcd_term_meta; 0 for anything else */
+uint64_t dcd_struct_size(int32_t which);
 /* copies the calling thread's last error message (UTF-8, NUL-terminated); returns its length */
 int32_t dcd_last_error(char* buf, size_t cap);
 int32_t dcd_device_count(int32_t* n);
@@ -226,6 +232,10 @@ int32_t dcd_index_from_images(const uint8_t* index_img, size_t n_index, const ui
 int32_t dcd_index_open_lazy(const char* dir_utf8, int32_t device, uint64_t resident_bytes, dcd_index** out);
 int32_t dcd_index_lazy_stats(dcd_index* h, uint64_t* lists_read, uint64_t* bytes_read, uint64_t* resident_terms);
 void dcd_index_free(dcd_index* h);
+/* Releases what the handle keeps between query batches -- the work arena of dcd_query_batch (at most an eighth of the device
+ * memory) and, for an on-disk index, the resident posting lists -- and returns the library's cached device blocks to the device.
+ * The index stays usable; the next batch allocates again.  For processes that keep several indexes open on one device. */
+int32_t dcd_index_trim(dcd_index* h);
 int32_t dcd_index_count(dcd_index* h, uint64_t* n_terms);              /* Index.Count */
 int32_t dcd_index_max_coord(dcd_index* h, uint64_t* v);                /* Index.MaxCoord */
 int32_t dcd_index_n_units(dcd_index* h, uint64_t* n);                  /* ushort units of all posting lists together */
@@ -301,6 +311,10 @@ typedef struct dcd_results_view {
   const int32_t* seq_R;
   float ms_device;              /* device time of the batch (HIP events) */
   uint64_t n_pages_total, n_pos_total, n_docs_total;   /* sizes of the page / position / document arrays (also with no_download) */
+  /* ABI version 2.  Common sub-expressions: operators (* / +) the programs of the batch name, and how many were evaluated -- an
+   * operator with the same operands, R values and opcode as an earlier one of the (sub-)batch refers to that one's result;
+   * units_*: ushort units of the index-term operands of those operators (2 bytes each: the bytes the operators had to read) */
+  uint64_t ops_named, ops_evaluated, units_named, units_evaluated;
 } dcd_results_view;
 int32_t dcd_results_get(dcd_results* r, dcd_results_view* out);
 void dcd_results_free(dcd_results* r);

@@ -200,19 +200,19 @@ def test_three_term_queries_small_partitions(synth_index, monkeypatch):
     a = ix.query_batch(prog, off, want_sequences=True)
     monkeypatch.setenv("DOCODO_QUERY_PART", "200")
     b = ix.query_batch(prog, off, want_sequences=True)
-    for name in ("status", "page_off", "page_index", "page_rank", "pos_off", "pos", "doc_off", "doc_index", "doc_rank",
-                 "doc_n_pages", "seq_off", "seq_units", "seq_R"):
+    for name in _RESULT_ARRAYS:
         assert np.array_equal(getattr(a, name), getattr(b, name)), name
 
 
-def test_out_of_memory_sub_batches_are_retried_smaller(synth_index, monkeypatch):
-    """A sub-batch that does not fit (here: injected for sub-batches of more than 7 queries) is retried with half the
-    budget until it does; the concatenated result equals the one-shot evaluation."""
+_RESULT_ARRAYS = ("status", "page_off", "page_index", "page_rank", "pos_off", "pos", "doc_off", "doc_index", "doc_rank",
+                  "doc_n_pages", "seq_off", "seq_units", "seq_R")
+
+
+def _and_programs(ix, ranks):
     import docodo_amd
     from docodo_amd import synth
-    ix, oix, _, _ = synth_index
     prog, off = [], [0]
-    for row in synth.query_ranks(100, 3, lo_rank=5):
+    for row in ranks:
         ts = [ix.find(synth.term(int(k))) for k in row]
         if any(t is None for t in ts):
             continue
@@ -221,40 +221,63 @@ def test_out_of_memory_sub_batches_are_retried_smaller(synth_index, monkeypatch)
             if k:
                 prog.append(docodo_amd.DCD_OP_AND)
         off.append(len(prog))
-    monkeypatch.delenv("DOCODO_QUERY_TEST_NOMEM", raising=False)
-    a = ix.query_batch(prog, off, want_sequences=True)
-    monkeypatch.setenv("DOCODO_QUERY_TEST_NOMEM", "7")
-    b = ix.query_batch(prog, off, want_sequences=True)
-    for name in ("status", "page_off", "page_index", "page_rank", "pos_off", "pos", "doc_off", "doc_index", "doc_rank",
-                 "doc_n_pages", "seq_off", "seq_units", "seq_R"):
-        assert np.array_equal(getattr(a, name), getattr(b, name)), name
+    return prog, off
 
 
-def test_late_out_of_memory_of_the_single_attempt_leaves_no_stale_results(synth_index, monkeypatch):
-    """The one-shot attempt can fail AFTER it filled its result arrays (the want_sequences re-encode allocates per
-    query; injected here for batches of more than 9 queries).  The retry in sub-batches must start from an empty
-    result: same arrays as the undisturbed evaluation, n_queries unchanged."""
+def test_a_full_work_pool_is_retried_with_smaller_sub_batches(synth_index, monkeypatch):
+    """Operator results are placed in the work pool by the device, one behind the other (round 4).  When the pool runs full the
+    sub-batch is abandoned (every kernel behind that point leaves at once, nothing of the attempt is kept) and evaluated again
+    as two halves, each with a pool and a table of common sub-expressions of its own.  Pools from far too large down to too
+    small for a single query: every evaluation that succeeds equals the undisturbed one; one that cannot succeed says NOMEM."""
     import docodo_amd
     from docodo_amd import synth
     ix, oix, _, _ = synth_index
-    prog, off = [], [0]
-    for row in synth.query_ranks(60, 2, lo_rank=5):
-        ts = [ix.find(synth.term(int(k))) for k in row]
-        if any(t is None for t in ts):
-            continue
-        for k, t in enumerate(ts):
-            prog += [docodo_amd.DCD_OP_TERM, t, 255 + len(synth.term(int(row[k])))]
-            if k:
-                prog.append(docodo_amd.DCD_OP_AND)
-        off.append(len(prog))
-    monkeypatch.delenv("DOCODO_QUERY_TEST_NOMEM_LATE", raising=False)
+    prog, off = _and_programs(ix, synth.query_ranks(100, 3, lo_rank=5))
+    monkeypatch.delenv("DOCODO_QUERY_POOL_ELEMS", raising=False)
     a = ix.query_batch(prog, off, want_sequences=True)
-    monkeypatch.setenv("DOCODO_QUERY_TEST_NOMEM_LATE", "9")
+    split, failed = 0, 0
+    for lg in range(22, 7, -1):
+        monkeypatch.setenv("DOCODO_QUERY_POOL_ELEMS", str(1 << lg))
+        try:
+            b = ix.query_batch(prog, off, want_sequences=True)
+        except docodo_amd.DocodoError as e:
+            assert e.code == docodo_amd.DCD_E_NOMEM
+            failed += 1
+            continue
+        assert failed == 0, "a smaller pool worked after a larger one had failed"
+        assert len(b.status) == len(off) - 1
+        for name in _RESULT_ARRAYS:
+            assert np.array_equal(getattr(a, name), getattr(b, name)), (lg, name)
+        if (1 << lg) < a.pos.size:        # the final sequences alone (>= the positions they yield) exceed the pool: it was split
+            split += 1
+    assert split >= 1
+
+
+def test_chunked_batches_and_shared_operators(synth_index, monkeypatch):
+    """A batch runs in chunks whose plans are made on a helper thread while the previous chunk is on the device, and an operator
+    that an earlier query of the sub-batch named (same operands, R values, opcode) is evaluated once -- also across chunks.
+    Every query here occurs three times, spread over the batch; chunks of 7 queries; results as in one chunk, each copy equal."""
+    import docodo_amd
+    from docodo_amd import synth
+    ix, oix, _, _ = synth_index
+    ranks = synth.query_ranks(40, 3, lo_rank=10)
+    ranks = np.concatenate([ranks, ranks[::-1], ranks])
+    prog, off = _and_programs(ix, ranks)
+    monkeypatch.delenv("DOCODO_QUERY_CHUNK", raising=False)
+    a = ix.query_batch(prog, off, want_sequences=True)
+    monkeypatch.setenv("DOCODO_QUERY_CHUNK", "7")
     b = ix.query_batch(prog, off, want_sequences=True)
-    assert len(b.status) == len(off) - 1
-    for name in ("status", "page_off", "page_index", "page_rank", "pos_off", "pos", "doc_off", "doc_index", "doc_rank",
-                 "doc_n_pages", "seq_off", "seq_units", "seq_R"):
+    for name in _RESULT_ARRAYS:
         assert np.array_equal(getattr(a, name), getattr(b, name)), name
+    n = (len(off) - 1) // 3
+    assert 3 * n == len(off) - 1
+    for q in range(n):
+        for c in (2 * n - 1 - q, 2 * n + q):
+            assert np.array_equal(a.seq_units[a.seq_off[q]:a.seq_off[q + 1]], a.seq_units[a.seq_off[c]:a.seq_off[c + 1]])
+            assert a.page_off[q + 1] - a.page_off[q] == a.page_off[c + 1] - a.page_off[c]
+    # 2 operators per query named, at most one third of them evaluated
+    assert a.ops_named == 2 * (len(off) - 1) and a.ops_evaluated <= a.ops_named // 3
+    assert b.ops_evaluated == a.ops_evaluated
 
 
 def test_concurrent_batches_on_one_index(synth_index):
@@ -352,8 +375,7 @@ def test_sub_batching_matches_single_batch(synth_index, monkeypatch):
     a = ix.query_batch(prog, off, want_sequences=True)
     monkeypatch.setenv("DOCODO_QUERY_POOL_ELEMS", "200000")
     b = ix.query_batch(prog, off, want_sequences=True)
-    for name in ("status", "page_off", "page_index", "page_rank", "pos_off", "pos", "doc_off", "doc_index", "doc_rank",
-                 "doc_n_pages", "seq_off", "seq_units", "seq_R"):
+    for name in _RESULT_ARRAYS:
         assert np.array_equal(getattr(a, name), getattr(b, name)), name
 
 
