@@ -58,7 +58,8 @@ class ResultsView(C.Structure):
                 ("doc_n_pages", C.POINTER(C.c_uint32)), ("seq_off", C.POINTER(C.c_uint64)),
                 ("seq_units", C.POINTER(C.c_uint16)), ("seq_R", C.POINTER(C.c_int32)), ("ms_device", C.c_float),
                 ("n_pages_total", C.c_uint64), ("n_pos_total", C.c_uint64), ("n_docs_total", C.c_uint64),
-                ("ops_named", C.c_uint64), ("ops_evaluated", C.c_uint64), ("units_named", C.c_uint64), ("units_evaluated", C.c_uint64)]
+                ("ops_named", C.c_uint64), ("ops_evaluated", C.c_uint64), ("units_named", C.c_uint64), ("units_evaluated", C.c_uint64),
+                ("sub_batches", C.c_uint64)]
 
 
 # name -> (restype, argtypes); mirrors include/docodo_hip.h one to one

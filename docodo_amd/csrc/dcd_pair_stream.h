@@ -1,0 +1,403 @@
+// dcd_pair_stream.h -- the streaming form of IndexSequence '*' / '+' (IndexSequence.cs:218-322) on 32-bit TILE-RELATIVE keys.
+//
+// Round 4.  k_pair_parts merges on 64-bit keys (coordinate << 1 | operand): every compare-exchange of its bitonic network is two
+// LDS-crossbar shuffles, a 64-bit compare and two selects, its chain scans are log-step shuffles, and it shares one register
+// budget with the galloping path (106 SGPRs + 135 spilled).  This kernel evaluates the SAME work items -- partitions of the
+// operand union cut at fixed diagonals, a wavefront per item, chains owned by the partition they start in, exactly the rules of
+// k_pair_parts -- with:
+//   * keys (coordinate - tile base) << 1 | operand in 32 bits.  The base is the smallest staged coordinate, so every key is exact
+//     by construction; a staged element 2^31 - 1 or more beyond the base gets the key +inf, i.e. counts as not staged yet: the
+//     tile then consumes fewer than 256 elements (at least the base element itself) and the next tile starts from a new base.
+//     No 64-bit fallback path exists or is needed;
+//   * the bitonic merge as ONE v_med3_u32 per compare-exchange (med3(x, y, 0) = min, med3(x, y, ~0) = max: the third operand is
+//     the lane's side of the stage), partners fetched by DPP (row_ror:8, quad_perm, row_shl/shr:4) and by the gfx950 lane swaps
+//     v_permlane32_swap / v_permlane16_swap -- no LDS crossbar, no address registers;
+//   * the chain logic on BALLOT MASKS: a lane summarises its four consecutive elements (break inside? flags of the part that
+//     belongs to the chain entering / leaving the lane), the cross-lane part -- "does the chain hold a contact", "a left element
+//     at or before me" -- is a segmented OR over 64 lanes, which is the carry chain of ONE 64-bit scalar addition
+//     (generate = the lanes' flags, propagate = lanes without a break); positions come from s_ff1 / s_flbit, counts from s_bcnt1;
+//   * operand rings in LDS as four planes (element j at plane j & 3): the lane's four consecutive elements are read without bank
+//     conflicts.
+// Results are bit-identical to k_pair_parts (tests/test_gpu_query.py, stress_ops.py, stress_queries.py run both).
+#pragma once
+
+namespace dcd {
+
+#ifndef DCD_SK_WAVES
+#define DCD_SK_WAVES 8
+#endif
+constexpr u32 SK_TILE = 256;
+constexpr u32 SK_PLANE = 64 + 4;                 // elements per ring plane (padded: the refill's 8-byte stores hit distinct banks)
+constexpr u32 SK_RING = 4 * SK_PLANE;
+constexpr u32 SK_INF = 0xFFFFFFFFu;
+constexpr u64 SK_LIM = 0x7FFFFFFFull;            // relative coordinates below this are representable (key <= 0xFFFFFFFD)
+
+__device__ __forceinline__ u32 sk_phys(u32 j) { return (j & 3u) * SK_PLANE + (j >> 2); }   // ring slot j in [0, 256)
+__device__ __forceinline__ u32 sk_med3(u32 a, u32 b, u32 c) {
+  u32 r;
+  asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+// bit `lane` of a wave-uniform mask as 0 / 1 (one v_cndmask on the SGPR pair)
+__device__ __forceinline__ u32 sk_lane_bit(u64 m) {
+  u32 r;
+  asm("v_cndmask_b32 %0, 0, 1, %1" : "=v"(r) : "s"(m));
+  return r;
+}
+template <int CTRL>
+__device__ __forceinline__ u32 sk_dpp(u32 v) { return (u32)__builtin_amdgcn_mov_dpp((int)v, CTRL, 0xF, 0xF, true); }
+// compare-exchange with the lane whose number differs in one bit; side = 0 in the lanes that keep the minimum, ~0 in the others
+__device__ __forceinline__ u32 sk_cx32(u32 x, u32 side) {
+  u32 a = x, b = x;
+  asm("v_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));     // a = {x[0..31], x[0..31]}, b = {x[32..63], x[32..63]}
+  return sk_med3(a, b, side);
+}
+__device__ __forceinline__ u32 sk_cx16(u32 x, u32 side) {
+  u32 a = x, b = x;
+  asm("v_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));     // a = rows {0, 0, 2, 2} of x, b = rows {1, 1, 3, 3}
+  return sk_med3(a, b, side);
+}
+__device__ __forceinline__ u32 sk_cx8(u32 x, u32 side) { return sk_med3(x, sk_dpp<0x128>(x), side); }        // row_ror:8 = lane ^ 8
+__device__ __forceinline__ u32 sk_cx4(u32 x, u32 side) {
+  u32 y = (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x104, 0xF, 0x5, false);       // row_shl:4 -> banks 0, 2 read lane + 4
+  y = (u32)__builtin_amdgcn_update_dpp((int)y, (int)x, 0x114, 0xF, 0xA, false);      // row_shr:4 -> banks 1, 3 read lane - 4
+  return sk_med3(x, y, side);
+}
+__device__ __forceinline__ u32 sk_cx2(u32 x, u32 side) { return sk_med3(x, sk_dpp<0x4E>(x), side); }         // quad_perm [2,3,0,1]
+__device__ __forceinline__ u32 sk_cx1(u32 x, u32 side) { return sk_med3(x, sk_dpp<0xB1>(x), side); }         // quad_perm [1,0,3,2]
+
+// filled[i] = g[i] | (p[i] & filled[i - 1]), filled[-1] = cin: the carry chain of (g | p) + g + cin
+__device__ __forceinline__ u64 sk_fill_fwd(u64 g, u64 p, u32 cin) {
+  const u64 A = g | p, B = g;
+  const u64 S = A + B + (u64)cin;
+  const u64 c = S ^ A ^ B;                                          // c[i] = carry into bit i
+  const u64 cout = ((A & B) | ((A | B) & ~S)) >> 63;                // carry out of bit 63
+  return (c >> 1) | (cout << 63);
+}
+// filled[i] = g[i] | (p[i] & filled[i + 1])
+__device__ __forceinline__ u64 sk_fill_bwd(u64 g, u64 p) { return __brevll(sk_fill_fwd(__brevll(g), __brevll(p), 0u)); }
+
+__device__ __forceinline__ u64 sk_split(const u64* __restrict__ A, u64 na, const u64* __restrict__ B, u64 nb, u64 d) {
+  u64 lo = d > nb ? d - nb : 0, hi = d < na ? d : na;
+  const u32 lane = lane_id();
+  while (lo < hi) {
+    const u64 step = (hi - lo + 63) >> 6;
+    const u64 p = lo + (u64)lane * step + (step - 1);
+    bool pr = false;
+    if (p < hi) pr = A[p] <= B[d - 1 - p];
+    const u32 c = popc64(ballot64(pr));          // the predicate is monotone: the true lanes form a prefix
+    const u64 nlo = lo + (u64)c * step;
+    const u64 nhi = nlo + step - 1;
+    lo = nlo;
+    hi = nhi < hi ? nhi : hi;
+  }
+  return lo;
+}
+
+// kind_base: exclusive scan of the STREAMING work items per operator (this kernel's items); part_base: of all items (where an
+// item's count and scratch slot are recorded).  idx_v64: the index's resident coordinates (never the packed planes).
+__global__ __launch_bounds__(64, DCD_SK_WAVES) void k_pair_stream(const PairOp* __restrict__ ops, u32 n_ops, const u64* __restrict__ kind_base,
+                                                                  const u64* __restrict__ part_base, const u64* __restrict__ idx_v64, Pool pool,
+                                                                  u64* __restrict__ tmp, u64* __restrict__ part_count, u64* __restrict__ part_src,
+                                                                  u64 PART, unsigned long long* __restrict__ work_ctr) {
+  __shared__ __attribute__((aligned(16))) u64 s_ring[2 * SK_RING];
+  u64* sA = s_ring;
+  u64* sB = s_ring + SK_RING;
+  const u32 lane = threadIdx.x;
+  // side of the lane in the six cross-lane stages of the merge network (0 = keeps the minimum)
+  const u32 sd32 = (u32)((int)(lane << 26) >> 31), sd16 = (u32)((int)(lane << 27) >> 31), sd8 = (u32)((int)(lane << 28) >> 31);
+  const u32 sd4 = (u32)((int)(lane << 29) >> 31), sd2 = (u32)((int)(lane << 30) >> 31), sd1 = (u32)((int)(lane << 31) >> 31);
+  const u64 n_items = kind_base[n_ops];
+  u64 w = blockIdx.x;
+  while (w < n_items) {
+    unsigned long long w_next = 0;
+    if (lane == 0) w_next = atomicAdd(work_ctr, 1ull) + gridDim.x;
+    u32 oi;
+    {   // operator of this work item: last op with kind_base[op] <= w
+      u32 lo = 0, hi = n_ops;
+      while (lo + 1 < hi) { u32 m = (lo + hi) >> 1; if (kind_base[m] <= w) lo = m; else hi = m; }
+      oi = lo;
+    }
+    const u64 p = w - kind_base[oi];
+    const u64 wi = part_base[oi] + p;
+    const PairOp op = ops[oi];
+    const u64* __restrict__ A = op.a.kind ? pool.base + pool.res_off[op.a.cnt_ref] : idx_v64 + op.a.off;
+    const u64* __restrict__ B = op.b.kind ? pool.base + pool.res_off[op.b.cnt_ref] : idx_v64 + op.b.off;
+    const u64 na = seg_cnt(op.a, pool), nb = seg_cnt(op.b, pool);
+    u64* tmp_op = tmp + op.tmp_off;
+    const u32 absR = (u32)max(abs(op.Ra), abs(op.Rb));
+    const bool ordered = op.Ra < 0 && op.Rb < 0 && absR != 0;   // R = -absR < 0  (IndexSequence.cs:221-222)
+    const bool is_or = op.op == DCD_OP_OR;
+    const u32 thr = absR != 0 ? absR : 0xFFFFFFFFu;             // absR == 0: nothing ever breaks a chain
+    const u64 d_begin = p * PART, d_end = d_begin + PART;
+    u64 ia = rfl64(sk_split(A, na, B, nb, d_begin)), ib = d_begin - ia;
+    u64 prev_val = 0;
+    u32 prev_src = 0, have_prev = 0;
+    if (d_begin > 0) {
+      have_prev = 1;
+      const bool ua = ia > 0, ub = ib > 0;
+      const u64 pa = ua ? A[ia - 1] : 0, pb = ub ? B[ib - 1] : 0;
+      if (ua && ub) { if (pb >= pa) { prev_val = pb; prev_src = 1; } else { prev_val = pa; prev_src = 0; } }
+      else if (ua) { prev_val = pa; prev_src = 0; }
+      else { prev_val = pb; prev_src = 1; }
+      prev_val = rfl64(prev_val); prev_src = rfl(prev_src);
+    }
+    u64 g = d_begin;                 // union index of the next unconsumed element
+    u64 cursor = 0, out_start = 0;
+    u32 open = 0, committed = 0, seenA = 0;
+    u32 hA = 0, hB = 0;
+    bool skipping = !is_or;          // '*': nothing is owned before the first chain break of the partition
+    u64 slot = d_begin;
+    u64* out = tmp_op + slot;
+    u32 ra = (u32)min((u64)SK_TILE, na - ia), rb = (u32)min((u64)SK_TILE, nb - ib);
+    for (u32 i = lane; i < ra; i += 64) sA[sk_phys(i)] = A[ia + i];
+    for (u32 i = lane; i < rb; i += 64) sB[sk_phys(i)] = B[ib + i];
+    wsync();
+    while (ra + rb != 0) {
+      if (g >= d_end && (skipping || is_or)) break;
+      // ---- keys relative to the smallest staged coordinate --------------------------------------------------------
+      u64 base;
+      {
+        const u64 ha = ra ? sA[sk_phys(hA)] : ~0ull, hb = rb ? sB[sk_phys(hB)] : ~0ull;     // (one address: every lane gets the value)
+        base = rfl64(ha < hb ? ha : hb);
+      }
+      u32 x[4];
+      u32 ca = 0, cb = 0;
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const u32 t = lane * 4u + (u32)k, u = SK_TILE - 1u - t;
+        const u64 da = sA[sk_phys((hA + t) & (SK_TILE - 1u))] - base, db = sB[sk_phys((hB + u) & (SK_TILE - 1u))] - base;
+        const u32 ka = (t < ra && da < SK_LIM) ? ((u32)da << 1) : SK_INF;
+        const u32 kb = (u < rb && db < SK_LIM) ? (((u32)db << 1) | 1u) : SK_INF;
+        const bool ta = ka <= kb;                              // (equal only when both are +inf)
+        x[k] = ta ? ka : kb;
+        ca += popc64(ballot64(ta && ka != SK_INF));
+        cb += popc64(ballot64(!ta && kb != SK_INF));
+      }
+      ca = rfl(ca); cb = rfl(cb);
+      const u32 cnt = ca + cb;                                 // >= 1: the base element itself
+      // ---- request the refill (one stream of four loads per lane covers both operands) ---------------------------
+      const u32 keepA = ra - ca, keepB = rb - cb;
+      const u32 nra = (u32)min((u64)SK_TILE, na - ia - ca), nrb = (u32)min((u64)SK_TILE, nb - ib - cb);
+      const u32 newA = nra - keepA, newB = nrb - keepB;        // newA + newB <= 256: the tile frees ca + cb slots
+      u64 pf[4];
+      {
+        const u64 offA = ia + ra, offB = ib + rb - newA;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const u32 xx = lane + (u32)q * 64u;
+          const bool fa = xx < newA, act = xx < newA + newB;
+          const u64* src = fa ? A + offA : B + offB;
+          pf[q] = act ? src[xx] : 0ull;
+        }
+      }
+      // ---- bitonic merge: distances 128 .. 4 across lanes, 2 and 1 inside the lane (element t = 4 * lane + k) -------
+#pragma unroll
+      for (int k = 0; k < 4; k++) x[k] = sk_cx32(x[k], sd32);
+#pragma unroll
+      for (int k = 0; k < 4; k++) x[k] = sk_cx16(x[k], sd16);
+#pragma unroll
+      for (int k = 0; k < 4; k++) x[k] = sk_cx8(x[k], sd8);
+#pragma unroll
+      for (int k = 0; k < 4; k++) x[k] = sk_cx4(x[k], sd4);
+#pragma unroll
+      for (int k = 0; k < 4; k++) x[k] = sk_cx2(x[k], sd2);
+#pragma unroll
+      for (int k = 0; k < 4; k++) x[k] = sk_cx1(x[k], sd1);
+      {
+        const u32 t0 = min(x[0], x[2]), t2 = max(x[0], x[2]), t1 = min(x[1], x[3]), t3 = max(x[1], x[3]);
+        x[0] = min(t0, t1); x[1] = max(t0, t1); x[2] = min(t2, t3); x[3] = max(t2, t3);
+      }
+      // ---- neighbours: gap to the predecessor, chain breaks, duplicates, cross-operand contacts -------------------
+      // (the element before the tile is the carried one: its distance to the base saturates far above any absR)
+      u32 pgap = 0xFFFFFFFFu;
+      if (have_prev) { const u64 dd = base - prev_val; pgap = dd < 0xFFFFFFFFull ? (u32)dd : 0xFFFFFFFFu; }
+      u32 brk[4], dup[4], ctc[4], al[4], src[4];
+      {
+        u32 pkey = (u32)__builtin_amdgcn_update_dpp(0, (int)x[3], 0x138, 0xF, 0xF, false);     // wave_shr:1: x[3] of the lane below
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const bool valid = x[k] != SK_INF;                   // (the cnt valid keys are the first cnt elements)
+          const u32 sr = x[k] & 1u;
+          u32 gap = (x[k] >> 1) - (pkey >> 1), psrc = pkey & 1u, hp = 1u;
+          if (k == 0) {
+            const bool l0 = lane == 0;
+            gap = l0 ? pgap : gap; psrc = l0 ? prev_src : psrc; hp = l0 ? have_prev : 1u;
+          }
+          const bool bk = !hp || gap > thr;
+          src[k] = valid ? sr : 0u;
+          al[k] = valid ? 1u : 0u;
+          brk[k] = (valid && bk) ? 1u : 0u;
+          dup[k] = (valid && sr == 1u && hp && psrc == 0u && gap == 0u) ? 1u : 0u;
+          ctc[k] = (valid && hp && psrc != sr && !bk) ? 1u : 0u;   // neighbours from different operands within absR
+          pkey = x[k];
+        }
+      }
+      // the rings have been read: store the refill (visible to the next tile after the wsync that ends this one)
+      wsync();
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const u32 xx = lane + (u32)q * 64u;
+        if (xx < newA) sA[sk_phys((hA + ra + xx) & (SK_TILE - 1u))] = pf[q];
+        else if (xx < newA + newB) sB[sk_phys((hB + rb + xx - newA) & (SK_TILE - 1u))] = pf[q];
+      }
+      // the tile's last element
+      const u32 last_lane = (cnt - 1u) >> 2, last_k = (cnt - 1u) & 3u;
+      u32 lkey = x[0];
+#pragma unroll
+      for (int k = 1; k < 4; k++) lkey = (u32)k == last_k ? x[k] : lkey;
+      lkey = rdl(lkey, last_lane);
+      const u64 t_last_val = base + (u64)(lkey >> 1);
+      const u32 t_last_src = lkey & 1u;
+      const bool inputs_end = (ia + ca == na) && (ib + cb == nb);
+      // ---- ownership: [t_lo, t_hi) of this tile belongs to the work item ------------------------------------------
+      u32 t_lo = 0, t_hi = cnt;
+      const bool may_end = g + cnt > d_end;
+      if (skipping || may_end) {
+        const u32 lim = may_end ? (d_end > g ? (u32)(d_end - g) : 0u) : 0xFFFFFFFFu;
+        u32 fbk = 4, fek = 4;
+#pragma unroll
+        for (int k = 3; k >= 0; k--) {
+          const bool c = al[k] && (is_or || brk[k]);
+          if (c) fbk = (u32)k;
+          if (c && lane * 4u + (u32)k >= lim) fek = (u32)k;
+        }
+        const u64 Bf = ballot64(fbk < 4u), Ef = ballot64(fek < 4u);
+        u32 fb = NONE32, fe = NONE32;
+        if (Bf) { const u32 l = (u32)__builtin_ctzll(Bf); fb = l * 4u + rdl(fbk, l); }
+        if (Ef) { const u32 l = (u32)__builtin_ctzll(Ef); fe = l * 4u + rdl(fek, l); }
+        if (skipping) t_lo = min(fb, cnt);
+        if (may_end) t_hi = min(fe, cnt);
+        if (t_hi < t_lo) t_hi = t_lo;
+      }
+      const bool ends_here = t_hi < cnt;       // a chain break at or beyond the partition end: stop before it
+      auto advance = [&]() {
+        ia += ca; ib += cb;
+        hA = (hA + ca) & (SK_TILE - 1u); hB = (hB + cb) & (SK_TILE - 1u);
+        ra = nra; rb = nrb;
+        prev_val = t_last_val; prev_src = t_last_src; have_prev = 1;
+        g += cnt;
+      };
+      if (t_lo >= t_hi) {                      // nothing owned in this tile
+        if (ends_here) {
+          if (open && !committed) cursor = out_start;   // the carried chain closes without the other operand
+          open = 0;
+          break;
+        }
+        advance();
+        wsync();
+        continue;
+      }
+      if (skipping) { skipping = false; slot = g + t_lo; out = tmp_op + slot; }
+      if (t_lo > 0 || ends_here) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const u32 t = lane * 4u + (u32)k;
+          const bool a = t >= t_lo && t < t_hi;
+          if (!a) { al[k] = 0; brk[k] = 0; ctc[k] = 0; }
+        }
+      }
+      const bool final_tile = ends_here || inputs_end;
+      // ---- chains ----------------------------------------------------------------------------------------------------
+      // A chain is emitted iff it holds both operands, i.e. iff two NEIGHBOURS of it come from different operands (ordered
+      // mode: an element of the right operand directly after one of the left operand -- "a right element at or after the
+      // first left element"), and ordered mode emits only from the first left element of the chain on.
+      // In the lane: running ORs since the lane's last break (forward) and up to its next break (backward).
+      u32 fx[4], fa[4], bx[4], head[4], tailp[4];
+      u32 any_brk = 0, tail_x, tail_a, head_x, last_bk = 0;
+      {
+        u32 ax = 0, aa = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const u32 xq = (ctc[k] && (!ordered || src[k] == 1u)) ? 1u : 0u;     // contact with the predecessor (never on a break)
+          const u32 aq = (al[k] && src[k] == 0u) ? 1u : 0u;
+          if (brk[k]) { ax = 0; aa = 0; any_brk = 1; last_bk = (u32)k; }
+          ax |= xq; aa |= aq;
+          fx[k] = ax; fa[k] = aa;
+          head[k] = any_brk ^ 1u;                                              // no break at or before k in this lane
+          bx[k] = xq;
+        }
+        tail_x = ax; tail_a = aa;
+        u32 b = 0, later_brk = 0;
+#pragma unroll
+        for (int k = 3; k >= 0; k--) {
+          b |= bx[k];
+          bx[k] = b;                                                           // OR from k to the end of its run inside the lane
+          tailp[k] = later_brk ^ 1u;                                           // no break behind k in this lane
+          if (brk[k]) { b = 0; later_brk = 1; }
+        }
+        head_x = b;                                                            // OR over the elements before the lane's first break
+      }
+      // Across the lanes: a chain runs from the tail part of a lane with a break through the lanes without one into the head
+      // part of the next lane with a break -- segmented ORs over 64 lanes = carry chains of one scalar addition each.
+      const u64 Bm = ballot64(any_brk != 0u);
+      const u64 Pm = ~Bm;
+      const u64 Fx = sk_fill_fwd(ballot64(tail_x != 0u), Pm, committed);       // chain leaving lane l holds a contact (so far)
+      const u64 Gx = sk_fill_bwd(ballot64(head_x != 0u), Pm);                  // chain entering lane l holds one further on
+      const u32 in_x = sk_lane_bit((Fx << 1) | (u64)committed), out_x = sk_lane_bit(Gx >> 1);
+      u32 in_a = 1u;
+      u64 Fa = 0;
+      if (ordered) {
+        Fa = sk_fill_fwd(ballot64(tail_a != 0u), Pm, seenA);
+        in_a = sk_lane_bit((Fa << 1) | (u64)seenA);
+      }
+      const bool has_brk = Bm != 0ull;                                         // a chain starts in this tile
+      u32 LB = 0;                                                              // position of the tile's last break
+      if (has_brk) { const u32 l = 63u - (u32)__builtin_clzll(Bm); LB = l * 4u + rdl(last_bk, l); }
+      const bool chain0_commit = committed || ((Gx & 1ull) != 0ull);           // (Gx bit 0: a contact before the tile's first break)
+      if (!is_or && open && !committed && (has_brk || final_tile) && !chain0_commit) cursor = out_start;   // roll back
+      u32 emit[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const u32 t = lane * 4u + (u32)k;
+        u32 e = 0;
+        if (al[k] && !dup[k]) {
+          if (is_or) e = 1;
+          else {
+            const u32 cm = fx[k] | bx[k] | (head[k] & in_x) | (tailp[k] & out_x);
+            const u32 sa = ordered ? (fa[k] | (head[k] & in_a)) : 1u;
+            const bool closed = final_tile || (has_brk && t < LB);
+            e = (sa && (closed ? cm : 1u)) ? 1u : 0u;
+          }
+        }
+        emit[k] = e;
+      }
+      // compaction: position = emitted elements before (lanes below: v_mbcnt over the four ballots; in the lane: running sum)
+      u64 Em[4];
+      u32 pos = 0, total_emit = 0;
+#pragma unroll
+      for (int k = 0; k < 4; k++) { Em[k] = ballot64(emit[k] != 0u); pos += mbcnt(Em[k]); total_emit += popc64(Em[k]); }
+      {
+        u32 e = pos;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          if (emit[k]) out[cursor + e] = base + (u64)(x[k] >> 1);
+          e += emit[k];
+        }
+      }
+      {
+        // the chain that is open at the end of the tile: where its output starts, whether it holds a contact / a left element
+        u32 before_lb = 0;                                                     // emitted elements in front of the last break
+        if (has_brk) {
+          const u32 ll = LB >> 2, lk = LB & 3u;
+          const u64 below = (1ull << ll) - 1ull, incl = below | (1ull << ll);
+#pragma unroll
+          for (int k = 0; k < 4; k++) before_lb += popc64(Em[k] & ((u32)k < lk ? incl : below));
+        }
+        const bool com = (Fx >> 63) != 0ull;
+        const bool hasA = (Fa >> 63) != 0ull;                                  // (only ordered mode looks at it)
+        if (has_brk || !open) out_start = cursor + before_lb;
+        open = 1; seenA = hasA ? 1u : 0u; committed = com ? 1u : 0u;
+        cursor += total_emit;
+      }
+      if (ends_here) { open = 0; break; }
+      advance();
+      wsync();
+    }
+    if (lane == 0) { part_count[wi] = cursor; part_src[wi] = slot; }
+    wsync();                                                     // (the next item reuses the rings)
+    w = rfl64(w_next);
+  }
+}
+
+}  // namespace dcd

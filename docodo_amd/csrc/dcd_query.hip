@@ -644,18 +644,22 @@ __device__ void part_gallop(const CV& Sv, u64 ns, const CV& Lv, u64 nl, bool s_i
 #endif
 constexpr u32 GAL_PER = DCD_GAL_PER;
 static_assert(DCD_GAL_PER <= 65536, "part_gallop's walk-list entries are 16-bit element indices");      // short-list elements per galloping work item (256 / 512 / 1024 / 2048 -> 26.5 / 24.3 / 23.8 / 23.8 ms per 20 k C4 queries)
-constexpr u8 MODE_NONE = 0, MODE_STREAM = 1, MODE_GALLOP = 2;
+constexpr u8 MODE_NONE = 0, MODE_STREAM = 1, MODE_GALLOP = 2, MODE_STREAM32 = 3;
+// items_all: work items of the operator; items_old / items_s32: the same number in the array of the kernel that evaluates them
+// (k_pair_parts: galloping items and, with stream32 == 0, the streaming ones; k_pair_stream: the streaming items) -- each kernel
+// numbers its own items through the scan of its array and records an item at the operator's place in the scan of items_all.
 __global__ void k_pair_plan(const PairOp* __restrict__ ops, u32 n_ops, IdxVals idx_values, Pool pool,
-                            u64 PART, u32* __restrict__ items, u8* __restrict__ mode, u32 gal_ratio) {
+                            u64 PART, u32* __restrict__ items_all, u32* __restrict__ items_old, u32* __restrict__ items_s32,
+                            u8* __restrict__ mode, u32 gal_ratio, u32 stream32) {
   u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i > n_ops) return;
-  if (i == n_ops) { items[i] = 0; return; }
-  if (*pool.overflow) { items[i] = 0; mode[i] = MODE_NONE; return; }     // the pool ran full: the sub-batch is abandoned
+  if (i == n_ops) { items_all[i] = 0; items_old[i] = 0; items_s32[i] = 0; return; }
+  if (*pool.overflow) { items_all[i] = 0; items_old[i] = 0; items_s32[i] = 0; mode[i] = MODE_NONE; return; }     // the pool ran full: the sub-batch is abandoned
   const PairOp op = ops[i];
   const u64 na = seg_cnt(op.a, pool), nb = seg_cnt(op.b, pool);
   const bool is_or = op.op == DCD_OP_OR;
   const u32 absR = (u32)max(abs(op.Ra), abs(op.Rb));
-  u8 m = MODE_STREAM;
+  u8 m = stream32 ? MODE_STREAM32 : MODE_STREAM;
   u64 n = (na + nb + PART - 1) / PART;
   if (!is_or && (na == 0 || nb == 0)) { m = MODE_NONE; n = 0; }          // '*' with an empty operand is empty
   else if (!is_or && absR != 0) {
@@ -664,11 +668,14 @@ __global__ void k_pair_plan(const PairOp* __restrict__ ops, u32 n_ops, IdxVals i
     const CV Lv = seg_cv(a_short ? op.b : op.a, idx_values, pool);
     if (ns * (u64)gal_ratio <= nl && (Lv[nl - 1] - Lv[0]) / nl > 4ull * absR) { m = MODE_GALLOP; n = (ns + GAL_PER - 1) / GAL_PER; }
   }
-  items[i] = (u32)n;
+  items_all[i] = (u32)n;
+  items_old[i] = m == MODE_STREAM32 ? 0u : (u32)n;
+  items_s32[i] = m == MODE_STREAM32 ? (u32)n : 0u;
   mode[i] = m;
 }
 
-__global__ __launch_bounds__(PW_T, DCD_PW_WAVES) void k_pair_parts(const PairOp* __restrict__ ops, u32 n_ops, const u64* __restrict__ part_base,
+__global__ __launch_bounds__(PW_T, DCD_PW_WAVES) void k_pair_parts(const PairOp* __restrict__ ops, u32 n_ops, const u64* __restrict__ kind_base,
+                                                    const u64* __restrict__ part_base,
                                                     IdxVals idx_values, Pool pool, u64* __restrict__ tmp, u64* __restrict__ part_count,
                                                     u64* __restrict__ part_src, u64 PART, const u32* __restrict__ dirs,
                                                     u64 dir_max_coord, const u8* __restrict__ op_mode, u64 W_cap, unsigned long long* __restrict__ work_ctr) {
@@ -684,21 +691,24 @@ __global__ __launch_bounds__(PW_T, DCD_PW_WAVES) void k_pair_parts(const PairOp*
   // once in the second round of a configs[3] batch (the bound of an intermediate result is the sum of its operands): 0.7 ns
   // each, 1 - 2 ms of a 20 ms batch.  (A static stride over the items instead of the counter was 10 % slower on configs[3]:
   // the items differ too much.)  The counter is read one item ahead, so its round trip hides behind the item's work.
-  const u64 n_items = part_base[n_ops];
-  for (u64 x = n_items + (u64)blockIdx.x * PW_T + lane; x < W_cap; x += (u64)gridDim.x * PW_T) { part_count[x] = 0; part_src[x] = 0; }   // (the scans run over the capacity)
+  // (kind_base: exclusive scan of THIS kernel's items per operator; part_base: of all items of the slice -- the streaming items
+  // may belong to k_pair_stream, which runs beside this kernel)
+  const u64 n_items = kind_base[n_ops];
+  for (u64 x = part_base[n_ops] + (u64)blockIdx.x * PW_T + lane; x < W_cap; x += (u64)gridDim.x * PW_T) { part_count[x] = 0; part_src[x] = 0; }   // (the scans run over the capacity)
   u64 w = blockIdx.x;
   while (w < n_items) {
   unsigned long long w_next = 0;
   if (lane == 0) w_next = atomicAdd(work_ctr, 1ull) + gridDim.x;
   PROF_T();
   u32 oi;
-  {   // operator of this work item: last op with part_base[op] <= w
+  {   // operator of this work item: last op with kind_base[op] <= w
     u32 lo = 0, hi = n_ops;
-    while (lo + 1 < hi) { u32 m = (lo + hi) >> 1; if (part_base[m] <= w) lo = m; else hi = m; }
+    while (lo + 1 < hi) { u32 m = (lo + hi) >> 1; if (kind_base[m] <= w) lo = m; else hi = m; }
     oi = lo;
   }
   PROF(0);   // operator lookup
-  const u64 p = w - part_base[oi];
+  const u64 p = w - kind_base[oi];
+  const u64 wi = part_base[oi] + p;              // the item's place among all items of the slice
   const PairOp op = ops[oi];
   const CV A = seg_cv(op.a, idx_values, pool);
   const CV B = seg_cv(op.b, idx_values, pool);
@@ -1051,13 +1061,17 @@ __global__ __launch_bounds__(PW_T, DCD_PW_WAVES) void k_pair_parts(const PairOp*
       count = cursor;
     }
   }
-  if (lane == 0) { part_count[w] = count; part_src[w] = slot; }
+  if (lane == 0) { part_count[wi] = count; part_src[wi] = slot; }
   PROF(10);
   wsync();                                                     // (the next item reuses the rings / records)
   w = rfl64(w_next);
   }
   PROF_END();
 }
+
+}  // namespace dcd
+#include "dcd_pair_stream.h"
+namespace dcd {
 
 // out[...] <- scratch: one group of EIGHT LANES per work item (64 bytes per step), eight items per wavefront at a time.
 // (Round 3.  It used to be 64 items per wavefront, copied eight at a time one group after the other: with ~100 values per item
@@ -1373,6 +1387,7 @@ struct dcd_results {
   bool downloaded = true;        // false: dcd_query_opts.no_download -- only status / page_off / doc_off and the totals are here
   u64 n_pages_total = 0, n_pos_total = 0, n_docs_total = 0;
   u64 ops_named = 0, ops_evaluated = 0, units_named = 0, units_evaluated = 0;   // common sub-expressions, see SubBatch
+  u64 sub_batches = 0;
 };
 
 static int32_t ensure_values(dcd_index* h) {
@@ -1758,10 +1773,15 @@ static int32_t exec_chunk(dcd_index* h, const dcd_query_opts& o, SubBatchDev& D,
   // ---- device buffers of the chunk (from the library's device cache) --------------------------------
   DevBuf<PairOp> d_ops;
   DevBuf<u64> d_part_base, d_part_count, d_part_src, d_part_excl, d_part_scr, d_slice_cnt, d_slice_off, d_slice_scr, d_work_ctr;
-  DevBuf<u32> d_items;
+  DevBuf<u32> d_items, d_items_old, d_items_s32;
+  DevBuf<u64> d_base_old, d_base_s32;
   DevBuf<u8> d_mode;
   DCD_TRY(d_ops.alloc(dev, C.n_ops ? C.n_ops : 1));
   DCD_TRY(d_items.alloc(dev, (size_t)C.max_slice_ops + 1));
+  DCD_TRY(d_items_old.alloc(dev, (size_t)C.max_slice_ops + 1));
+  DCD_TRY(d_items_s32.alloc(dev, (size_t)C.max_slice_ops + 1));
+  DCD_TRY(d_base_old.alloc(dev, (size_t)C.max_slice_ops + 1));
+  DCD_TRY(d_base_s32.alloc(dev, (size_t)C.max_slice_ops + 1));
   DCD_TRY(d_mode.alloc(dev, (size_t)C.max_slice_ops + 1));
   DCD_TRY(d_part_base.alloc(dev, (size_t)C.max_slice_ops + 1));
   DCD_TRY(d_slice_cnt.alloc(dev, (size_t)C.max_slice_ops + 1));
@@ -1771,7 +1791,7 @@ static int32_t exec_chunk(dcd_index* h, const dcd_query_opts& o, SubBatchDev& D,
   DCD_TRY(d_part_src.alloc(dev, C.max_W + 1));
   DCD_TRY(d_part_excl.alloc(dev, C.max_W + 1));
   DCD_TRY(d_part_scr.alloc(dev, scan_scratch_elems(C.max_W + 1)));
-  DCD_TRY(d_work_ctr.alloc(dev, std::max<size_t>(1, C.slices.size())));
+  DCD_TRY(d_work_ctr.alloc(dev, std::max<size_t>(1, 2 * C.slices.size())));
   DevBuf<FinalSeq> d_fin;
   DCD_TRY(d_fin.alloc(dev, nq ? nq : 1));
   DevBuf<QCounts> d_qc;
@@ -1782,12 +1802,28 @@ static int32_t exec_chunk(dcd_index* h, const dcd_query_opts& o, SubBatchDev& D,
   // the plan was written into pinned staging by the planner: two asynchronous uploads
   if (C.n_ops) DCD_HIP(hipMemcpyAsync(d_ops.p, C.ops, C.n_ops * sizeof(PairOp), hipMemcpyHostToDevice, st));
   if (nq) DCD_HIP(hipMemcpyAsync(d_fin.p, C.finals, nq * sizeof(FinalSeq), hipMemcpyHostToDevice, st));
-  DCD_HIP(hipMemsetAsync(d_work_ctr.p, 0, std::max<size_t>(1, C.slices.size()) * sizeof(u64), st));
+  DCD_HIP(hipMemsetAsync(d_work_ctr.p, 0, std::max<size_t>(1, 2 * C.slices.size()) * sizeof(u64), st));
+  // k_pair_stream (32-bit tile-relative keys) takes the streaming work items unless the resident coordinates are packed planes
+  static const bool env_s32 = !(getenv("DOCODO_QUERY_STREAM32") && atoi(getenv("DOCODO_QUERY_STREAM32")) == 0);   // (A/B knob)
+  const bool stream32 = env_s32 && idx_values.v64 != nullptr && !C.slices.empty();
+  struct SideStream {                                       // second stream + the two events that order it against the main one
+    int dev; hipStream_t s = nullptr; hipEvent_t a = nullptr, b = nullptr;
+    ~SideStream() { if (s) stream_release(dev, s); if (a) event_release(dev, a); if (b) event_release(dev, b); }
+  } side{dev};
+  hipStream_t st2 = nullptr;
+  hipEvent_t ev_plan = nullptr, ev_s32 = nullptr;
+  if (stream32) {
+    DCD_TRY(stream_acquire(dev, &side.s));
+    side.a = event_acquire(dev); side.b = event_acquire(dev);
+    if (!side.a || !side.b) DCD_FAIL(DCD_E_HIP, "hipEventCreate failed");
+    st2 = side.s; ev_plan = side.a; ev_s32 = side.b;
+  }
 
   EvTimer tm;
   DCD_TRY(tm.init(st, dev));
   DCD_TRY(tm.start());
   const u64 pw_grid = pw_grid_of(dev);
+  const u64 sk_grid = std::max<u64>(1, pw_grid * DCD_SK_WAVES / DCD_PW_WAVES);       // (the same multiple of ITS wavefront slots)
   static const u32 gal_ratio = getenv("DOCODO_QUERY_GAL_RATIO") ? (u32)atoi(getenv("DOCODO_QUERY_GAL_RATIO")) : GAL_RATIO;   // (A/B knob)
   for (size_t s = 0; s < C.slices.size(); s++) {
     const SliceInfo& sl = C.slices[s];
@@ -1796,12 +1832,25 @@ static int32_t exec_chunk(dcd_index* h, const dcd_query_opts& o, SubBatchDev& D,
     const PairOp* ops = d_ops.p + sl.first;
     if (sl.tmp_elems > D.scratch_cap) DCD_FAIL(DCD_E_NOMEM, "query slice needs %llu scratch elements, the arena has %llu",
                                                (unsigned long long)sl.tmp_elems, (unsigned long long)D.scratch_cap);
-    // device plan: item count + mode per operator, exclusive scan -> first work item of every operator
-    hipLaunchKernelGGL(k_pair_plan, dim3(div_up(n + 1, 256)), dim3(256), 0, st, ops, n, idx_values, pool, PART, d_items.p, d_mode.p, gal_ratio);
+    // device plan: item count + mode per operator, exclusive scans -> first work item of every operator (of all items, and per kernel)
+    hipLaunchKernelGGL(k_pair_plan, dim3((u32)div_up((u64)n + 1, 256)), dim3(256), 0, st, ops, n, idx_values, pool, PART, d_items.p, d_items_old.p,
+                       d_items_s32.p, d_mode.p, gal_ratio, stream32 ? 1u : 0u);
     scan_exclusive<u32, u64>(d_items.p, d_part_base.p, (u64)n + 1, d_part_scr.p, st);
-    hipLaunchKernelGGL(k_pair_parts, dim3((u32)std::min<u64>(W, pw_grid)), dim3(PW_T), 0, st, ops, n, d_part_base.p, idx_values, pool,
+    scan_exclusive<u32, u64>(d_items_old.p, d_base_old.p, (u64)n + 1, d_part_scr.p, st);
+    if (stream32) {
+      // the streaming items run BESIDE the galloping ones, on a second stream: memory-bound galloping wavefronts and the
+      // merging ones share the CUs (round 3 measured the two kinds in consecutive launches: 35 % slower than in one)
+      scan_exclusive<u32, u64>(d_items_s32.p, d_base_s32.p, (u64)n + 1, d_part_scr.p, st);
+      DCD_HIP(hipEventRecord(ev_plan, st));
+      DCD_HIP(hipStreamWaitEvent(st2, ev_plan, 0));
+      hipLaunchKernelGGL(k_pair_stream, dim3((u32)std::min<u64>(W, sk_grid)), dim3(64), 0, st2, ops, n, d_base_s32.p, d_part_base.p, idx_values.v64,
+                         pool, D.tmp, d_part_count.p, d_part_src.p, PART, reinterpret_cast<unsigned long long*>(d_work_ctr.p + 2 * s + 1));
+      DCD_HIP(hipEventRecord(ev_s32, st2));
+    }
+    hipLaunchKernelGGL(k_pair_parts, dim3((u32)std::min<u64>(W, pw_grid)), dim3(PW_T), 0, st, ops, n, d_base_old.p, d_part_base.p, idx_values, pool,
                        D.tmp, d_part_count.p, d_part_src.p, PART, ext_values ? nullptr : h->dir.p, ix.max_coord, d_mode.p, W,
-                       reinterpret_cast<unsigned long long*>(d_work_ctr.p + s));
+                       reinterpret_cast<unsigned long long*>(d_work_ctr.p + 2 * s));
+    if (stream32) DCD_HIP(hipStreamWaitEvent(st, ev_s32, 0));
     DCD_HIP(hipMemsetAsync(d_part_count.p + W, 0, 8, st));
     scan_exclusive<u64, u64>(d_part_count.p, d_part_excl.p, W + 1, d_part_scr.p, st);
     // result lengths -> their places in the pool (device-side bump allocation) -> copy out of the scratch
@@ -2012,6 +2061,7 @@ static void append_results(dcd_results& dst, const dcd_results& src) {
   dst.ms_device += src.ms_device;
   dst.ops_named += src.ops_named; dst.ops_evaluated += src.ops_evaluated;
   dst.units_named += src.units_named; dst.units_evaluated += src.units_evaluated;
+  dst.sub_batches += src.sub_batches;
 }
 
 // The handle's work arena = [pool | scratch].  Round 4: its DEFAULT size is an eighth of the device memory (round 3: half of
@@ -2125,6 +2175,7 @@ static int32_t run_sub_batch(dcd_index* h, const int32_t* prog, const u64* prog_
   R->ops_evaluated += sb.n_refs;
   R->units_named += sb.units_named;
   R->units_evaluated += sb.units_evaluated;
+  R->sub_batches += 1;
   return DCD_OK;
 }
 
@@ -2299,6 +2350,7 @@ int32_t dcd_results_get(dcd_results* r, dcd_results_view* v) {
   v->n_pages_total = r->n_pages_total; v->n_pos_total = r->n_pos_total; v->n_docs_total = r->n_docs_total;
   v->ops_named = r->ops_named; v->ops_evaluated = r->ops_evaluated;
   v->units_named = r->units_named; v->units_evaluated = r->units_evaluated;
+  v->sub_batches = r->sub_batches;
   if (!r->downloaded) {          // (no_download: the CSR arrays stayed on the device and are gone; the offsets and totals are valid)
     v->page_index = nullptr; v->page_rank = nullptr; v->pos_off = nullptr; v->pos = nullptr;
     v->doc_index = nullptr; v->doc_rank = nullptr; v->doc_n_pages = nullptr;

@@ -199,6 +199,7 @@ class QueryBatchResult:
         # common sub-expressions (dcd_results_view, ABI 2): operators named by the programs / evaluated, units of their index terms
         self.ops_named, self.ops_evaluated = int(view.ops_named), int(view.ops_evaluated)
         self.units_named, self.units_evaluated = int(view.units_named), int(view.units_evaluated)
+        self.sub_batches = int(view.sub_batches)
 
     def pages(self, q):
         a, b = int(self.page_off[q]), int(self.page_off[q + 1])
@@ -428,7 +429,8 @@ class Index:
             if totals:
                 return {"ms": float(v.ms_device), "n_pages": int(v.n_pages_total), "n_pos": int(v.n_pos_total), "n_docs": int(v.n_docs_total),
                         "ops_named": int(v.ops_named), "ops_evaluated": int(v.ops_evaluated),
-                        "units_named": int(v.units_named), "units_evaluated": int(v.units_evaluated)}
+                        "units_named": int(v.units_named), "units_evaluated": int(v.units_evaluated),
+                        "sub_batches": int(v.sub_batches)}
             if keep_handle:
                 return v.ms_device
             return QueryBatchResult(v)

@@ -315,6 +315,7 @@ typedef struct dcd_results_view {
    * operator with the same operands, R values and opcode as an earlier one of the (sub-)batch refers to that one's result;
    * units_*: ushort units of the index-term operands of those operators (2 bytes each: the bytes the operators had to read) */
   uint64_t ops_named, ops_evaluated, units_named, units_evaluated;
+  uint64_t sub_batches;         /* 1, or more when the results of the batch's operators did not fit the work pool together */
 } dcd_results_view;
 int32_t dcd_results_get(dcd_results* r, dcd_results_view* out);
 void dcd_results_free(dcd_results* r);

@@ -248,9 +248,8 @@ def test_a_full_work_pool_is_retried_with_smaller_sub_batches(synth_index, monke
         assert len(b.status) == len(off) - 1
         for name in _RESULT_ARRAYS:
             assert np.array_equal(getattr(a, name), getattr(b, name)), (lg, name)
-        if (1 << lg) < a.pos.size:        # the final sequences alone (>= the positions they yield) exceed the pool: it was split
-            split += 1
-    assert split >= 1
+        split += b.sub_batches > 1
+    assert a.sub_batches == 1 and split >= 1
 
 
 def test_chunked_batches_and_shared_operators(synth_index, monkeypatch):
