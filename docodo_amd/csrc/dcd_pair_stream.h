@@ -11,7 +11,7 @@
 //     No 64-bit fallback path exists or is needed;
 //   * the bitonic merge as ONE v_med3_u32 per compare-exchange (med3(x, y, 0) = min, med3(x, y, ~0) = max: the third operand is
 //     the lane's side of the stage), partners fetched by DPP (row_ror:8, quad_perm, row_shl/shr:4) and by the gfx950 lane swaps
-//     v_permlane32_swap / v_permlane16_swap -- no LDS crossbar, no address registers;
+//     v_permlane32_swap / v_permlane16_swap -- no LDS crossbar, no address registers; 61 instructions per 256-key tile;
 //   * the chain logic on BALLOT MASKS: a lane summarises its four consecutive elements (break inside? flags of the part that
 //     belongs to the chain entering / leaving the lane), the cross-lane part -- "does the chain hold a contact", "a left element
 //     at or before me" -- is a segmented OR over 64 lanes, which is the carry chain of ONE 64-bit scalar addition
@@ -44,27 +44,69 @@ __device__ __forceinline__ u32 sk_lane_bit(u64 m) {
   asm("v_cndmask_b32 %0, 0, 1, %1" : "=v"(r) : "s"(m));
   return r;
 }
-template <int CTRL>
-__device__ __forceinline__ u32 sk_dpp(u32 v) { return (u32)__builtin_amdgcn_mov_dpp((int)v, CTRL, 0xF, 0xF, true); }
-// compare-exchange with the lane whose number differs in one bit; side = 0 in the lanes that keep the minimum, ~0 in the others
-__device__ __forceinline__ u32 sk_cx32(u32 x, u32 side) {
-  u32 a = x, b = x;
-  asm("v_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));     // a = {x[0..31], x[0..31]}, b = {x[32..63], x[32..63]}
-  return sk_med3(a, b, side);
+// One stage of the merge network = the compare-exchange of all FOUR elements of the lane with the lane whose number differs in one
+// bit: x[k] = med3(x[k], partner's x[k], side), side = 0 in the lanes that keep the minimum, ~0 in the others.  Every stage is
+// ONE asm block in which the four elements are interleaved: a DPP move must not read a register less than two wait states after
+// a vector instruction wrote it (likewise the lane swaps), and the compiler cannot see that hazard between inline-asm statements
+// -- a block of 4 moves + 4 v_med3 keeps every such pair at least three instructions apart, with no s_nop.
+// (first block: the keys come straight from compiler-generated selects, hence the leading s_nop 1)
+#define SK_OPS4(x, t) "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "=&v"(t[0]), "=&v"(t[1]), "=&v"(t[2]), "=&v"(t[3])
+#define SK_MED3_4 "v_med3_u32 %0, %0, %4, %8\n v_med3_u32 %1, %1, %5, %8\n v_med3_u32 %2, %2, %6, %8\n v_med3_u32 %3, %3, %7, %8\n"
+__device__ __forceinline__ void sk_stage32(u32 (&x)[4], u32 side) {
+  u32 t[4];
+  asm volatile("s_nop 1\n"
+               "v_mov_b32 %4, %0\n v_mov_b32 %5, %1\n v_mov_b32 %6, %2\n v_mov_b32 %7, %3\n"
+               // v_permlane32_swap a, b: a = {a[0..31], b[0..31]}, b = {a[32..63], b[32..63]} -- with a == b == x: the low half of x
+               // in both halves of a, the high half in both halves of b: min belongs to lanes 0..31, max to lanes 32..63
+               "v_permlane32_swap_b32 %0, %4\n v_permlane32_swap_b32 %1, %5\n v_permlane32_swap_b32 %2, %6\n v_permlane32_swap_b32 %3, %7\n"
+               SK_MED3_4 : SK_OPS4(x, t) : "v"(side));
 }
-__device__ __forceinline__ u32 sk_cx16(u32 x, u32 side) {
-  u32 a = x, b = x;
-  asm("v_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));     // a = rows {0, 0, 2, 2} of x, b = rows {1, 1, 3, 3}
-  return sk_med3(a, b, side);
+__device__ __forceinline__ void sk_stage16(u32 (&x)[4], u32 side) {
+  u32 t[4];
+  asm volatile("v_mov_b32 %4, %0\n v_mov_b32 %5, %1\n v_mov_b32 %6, %2\n v_mov_b32 %7, %3\n"
+               // v_permlane16_swap a, b: odd rows of a <-> even rows of b: a = rows {0, 0, 2, 2} of x, b = rows {1, 1, 3, 3}
+               "v_permlane16_swap_b32 %0, %4\n v_permlane16_swap_b32 %1, %5\n v_permlane16_swap_b32 %2, %6\n v_permlane16_swap_b32 %3, %7\n"
+               SK_MED3_4 : SK_OPS4(x, t) : "v"(side));
 }
-__device__ __forceinline__ u32 sk_cx8(u32 x, u32 side) { return sk_med3(x, sk_dpp<0x128>(x), side); }        // row_ror:8 = lane ^ 8
-__device__ __forceinline__ u32 sk_cx4(u32 x, u32 side) {
-  u32 y = (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x104, 0xF, 0x5, false);       // row_shl:4 -> banks 0, 2 read lane + 4
-  y = (u32)__builtin_amdgcn_update_dpp((int)y, (int)x, 0x114, 0xF, 0xA, false);      // row_shr:4 -> banks 1, 3 read lane - 4
-  return sk_med3(x, y, side);
+#define SK_DPP4(ctrl) "v_mov_b32_dpp %4, %0 " ctrl "\n v_mov_b32_dpp %5, %1 " ctrl "\n v_mov_b32_dpp %6, %2 " ctrl "\n v_mov_b32_dpp %7, %3 " ctrl "\n"
+__device__ __forceinline__ void sk_stage8(u32 (&x)[4], u32 side) {      // row_ror:8 = lane ^ 8
+  u32 t[4];
+  asm volatile(SK_DPP4("row_ror:8 row_mask:0xf bank_mask:0xf") SK_MED3_4 : SK_OPS4(x, t) : "v"(side));
 }
-__device__ __forceinline__ u32 sk_cx2(u32 x, u32 side) { return sk_med3(x, sk_dpp<0x4E>(x), side); }         // quad_perm [2,3,0,1]
-__device__ __forceinline__ u32 sk_cx1(u32 x, u32 side) { return sk_med3(x, sk_dpp<0xB1>(x), side); }         // quad_perm [1,0,3,2]
+__device__ __forceinline__ void sk_stage4(u32 (&x)[4], u32 side) {      // banks 0, 2 read lane + 4 (row_shl:4), banks 1, 3 lane - 4 (row_shr:4)
+  u32 t[4];
+  asm volatile(SK_DPP4("row_shl:4 row_mask:0xf bank_mask:0x5") SK_DPP4("row_shr:4 row_mask:0xf bank_mask:0xa") SK_MED3_4
+               : SK_OPS4(x, t) : "v"(side));
+}
+__device__ __forceinline__ void sk_stage2(u32 (&x)[4], u32 side) {      // quad_perm [2,3,0,1] = lane ^ 2
+  u32 t[4];
+  asm volatile(SK_DPP4("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf") SK_MED3_4 : SK_OPS4(x, t) : "v"(side));
+}
+__device__ __forceinline__ void sk_stage1(u32 (&x)[4], u32 side) {      // quad_perm [1,0,3,2] = lane ^ 1
+  u32 t[4];
+  asm volatile(SK_DPP4("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf") SK_MED3_4 : SK_OPS4(x, t) : "v"(side));
+}
+// bitonic sequence of 256 keys (element t = 4 * lane + k) -> ascending: distances 128 .. 4 across lanes, 2 and 1 inside the lane
+__device__ __forceinline__ void sk_merge_network(u32 (&x)[4], u32 lane) {
+  sk_stage32(x, (u32)((int)(lane << 26) >> 31));
+  sk_stage16(x, (u32)((int)(lane << 27) >> 31));
+  sk_stage8(x, (u32)((int)(lane << 28) >> 31));
+  sk_stage4(x, (u32)((int)(lane << 29) >> 31));
+  sk_stage2(x, (u32)((int)(lane << 30) >> 31));
+  sk_stage1(x, (u32)((int)(lane << 31) >> 31));
+  const u32 t0 = min(x[0], x[2]), t2 = max(x[0], x[2]), t1 = min(x[1], x[3]), t3 = max(x[1], x[3]);
+  x[0] = min(t0, t1); x[1] = max(t0, t1); x[2] = min(t2, t3); x[3] = max(t2, t3);
+}
+// debug / tests: the network on 256 keys in memory
+__global__ void k_sk_network_probe(u32* __restrict__ keys) {
+  const u32 lane = threadIdx.x;
+  u32 x[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) x[k] = keys[lane * 4u + (u32)k];
+  sk_merge_network(x, lane);
+#pragma unroll
+  for (int k = 0; k < 4; k++) keys[lane * 4u + (u32)k] = x[k];
+}
 
 // filled[i] = g[i] | (p[i] & filled[i - 1]), filled[-1] = cin: the carry chain of (g | p) + g + cin
 __device__ __forceinline__ u64 sk_fill_fwd(u64 g, u64 p, u32 cin) {
@@ -104,9 +146,6 @@ __global__ __launch_bounds__(64, DCD_SK_WAVES) void k_pair_stream(const PairOp* 
   u64* sA = s_ring;
   u64* sB = s_ring + SK_RING;
   const u32 lane = threadIdx.x;
-  // side of the lane in the six cross-lane stages of the merge network (0 = keeps the minimum)
-  const u32 sd32 = (u32)((int)(lane << 26) >> 31), sd16 = (u32)((int)(lane << 27) >> 31), sd8 = (u32)((int)(lane << 28) >> 31);
-  const u32 sd4 = (u32)((int)(lane << 29) >> 31), sd2 = (u32)((int)(lane << 30) >> 31), sd1 = (u32)((int)(lane << 31) >> 31);
   const u64 n_items = kind_base[n_ops];
   u64 w = blockIdx.x;
   while (w < n_items) {
@@ -192,22 +231,7 @@ __global__ __launch_bounds__(64, DCD_SK_WAVES) void k_pair_stream(const PairOp* 
         }
       }
       // ---- bitonic merge: distances 128 .. 4 across lanes, 2 and 1 inside the lane (element t = 4 * lane + k) -------
-#pragma unroll
-      for (int k = 0; k < 4; k++) x[k] = sk_cx32(x[k], sd32);
-#pragma unroll
-      for (int k = 0; k < 4; k++) x[k] = sk_cx16(x[k], sd16);
-#pragma unroll
-      for (int k = 0; k < 4; k++) x[k] = sk_cx8(x[k], sd8);
-#pragma unroll
-      for (int k = 0; k < 4; k++) x[k] = sk_cx4(x[k], sd4);
-#pragma unroll
-      for (int k = 0; k < 4; k++) x[k] = sk_cx2(x[k], sd2);
-#pragma unroll
-      for (int k = 0; k < 4; k++) x[k] = sk_cx1(x[k], sd1);
-      {
-        const u32 t0 = min(x[0], x[2]), t2 = max(x[0], x[2]), t1 = min(x[1], x[3]), t3 = max(x[1], x[3]);
-        x[0] = min(t0, t1); x[1] = max(t0, t1); x[2] = min(t2, t3); x[3] = max(t2, t3);
-      }
+      sk_merge_network(x, lane);
       // ---- neighbours: gap to the predecessor, chain breaks, duplicates, cross-operand contacts -------------------
       // (the element before the tile is the carried one: its distance to the base saturates far above any absR)
       u32 pgap = 0xFFFFFFFFu;

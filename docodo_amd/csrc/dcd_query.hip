@@ -2318,6 +2318,24 @@ int32_t dcd_query_batch(dcd_index* h, const int32_t* prog, const uint64_t* prog_
   return DCD_OK;
 }
 
+// tests: the merge network of k_pair_stream on 256 keys (host memory, in place); the input must be a bitonic sequence
+int32_t dcd_debug_sk_network(uint32_t* keys256) {
+  if (!keys256) DCD_FAIL(DCD_E_BADARG, "dcd_debug_sk_network: NULL argument");
+  DCD_TRY(ensure_device(0));
+  hipStream_t st = nullptr;
+  DCD_TRY(stream_acquire(0, &st));
+  struct Guard { hipStream_t s; ~Guard() { stream_release(0, s); } } g{st};
+  StreamScope ss_(st);
+  DevBuf<u32> d;
+  DCD_TRY(d.alloc(0, 256));
+  DCD_HIP(hipMemcpyAsync(d.p, keys256, 1024, hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(k_sk_network_probe, dim3(1), dim3(64), 0, st, d.p);
+  DCD_HIP(hipMemcpyAsync(keys256, d.p, 1024, hipMemcpyDeviceToHost, st));
+  DCD_HIP(hipStreamSynchronize(st));
+  DCD_HIP(hipGetLastError());
+  return DCD_OK;
+}
+
 // gives the handle's work arena (and, for an on-disk index, the resident subset) back to the device
 int32_t dcd_index_trim(dcd_index* h) {
   if (!h) DCD_FAIL(DCD_E_BADARG, "dcd_index_trim: NULL argument");

@@ -236,6 +236,8 @@ void dcd_index_free(dcd_index* h);
  * memory) and, for an on-disk index, the resident posting lists -- and returns the library's cached device blocks to the device.
  * The index stays usable; the next batch allocates again.  For processes that keep several indexes open on one device. */
 int32_t dcd_index_trim(dcd_index* h);
+/* tests: the 256-key merge network of the streaming operator kernel (k_pair_stream) on a bitonic sequence in host memory, in place */
+int32_t dcd_debug_sk_network(uint32_t* keys256);
 int32_t dcd_index_count(dcd_index* h, uint64_t* n_terms);              /* Index.Count */
 int32_t dcd_index_max_coord(dcd_index* h, uint64_t* v);                /* Index.MaxCoord */
 int32_t dcd_index_n_units(dcd_index* h, uint64_t* n);                  /* ushort units of all posting lists together */

@@ -30,6 +30,24 @@ def _ops_cases():
     return cases
 
 
+def test_stream_kernel_merge_network_sorts_bitonic_tiles():
+    """k_pair_stream's merge network (v_med3 compare-exchanges fed by DPP moves and the gfx950 lane swaps) on its own: the half-
+    cleaner output of two ascending key sequences -- min(A[t], B[255 - t]), a bitonic sequence incl. +inf padding -- must come
+    back ascending and as the same multiset."""
+    from docodo_amd import _lib
+    rng = np.random.default_rng(11)
+    for case in range(40):
+        na, nb = int(rng.integers(0, 257)), int(rng.integers(0, 257))
+        a = np.sort(rng.choice(1 << 20, na, replace=False).astype(np.uint32) << 1)
+        b = np.sort((rng.choice(1 << 20, nb, replace=False).astype(np.uint32) << 1) | 1)
+        A = np.full(256, 0xFFFFFFFF, np.uint32); A[:na] = a
+        B = np.full(256, 0xFFFFFFFF, np.uint32); B[:nb] = b
+        x = np.minimum(A, B[::-1]).copy()
+        want = np.sort(x)
+        _lib.check(_lib.lib().dcd_debug_sk_network(x.ctypes.data))
+        assert np.array_equal(x, want), (case, na, nb, int(np.argmax(x != want)))
+
+
 @pytest.mark.parametrize("Ra,Rb", [(258, 259), (0, 0), (-7, -9), (-7, 258), (258, -9), (40, 3), (-1, -1), (0, -5), (100000, 1)])
 def test_operators_parity(oracle_mod, Ra, Rb):
     import docodo_amd
