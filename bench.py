@@ -458,12 +458,16 @@ def main():
 
     from docodo_amd import dist as ddist
     merge_ms = []
+    # the library's own communicator (dcd_comm_create: RCCL over xGMI; the rehearsal on one GPU: the host transport).  torch.distributed
+    # only carries rank 0's id here, and the barriers / reductions of this script.
+    comm = ddist.Comm.from_torch(local_rank) if exchange else None
 
     def merge(b):
-        # exchange step: per-term segments travel to their owner (heavy terms: balanced by postings; the rest: hash(key) % world)
-        # with RCCL all-to-all over xGMI and are merged there; part of the timed step
+        # exchange step, inside the library (dcd_build_merge_distributed): per-term segments travel to their owner (heavy terms:
+        # balanced by postings; the rest: weighted hash slices) with ncclSend / ncclRecv groups and are merged there;
+        # part of the timed step
         t0 = time.perf_counter()
-        owned = ddist.distributed_merge(b, device_index=local_rank)
+        owned = ddist.distributed_merge(b, comm)
         merge_ms.append((time.perf_counter() - t0) * 1e3)      # (host time of the calls; the device side is covered by the fence)
         owned.close()
         b.close()
@@ -659,11 +663,13 @@ def main():
     torch.cuda.empty_cache()
     docodo_amd._lib.pool_trim(local_rank)
     if args.total_docs > 0 and not args.force_exchange:
-        big = big_index_legs(args, rank, world, local_rank, dist, cdev)
+        big = big_index_legs(args, rank, world, local_rank, dist, cdev, comm)
         if rank == 0:
             out["configs234"] = big
     if rank == 0:
         print(json.dumps(out), flush=True)
+    if comm is not None:
+        comm.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -721,7 +727,7 @@ def inflight_bench(n_threads, steps, text, D, device, T):
             "note": "extra: independent build handles driven from %d host threads (the reference's MaxDegreeOfParallelism); `value` is the one-builder figure" % n_threads}
 
 
-def big_index_legs(args, rank, world, device, dist, cdev):
+def big_index_legs(args, rank, world, device, dist, cdev, comm=None):
     """configs[2..4].  Build: total_docs documents, doc-range sharded over the ranks (strong scaling; a rank's range is cut
     into segments of < 2^32 characters), global coordinates, merged on the device -- N = 1: dcd_merge_shards over the
     segments; N > 1: exchange to the term owners + merge (the hash-partitioned index), then the replica all-gather, so that
@@ -748,8 +754,8 @@ def big_index_legs(args, rank, world, device, dist, cdev):
         if world == 1:
             ix = sb.finish()
         else:
-            owned = sb.finish_distributed()             # this rank's doc range -> its hash partition of the global index
-            ix = ddist.allgather_index(owned, device_index=device)
+            owned = sb.finish_distributed(comm)         # this rank's doc range -> its hash partition of the global index
+            ix = ddist.allgather_index(owned, comm)
             owned.close()
             ddist.set_uniform_pages(ix, total, synth.DOC_BYTES)
         return ix, n_seg, dev_ms, n_post

@@ -14,6 +14,7 @@ DCD_E_BADARG, DCD_E_OVERFLOW, DCD_E_IO, DCD_E_HIP, DCD_E_RCCL = -1, -2, -3, -4, 
 DCD_E_UNSUPPORTED, DCD_E_NOTFOUND, DCD_E_NOMEM, DCD_E_STATE = -6, -7, -8, -9
 DCD_ENC_LATIN1, DCD_ENC_UTF16LE = 1, 2
 DCD_OP_TERM, DCD_OP_AND, DCD_OP_OR, DCD_OP_SETR = 0, 1, 2, 3
+DCD_COMM_RCCL, DCD_COMM_HOST, DCD_COMM_ID_BYTES = 0, 1, 128
 
 
 class DocodoError(RuntimeError):
@@ -141,6 +142,17 @@ SIGNATURES = {
     "dcd_index_set_list_image": (_i32, [_vp, _vp, _sz]),
     "dcd_index_save": (_i32, [_vp, C.c_char_p]),
     "dcd_index_set_uniform_pages": (_i32, [_vp, _u64, _u32, _u64, _vp, _sz]),
+    "dcd_comm_unique_id": (_i32, [_i32, _vp]),
+    "dcd_comm_create": (_i32, [_i32, _i32, _vp, _i32, _i32, C.POINTER(_vp)]),
+    "dcd_comm_create_all": (_i32, [_i32, _vp, _i32, _vp]),
+    "dcd_comm_free": (None, [_vp]),
+    "dcd_comm_rank": (_i32, [_vp, _pi32, _pi32]),
+    "dcd_comm_allgather": (_i32, [_vp, _vp, _sz, _vp]),
+    "dcd_build_merge_distributed": (_i32, [_vp, _vp, _i32, C.POINTER(_vp)]),
+    "dcd_index_merge_distributed": (_i32, [_vp, _vp, _i32, C.POINTER(_vp)]),
+    "dcd_index_allgather": (_i32, [_vp, _vp, C.POINTER(_vp)]),
+    "dcd_index_gather": (_i32, [_vp, _vp, _i32, C.POINTER(_vp)]),
+    "dcd_balance_owners": (_i32, [_u32, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _pz, _vp]),
     "dcd_synth_corpus_host": (_i32, [_vp, _u64, _u64, _u32, _u32, C.c_double, _u64]),
     "dcd_synth_corpus_dev": (_i32, [_vp, _u64, _u64, _u32, _u32, C.c_double, _u64, _i32]),
     "dcd_synth_term": (_i32, [_u32, _u32, C.c_char_p, _sz, _pz]),

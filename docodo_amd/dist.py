@@ -1,13 +1,12 @@
 """Doc-range sharded build: the exchange step between GPUs.
 
-Each rank builds the index of its document range with GLOBAL coordinates (`Builder(coord_base=...)`),
-exports its per-term segments grouped by owner = hash(key) % world, the three export buffers travel
-with ONE all-to-all each (RCCL over xGMI on GPUs; gloo in the CPU plumbing tests), and every owner
-merges what it received with `dcd_merge_shards` (re-codes the first delta of each appended segment:
-IndexSequence.Shift + AddRange semantics of MergeFiles, Index.cs:665-674).  The result is a
-hash-partitioned index: every rank holds the complete posting lists of the terms it owns.
-
-The library itself never communicates; this module is the only place that calls torch.distributed.
+Each rank builds the index of its document range with GLOBAL coordinates (`Builder(coord_base=...)`); the exchange --
+per-term segments grouped by owner, heavy terms balanced by posting units, all-to-all-v of the three export buffers over RCCL /
+xGMI, merge at the owner (IndexSequence.Shift + AddRange semantics of MergeFiles, Index.cs:665-674) -- happens INSIDE the library
+(round 4: dcd_comm_create, dcd_build_merge_distributed, dcd_index_allgather, dcd_index_gather; docodo_amd/csrc/dcd_comm.cpp).
+This module is a thin caller: `Comm` wraps a dcd_comm (the 128-byte id travels over whatever rendezvous the host already has --
+here torch.distributed, once, at construction), the single-process helpers (`local_merge`, ...) feed the export / merge entry
+points directly for the one-GPU tests.  `assign_heavy` is the Python twin of dcd_balance_owners (tests compare them).
 """
 import ctypes as C
 
@@ -74,30 +73,67 @@ def assign_heavy(lists, totals, n_owners):
     return np.array(fps, np.uint64), np.array([owner[f] for f in fps], np.uint32), np.array(thr, np.uint32)
 
 
-def balance_owners(builder, group=None):
-    """One small all-gather: every rank's heavy terms (at least 1 / (8 N) of its shard's posting units: at most 8 N of them)
-    -> the same owner table on every rank (assign_heavy: heavy terms to the least loaded owners, the light ones weighted so
-    that every owner ends near the mean).  With Zipf-1.1 the first term alone is 13 % of all units; under hash(key) % 8 its
-    owner receives 1.9 x the mean, and the all-to-all and the merge wait for that rank."""
-    import torch.distributed as dist
-    G = dist.get_world_size(group)
-    if G == 1:
-        return None
-    U = int(builder.n_units if isinstance(builder, Index) else builder.stats.n_units)
-    cap = 8 * G
-    fp, un = heavy_terms(builder, max(1, -(-U // cap)), cap)       # (>= ceil(U / 8N) units each: no more than 8N terms)
-    mine = np.zeros(2 + 2 * cap, np.int64)
-    mine[0], mine[1] = fp.size, U
-    mine[2:2 + fp.size] = fp.view(np.int64)
-    mine[2 + cap:2 + cap + un.size] = un.view(np.int64)
-    backend = dist.get_backend(group)
-    dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
-    t = torch.from_numpy(mine).to(dev)
-    parts = [torch.empty_like(t) for _ in range(G)]
-    dist.all_gather(parts, t, group=group)
-    allm = torch.stack(parts).cpu().numpy()
-    lists = [(allm[r, 2:2 + allm[r, 0]].view(np.uint64), allm[r, 2 + cap:2 + cap + allm[r, 0]].view(np.uint64)) for r in range(G)]
-    return assign_heavy(lists, allm[:, 1], G)
+def balance_table(lists, totals, n_owners):
+    """dcd_balance_owners: the C twin of assign_heavy (same arguments, same result)."""
+    off = np.zeros(len(lists) + 1, np.uint64)
+    off[1:] = np.cumsum([len(fp) for fp, _ in lists])
+    fp = np.ascontiguousarray(np.concatenate([np.asarray(f, np.uint64) for f, _ in lists]) if lists else np.empty(0, np.uint64))
+    un = np.ascontiguousarray(np.concatenate([np.asarray(u, np.uint64) for _, u in lists]) if lists else np.empty(0, np.uint64))
+    tot = np.ascontiguousarray(totals, np.uint64)
+    cap = max(1, fp.size)
+    ofp, oow, thr = np.zeros(cap, np.uint64), np.zeros(cap, np.uint32), np.zeros(n_owners, np.uint32)
+    n = C.c_size_t(0)
+    check(lib().dcd_balance_owners(n_owners, len(lists), off.ctypes.data, fp.ctypes.data, un.ctypes.data, tot.ctypes.data, ofp.ctypes.data,
+                                   oow.ctypes.data, cap, C.byref(n), thr.ctypes.data))
+    return ofp[:n.value].copy(), oow[:n.value].copy(), thr
+
+
+class Comm:
+    """A dcd_comm: one communicator per GPU.  transport: _lib.DCD_COMM_RCCL (ncclSend / ncclRecv over xGMI) or _lib.DCD_COMM_HOST
+    (buffers staged through shared memory: tests and rehearsals with several ranks on one GPU)."""
+
+    def __init__(self, n_ranks, rank, comm_id, device, transport=_lib.DCD_COMM_RCCL):
+        self.n, self.rank, self.device, self.transport = n_ranks, rank, device, transport
+        self.h = C.c_void_p()
+        idb = (C.c_uint8 * _lib.DCD_COMM_ID_BYTES).from_buffer_copy(bytes(comm_id)) if comm_id is not None else None
+        check(lib().dcd_comm_create(n_ranks, rank, idb, device, transport, C.byref(self.h)))
+
+    @staticmethod
+    def unique_id(transport=_lib.DCD_COMM_RCCL):
+        idb = (C.c_uint8 * _lib.DCD_COMM_ID_BYTES)()
+        check(lib().dcd_comm_unique_id(transport, idb))
+        return bytes(idb)
+
+    @classmethod
+    def from_torch(cls, device, group=None, transport=None):
+        """Rendezvous over an initialised torch.distributed group: rank 0 makes the id, one broadcast carries it.  transport
+        None: RCCL when the group's backend is nccl, else the host transport."""
+        import torch.distributed as dist
+        n, rank = dist.get_world_size(group), dist.get_rank(group)
+        if transport is None:
+            transport = _lib.DCD_COMM_RCCL if dist.get_backend(group) == "nccl" else _lib.DCD_COMM_HOST
+        box = [cls.unique_id(transport) if rank == 0 else None]
+        if n > 1:
+            dist.broadcast_object_list(box, src=0, group=group)
+        return cls(n, rank, box[0], device, transport)
+
+    def allgather(self, arr):
+        """Small host arrays: -> [n_ranks, ...] (dcd_comm_allgather)."""
+        a = np.ascontiguousarray(arr)
+        out = np.zeros((self.n,) + a.shape, a.dtype)
+        check(lib().dcd_comm_allgather(self.h, a.ctypes.data, a.nbytes, out.ctypes.data))
+        return out
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().dcd_comm_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def export_shard(builder, n_owners, device=None, overrides=None):
@@ -217,77 +253,14 @@ def local_merge(exports, owner, device_index=0, two_phase=False):
     return merge_received(tc, kc, uc, meta, keys, units, max(e.max_coord for e in exports), device_index, two_phase)
 
 
-def exchange(export, group=None, overlap=False):
-    """All-to-all of the three export buffers.  Works on CUDA tensors with the nccl (= RCCL) backend
-    and on CPU tensors with gloo (plumbing tests).  Returns (term_count, key_count, unit_count per
-    SOURCE, meta, keys, units received, global max_coord)."""
-    import torch.distributed as dist
-    G = dist.get_world_size(group)
-    dev = export.meta.device
-    # gloo has no all-to-all on device tensors: stage through the host (rehearsals of the N > 1 path on one GPU)
-    staged = dev.type == "cuda" and dist.get_backend(group) == "gloo"
-    if staged:
-        host = ShardExport(export.term_count, export.key_count, export.unit_count, export.meta.cpu(), export.keys.cpu(),
-                           export.units.cpu(), export.max_coord)
-        tc, kc, uc, meta, keys, units, mx = exchange(host, group)
-        res = (tc, kc, uc, meta.to(dev), keys.to(dev), units.to(dev), mx)
-        torch.cuda.current_stream(dev).synchronize()
-        return res + ((lambda: None),) if overlap else res
-    # ONE small all-gather tells every rank all the split sizes and the global MaxCoord (one collective and one host
-    # round trip instead of an all-to-all + an all-reduce with a sync each)
-    mine = np.concatenate([np.stack([export.term_count, export.key_count, export.unit_count], 1).astype(np.int64).ravel(),
-                           np.array([int(export.max_coord)], np.int64)])
-    mine_t = torch.from_numpy(mine).to(dev)
-    all_t = torch.empty(G * mine.size, dtype=torch.int64, device=dev)
-    dist.all_gather_into_tensor(all_t, mine_t, group=group)
-    allc = all_t.cpu().numpy().reshape(G, 3 * G + 1)
-    me = dist.get_rank(group)
-    rc = allc[:, :3 * G].reshape(G, G, 3)[:, me, :].astype(np.uint64)      # row s = what source s sends to me
-    mx_val = int(allc[:, 3 * G].max())
-    bufs = ((export.meta, export.term_count * META_BYTES, rc[:, 0] * META_BYTES),
-            (export.keys, export.key_count * 2, rc[:, 1] * 2),
-            (export.units, export.unit_count * 2, rc[:, 2] * 2))
-    out, works = [], []
-    for buf, send, recv in bufs:
-        r = torch.empty(int(recv.sum()), dtype=torch.uint8, device=dev)
-        w = dist.all_to_all_single(r, buf, output_split_sizes=[int(x) for x in recv], input_split_sizes=[int(x) for x in send],
-                                   group=group, async_op=overlap)
-        out.append(r)
-        works.append(w)
-    counts = (rc[:, 0].copy(), rc[:, 1].copy(), rc[:, 2].copy())
-    if overlap:
-        # the collectives of one communicator run in issue order: once meta and keys have landed the caller may start
-        # dcd_merge_begin while the (much larger) unit exchange is still on the fabric; `wait_units` ends it
-        _host_wait(works[0], dev)
-        _host_wait(works[1], dev)
-        return counts + (out[0], out[1], out[2], mx_val, lambda: _host_wait(works[2], dev))
-    if dev.type == "cuda":
-        # the collectives ran on torch's stream; the library works on its own streams
-        torch.cuda.current_stream(dev).synchronize()
-    return counts + (out[0], out[1], out[2], mx_val)
-
-
-def _host_wait(work, dev):
-    """Blocks the HOST until an async collective has finished (the library's streams know nothing of torch's)."""
-    work.wait()                      # nccl: orders torch's current stream after the collective; gloo: blocks
-    if dev.type == "cuda":
-        torch.cuda.current_stream(dev).synchronize()
-
-
-def distributed_merge(builder, group=None, device_index=None, balanced=True):
-    """export -> all-to-all (RCCL) -> merge.  Returns this rank's owned sub-index.  `builder`: a finished Builder, or an Index
-    handle that holds this rank's shard (several segments merged on the device).  balanced: the heavy terms are assigned to
-    owners by posting units (balance_owners: one small all-gather in front of the export), the others by hash."""
-    import torch.distributed as dist
-    G = dist.get_world_size(group)
-    if device_index is None:
-        device_index = torch.cuda.current_device()
-    e = export_shard(builder, G, overrides=balance_owners(builder, group) if balanced else None)
-    # vocabulary / ranks / layout of the merge run while the posting units are still being exchanged
-    tc, kc, uc, meta, keys, units, mx, wait_units = exchange(e, group, overlap=True)
-    pending = PendingMerge(tc, kc, uc, meta, keys, mx, device_index)
-    wait_units()
-    return pending.finish(units)
+def distributed_merge(builder, comm, balanced=True):
+    """dcd_build_merge_distributed / dcd_index_merge_distributed: export -> balanced owners -> all-to-all-v -> merge, inside the
+    library.  Returns this rank's owned sub-index.  `builder`: a finished Builder, or an Index handle that holds this rank's shard
+    (several segments merged on the device)."""
+    out = C.c_void_p()
+    fn = lib().dcd_index_merge_distributed if isinstance(builder, Index) else lib().dcd_build_merge_distributed
+    check(fn(builder.h, comm.h, 1 if balanced else 0, C.byref(out)))
+    return Index(out, comm.device)
 
 
 def local_gather(owned, device_index=0):
@@ -296,69 +269,20 @@ def local_gather(owned, device_index=0):
     return local_merge(exports, 0, device_index)
 
 
-def gather_index(owned, dst=0, group=None, device_index=None):
-    """Gathers the hash partitions on rank `dst`: every rank exports its owned partition (one owner), the buffers travel
-    with all-to-all calls in which only `dst` receives, `dst` merges them (every term has exactly one segment) into the
-    complete index; its ".index" is then what a single builder writes for the whole corpus.  Returns the Index on `dst`,
-    None elsewhere.  (Attach the page table with Index.set_list_image or dist.set_uniform_pages.)"""
-    import torch.distributed as dist
-    G, me = dist.get_world_size(group), dist.get_rank(group)
-    if device_index is None:
-        device_index = torch.cuda.current_device()
-    e1 = export_index(owned, 1)
-    # re-label the single-owner export as "everything goes to dst"
-    z = np.zeros(G, np.uint64)
-    tc, kc, uc = z.copy(), z.copy(), z.copy()
-    tc[dst], kc[dst], uc[dst] = e1.term_count[0], e1.key_count[0], e1.unit_count[0]
-    e = ShardExport(tc, kc, uc, e1.meta, e1.keys, e1.units, e1.max_coord)
-    rtc, rkc, ruc, meta, keys, units, mx = exchange(e, group)
-    if me != dst:
-        return None
-    return merge_received(rtc, rkc, ruc, meta, keys, units, mx, device_index)
+def gather_index(owned, comm, dst=0):
+    """dcd_index_gather: the hash partitions -> the complete index on rank `dst` (None elsewhere); its ".index" is what a single
+    builder writes for the whole corpus.  (Attach the page table with Index.set_list_image or dist.set_uniform_pages.)"""
+    out = C.c_void_p()
+    check(lib().dcd_index_gather(owned.h, comm.h, dst, C.byref(out)))
+    return Index(out, comm.device) if out.value else None
 
 
-def allgather_export(e, group=None):
-    """All-gather of a ONE-owner export (export_index(ix, 1)): every rank receives every rank's three buffers, back to back in
-    rank order.  Returns (term_count, key_count, unit_count per SOURCE, meta, keys, units, global max_coord) -- the arguments of
-    merge_received.  CUDA tensors over nccl (= RCCL ring over xGMI), CPU tensors over gloo; CUDA tensors over gloo
-    (rehearsals: N ranks on one GPU) are staged through the host."""
-    import torch.distributed as dist
-    G, me = dist.get_world_size(group), dist.get_rank(group)
-    dev = e.meta.device
-    staged = dev.type == "cuda" and dist.get_backend(group) == "gloo"
-    cdev = torch.device("cpu") if staged else dev
-    mine = torch.tensor([int(e.term_count[0]), int(e.key_count[0]), int(e.unit_count[0]), int(e.max_coord)], dtype=torch.int64, device=cdev)
-    allc = [torch.empty_like(mine) for _ in range(G)]
-    dist.all_gather(allc, mine, group=group)
-    allc = torch.stack(allc).cpu().numpy()                                 # [G, 4]
-    tc, kc, uc = (allc[:, i].astype(np.uint64) for i in range(3))
-    mx = int(allc[:, 3].max())
-    out = []
-    for buf, counts, width in ((e.meta, tc, META_BYTES), (e.keys, kc, 2), (e.units, uc, 2)):
-        sizes = [int(c) * width for c in counts]
-        pad = max(max(sizes), 1)
-        # all-gather wants equal parts: pad to the largest partition (partitions are balanced by postings, see balance_owners),
-        # then close the gaps with one copy
-        src = torch.zeros(pad, dtype=torch.uint8, device=cdev)
-        src[:sizes[me]] = buf.to(cdev) if staged else buf
-        parts = [torch.empty(pad, dtype=torch.uint8, device=cdev) for _ in range(G)]
-        dist.all_gather(parts, src, group=group)
-        got = torch.cat([parts[s][:sizes[s]] for s in range(G)])
-        out.append(got.to(dev) if staged else got)
-    return tc, kc, uc, out[0], out[1], out[2], mx
-
-
-def allgather_index(owned, group=None, device_index=None):
-    """Every rank ends with a REPLICA of the complete index (what CreateAsync ends with: one searchable index, Index.cs:488,
-    512 -- here on every GPU, so that query batches shard by query with no routing).  Every rank exports its owned
-    hash partition once (one owner), the three buffers travel with ONE all-gather each (every rank receives (N - 1) / N of the
-    index), and every rank merges what it received -- every term has exactly one segment, so the merge is the ordinal sort of
-    the union vocabulary plus one copy of the units.  The ".index" of a replica is what a single builder writes for the whole
-    corpus.  (Attach the page table with Index.set_list_image or dist.set_uniform_pages.)"""
-    if device_index is None:
-        device_index = torch.cuda.current_device()
-    tc, kc, uc, meta, keys, units, mx = allgather_export(export_index(owned, 1), group)
-    return merge_received(tc, kc, uc, meta, keys, units, mx, device_index)
+def allgather_index(owned, comm):
+    """dcd_index_allgather: every rank ends with a REPLICA of the complete index (what CreateAsync ends with: one searchable
+    index, Index.cs:488, 512 -- here on every GPU, so that query batches shard by query with no routing)."""
+    out = C.c_void_p()
+    check(lib().dcd_index_allgather(owned.h, comm.h, C.byref(out)))
+    return Index(out, comm.device)
 
 
 def set_uniform_pages(index, n_pages, page_chars, first_doc=0, source="syn"):
@@ -419,16 +343,16 @@ class SegmentedBuilder:
             set_uniform_pages(ix, self.n_pages, self.page_chars, self.first_page, self.source)
         return ix
 
-    def finish_distributed(self, group=None, balanced=True):
+    def finish_distributed(self, comm, balanced=True):
         """This rank's doc range -> its hash partition of the global index (export -> all-to-all -> merge).  One segment: the
         builder is exported to the owners directly; several: they are merged on this device first (one shard per rank)."""
         if len(self.builders) == 1 and not self.exports:
             b = self.builders.pop()
-            owned = distributed_merge(b, group, self.device, balanced)
+            owned = distributed_merge(b, comm, balanced)
             b.close()
             return owned
         part = self.finish(pages=False)
-        owned = distributed_merge(part, group, self.device, balanced)
+        owned = distributed_merge(part, comm, balanced)
         part.close()
         return owned
 

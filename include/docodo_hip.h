@@ -329,7 +329,8 @@ void dcd_results_free(dcd_results* r);
  * (IndexSequence.Shift + AddRange semantics, Index.cs:665-674).  Shards were built with
  * dcd_build_opts.coord_base = text length of all previous shards, so coordinates are already global.
  * A term is owned by shard-merge participant  hash(key) % n_owners;  the caller moves the three
- * export buffers between GPUs (RCCL all-to-all over xGMI) -- this library never communicates.
+ * export buffers between GPUs itself (the functions of this section never communicate), or lets the library do it:
+ * dcd_build_merge_distributed below.
  * ------------------------------------------------------------------------------------------ */
 typedef struct dcd_term_meta {
   uint64_t first, last;   /* first / last absolute coordinate of this shard's postings of the term */
@@ -399,6 +400,45 @@ int32_t dcd_index_set_uniform_pages(dcd_index* h, uint64_t n_pages, uint32_t pag
  * MaxCoord = max of the inputs (Index.cs:596).  A key in two inputs is DCD_E_BADARG.  The result is opened with
  * dcd_index_open or, when it does not fit, dcd_index_open_lazy. */
 int32_t dcd_merge_index_files(const char* const* paths_utf8, size_t n, const char* out_path_utf8);
+
+/* ------------------------------------------------------------------------------------------
+ * The exchange INSIDE the library (round 4): a host that drives several GPUs -- one process per GPU, or one process that owns all
+ * of them -- builds one doc-range shard per GPU (dcd_build_opts.coord_base = text length of all previous shards,
+ * DCD_BUILD_SHARD_ONLY) and calls dcd_build_merge_distributed on every rank: heavy-term all-gather -> balanced owners ->
+ * all-to-all-v of meta / keys / units (RCCL ncclSend / ncclRecv groups over xGMI, on the communicator's own stream) ->
+ * dcd_merge_begin while the units travel -> dcd_merge_finish.  This is what CreateAsync does with its index tasks and MergeAll
+ * on one host (Index.cs:464-488, 537-573).  Every call below is COLLECTIVE: all ranks of the communicator call it, in the same
+ * order; in a single process that owns several communicators (dcd_comm_create_all) each communicator is driven by its own host
+ * thread (as the reference's index tasks are, Index.cs:464-465).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct dcd_comm dcd_comm;
+#define DCD_COMM_RCCL 0   /* RCCL (librccl.so.1, loaded on first use) over xGMI / PCIe */
+#define DCD_COMM_HOST 1   /* buffers staged through POSIX shared memory: tests and rehearsals (several ranks on one GPU), not for speed */
+#define DCD_COMM_ID_BYTES 128
+/* rank 0 makes the id and hands it to the other ranks by whatever means the host has (the 128 bytes of an ncclUniqueId) */
+int32_t dcd_comm_unique_id(int32_t transport, uint8_t id[DCD_COMM_ID_BYTES]);
+/* device < 0 with DCD_COMM_HOST: a host-only communicator (dcd_comm_allgather works, the merge calls need a device) */
+int32_t dcd_comm_create(int32_t n_ranks, int32_t rank, const uint8_t id[DCD_COMM_ID_BYTES], int32_t device, int32_t transport, dcd_comm** out);
+/* one process, n devices: out[i] is the communicator of devices[i] with rank i (ncclCommInitAll) */
+int32_t dcd_comm_create_all(int32_t n, const int32_t* devices, int32_t transport, dcd_comm** out);
+void dcd_comm_free(dcd_comm* c);
+int32_t dcd_comm_rank(dcd_comm* c, int32_t* rank, int32_t* n_ranks);
+/* all[r * bytes ..] = rank r's `mine` (host memory, small: e.g. the shards' text lengths, whose prefix sums are the coord_base values) */
+int32_t dcd_comm_allgather(dcd_comm* c, const void* mine, size_t bytes, void* all);
+/* this rank's shard -> this rank's hash partition of the global index (complete posting lists of the terms it owns).
+ * balanced != 0: owners balanced by posting units (heavy terms placed one by one, light terms over weighted hash slices). */
+int32_t dcd_build_merge_distributed(dcd_build* b, dcd_comm* c, int32_t balanced, dcd_index** owned);
+int32_t dcd_index_merge_distributed(dcd_index* shard, dcd_comm* c, int32_t balanced, dcd_index** owned);   /* shard = several segments merged on the device */
+/* every rank ends with a REPLICA of the complete index (query batches then shard by query, no routing); its ".index" is what a
+ * single builder writes for the whole corpus.  Attach the page table with dcd_index_set_list_image / dcd_index_set_uniform_pages. */
+int32_t dcd_index_allgather(dcd_index* owned, dcd_comm* c, dcd_index** replica);
+/* the complete index on rank dst only (*out = NULL elsewhere) */
+int32_t dcd_index_gather(dcd_index* owned, dcd_comm* c, int32_t dst, dcd_index** out);
+/* The owner table of a balanced export as a pure function (every rank computes it from the same all-gathered lists): list l =
+ * fp / units [list_off[l], list_off[l + 1]) are the heavy terms of shard l, totals[l] its posting units.  Out: the heavy terms'
+ * fingerprints (ascending) with their owners, and light_thr[n_owners] for dcd_build_export_plan_balanced. */
+int32_t dcd_balance_owners(uint32_t n_owners, uint32_t n_lists, const uint64_t* list_off, const uint64_t* fp, const uint64_t* units,
+                           const uint64_t* totals, uint64_t* out_fp, uint32_t* out_owner, size_t cap, size_t* n_out, uint32_t* light_thr);
 
 /* ------------------------------------------------------------------------------------------
  * Measurement support (bench.py / tests): the synthetic corpus of SURVEY.md Appendix F.

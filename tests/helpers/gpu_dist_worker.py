@@ -1,8 +1,10 @@
 """Worker of tests/test_gpu_merge.py::test_three_ranks_on_one_gpu_give_the_one_shot_index: the whole N > 1 path -- doc-range
 shards with global coordinates built on the GPU, export, all-to-all, overlapped merge, gather of the hash partitions -- with
-three ranks sharing the one GPU of the box.  RCCL cannot place two ranks on one device, so the collectives run over gloo with
-the device buffers staged through the host (docodo_amd.dist.exchange does that by itself); everything on the device side is the
-code that runs at N > 1 on a multi-GPU node."""
+three ranks sharing the one GPU of the box, THROUGH THE C ENTRY POINTS ONLY (round 4: dcd_comm_create,
+dcd_build_merge_distributed, dcd_index_gather, dcd_index_allgather).  RCCL cannot place two ranks on one device, so the
+communicator uses the library's host transport (DCD_COMM_HOST: the buffers staged through shared memory); everything else --
+heavy-term balance, export, all-to-all-v, overlapped merge -- is the code that runs at N > 1 on a multi-GPU node.  torch.distributed
+(gloo) only carries the communicator id once and compares digests."""
 import os
 import sys
 
@@ -25,12 +27,17 @@ def main():
     total = sum(7000 + 500 * r for r in range(world))
     d = torch.empty(per * synth.DOC_BYTES, dtype=torch.uint8, device="cuda")
     synth.corpus_dev(d.data_ptr(), per, first_doc=first)
+    comm = ddist.Comm.from_torch(0)                           # gloo group -> host transport; rank 0's id by one broadcast
+    assert comm.transport == docodo_amd._lib.DCD_COMM_HOST and comm.n == world
+    lens = comm.allgather(np.array([per * synth.DOC_BYTES], np.uint64))[:, 0]       # dcd_comm_allgather: the shards' text lengths ...
+    assert int(lens[:rank].sum()) == first * synth.DOC_BYTES                       # ... whose prefix sums are the coord_base values
     for rnd in range(2):                                      # twice: both allocators recycle their buffers
         b = docodo_amd.Builder(coord_base=first * synth.DOC_BYTES)
         b.AddUniformPagesDev(d.data_ptr(), per, synth.DOC_BYTES, first_doc=first)
         b.Finish()
-        owned = ddist.distributed_merge(b, device_index=0)
-        got = ddist.gather_index(owned, dst=0, device_index=0)
+        owned = ddist.distributed_merge(b, comm)
+        got = ddist.gather_index(owned, comm, dst=0)
+        assert (got is not None) == (rank == 0)
         if rank == 0:
             text = synth.corpus_host(total)
             off = np.arange(total + 1, dtype=np.uint64) * synth.DOC_BYTES
@@ -46,7 +53,7 @@ def main():
             one.close()
             got.close()
         # ... and the replica route: EVERY rank ends with the complete index (query batches shard by query)
-        rep = ddist.allgather_index(owned, device_index=0)
+        rep = ddist.allgather_index(owned, comm)
         ddist.set_uniform_pages(rep, total, synth.DOC_BYTES)
         import hashlib
         digest = hashlib.sha256(rep.index_image()).digest() + hashlib.sha256(rep.list_image()).digest()
@@ -62,6 +69,7 @@ def main():
         owned.close()
         b.close()
         dist.barrier()
+    comm.close()
     dist.destroy_process_group()
     print("rank %d ok" % rank, flush=True)
 

@@ -1,23 +1,19 @@
-"""Worker of tests/test_gpu_merge.py::test_distributed_merge_over_rccl_world1: the real RCCL code path of
-docodo_amd.dist.distributed_merge (all-gather of sizes, three async all-to-alls, overlapped dcd_merge_begin,
-dcd_merge_finish) with world_size 1 on the one GPU of the box -- same collectives, streams and waits as N > 1."""
+"""Worker of tests/test_gpu_merge.py::test_distributed_merge_over_rccl_world1: the RCCL transport of the library's own exchange
+(dcd_comm_create with an ncclUniqueId -> ncclCommInitRank; dcd_build_merge_distributed: size all-gather over ncclAllGather, the
+three all-to-all-v, overlapped dcd_merge_begin, dcd_merge_finish; dcd_index_gather; dcd_index_allgather) with world_size 1 on the
+one GPU of the box -- same code, streams and waits as N > 1.  No torch.distributed anywhere: what a C# host would do."""
 import os
 import sys
 
 import numpy as np
-import torch
-import torch.distributed as dist
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 
 
 def main():
-    torch.cuda.set_device(0)
-    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%s" % os.environ.get("DCD_PORT", "29671"), rank=0, world_size=1,
-                            device_id=torch.device("cuda", 0))
     import docodo_amd
-    from docodo_amd import dist as ddist, synth
+    from docodo_amd import _lib, dist as ddist, synth
     n_docs = 20000
     text = synth.corpus_host(n_docs)
     off = np.arange(n_docs + 1, dtype=np.uint64) * synth.DOC_BYTES
@@ -25,13 +21,18 @@ def main():
     b.AddPages(text, off, docs_per_page=True)
     b.Finish()
     want = b.index_image()
-    for _ in range(3):                      # repeated: buffers are recycled by both allocators between rounds
-        owned = ddist.distributed_merge(b, device_index=0)
+    comm = ddist.Comm(1, 0, ddist.Comm.unique_id(_lib.DCD_COMM_RCCL), 0, _lib.DCD_COMM_RCCL)     # a real ncclComm of one rank
+    assert comm.allgather(np.array([7, 9], np.uint64)).tolist() == [[7, 9]]
+    for _ in range(3):                      # repeated: buffers are recycled between rounds
+        owned = ddist.distributed_merge(b, comm)
         assert owned.index_image() == want
-        got = ddist.gather_index(owned, dst=0, device_index=0)
+        got = ddist.gather_index(owned, comm, dst=0)
         assert got.index_image() == want
-    dist.barrier()
-    dist.destroy_process_group()
+        rep = ddist.allgather_index(owned, comm)
+        assert rep.index_image() == want
+        for x in (owned, got, rep):
+            x.close()
+    comm.close()
     print("rccl world1 ok")
 
 

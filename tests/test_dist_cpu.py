@@ -1,5 +1,5 @@
-"""N > 1 plumbing on CPU: world_size-2 and -3 gloo runs of the exchange step (docodo_amd.dist.exchange) and of the replica
-all-gather (docodo_amd.dist.allgather_export)."""
+"""N > 1 plumbing on CPU: world_size-2 and -3 runs of the library's own communicator (dcd_comm_create with the host transport,
+dcd_comm_allgather; the id travels over gloo), and the owner balance as a pure function (dcd_balance_owners == dist.assign_heavy)."""
 import os
 import subprocess
 import sys
@@ -11,7 +11,7 @@ import pytest
 
 
 @pytest.mark.parametrize("world,port", [(2, 29613), (3, 29617)])
-def test_exchange_and_allgather_gloo(world, port):
+def test_comm_rendezvous_and_allgather(world, port):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % world, "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "tests", "helpers", "gloo_exchange_worker.py")]
@@ -56,3 +56,10 @@ def test_assign_heavy_balances_a_zipf_vocabulary():
     assert f0.size == 0 and t0.tolist() == [0x55555554, 0xAAAAAAA9, 0xFFFFFFFF]
     f1, o1, t1 = assign_heavy([(np.array([7], np.uint64), np.array([5], np.uint64))], [9], 1)
     assert o1.tolist() == [0] and t1.tolist() == [0xFFFFFFFF]
+    # the C twin the library itself uses inside dcd_build_merge_distributed: the same tables
+    from docodo_amd.dist import balance_table
+    for ls, ts, g in ((lists, totals, G), (lists[:3], totals[:3], 3), ([(np.empty(0, np.uint64), np.empty(0, np.uint64))] * 3, [10, 10, 10], 3),
+                      ([(np.array([7], np.uint64), np.array([5], np.uint64))], [9], 1), (lists, [0] * G, G)):
+        a, b = assign_heavy(ls, ts, g), balance_table(ls, ts, g)
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y), (g, x[:8], y[:8])
