@@ -45,6 +45,7 @@ struct dcd_index {
   // work pool + scratch arena of the query batches (dcd_query.hip run_batch): grown on demand, kept until the handle is freed
   dcd::DevBuf<u64> work_pool;       // (pool first, scratch behind it)
   u64 work_pool_elems = 0;
+  dcd::DevBuf<u8> res_arena;        // result arrays of the chunk in flight (pages, positions, ranks, documents): grown on demand
   // ".index" bytes of this index, generated on demand (dcd_index_image / dcd_index_save)
   dcd::DevBuf<u8> image;
   u64 image_bytes = 0;

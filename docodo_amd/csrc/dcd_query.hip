@@ -131,6 +131,167 @@ __global__ void k_build_dir(CV values, u64 n, const u64* __restrict__ item_start
   if (li + 1 == cnt) for (u64 x = c + 1; x <= n_cells; x++) d[x] = (u32)cnt;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Round 4: adoption in TWO passes over the units.  The resident coordinates and the cell directories used to be made by five
+// kernels and two scans over 8-byte arrays -- terminator count, per-value group gather, a prefix sum over all values, a binary
+// search over the term table per posting (twice) -- 60 ms for the 10 M-doc index, 1.6 x the build it follows.  Now:
+//   k_adopt_reduce   per tile of 2048 units: values that end in the tile, sum of their deltas                  (reads 2 U)
+//   two scans over the tile totals; k_adopt_terms: running delta sum in front of every term's first value      (small)
+//   k_adopt_apply    per tile: decode again, block scan, term of every value from a slice of the term table staged in LDS,
+//                    coordinate = running sum - the term's start sum, directory cells from the coordinate and its delta
+//                    (the previous posting of the term is coordinate - delta)                       (reads 2 U, writes 8 N + cells)
+// ------------------------------------------------------------------------------------------------
+constexpr u32 AD_T = 256, AD_ITEMS = 8, AD_TILE = AD_T * AD_ITEMS;
+// delta of the value whose LAST unit is u[i] (low group first; C# shifts a ulong by (15 k) & 63, IndexSequence.cs:126)
+__device__ __forceinline__ u64 ad_delta_at(const u16* __restrict__ u, u64 i) {
+  u64 s = i;
+  while (s > 0 && (u[s - 1] & 0x8000u)) s--;
+  u64 d = 0;
+  u32 sh = 0;
+  for (u64 k = s; k <= i; k++) { d += ((u64)(u[k] & 0x7FFFu)) << (sh & 63u); sh += 15; }
+  return d;
+}
+// the lane's eight units: number of values that end among them, sum of their deltas (dl[j] = delta of a value ending at unit j)
+__device__ __forceinline__ void ad_lane(const u16* __restrict__ u, u64 n, u64 base, u16 (&v)[AD_ITEMS], u64 (&dl)[AD_ITEMS], u32& cnt, u64& sum) {
+  if (base + AD_ITEMS <= n) {
+    const uint4 q = *reinterpret_cast<const uint4*>(u + base);                 // (tiles start at multiples of 2048 units: 16-byte aligned)
+    v[0] = (u16)q.x; v[1] = (u16)(q.x >> 16); v[2] = (u16)q.y; v[3] = (u16)(q.y >> 16);
+    v[4] = (u16)q.z; v[5] = (u16)(q.z >> 16); v[6] = (u16)q.w; v[7] = (u16)(q.w >> 16);
+  } else {
+#pragma unroll
+    for (int j = 0; j < (int)AD_ITEMS; j++) v[j] = base + j < n ? u[base + j] : (u16)0x8000;
+  }
+  cnt = 0; sum = 0;
+  // a value of one unit (every delta below 2^15: the dense lists) needs no look-back beyond the lane's own registers
+  u64 d = 0;
+  u32 sh = 0;
+  bool whole = !(base > 0 && (u[base - 1] & 0x8000u));                          // the lane's first unit starts a value
+#pragma unroll
+  for (int j = 0; j < (int)AD_ITEMS; j++) {
+    dl[j] = 0;
+    const bool in = base + j < n;
+    if (!in) continue;
+    d += ((u64)(v[j] & 0x7FFFu)) << (sh & 63u);
+    sh += 15;
+    if (!(v[j] & 0x8000u)) {
+      const u64 dv = whole ? d : ad_delta_at(u, base + j);                     // (a value that began before the lane: walk back)
+      dl[j] = dv; sum += dv; cnt++;
+      d = 0; sh = 0; whole = true;
+    }
+  }
+}
+__global__ __launch_bounds__(AD_T) void k_adopt_reduce(const u16* __restrict__ u, u64 n, u64* __restrict__ tile_cnt, u64* __restrict__ tile_sum) {
+  __shared__ u64 lds[2 * (AD_T / 64)];
+  u16 v[AD_ITEMS];
+  u64 dl[AD_ITEMS];
+  u32 cnt; u64 sum;
+  ad_lane(u, n, (u64)blockIdx.x * AD_TILE + (u64)threadIdx.x * AD_ITEMS, v, dl, cnt, sum);
+  const u64 c = wave_sum((u64)cnt), sm = wave_sum(sum);
+  if (lane_id() == 0) { lds[threadIdx.x >> 6] = c; lds[AD_T / 64 + (threadIdx.x >> 6)] = sm; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    u64 a = 0, b = 0;
+    for (u32 w = 0; w < AD_T / 64; w++) { a += lds[w]; b += lds[AD_T / 64 + w]; }
+    tile_cnt[blockIdx.x] = a; tile_sum[blockIdx.x] = b;
+  }
+}
+// g0[t] = sum of the deltas of all values in front of term t's first value (running over the whole unit stream)
+__global__ void k_adopt_terms(const u16* __restrict__ u, u64 n, const u64* __restrict__ unit_start, u64 n_terms, const u64* __restrict__ tile_sum_excl,
+                              u64* __restrict__ g0) {
+  const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_terms) return;
+  const u64 us = unit_start[t];
+  if (us >= n) { g0[t] = 0; return; }                                          // (no unit: no value will ask)
+  const u64 b = us / AD_TILE, t0 = b * AD_TILE;
+  u64 acc = tile_sum_excl[b];
+  // values that END in [t0, us): the first of them may have begun in front of the tile
+  u64 s = t0;
+  while (s > 0 && (u[s - 1] & 0x8000u)) s--;
+  u64 d = 0;
+  u32 sh = 0;
+  for (u64 k = s; k < us; k++) {
+    const u16 x = u[k];
+    d += ((u64)(x & 0x7FFFu)) << (sh & 63u);
+    sh += 15;
+    if (!(x & 0x8000u)) { acc += d; d = 0; sh = 0; }
+  }
+  g0[t] = acc;
+}
+__global__ __launch_bounds__(AD_T) void k_adopt_apply(const u16* __restrict__ u, u64 n, const u64* __restrict__ tile_cnt_excl, const u64* __restrict__ tile_sum_excl,
+                                                     const u64* __restrict__ item_start, u64 n_terms, const u64* __restrict__ g0,
+                                                     const u64* __restrict__ dir_off, const u8* __restrict__ dir_shift, u64* __restrict__ values,
+                                                     u32* __restrict__ dir) {
+  __shared__ u32 s_cnt[AD_T / 64 + 1];
+  __shared__ u64 s_sum[AD_T / 64 + 1];
+  __shared__ u32 s_rel[AD_TILE + 2];                     // first value (relative to the tile's first) of the terms the tile touches
+  __shared__ u64 s_t[2];
+  u16 v[AD_ITEMS];
+  u64 dl[AD_ITEMS];
+  u32 cnt; u64 sum;
+  ad_lane(u, n, (u64)blockIdx.x * AD_TILE + (u64)threadIdx.x * AD_ITEMS, v, dl, cnt, sum);
+  u32 tot_c; u64 tot_s;
+  const u32 ex_c = block_scan_excl<u32, (int)(AD_T / 64)>(cnt, s_cnt, &tot_c);
+  const u64 ex_s = block_scan_excl<u64, (int)(AD_T / 64)>(sum, s_sum, &tot_s);
+  if (!tot_c) return;
+  const u64 v0 = tile_cnt_excl[blockIdx.x];              // index of the tile's first value
+  // terms of the tile's first and last value: last t with item_start[t] <= value (empty terms share their successor's start)
+  if (threadIdx.x < 2) {
+    const u64 x = threadIdx.x ? v0 + tot_c - 1 : v0;
+    u64 a = 0, b = n_terms;
+    while (a + 1 < b) { const u64 m = (a + b) >> 1; if (item_start[m] <= x) a = m; else b = m; }
+    s_t[threadIdx.x] = a;
+  }
+  __syncthreads();
+  const u64 t_first = s_t[0], t_last = s_t[1];
+  const bool staged = t_last - t_first <= AD_TILE;
+  if (staged) {
+    for (u64 k = threadIdx.x; k <= t_last - t_first + 1; k += AD_T) {
+      const u64 st = t_first + k <= n_terms ? item_start[t_first + k] : ~0ull;
+      s_rel[k] = st <= v0 ? 0u : (st - v0 > (u64)AD_TILE ? AD_TILE + 1u : (u32)(st - v0));
+    }
+  }
+  __syncthreads();
+  if (!cnt) return;
+  // term of the lane's first value
+  u64 t;
+  if (staged) {
+    u32 a = 0, b = (u32)(t_last - t_first) + 1u;        // last k with s_rel[k] <= ex_c
+    while (a + 1 < b) { const u32 m = (a + b) >> 1; if (s_rel[m] <= ex_c) a = m; else b = m; }
+    t = t_first + a;
+  } else {
+    u64 a = t_first, b = t_last + 1;
+    while (a + 1 < b) { const u64 m = (a + b) >> 1; if (item_start[m] <= v0 + ex_c) a = m; else b = m; }
+    t = a;
+  }
+  u64 vi = v0 + ex_c, G = tile_sum_excl[blockIdx.x] + ex_s;
+  u64 t_end = item_start[t + 1], t_beg = item_start[t], tg0 = g0[t];
+  u32 sh = dir_shift[t];
+  u64 doff = dir_off[t], n_cells = sh != 255u ? dir_off[t + 1] - doff - 1 : 0;
+#pragma unroll
+  for (int j = 0; j < (int)AD_ITEMS; j++) {
+    if ((v[j] & 0x8000u) || (u64)blockIdx.x * AD_TILE + (u64)threadIdx.x * AD_ITEMS + j >= n) continue;
+    while (vi >= t_end) {                                // (skips empty terms)
+      t++;
+      t_beg = t_end; t_end = item_start[t + 1]; tg0 = g0[t];
+      sh = dir_shift[t]; doff = dir_off[t]; n_cells = sh != 255u ? dir_off[t + 1] - doff - 1 : 0;
+    }
+    G += dl[j];
+    const u64 c = G - tg0;
+    values[vi] = c;
+    if (sh != 255u) {
+      // posting li of the term writes the directory entries of the cells between its predecessor's cell (exclusive) and its own
+      // (inclusive); the last posting also fills the cells behind it with the posting count
+      const u64 li = vi - t_beg, cntt = t_end - t_beg;
+      u32* dd = dir + doff;
+      const u64 cell = min(c >> sh, n_cells - 1);
+      const u64 c0 = li ? min((c - dl[j]) >> sh, n_cells - 1) + 1 : 0;
+      for (u64 x = c0; x <= cell; x++) dd[x] = (u32)li;
+      if (li + 1 == cntt) for (u64 x = cell + 1; x <= n_cells; x++) dd[x] = (u32)cntt;
+    }
+    vi++;
+  }
+}
+
 __global__ void k_unpack(const u32* __restrict__ lo, const u8* __restrict__ hi, u64 n, u64* __restrict__ out) {
   u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] = ((u64)hi[i] << 32) | lo[i];
@@ -1408,24 +1569,6 @@ static int32_t ensure_values(dcd_index* h) {
   CV all;
   all.v = h->values_packed ? nullptr : h->values.p; all.lo = h->values_packed ? h->val_lo.p : nullptr; all.hi = h->values_packed ? h->val_hi.p : nullptr;
   if (N) {
-    DevBuf<u64> part, deltas, excl, sscr;
-    u64 nb = div_up(U, CODEC_TILE);
-    DCD_TRY(part.alloc(dev, nb + 1));
-    DCD_TRY(deltas.alloc(dev, N));
-    DCD_TRY(excl.alloc(dev, N));
-    DCD_TRY(sscr.alloc(dev, scan_scratch_elems(N)));
-    decode_count_launch(ix.units.p, U, part.p, st);
-    {   // the posting counts of the term directory must match the unit stream (a damaged image would overrun below)
-      u64 nv = 0;
-      DCD_HIP(hipMemcpyAsync(&nv, part.p + nb, 8, hipMemcpyDeviceToHost, st));
-      DCD_HIP(hipStreamSynchronize(st));
-      if (nv != N) DCD_FAIL(DCD_E_BADARG, "index is inconsistent: %llu postings in the unit stream, %llu in the term directory",
-                            (unsigned long long)nv, (unsigned long long)N);
-    }
-    hipLaunchKernelGGL(k_dec_deltas, dim3((u32)nb), dim3(CODEC_THREADS), 0, st, ix.units.p, U, part.p, deltas.p);
-    scan_exclusive<u64, u64>(deltas.p, excl.p, N, sscr.p, st);
-    hipLaunchKernelGGL(k_term_relative, dim3((u32)div_up(N, 256)), dim3(256), 0, st, excl.p, deltas.p, N, ix.term_item_start.p, V,
-                       (u64*)all.v, (u32*)all.lo, (u8*)all.hi);
     // cell directories for the longer lists: about one cell per posting (cell width 2^shift)
     constexpr u64 DIR_MIN = 1024;
     const u32 coord_bits = log2_ceil(ix.max_coord + 2);
@@ -1446,15 +1589,54 @@ static int32_t ensure_values(dcd_index* h) {
     h->h_dir_off[V] = tot;
     if (tot >= (1ull << 40)) DCD_FAIL(DCD_E_OVERFLOW, "cell directories too large");
     DCD_TRY(h->dir.alloc(dev, tot ? tot : 1));
-    if (tot) {
-      DevBuf<u64> d_off;
-      DevBuf<u8> d_sh;
-      DCD_TRY(d_off.alloc(dev, V + 1));
-      DCD_TRY(d_sh.alloc(dev, V));
-      DCD_HIP(hipMemcpyAsync(d_off.p, h->h_dir_off.data(), (V + 1) * 8, hipMemcpyHostToDevice, st));
-      DCD_HIP(hipMemcpyAsync(d_sh.p, h->h_dir_shift.data(), V, hipMemcpyHostToDevice, st));
-      hipLaunchKernelGGL(k_build_dir, dim3((u32)div_up(N, 256)), dim3(256), 0, st, all, N, ix.term_item_start.p, V, d_off.p, d_sh.p,
-                         h->dir.p);
+    DevBuf<u64> d_off;
+    DevBuf<u8> d_sh;
+    DCD_TRY(d_off.alloc(dev, V + 1));
+    DCD_TRY(d_sh.alloc(dev, V ? V : 1));
+    StagedUploads up;
+    DCD_TRY(up.copy(d_off.p, h->h_dir_off.data(), (V + 1) * 8, st));
+    DCD_TRY(up.copy(d_sh.p, h->h_dir_shift.data(), V, st));
+    u64* pw = pinned_words();
+    if (!pw) DCD_FAIL(DCD_E_NOMEM, "no pinned host memory");
+    static const bool env_fused = !(getenv("DOCODO_QUERY_ADOPT_FUSED") && atoi(getenv("DOCODO_QUERY_ADOPT_FUSED")) == 0);   // (A/B knob)
+    if (env_fused && !h->values_packed) {
+      // two passes over the units (see k_adopt_reduce / k_adopt_apply)
+      const u64 nt = div_up(U, AD_TILE);
+      DevBuf<u64> t_cnt, t_sum, t_cnt_ex, t_sum_ex, g0, sscr;
+      DCD_TRY(t_cnt.alloc(dev, nt)); DCD_TRY(t_sum.alloc(dev, nt)); DCD_TRY(t_cnt_ex.alloc(dev, nt + 1)); DCD_TRY(t_sum_ex.alloc(dev, nt + 1));
+      DCD_TRY(g0.alloc(dev, V ? V : 1));
+      DCD_TRY(sscr.alloc(dev, scan_scratch_elems(nt)));
+      hipLaunchKernelGGL(k_adopt_reduce, dim3((u32)nt), dim3(AD_T), 0, st, ix.units.p, U, t_cnt.p, t_sum.p);
+      scan_exclusive<u64, u64>(t_cnt.p, t_cnt_ex.p, nt, sscr.p, st);
+      DCD_HIP(hipMemcpyAsync(&pw[8], sscr.p + scan_nblocks(nt), 8, hipMemcpyDeviceToHost, st));
+      scan_exclusive<u64, u64>(t_sum.p, t_sum_ex.p, nt, sscr.p, st);
+      hipLaunchKernelGGL(k_adopt_terms, dim3((u32)div_up(V, 256)), dim3(256), 0, st, ix.units.p, U, ix.term_unit_start.p, V, t_sum_ex.p, g0.p);
+      // (queued before the check of the count comes back: a damaged image overruns nothing -- k_adopt_apply addresses `values`
+      // by the scanned tile counts, so the check below must come first)
+      DCD_HIP(hipStreamSynchronize(st));
+      if (pw[8] != N) DCD_FAIL(DCD_E_BADARG, "index is inconsistent: %llu postings in the unit stream, %llu in the term directory",
+                               (unsigned long long)pw[8], (unsigned long long)N);
+      hipLaunchKernelGGL(k_adopt_apply, dim3((u32)nt), dim3(AD_T), 0, st, ix.units.p, U, t_cnt_ex.p, t_sum_ex.p, ix.term_item_start.p, V, g0.p, d_off.p,
+                         d_sh.p, h->values.p, h->dir.p);
+    } else {
+      DevBuf<u64> part, deltas, excl, sscr;
+      u64 nb = div_up(U, CODEC_TILE);
+      DCD_TRY(part.alloc(dev, nb + 1));
+      DCD_TRY(deltas.alloc(dev, N));
+      DCD_TRY(excl.alloc(dev, N));
+      DCD_TRY(sscr.alloc(dev, scan_scratch_elems(N)));
+      decode_count_launch(ix.units.p, U, part.p, st);
+      {   // the posting counts of the term directory must match the unit stream (a damaged image would overrun below)
+        DCD_HIP(hipMemcpyAsync(&pw[8], part.p + nb, 8, hipMemcpyDeviceToHost, st));
+        DCD_HIP(hipStreamSynchronize(st));
+        if (pw[8] != N) DCD_FAIL(DCD_E_BADARG, "index is inconsistent: %llu postings in the unit stream, %llu in the term directory",
+                                 (unsigned long long)pw[8], (unsigned long long)N);
+      }
+      hipLaunchKernelGGL(k_dec_deltas, dim3((u32)nb), dim3(CODEC_THREADS), 0, st, ix.units.p, U, part.p, deltas.p);
+      scan_exclusive<u64, u64>(deltas.p, excl.p, N, sscr.p, st);
+      hipLaunchKernelGGL(k_term_relative, dim3((u32)div_up(N, 256)), dim3(256), 0, st, excl.p, deltas.p, N, ix.term_item_start.p, V,
+                         (u64*)all.v, (u32*)all.lo, (u8*)all.hi);
+      if (tot) hipLaunchKernelGGL(k_build_dir, dim3((u32)div_up(N, 256)), dim3(256), 0, st, all, N, ix.term_item_start.p, V, d_off.p, d_sh.p, h->dir.p);
     }
     DCD_HIP(hipStreamSynchronize(st));
     DCD_HIP(hipGetLastError());
@@ -1745,6 +1927,11 @@ static u64 pw_grid_of(int dev) {
   return per_dev[dev];
 }
 
+struct ResCarve {        // consecutive 256-byte aligned arrays out of one block
+  u8* base;
+  size_t cap, at = 0;
+  template <typename T> T* take(size_t n) { at = (at + 255) & ~(size_t)255; T* p = reinterpret_cast<T*>(base + at); at += n * sizeof(T); return p; }
+};
 struct PinnedBlock {     // pinned staging returned to the cache when the scope ends
   void* p = nullptr;
   PinnedBlock() {}
@@ -1890,15 +2077,22 @@ static int32_t exec_chunk(dcd_index* h, const dcd_query_opts& o, SubBatchDev& D,
   DCD_HIP(hipStreamSynchronize(st));
   if ((u32)pw[3] != 0) DCD_FAIL(DCD_E_NOMEM, "query work pool full (%llu elements)", (unsigned long long)D.pool_cap);
   const u64 tot_pages = pw[0], tot_pos = pw[1], tot_docs = pw[2];
-  DevBuf<u32> o_page_index, o_doc_index_tmp, o_doc_first, o_doc_index, o_doc_np;
-  DevBuf<u64> o_pos_off;
-  DevBuf<int32_t> o_pos;
-  DevBuf<float> o_page_rank, o_doc_rank;
-  DCD_TRY(o_page_index.alloc(dev, tot_pages + 1)); DCD_TRY(o_pos_off.alloc(dev, tot_pages + 1));
-  DCD_TRY(o_pos.alloc(dev, tot_pos + 1)); DCD_TRY(o_page_rank.alloc(dev, tot_pages + 1));
-  DCD_TRY(o_doc_index_tmp.alloc(dev, tot_docs + 1)); DCD_TRY(o_doc_index.alloc(dev, tot_docs + 1));
-  DCD_TRY(o_doc_first.alloc(dev, tot_docs + nq + 1));  // n_docs + 1 entries per query
-  DCD_TRY(o_doc_rank.alloc(dev, tot_docs + 1)); DCD_TRY(o_doc_np.alloc(dev, tot_docs + 1));
+  // The result arrays of a chunk come out of ONE block that belongs to the handle and only grows (x 1.5): their sizes differ from
+  // chunk to chunk, so the device cache (which hands out a cached block only to requests within 25 % of its size) answered every
+  // chunk of 16 k phrase queries -- gigabytes of positions -- with nine hipMalloc / hipFree pairs: 2.4 s of host time per 100 k.
+  const size_t res_need = 256 * 10 + (tot_pages + 1) * (4 + 8 + 4) + (tot_pos + 1) * 4 + (tot_docs + 1) * (4 + 4 + 4 + 4) + (tot_docs + nq + 1) * 4;
+  if (res_need > h->res_arena.n) {
+    const size_t want = std::max(res_need, h->res_arena.n + h->res_arena.n / 2);
+    h->res_arena.reset();
+    if (h->res_arena.alloc(dev, want) != DCD_OK) DCD_TRY(h->res_arena.alloc(dev, res_need));
+  }
+  ResCarve cv{h->res_arena.p, h->res_arena.n};
+  struct { u32* p; } o_page_index{cv.take<u32>(tot_pages + 1)}, o_doc_index_tmp{cv.take<u32>(tot_docs + 1)}, o_doc_first{cv.take<u32>(tot_docs + nq + 1)},
+      o_doc_index{cv.take<u32>(tot_docs + 1)}, o_doc_np{cv.take<u32>(tot_docs + 1)};
+  struct { u64* p; } o_pos_off{cv.take<u64>(tot_pages + 1)};
+  struct { int32_t* p; } o_pos{cv.take<int32_t>(tot_pos + 1)};
+  struct { float* p; } o_page_rank{cv.take<float>(tot_pages + 1)}, o_doc_rank{cv.take<float>(tot_docs + 1)};
+  if (cv.at > cv.cap) DCD_FAIL(DCD_E_NOMEM, "result arena too small (%zu of %zu bytes)", cv.cap, cv.at);
   pw[4] = tot_pos;
   DCD_HIP(hipMemcpyAsync(o_pos_off.p + tot_pages, &pw[4], 8, hipMemcpyHostToDevice, st));   // (also for an empty batch: pos_off = [0])
   if (nq) {
@@ -2344,6 +2538,7 @@ int32_t dcd_index_trim(dcd_index* h) {
   if (h->st) DCD_HIP(hipStreamSynchronize(h->st));
   h->work_pool.reset();
   h->work_pool_elems = 0;
+  h->res_arena.reset();
   if (h->lazy && h->lazy->sub) { dcd_index* old = h->lazy->sub.release(); dcd_index_free(old); h->lazy->terms.clear(); }
   dev_pool_trim(h->ix.device);
   return DCD_OK;
