@@ -141,7 +141,7 @@ __device__ __forceinline__ u64 sk_split(const u64* __restrict__ A, u64 na, const
 __global__ __launch_bounds__(64, DCD_SK_WAVES) void k_pair_stream(const PairOp* __restrict__ ops, u32 n_ops, const u64* __restrict__ kind_base,
                                                                   const u64* __restrict__ part_base, const u64* __restrict__ idx_v64, Pool pool,
                                                                   u64* __restrict__ tmp, u64* __restrict__ part_count, u64* __restrict__ part_src,
-                                                                  u64 PART, unsigned long long* __restrict__ work_ctr) {
+                                                                  u64 PART, unsigned long long* __restrict__ work_ctr, const u64* __restrict__ tmp_off) {
   __shared__ __attribute__((aligned(16))) u64 s_ring[2 * SK_RING];
   u64* sA = s_ring;
   u64* sB = s_ring + SK_RING;
@@ -163,7 +163,7 @@ __global__ __launch_bounds__(64, DCD_SK_WAVES) void k_pair_stream(const PairOp* 
     const u64* __restrict__ A = op.a.kind ? pool.base + pool.res_off[op.a.cnt_ref] : idx_v64 + op.a.off;
     const u64* __restrict__ B = op.b.kind ? pool.base + pool.res_off[op.b.cnt_ref] : idx_v64 + op.b.off;
     const u64 na = seg_cnt(op.a, pool), nb = seg_cnt(op.b, pool);
-    u64* tmp_op = tmp + op.tmp_off;
+    u64* tmp_op = tmp + tmp_off[oi];
     const u32 absR = (u32)max(abs(op.Ra), abs(op.Rb));
     const bool ordered = op.Ra < 0 && op.Rb < 0 && absR != 0;   // R = -absR < 0  (IndexSequence.cs:221-222)
     const bool is_or = op.op == DCD_OP_OR;

@@ -56,8 +56,8 @@ struct PairOp {
   int32_t Ra, Rb;
   u32 op;          // DCD_OP_AND / DCD_OP_OR
   u32 out_cnt_ref; // number of this operator's result: counts[ref] values at pool + res_off[ref], both written on the device
-  u64 cap;         // host-side bound of the result length = cap(a) + cap(b) (sizes the scratch region)
-  u64 tmp_off;     // into the slice's scratch region (cap elements)
+  u64 cap;         // host-side bound of the result length = cap(a) + cap(b)
+  u64 pad2;
 };
 // The work pool as the kernels see it.  Round 4: results are placed by the DEVICE, back to back in the order the slices complete
 // (res_off[ref] = pool elements used so far + exclusive scan of the slice's result counts), so the pool holds what the operators
@@ -432,9 +432,15 @@ __shared__ unsigned long long s_prof[24];
 #define PROF_CNT(i, n)
 #endif
 // ---- galloping, one slice of the short operand per work item ------------------------------------------------
+// gmode: GAL_SCRATCH = the item's output goes compactly into the operator's scratch region, at the union index of its first
+// emitted element (slot_out); GAL_COUNT = nothing is written, only counted; GAL_WRITE = written from tmp_op[0] on (the item's
+// final place in the pool).  Round 4: an operator whose long list is many times its short one is evaluated TWICE (count, then
+// write): its scratch region would be as long as the long list -- 1.8e8 elements for every phrase with the most frequent term --
+// and slices of a few such operators each ran at a tenth of the device (one launch per slice, a handful of wavefronts).
+constexpr int GAL_SCRATCH = 0, GAL_COUNT = 1, GAL_WRITE = 2;
 __device__ void part_gallop(const CV& Sv, u64 ns, const CV& Lv, u64 nl, bool s_is_a, u32 absR, bool ordered,
                             u64 i_begin, u64 i_end, u64* __restrict__ tmp_op, u32* rec_lds, u64& count_out, u64& slot_out,
-                            const u32* __restrict__ ldir, u32 ldir_shift, u64 ldir_last) {
+                            const u32* __restrict__ ldir, u32 ldir_shift, u64 ldir_last, int gmode) {
   const u32 lane = threadIdx.x;
   // records of the LISTED elements, by position in the list: the chains the dense passes resolved (finished records, only their
   // emission is left) and the ones that have to walk (r_n = NONE32 until flush() has walked them); an element without a neighbour
@@ -538,7 +544,7 @@ __device__ void part_gallop(const CV& Sv, u64 ns, const CV& Lv, u64 nl, bool s_i
       exq[q] = total + incl - nq_[q];
       total += rdl(incl, 63);
     }
-    if (!have_slot && total) {
+    if (gmode == GAL_SCRATCH && !have_slot && total) {
       // scratch slot of this work item = union index (S index + L index) of its first emitted element
       u64 cand = 0;
       bool found = false;
@@ -555,12 +561,14 @@ __device__ void part_gallop(const CV& Sv, u64 ns, const CV& Lv, u64 nl, bool s_i
       have_slot = true;
     }
     u64* out = tmp_op + slot;
+    if (gmode != GAL_COUNT) {
 #pragma unroll
-    for (int q = 0; q < (int)PW_ITEMS; q++) {
-      const u32 p = (u32)q * PW_T + lane;
-      if (nq_[q]) {
-        u64 o = cursor + exq[q];
-        gal_merge(Sv, i_begin + r_s0[p], i_begin + r_s1[p], Lv, r_b[p], r_b[p] + r_d[p], [&](u64 v) { out[o++] = v; });
+      for (int q = 0; q < (int)PW_ITEMS; q++) {
+        const u32 p = (u32)q * PW_T + lane;
+        if (nq_[q]) {
+          u64 o = cursor + exq[q];
+          gal_merge(Sv, i_begin + r_s0[p], i_begin + r_s1[p], Lv, r_b[p], r_b[p] + r_d[p], [&](u64 v) { out[o++] = v; });
+        }
       }
     }
     cursor += total;
@@ -805,17 +813,27 @@ __device__ void part_gallop(const CV& Sv, u64 ns, const CV& Lv, u64 nl, bool s_i
 #endif
 constexpr u32 GAL_PER = DCD_GAL_PER;
 static_assert(DCD_GAL_PER <= 65536, "part_gallop's walk-list entries are 16-bit element indices");      // short-list elements per galloping work item (256 / 512 / 1024 / 2048 -> 26.5 / 24.3 / 23.8 / 23.8 ms per 20 k C4 queries)
-constexpr u8 MODE_NONE = 0, MODE_STREAM = 1, MODE_GALLOP = 2, MODE_STREAM32 = 3;
-// items_all: work items of the operator; items_old / items_s32: the same number in the array of the kernel that evaluates them
-// (k_pair_parts: galloping items and, with stream32 == 0, the streaming ones; k_pair_stream: the streaming items) -- each kernel
-// numbers its own items through the scan of its array and records an item at the operator's place in the scan of items_all.
+constexpr u8 MODE_NONE = 0, MODE_STREAM = 1, MODE_GALLOP = 2, MODE_STREAM32 = 3, MODE_GALLOP2 = 4;
+#ifndef DCD_GAL2_RATIO
+#define DCD_GAL2_RATIO 16
+#endif
+// Work plan of the operators [0, n_ops) of a round that are still to be evaluated, computed on the device once the operand counts
+// are known.  Per operator: mode, work items, and the scratch it NEEDS -- |a| + |b| REAL elements (not the host's capacity bound)
+// for a streaming or galloping operator, nothing for a two-pass galloping one (long list >= DCD_GAL2_RATIO x short list).
+// items_all: work items of the operator; items_old / items_s32 / items_g2: the same number in the array of the kernel launch that
+// evaluates them (k_pair_parts: galloping items and, with stream32 == 0, the streaming ones; k_pair_stream: the streaming items;
+// the write pass of k_pair_parts: the two-pass items again) -- each launch numbers its own items through the scan of its array
+// and records an item at the operator's place in the scan of items_all.
+struct PlanOut { u64* need; u32* items_all; u32* items_old; u32* items_s32; u32* items_g2; u8* mode; };
 __global__ void k_pair_plan(const PairOp* __restrict__ ops, u32 n_ops, IdxVals idx_values, Pool pool,
-                            u64 PART, u32* __restrict__ items_all, u32* __restrict__ items_old, u32* __restrict__ items_s32,
-                            u8* __restrict__ mode, u32 gal_ratio, u32 stream32) {
+                            u64 PART, PlanOut o, u32 gal_ratio, u32 stream32) {
   u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i > n_ops) return;
-  if (i == n_ops) { items_all[i] = 0; items_old[i] = 0; items_s32[i] = 0; return; }
-  if (*pool.overflow) { items_all[i] = 0; items_old[i] = 0; items_s32[i] = 0; mode[i] = MODE_NONE; return; }     // the pool ran full: the sub-batch is abandoned
+  if (i == n_ops || *pool.overflow) {                     // (overflow: the pool ran full, the sub-batch is abandoned)
+    o.need[i] = 0; o.items_all[i] = 0; o.items_old[i] = 0; o.items_s32[i] = 0; o.items_g2[i] = 0;
+    if (i < n_ops) o.mode[i] = MODE_NONE;
+    return;
+  }
   const PairOp op = ops[i];
   const u64 na = seg_cnt(op.a, pool), nb = seg_cnt(op.b, pool);
   const bool is_or = op.op == DCD_OP_OR;
@@ -827,19 +845,37 @@ __global__ void k_pair_plan(const PairOp* __restrict__ ops, u32 n_ops, IdxVals i
     const bool a_short = na <= nb;
     const u64 ns = a_short ? na : nb, nl = a_short ? nb : na;
     const CV Lv = seg_cv(a_short ? op.b : op.a, idx_values, pool);
-    if (ns * (u64)gal_ratio <= nl && (Lv[nl - 1] - Lv[0]) / nl > 4ull * absR) { m = MODE_GALLOP; n = (ns + GAL_PER - 1) / GAL_PER; }
+    if (ns * (u64)gal_ratio <= nl && (Lv[nl - 1] - Lv[0]) / nl > 4ull * absR) {
+      m = ns * (u64)DCD_GAL2_RATIO <= nl ? MODE_GALLOP2 : MODE_GALLOP;
+      n = (ns + GAL_PER - 1) / GAL_PER;
+    }
   }
-  items_all[i] = (u32)n;
-  items_old[i] = m == MODE_STREAM32 ? 0u : (u32)n;
-  items_s32[i] = m == MODE_STREAM32 ? (u32)n : 0u;
-  mode[i] = m;
+  o.need[i] = (m == MODE_NONE || m == MODE_GALLOP2) ? 0ull : na + nb;
+  o.items_all[i] = (u32)n;
+  o.items_old[i] = m == MODE_STREAM32 ? 0u : (u32)n;
+  o.items_s32[i] = m == MODE_STREAM32 ? (u32)n : 0u;
+  o.items_g2[i] = m == MODE_GALLOP2 ? (u32)n : 0u;
+  o.mode[i] = m;
+}
+// how many of the planned operators run in this pass: the longest prefix whose scratch needs and work items fit (at least one:
+// the arena holds the largest single operator by construction)
+__global__ void k_pair_admit(u32 n_ops, const u64* __restrict__ need_off, const u64* __restrict__ part_base, u64 scratch_cap, u64 item_cap,
+                             u64* __restrict__ n_adm) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  u32 lo = 0, hi = n_ops;                                  // largest m with need_off[m] <= scratch_cap && part_base[m] <= item_cap
+  while (lo < hi) { const u32 m = (lo + hi + 1) >> 1; if (need_off[m] <= scratch_cap && part_base[m] <= item_cap) lo = m; else hi = m - 1; }
+  *n_adm = lo ? lo : 1u;
 }
 
 __global__ __launch_bounds__(PW_T, DCD_PW_WAVES) void k_pair_parts(const PairOp* __restrict__ ops, u32 n_ops, const u64* __restrict__ kind_base,
                                                     const u64* __restrict__ part_base,
                                                     IdxVals idx_values, Pool pool, u64* __restrict__ tmp, u64* __restrict__ part_count,
                                                     u64* __restrict__ part_src, u64 PART, const u32* __restrict__ dirs,
-                                                    u64 dir_max_coord, const u8* __restrict__ op_mode, u64 W_cap, unsigned long long* __restrict__ work_ctr) {
+                                                    u64 dir_max_coord, const u8* __restrict__ op_mode, u64 W_cap, unsigned long long* __restrict__ work_ctr,
+                                                    const u64* __restrict__ tmp_off, int pass, u64* __restrict__ pool_w, const u64* __restrict__ excl) {
+  // pass 0: every item of this launch's kind; two-pass galloping operators are only COUNTED.  pass 1 (kind_base = the scan of the
+  // two-pass items): those operators again, written to their final place in the pool (res_off is known by now).
+  if (pass != 0 && *pool.overflow) return;                 // (the results do not fit the pool: nothing is written, the host retries)
   constexpr u32 RAW_WORDS = 6u * PW_TILE + PW_TILE / 2u + 160u + 320u + 16u;   // rings + chain flags, or the gallop records + walk list + candidate list
   __shared__ __attribute__((aligned(16))) u32 s_raw[RAW_WORDS];
   u64* sA = reinterpret_cast<u64*>(s_raw);
@@ -855,7 +891,8 @@ __global__ __launch_bounds__(PW_T, DCD_PW_WAVES) void k_pair_parts(const PairOp*
   // (kind_base: exclusive scan of THIS kernel's items per operator; part_base: of all items of the slice -- the streaming items
   // may belong to k_pair_stream, which runs beside this kernel)
   const u64 n_items = kind_base[n_ops];
-  for (u64 x = part_base[n_ops] + (u64)blockIdx.x * PW_T + lane; x < W_cap; x += (u64)gridDim.x * PW_T) { part_count[x] = 0; part_src[x] = 0; }   // (the scans run over the capacity)
+  if (pass == 0)
+    for (u64 x = part_base[n_ops] + (u64)blockIdx.x * PW_T + lane; x < W_cap; x += (u64)gridDim.x * PW_T) { part_count[x] = 0; part_src[x] = 0; }   // (the scans run over the capacity)
   u64 w = blockIdx.x;
   while (w < n_items) {
   unsigned long long w_next = 0;
@@ -874,11 +911,13 @@ __global__ __launch_bounds__(PW_T, DCD_PW_WAVES) void k_pair_parts(const PairOp*
   const CV A = seg_cv(op.a, idx_values, pool);
   const CV B = seg_cv(op.b, idx_values, pool);
   const u64 na = seg_cnt(op.a, pool), nb = seg_cnt(op.b, pool);
-  u64* tmp_op = tmp + op.tmp_off;
+  const u8 omode = op_mode[oi];
+  const int gmode = omode == MODE_GALLOP2 ? (pass == 0 ? GAL_COUNT : GAL_WRITE) : GAL_SCRATCH;
+  u64* tmp_op = gmode == GAL_WRITE ? pool_w + pool.res_off[op.out_cnt_ref] + (excl[wi] - excl[part_base[oi]]) : tmp + tmp_off[oi];
   const u32 absR = (u32)max(abs(op.Ra), abs(op.Rb));
   const bool ordered = op.Ra < 0 && op.Rb < 0 && absR != 0;   // R = -absR < 0  (IndexSequence.cs:221-222)
   const bool is_or = op.op == DCD_OP_OR;
-  const bool gallop = op_mode[oi] == MODE_GALLOP;
+  const bool gallop = omode == MODE_GALLOP || omode == MODE_GALLOP2;
   u64 count = 0, slot = 0;
   {
     if (gallop) {
@@ -890,7 +929,7 @@ __global__ __launch_bounds__(PW_T, DCD_PW_WAVES) void k_pair_parts(const PairOp*
       const Seg& ls = a_short ? op.b : op.a;
       const u32* ldir = (ls.kind == 0 && ls.dir_shift != NONE32) ? dirs + ls.dir_off : nullptr;
       if (i_begin < i_end) part_gallop(Sv, ns, Lv, nl, a_short, absR, ordered, i_begin, i_end, tmp_op, s_raw, count, slot, ldir, ls.dir_shift,
-                                       ldir ? dir_max_coord >> ls.dir_shift : 0);
+                                       ldir ? dir_max_coord >> ls.dir_shift : 0, gmode);
     }
     PROF(1);   // operands, mode (gallop: everything)
     if (!gallop) {
@@ -1222,7 +1261,7 @@ __global__ __launch_bounds__(PW_T, DCD_PW_WAVES) void k_pair_parts(const PairOp*
       count = cursor;
     }
   }
-  if (lane == 0) { part_count[wi] = count; part_src[wi] = slot; }
+  if (lane == 0 && pass == 0) { part_count[wi] = count; part_src[wi] = slot; }
   PROF(10);
   wsync();                                                     // (the next item reuses the rings / records)
   w = rfl64(w_next);
@@ -1240,7 +1279,8 @@ namespace dcd {
 __global__ __launch_bounds__(256) void k_pair_gather(const PairOp* __restrict__ ops, u32 n_ops, const u64* __restrict__ part_base, u64 W,
                                                     const u64* __restrict__ part_count, const u64* __restrict__ part_src,
                                                     const u64* __restrict__ excl, const u64* __restrict__ tmp, u64* __restrict__ pool,
-                                                    const u64* __restrict__ res_off, const u32* __restrict__ overflow) {
+                                                    const u64* __restrict__ res_off, const u32* __restrict__ overflow,
+                                                    const u64* __restrict__ tmp_off, const u8* __restrict__ op_mode) {
   if (*overflow) return;                                   // (the slice's results do not fit the pool: nothing is copied, the host retries)
   const u32 lane = lane_id();
   const u64 gw = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = ((u64)gridDim.x * blockDim.x) >> 6;
@@ -1252,7 +1292,8 @@ __global__ __launch_bounds__(256) void k_pair_gather(const PairOp* __restrict__ 
     if (!c) continue;
     u32 lo = 0, hi = n_ops;                                  // operator of the item (the eight lanes read the same words)
     while (lo + 1 < hi) { u32 mid = (lo + hi) >> 1; if (part_base[mid] <= w) lo = mid; else hi = mid; }
-    const u64* sp = tmp + ops[lo].tmp_off + part_src[w];
+    if (op_mode[lo] == MODE_GALLOP2) continue;               // (written in place by the second pass of k_pair_parts)
+    const u64* sp = tmp + tmp_off[lo] + part_src[w];
     u64* dp = pool + res_off[ops[lo].out_cnt_ref] + (excl[w] - excl[part_base[lo]]);
     u64 k = sub;
     for (; k + 24 < c; k += 32) {                            // four steps in flight
@@ -1693,8 +1734,11 @@ struct SubBatch {
   u64 ops_total = 0, ops_shared = 0, units_named = 0, units_evaluated = 0;
 };
 
-// A SLICE = consecutive operators of one round whose scratch regions (cap elements each) fit the scratch arena together.
-struct SliceInfo { u32 first, n; u64 W, tmp_elems; };
+// A ROUND = the new operators of a chunk whose operands are all known once the previous round has run.  How many of a round's
+// operators run together is decided ON THE DEVICE, pass by pass, from their REAL operand lengths (k_pair_plan / k_pair_admit):
+// the host only knows capacity bounds (a result is at most as long as its operands together), which overstate a phrase match by
+// orders of magnitude.
+struct RoundInfo { u32 first, n; };
 struct ChunkPlan {
   size_t q0 = 0, q1 = 0;
   u32 chunk = 0;
@@ -1702,9 +1746,10 @@ struct ChunkPlan {
   FinalSeq* finals = nullptr;    // pinned staging: [q1 - q0]
   size_t ops_cap = 0, n_ops = 0;
   std::vector<int32_t> finalR;
-  std::vector<SliceInfo> slices;
-  u64 max_W = 0;
-  u32 max_slice_ops = 0;
+  std::vector<RoundInfo> rounds;
+  std::vector<u64> cap_prefix, w_prefix;   // [n_ops + 1] prefix sums of the operators' capacity bounds / work-item bounds
+  u64 max_op_W = 0;              // largest work-item bound of a single operator
+  u32 max_round_ops = 0;
   int32_t status = DCD_OK;
   std::string err;
 };
@@ -1719,17 +1764,17 @@ static void plan_fail(ChunkPlan& P, int32_t code, const char* fmt, ...) {
   P.err = buf;
 }
 
-// queries [P.q0, P.q1) -> the operators that are new to the sub-batch (in execution order, cut into slices) + the final sequences
+// queries [P.q0, P.q1) -> the operators that are new to the sub-batch (in execution order, round by round) + the final sequences
 static void plan_chunk(const dcd_index* h, const std::vector<SymVal>* ext_leaves, SubBatch& sb, const int32_t* prog, const u64* prog_off,
-                       u64 PART, u64 slice_elems, ChunkPlan& P) {
+                       u64 PART, ChunkPlan& P) {
   const DeviceIndex& ix = h->ix;
   struct Ord { u32 round; u32 idx; u64 key; };
   std::vector<PairOp> ops;
   std::vector<Ord> ord;
   std::vector<SymVal> stk;
   P.finalR.assign(P.q1 - P.q0, 0);
-  P.slices.clear();
-  P.n_ops = 0; P.max_W = 0; P.max_slice_ops = 0;
+  P.rounds.clear();
+  P.n_ops = 0; P.max_op_W = 0; P.max_round_ops = 0;
   const bool have_dir = !h->h_dir_off.empty();
   for (size_t q = P.q0; q < P.q1; q++) {
     stk.clear();
@@ -1782,7 +1827,7 @@ static void plan_chunk(const dcd_index* h, const std::vector<SymVal>* ext_leaves
           sb.ref_round.push_back(r.round);
           PairOp p;
           p.a = a.s; p.b = b.s; p.Ra = a.R; p.Rb = b.R; p.op = (u32)opc;
-          p.out_cnt_ref = ref; p.cap = a.cap + b.cap; p.tmp_off = 0;
+          p.out_cnt_ref = ref; p.cap = a.cap + b.cap; p.pad2 = 0;
           // operators of a round run in the order of their LONGER index-term operand, so that the queries of a batch that probe the
           // same posting list (the head terms of a Zipf query load) do so at about the same time and share its cache lines
           const bool ta = a.s.kind == 0, tb = b.s.kind == 0;
@@ -1817,30 +1862,23 @@ static void plan_chunk(const dcd_index* h, const std::vector<SymVal>* ext_leaves
   if (sort_ops) std::sort(ord.begin(), ord.end(), [](const Ord& x, const Ord& y) {
     return x.round != y.round ? x.round < y.round : (x.key != y.key ? x.key < y.key : x.idx < y.idx); });
   else std::stable_sort(ord.begin(), ord.end(), [](const Ord& x, const Ord& y) { return x.round < y.round; });
-  // slices: work items of an operator = ceil(cap / PART) partitions of the union, or ceil(|short| / GAL_PER) when it gallops
-  // (upper bound of the device's plan); scratch region = cap elements
-  SliceInfo cur{0, 0, 0, 0};
-  u32 cur_round = 0;
-  auto close = [&]() {
-    if (!cur.n) return;
-    P.slices.push_back(cur);
-    P.max_W = std::max(P.max_W, cur.W);
-    P.max_slice_ops = std::max(P.max_slice_ops, cur.n);
-  };
+  // work items of an operator <= ceil(cap / PART) partitions of the union, or ceil(|short| / GAL_PER) when it gallops
+  P.cap_prefix.assign(ord.size() + 1, 0);
+  P.w_prefix.assign(ord.size() + 1, 0);
   for (size_t k = 0; k < ord.size(); k++) {
-    PairOp p = ops[ord[k].idx];
-    if (cur.n && (ord[k].round != cur_round || cur.tmp_elems + p.cap > slice_elems)) { close(); cur = SliceInfo{(u32)k, 0, 0, 0}; }
-    if (!cur.n) { cur.first = (u32)k; cur_round = ord[k].round; }
+    const PairOp& p = ops[ord[k].idx];
+    if (P.rounds.empty() || ord[k].round != ord[k - 1].round) P.rounds.push_back(RoundInfo{(u32)k, 0});
+    P.rounds.back().n++;
     const u64 ca = p.a.kind == 0 ? p.a.cnt_imm : sb.ref_cap[p.a.cnt_ref];
     const u64 cb = p.b.kind == 0 ? p.b.cnt_imm : sb.ref_cap[p.b.cnt_ref];
-    p.tmp_off = cur.tmp_elems;
-    cur.tmp_elems += p.cap;
-    cur.W += std::max<u64>(std::max<u64>(1, div_up(ca + cb, PART)), div_up(std::min(ca, cb), GAL_PER));
-    cur.n++;
+    const u64 W = std::max<u64>(std::max<u64>(1, div_up(ca + cb, PART)), div_up(std::min(ca, cb), GAL_PER));
+    if (W >= (1ull << 31)) return plan_fail(P, DCD_E_OVERFLOW, "operator too large: %llu work items", (unsigned long long)W);
+    P.max_op_W = std::max(P.max_op_W, W);
+    P.cap_prefix[k + 1] = P.cap_prefix[k] + p.cap;
+    P.w_prefix[k + 1] = P.w_prefix[k] + W;
     P.ops[k] = p;
-    if (cur.W >= (1ull << 31)) return plan_fail(P, DCD_E_OVERFLOW, "query batch too large: %llu work items in one slice", (unsigned long long)cur.W);
   }
-  close();
+  for (const RoundInfo& r : P.rounds) P.max_round_ops = std::max(P.max_round_ops, r.n);
   P.n_ops = ord.size();
 }
 
@@ -1860,7 +1898,7 @@ struct SubBatchDev {
   u64* pool = nullptr;             // pool_cap elements
   u64* tmp = nullptr;              // scratch_cap elements
   u64 pool_cap = 0, scratch_cap = 0;
-  u32 seq = 0;                     // slices executed so far
+  u32 seq = 0;                     // passes executed so far
   PageDev pd;
   ResParams P;
 };
@@ -1960,25 +1998,31 @@ static int32_t exec_chunk(dcd_index* h, const dcd_query_opts& o, SubBatchDev& D,
   // ---- device buffers of the chunk (from the library's device cache) --------------------------------
   DevBuf<PairOp> d_ops;
   DevBuf<u64> d_part_base, d_part_count, d_part_src, d_part_excl, d_part_scr, d_slice_cnt, d_slice_off, d_slice_scr, d_work_ctr;
-  DevBuf<u32> d_items, d_items_old, d_items_s32;
-  DevBuf<u64> d_base_old, d_base_s32;
+  DevBuf<u64> d_need, d_need_off, d_base_old, d_base_s32, d_base_g2, d_nadm;
+  DevBuf<u32> d_items, d_items_old, d_items_s32, d_items_g2;
   DevBuf<u8> d_mode;
+  // work items a pass may hold (its three per-item arrays): as many as the largest round can need, at most ~4 M, at least the
+  // largest single operator
+  constexpr u64 W_PASS = 4ull << 20;
+  u64 W_cap = 1;
+  for (const RoundInfo& r : C.rounds) W_cap = std::max(W_cap, C.w_prefix[r.first + r.n] - C.w_prefix[r.first]);
+  W_cap = std::max(std::min(W_cap, W_PASS), C.max_op_W);
+  const size_t mro = (size_t)C.max_round_ops + 1;
   DCD_TRY(d_ops.alloc(dev, C.n_ops ? C.n_ops : 1));
-  DCD_TRY(d_items.alloc(dev, (size_t)C.max_slice_ops + 1));
-  DCD_TRY(d_items_old.alloc(dev, (size_t)C.max_slice_ops + 1));
-  DCD_TRY(d_items_s32.alloc(dev, (size_t)C.max_slice_ops + 1));
-  DCD_TRY(d_base_old.alloc(dev, (size_t)C.max_slice_ops + 1));
-  DCD_TRY(d_base_s32.alloc(dev, (size_t)C.max_slice_ops + 1));
-  DCD_TRY(d_mode.alloc(dev, (size_t)C.max_slice_ops + 1));
-  DCD_TRY(d_part_base.alloc(dev, (size_t)C.max_slice_ops + 1));
-  DCD_TRY(d_slice_cnt.alloc(dev, (size_t)C.max_slice_ops + 1));
-  DCD_TRY(d_slice_off.alloc(dev, (size_t)C.max_slice_ops + 1));
-  DCD_TRY(d_slice_scr.alloc(dev, scan_scratch_elems((u64)C.max_slice_ops + 1)));
-  DCD_TRY(d_part_count.alloc(dev, C.max_W + 1));
-  DCD_TRY(d_part_src.alloc(dev, C.max_W + 1));
-  DCD_TRY(d_part_excl.alloc(dev, C.max_W + 1));
-  DCD_TRY(d_part_scr.alloc(dev, scan_scratch_elems(C.max_W + 1)));
-  DCD_TRY(d_work_ctr.alloc(dev, std::max<size_t>(1, 2 * C.slices.size())));
+  DCD_TRY(d_need.alloc(dev, mro)); DCD_TRY(d_need_off.alloc(dev, mro));
+  DCD_TRY(d_items.alloc(dev, mro)); DCD_TRY(d_items_old.alloc(dev, mro)); DCD_TRY(d_items_s32.alloc(dev, mro)); DCD_TRY(d_items_g2.alloc(dev, mro));
+  DCD_TRY(d_base_old.alloc(dev, mro)); DCD_TRY(d_base_s32.alloc(dev, mro)); DCD_TRY(d_base_g2.alloc(dev, mro));
+  DCD_TRY(d_mode.alloc(dev, mro));
+  DCD_TRY(d_part_base.alloc(dev, mro));
+  DCD_TRY(d_slice_cnt.alloc(dev, mro));
+  DCD_TRY(d_slice_off.alloc(dev, mro));
+  DCD_TRY(d_slice_scr.alloc(dev, scan_scratch_elems((u64)mro)));
+  DCD_TRY(d_part_count.alloc(dev, W_cap + 1));
+  DCD_TRY(d_part_src.alloc(dev, W_cap + 1));
+  DCD_TRY(d_part_excl.alloc(dev, W_cap + 1));
+  DCD_TRY(d_part_scr.alloc(dev, scan_scratch_elems(std::max<u64>(W_cap + 1, mro))));
+  DCD_TRY(d_work_ctr.alloc(dev, 4));
+  DCD_TRY(d_nadm.alloc(dev, 1));
   DevBuf<FinalSeq> d_fin;
   DCD_TRY(d_fin.alloc(dev, nq ? nq : 1));
   DevBuf<QCounts> d_qc;
@@ -1989,10 +2033,9 @@ static int32_t exec_chunk(dcd_index* h, const dcd_query_opts& o, SubBatchDev& D,
   // the plan was written into pinned staging by the planner: two asynchronous uploads
   if (C.n_ops) DCD_HIP(hipMemcpyAsync(d_ops.p, C.ops, C.n_ops * sizeof(PairOp), hipMemcpyHostToDevice, st));
   if (nq) DCD_HIP(hipMemcpyAsync(d_fin.p, C.finals, nq * sizeof(FinalSeq), hipMemcpyHostToDevice, st));
-  DCD_HIP(hipMemsetAsync(d_work_ctr.p, 0, std::max<size_t>(1, 2 * C.slices.size()) * sizeof(u64), st));
   // k_pair_stream (32-bit tile-relative keys) takes the streaming work items unless the resident coordinates are packed planes
   static const bool env_s32 = !(getenv("DOCODO_QUERY_STREAM32") && atoi(getenv("DOCODO_QUERY_STREAM32")) == 0);   // (A/B knob)
-  const bool stream32 = env_s32 && idx_values.v64 != nullptr && !C.slices.empty();
+  const bool stream32 = env_s32 && idx_values.v64 != nullptr && !C.rounds.empty();
   struct SideStream {                                       // second stream + the two events that order it against the main one
     int dev; hipStream_t s = nullptr; hipEvent_t a = nullptr, b = nullptr;
     ~SideStream() { if (s) stream_release(dev, s); if (a) event_release(dev, a); if (b) event_release(dev, b); }
@@ -2012,43 +2055,62 @@ static int32_t exec_chunk(dcd_index* h, const dcd_query_opts& o, SubBatchDev& D,
   const u64 pw_grid = pw_grid_of(dev);
   const u64 sk_grid = std::max<u64>(1, pw_grid * DCD_SK_WAVES / DCD_PW_WAVES);       // (the same multiple of ITS wavefront slots)
   static const u32 gal_ratio = getenv("DOCODO_QUERY_GAL_RATIO") ? (u32)atoi(getenv("DOCODO_QUERY_GAL_RATIO")) : GAL_RATIO;   // (A/B knob)
-  for (size_t s = 0; s < C.slices.size(); s++) {
-    const SliceInfo& sl = C.slices[s];
-    const u32 n = sl.n;
-    const u64 W = sl.W;
-    const PairOp* ops = d_ops.p + sl.first;
-    if (sl.tmp_elems > D.scratch_cap) DCD_FAIL(DCD_E_NOMEM, "query slice needs %llu scratch elements, the arena has %llu",
-                                               (unsigned long long)sl.tmp_elems, (unsigned long long)D.scratch_cap);
-    // device plan: item count + mode per operator, exclusive scans -> first work item of every operator (of all items, and per kernel)
-    hipLaunchKernelGGL(k_pair_plan, dim3((u32)div_up((u64)n + 1, 256)), dim3(256), 0, st, ops, n, idx_values, pool, PART, d_items.p, d_items_old.p,
-                       d_items_s32.p, d_mode.p, gal_ratio, stream32 ? 1u : 0u);
-    scan_exclusive<u32, u64>(d_items.p, d_part_base.p, (u64)n + 1, d_part_scr.p, st);
-    scan_exclusive<u32, u64>(d_items_old.p, d_base_old.p, (u64)n + 1, d_part_scr.p, st);
-    if (stream32) {
-      // the streaming items run BESIDE the galloping ones, on a second stream: memory-bound galloping wavefronts and the
-      // merging ones share the CUs (round 3 measured the two kinds in consecutive launches: 35 % slower than in one)
-      scan_exclusive<u32, u64>(d_items_s32.p, d_base_s32.p, (u64)n + 1, d_part_scr.p, st);
-      DCD_HIP(hipEventRecord(ev_plan, st));
-      DCD_HIP(hipStreamWaitEvent(st2, ev_plan, 0));
-      hipLaunchKernelGGL(k_pair_stream, dim3((u32)std::min<u64>(W, sk_grid)), dim3(64), 0, st2, ops, n, d_base_s32.p, d_part_base.p, idx_values.v64,
-                         pool, D.tmp, d_part_count.p, d_part_src.p, PART, reinterpret_cast<unsigned long long*>(d_work_ctr.p + 2 * s + 1));
-      DCD_HIP(hipEventRecord(ev_s32, st2));
+  u64* pwa = pinned_words();
+  if (!pwa) DCD_FAIL(DCD_E_NOMEM, "no pinned host memory");
+  const PlanOut plan_out{d_need.p, d_items.p, d_items_old.p, d_items_s32.p, d_items_g2.p, d_mode.p};
+  for (const RoundInfo& rd : C.rounds) {
+    u32 first = rd.first;
+    const u32 end = rd.first + rd.n;
+    while (first < end) {
+      const u32 n_rem = end - first;
+      const PairOp* ops = d_ops.p + first;
+      // device plan of everything that is left of the round: mode, work items and REAL scratch need per operator, prefix sums
+      hipLaunchKernelGGL(k_pair_plan, dim3((u32)div_up((u64)n_rem + 1, 256)), dim3(256), 0, st, ops, n_rem, idx_values, pool, PART, plan_out, gal_ratio,
+                         stream32 ? 1u : 0u);
+      scan_exclusive<u64, u64>(d_need.p, d_need_off.p, (u64)n_rem + 1, d_part_scr.p, st);
+      scan_exclusive<u32, u64>(d_items.p, d_part_base.p, (u64)n_rem + 1, d_part_scr.p, st);
+      scan_exclusive<u32, u64>(d_items_old.p, d_base_old.p, (u64)n_rem + 1, d_part_scr.p, st);
+      scan_exclusive<u32, u64>(d_items_g2.p, d_base_g2.p, (u64)n_rem + 1, d_part_scr.p, st);
+      if (stream32) scan_exclusive<u32, u64>(d_items_s32.p, d_base_s32.p, (u64)n_rem + 1, d_part_scr.p, st);
+      DCD_HIP(hipMemsetAsync(d_work_ctr.p, 0, 4 * sizeof(u64), st));
+      // how many of them run in this pass: all, when even the host's bounds fit; else the device says (one round trip)
+      u32 n = n_rem;
+      if (C.cap_prefix[end] - C.cap_prefix[first] > D.scratch_cap || C.w_prefix[end] - C.w_prefix[first] > W_cap) {
+        hipLaunchKernelGGL(k_pair_admit, dim3(1), dim3(64), 0, st, n_rem, d_need_off.p, d_part_base.p, D.scratch_cap, W_cap, d_nadm.p);
+        DCD_HIP(hipMemcpyAsync(&pwa[9], d_nadm.p, 8, hipMemcpyDeviceToHost, st));
+        DCD_HIP(hipStreamSynchronize(st));
+        n = (u32)std::min<u64>(std::max<u64>(pwa[9], 1), n_rem);
+      }
+      const u64 W = std::min<u64>(W_cap, C.w_prefix[first + n] - C.w_prefix[first]);
+      if (stream32) {
+        // the streaming items run BESIDE the galloping ones, on a second stream: memory-bound galloping wavefronts and the
+        // merging ones share the CUs (round 3 measured the two kinds in consecutive launches: 35 % slower than in one)
+        DCD_HIP(hipEventRecord(ev_plan, st));
+        DCD_HIP(hipStreamWaitEvent(st2, ev_plan, 0));
+        hipLaunchKernelGGL(k_pair_stream, dim3((u32)std::min<u64>(W, sk_grid)), dim3(64), 0, st2, ops, n, d_base_s32.p, d_part_base.p, idx_values.v64,
+                           pool, D.tmp, d_part_count.p, d_part_src.p, PART, reinterpret_cast<unsigned long long*>(d_work_ctr.p + 1), d_need_off.p);
+        DCD_HIP(hipEventRecord(ev_s32, st2));
+      }
+      hipLaunchKernelGGL(k_pair_parts, dim3((u32)std::min<u64>(W, pw_grid)), dim3(PW_T), 0, st, ops, n, d_base_old.p, d_part_base.p, idx_values, pool,
+                         D.tmp, d_part_count.p, d_part_src.p, PART, ext_values ? nullptr : h->dir.p, ix.max_coord, d_mode.p, W,
+                         reinterpret_cast<unsigned long long*>(d_work_ctr.p), d_need_off.p, 0, D.pool, d_part_excl.p);
+      if (stream32) DCD_HIP(hipStreamWaitEvent(st, ev_s32, 0));
+      DCD_HIP(hipMemsetAsync(d_part_count.p + W, 0, 8, st));
+      scan_exclusive<u64, u64>(d_part_count.p, d_part_excl.p, W + 1, d_part_scr.p, st);
+      // result lengths -> their places in the pool (device-side bump allocation) -> copy out of the scratch / second pass
+      hipLaunchKernelGGL(k_pair_totals, dim3((u32)div_up((u64)n, 256)), dim3(256), 0, st, ops, n, d_part_base.p, d_part_excl.p, D.counts.p, d_slice_cnt.p);
+      scan_exclusive<u64, u64>(d_slice_cnt.p, d_slice_off.p, (u64)n, d_slice_scr.p, st);
+      hipLaunchKernelGGL(k_pair_assign, dim3((u32)div_up((u64)n, 256)), dim3(256), 0, st, ops, n, d_slice_off.p, d_slice_scr.p + scan_nblocks(n), D.used.p,
+                         D.seq, D.pool_cap, D.res_off.p, D.overflow.p);
+      D.seq++;
+      const u32 gg = (u32)std::min<u64>(div_up(div_up(W, 8), 4), 16384);
+      hipLaunchKernelGGL(k_pair_gather, dim3(gg), dim3(256), 0, st, ops, n, d_part_base.p, W, d_part_count.p, d_part_src.p, d_part_excl.p, D.tmp,
+                         D.pool, D.res_off.p, D.overflow.p, d_need_off.p, d_mode.p);
+      hipLaunchKernelGGL(k_pair_parts, dim3((u32)std::min<u64>(W, pw_grid)), dim3(PW_T), 0, st, ops, n, d_base_g2.p, d_part_base.p, idx_values, pool,
+                         D.tmp, d_part_count.p, d_part_src.p, PART, ext_values ? nullptr : h->dir.p, ix.max_coord, d_mode.p, W,
+                         reinterpret_cast<unsigned long long*>(d_work_ctr.p + 2), d_need_off.p, 1, D.pool, d_part_excl.p);
+      first += n;
     }
-    hipLaunchKernelGGL(k_pair_parts, dim3((u32)std::min<u64>(W, pw_grid)), dim3(PW_T), 0, st, ops, n, d_base_old.p, d_part_base.p, idx_values, pool,
-                       D.tmp, d_part_count.p, d_part_src.p, PART, ext_values ? nullptr : h->dir.p, ix.max_coord, d_mode.p, W,
-                       reinterpret_cast<unsigned long long*>(d_work_ctr.p + 2 * s));
-    if (stream32) DCD_HIP(hipStreamWaitEvent(st, ev_s32, 0));
-    DCD_HIP(hipMemsetAsync(d_part_count.p + W, 0, 8, st));
-    scan_exclusive<u64, u64>(d_part_count.p, d_part_excl.p, W + 1, d_part_scr.p, st);
-    // result lengths -> their places in the pool (device-side bump allocation) -> copy out of the scratch
-    hipLaunchKernelGGL(k_pair_totals, dim3(div_up(n, 256)), dim3(256), 0, st, ops, n, d_part_base.p, d_part_excl.p, D.counts.p, d_slice_cnt.p);
-    scan_exclusive<u64, u64>(d_slice_cnt.p, d_slice_off.p, (u64)n, d_slice_scr.p, st);
-    hipLaunchKernelGGL(k_pair_assign, dim3(div_up(n, 256)), dim3(256), 0, st, ops, n, d_slice_off.p, d_slice_scr.p + scan_nblocks(n), D.used.p,
-                       D.seq, D.pool_cap, D.res_off.p, D.overflow.p);
-    D.seq++;
-    const u32 gg = (u32)std::min<u64>(div_up(div_up(W, 8), 4), 16384);
-    hipLaunchKernelGGL(k_pair_gather, dim3(gg), dim3(256), 0, st, ops, n, d_part_base.p, W, d_part_count.p, d_part_src.p, d_part_excl.p, D.tmp,
-                       D.pool, D.res_off.p, D.overflow.p);
   }
   u64* pw = pinned_words();
   if (!pw) DCD_FAIL(DCD_E_NOMEM, "no pinned host memory");
@@ -2344,7 +2406,7 @@ static int32_t run_sub_batch(dcd_index* h, const int32_t* prog, const u64* prog_
     return DCD_OK;
   };
   DCD_TRY(prepare(0));
-  plan_chunk(h, ext_leaves, sb, prog, prog_off, PART, scratch_elems, plans[0]);
+  plan_chunk(h, ext_leaves, sb, prog, prog_off, PART, plans[0]);
   int32_t status = DCD_OK;
   for (size_t c = 0; c < n_chunks && status == DCD_OK; c++) {
     ChunkPlan& P = plans[c & 1];
@@ -2354,7 +2416,7 @@ static int32_t run_sub_batch(dcd_index* h, const int32_t* prog, const u64* prog_
     if (c + 1 < n_chunks) {
       status = prepare(c + 1);
       if (status != DCD_OK) break;
-      planner = std::thread(plan_chunk, h, ext_leaves, std::ref(sb), prog, prog_off, PART, scratch_elems, std::ref(plans[(c + 1) & 1]));
+      planner = std::thread(plan_chunk, h, ext_leaves, std::ref(sb), prog, prog_off, PART, std::ref(plans[(c + 1) & 1]));
     }
     if (n_chunks == 1) status = exec_chunk(h, o, D, P, PART, R, ext_values, refs_after);
     else {
