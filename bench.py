@@ -306,38 +306,22 @@ def oracle_query_sample(oix, progs, budget_s, min_q=8):
             "sample": "first %d queries of the leg on the same index bytes, oracle 1 thread, %.1f s" % (done, t_used)}
 
 
-def oracle_query_all_cores(img, lst, progs, n_1core, max_copies, budget_s):
+def oracle_query_all_cores(oix, progs, n_1core, budget_s):
     """the reference serialises Search under ONE lock (Search.cs:448; GetPage keeps a cursor in the page list,
-    Build.cs:74-97), so queries/s of one index object is the one-thread figure.  This is the query-sharded variant: one
-    private copy of the index per thread (the oracle's page cursor is per object too), the sample's queries dealt out in
-    contiguous slices, wall time of the slowest thread.  Copies are bounded by host memory (`max_copies`)."""
-    import concurrent.futures as cf
-    import oracle
+    Build.cs:74-97), so queries/s of one index object is the one-thread figure.  This is the query-sharded variant on ALL host
+    cores: the threads share the loaded index (posting lists and page table are only read), each with a page cursor of its own
+    (oracle.cpp orc_query_batch_mt) -- what one private copy of the index per thread gives, without the copies.  The sample's
+    queries in contiguous slices, wall time of the slowest thread."""
     C = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    C = max(1, min(C, max_copies))
     pa, oa = progs[0]
     n = int(min(oa.size - 1, max(C, n_1core * C)))                # ~ the one-thread sample's work per thread
     if C < 2 or n < C:
         return None
-
-    def load(_):
-        o = oracle.Index(stemmers=[])
-        o.load(img, lst)
-        return o
-
-    with cf.ThreadPoolExecutor(C) as ex:
-        copies = list(ex.map(load, range(C)))
-        cuts = [n * k // C for k in range(C + 1)]
-
-        def run(k):
-            a, b = cuts[k], cuts[k + 1]
-            if a < b:
-                copies[k].query_batch(pa[int(oa[a]):int(oa[b])], oa[a:b + 1] - oa[a])
-        t0 = time.perf_counter()
-        list(ex.map(run, range(C)))
-        dt = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    oix.query_batch_mt(pa[:int(oa[n])], oa[:n + 1], C)
+    dt = time.perf_counter() - t0
     return {"queries_per_s": round(n / dt, 2), "cores": C,
-            "sample": "first %d queries of the leg, %d threads with a private copy of the index each (query-sharded), %.1f s" % (n, C, dt)}
+            "sample": "first %d queries of the leg, %d threads on one shared index (query-sharded, private page cursors), %.1f s" % (n, C, dt)}
 
 
 def query_bench(ix, n_single, n_and3, cpu_sample, img=None, lst=None, seed_offset=0):
@@ -351,15 +335,19 @@ def query_bench(ix, n_single, n_and3, cpu_sample, img=None, lst=None, seed_offse
         import oracle
         oix = oracle.Index(stemmers=[])
         oix.load(img, lst)
-    ix.query_batch(np.array([0, 0, 258], np.int32), np.array([0, 3], np.uint64), totals=True)        # warm-up (decodes the index once)
+    # the FIRST batch of a handle also makes the resident coordinates and the cell directories (adoption: two passes over the units)
+    tw = time.perf_counter()
+    ix.query_batch(np.array([0, 0, 258], np.int32), np.array([0, 3], np.uint64), totals=True)
+    out["first_query_ready_ms"] = round((time.perf_counter() - tw) * 1e3, 2)
     for name, nq, nt in (("single_term", n_single, 1), ("and3", n_and3, 3)):
         if nq <= 0:
             continue
         qs = and_queries(synth.query_ranks(nq, nt, seed=synth.SEED_QUERY + seed_offset))
         out[name], progs = run_query_leg(ix, qs, info, max(nq, 1), "configs[1] index", reps=3)
+        out[name]["best_of"] = 3
         if oix is not None and progs:
             out[name]["cpu_baseline"] = oracle_query_sample(oix, progs, cpu_sample)
-            ac = oracle_query_all_cores(img, lst, progs, out[name]["cpu_baseline"]["queries"], 16, cpu_sample)
+            ac = oracle_query_all_cores(oix, progs, out[name]["cpu_baseline"]["queries"], cpu_sample)
             if ac:
                 out[name]["cpu_baseline"]["all_cores"] = ac
     return out
@@ -414,6 +402,7 @@ def main():
     ap.add_argument("--lean-events", type=int, default=0, help="1: the timed steps record HIP events around the dominant kernel only "
                     "(chosen in the fully instrumented warm-up steps: +1-2 %% value); 0 (default): every event in the timed steps -- the "
                     "default keeps the per-kernel and per-stage figures of the line measured in the timed region itself")
+    ap.add_argument("--host-legs", type=int, default=1, help="1: also time the UTF-16 build and the build from pinned host memory (extra legs of the line)")
     ap.add_argument("--force-exchange", action="store_true", help="rehearsal: run the N > 1 step (exchange + merge) with one rank")
     args = ap.parse_args()
 
@@ -641,6 +630,10 @@ def main():
         note("timed steps done: %.3f ms per step" % ms_step)
         if world == 1 and not exchange:
             out["general_pages"] = general_pages_leg(text, D, T, local_rank, max(3, args.steps // 2))
+        if world == 1 and not exchange and args.host_legs:
+            # the inputs a C# host really hands over: a `string` (UTF-16 code units) and host memory (PCIe in the timed region)
+            out["utf16"] = utf16_leg(text, D, local_rank, max(3, args.steps // 2))
+            out["pcie"] = pcie_leg(D, local_rank, 3)
         if world == 1 and args.inflight > 1 and not exchange:
             out["builders_in_flight"] = inflight_bench(args.inflight, args.steps, text, D, local_rank, T)
         if world == 1 and args.cpu_docs > 0 and not exchange:
@@ -696,6 +689,60 @@ def general_pages_leg(text, D, T, device, steps):
     w = float(np.mean(walls))
     return {"GB_per_s": round(T / 1e9 / w, 2), "ms_per_build_wall": round(w * 1e3, 3), "ms_per_build_device": round(float(np.mean(ms_dev)), 3),
             "builds": steps, "note": "explicit page offsets (dcd_build_add_pages_dev, host offset array); `value` is the uniform-pages entry point"}
+
+
+def utf16_leg(text, D, device, steps):
+    """The same corpus as UTF-16LE code units (what a C# `string` pins to; dcd_build_opts.encoding = DCD_ENC_UTF16LE), resident in
+    HBM: characters / s and bytes / s of the 2-byte text.  Never `value`."""
+    import docodo_amd
+    from docodo_amd import synth
+    t16 = text.to(torch.int16)
+    torch.cuda.synchronize()
+    ms_dev, walls = [], []
+    for i in range(steps + 1):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        b = docodo_amd.Builder(encoding=docodo_amd.DCD_ENC_UTF16LE, device=device)
+        b.AddUniformPagesDev(t16.data_ptr(), D, synth.DOC_BYTES)
+        st = b.Finish()
+        torch.cuda.synchronize()
+        if i:
+            walls.append(time.perf_counter() - t0)
+            ms_dev.append(st.ms_total)
+        b.close()
+    del t16
+    w = float(np.mean(walls))
+    n_chars = D * synth.DOC_BYTES
+    return {"Gchars_per_s": round(n_chars / 1e9 / w, 2), "GB_per_s_of_utf16_bytes": round(2 * n_chars / 1e9 / w, 2),
+            "ms_per_build_wall": round(w * 1e3, 3), "ms_per_build_device": round(float(np.mean(ms_dev)), 3), "builds": steps,
+            "note": "extra: the configs[1] corpus as UTF-16LE (a C# string), resident; `value` is the 1-byte text"}
+
+
+def pcie_leg(D, device, steps):
+    """The text starts in PINNED HOST memory and crosses PCIe inside the timed region: dcd_build_add_pages (what a C# host calls with a
+    pinned string / byte[]) + finish, end to end.  Never `value` (the contract's value has its input resident in HBM)."""
+    import docodo_amd
+    from docodo_amd import synth
+    text = torch.from_numpy(synth.corpus_host(D)).pin_memory().numpy()
+    off = np.arange(D + 1, dtype=np.uint64) * synth.DOC_BYTES
+    add_ms, fin_ms = [], []
+    for i in range(steps + 1):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        b = docodo_amd.Builder(device=device)
+        b.AddPages(text, off, docs_per_page=True)
+        t1 = time.perf_counter()
+        b.Finish()
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        b.close()
+        if i:
+            add_ms.append((t1 - t0) * 1e3)
+            fin_ms.append((t2 - t1) * 1e3)
+    tot = float(np.mean(add_ms)) + float(np.mean(fin_ms))
+    return {"GB_per_s": round(D * synth.DOC_BYTES / 1e9 / (tot / 1e3), 2), "add_pages_ms": round(float(np.mean(add_ms)), 2),
+            "finish_ms": round(float(np.mean(fin_ms)), 2), "builds": steps,
+            "note": "extra: host-resident (pinned) text through dcd_build_add_pages, H2D copy inside the timed region"}
 
 
 def inflight_bench(n_threads, steps, text, D, device, T):
@@ -783,11 +830,16 @@ def big_index_legs(args, rank, world, device, dist, cdev, comm=None):
                      "text_GB_per_s": round(total * synth.DOC_BYTES / 1e9 / dt, 2),
                      "pipeline": ("segments (shard-only) -> dcd_merge_shards" if world == 1 else
                                   "segments -> per-rank shard index -> RCCL exchange to balanced owners + merge -> replica all-gather + merge"),
-                     "note": "configs[2]: whole-job wall time from resident text to a queryable index on every GPU"}}
+                     "note": "configs[2]: whole-job wall time from resident text to the merged index on every GPU"}}
     note("configs[2] index built: %.1f ms" % (dt * 1e3))
     # ---- configs[3] / configs[4] ----
     info = TermInfo(ix)
-    ix.query_batch(np.array([0, 0, 258], np.int32), np.array([0, 3], np.uint64), totals=True)     # decodes the index once (auxiliary structure)
+    torch.cuda.synchronize()
+    tw = time.perf_counter()
+    ix.query_batch(np.array([0, 0, 258], np.int32), np.array([0, 3], np.uint64), totals=True)     # adoption: resident coordinates + cell directories
+    out["index"]["first_query_ready_ms"] = round((time.perf_counter() - tw) * 1e3, 2)
+    out["index"]["note"] = ("configs[2]: build_wall_ms = whole-job wall time from resident text to the merged index on every GPU; the first query batch "
+                            "then needs first_query_ready_ms more (resident coordinates + cell directories of the query side)")
     legs = []
     if args.c4_queries > 0:
         legs.append(("c4_and3", "configs[3]: 3-term AND, Dist = 255, terms ~ Zipf over ranks 101..100k", and_queries(synth.query_ranks(args.c4_queries, 3)), 4.0))
@@ -831,7 +883,7 @@ def big_index_legs(args, rank, world, device, dist, cdev, comm=None):
                 oix.load(big_img, big_lst)
                 note("oracle loaded the big index")
             res["cpu_baseline"] = oracle_query_sample(oix, progs, budget, min_q=2)
-            ac = oracle_query_all_cores(big_img, big_lst, progs, res["cpu_baseline"]["queries"], 8, budget)   # (8 copies of a 3.5 GB index)
+            ac = oracle_query_all_cores(oix, progs, res["cpu_baseline"]["queries"], budget)
             if ac:
                 res["cpu_baseline"]["all_cores"] = ac
             note("%s: oracle samples done" % name)

@@ -6,7 +6,7 @@
 //
 //   reference member                                   here
 //   ------------------------------------------------   ------------------------------------------------------------------
-//   Index.Load()                    Index.cs:312-380   LoadGpu()                -> dcd_index_open
+//   Index.Load()                    Index.cs:312-380   LoadGpu()                -> dcd_index_open / dcd_index_open_lazy (InMemory == false)
 //   Index.this[key] / LoadSequence  Index.cs:198-263   GpuSequence(key)         -> dcd_index_find + dcd_index_get
 //   Index.Count / MaxCoord          Index.cs:255, 310  GpuCount / GpuMaxCoord
 //   IndexTask(source)               Build.cs:445-564   IndexTaskGpu(source)     -> GpuBuilder.AddPages + Finish + Save
@@ -117,28 +117,10 @@ namespace Docodo
         const int DCD_OP_TERM = 0, DCD_OP_AND = 1, DCD_OP_OR = 2, DCD_OP_SETR = 3;
 
         // ---------------------------------------------------------------------------------------------------------------
-        // Index.Load, Index.cs:312-380 (both InMemory settings: the device holds the postings either way; the files stay
-        // loadable by the unmodified reference)
+        // Index.Load, Index.cs:312-380 (InMemory: the device holds the postings; !InMemory: they stay in ".index" and are read on
+        // demand, Index.cs:198-216, 346-348; the files stay loadable by the unmodified reference)
         // ---------------------------------------------------------------------------------------------------------------
-        public bool LoadGpu()
-        {
-            if (!File.Exists(Path.Combine(WorkPath, ".index")) || !File.Exists(Path.Combine(WorkPath, ".index.list"))) return false;
-            CanSearch = false;
-            DisposeGpu();
-            try
-            {
-                Native.Check(Native.dcd_index_open(WorkPath, GpuDevice, out gpuIndex));
-                ulong mc; Native.Check(Native.dcd_index_max_coord(gpuIndex, out mc));
-                MaxCoord = mc;
-                CanSearch = true;
-                return true;
-            }
-            catch (Exception e)
-            {
-                Console.WriteLine("Can't load: " + e.Message);     // as Index.cs:373-376
-                return false;
-            }
-        }
+        public bool LoadGpu() { return LoadGpuLazyAware(); }          // IndexGpuMulti.cs: dcd_index_open, or dcd_index_open_lazy when InMemory == false
 
         /// Index.Count, Index.cs:253
         public int GpuCount { get { ulong n; Native.Check(Native.dcd_index_count(gpuIndex, out n)); return (int)n; } }
@@ -178,13 +160,28 @@ namespace Docodo
             public int TotalCount { get; private set; } = 0;
             bool finished = false;
 
-            public GpuBuilder(Index parent, ulong coordBase = 0, bool shardOnly = false)
+            /// the native handle (IndexGpuMulti.cs: export / dcd_build_merge_distributed)
+            internal IntPtr Handle { get { return h; } }
+            /// maxCoord of the finished build (Build.cs:326, 377)
+            internal ulong MaxCoord { get { ulong* st = stackalloc ulong[32]; Native.Check(Native.dcd_build_get_stats(h, st)); return st[6]; } }   // dcd_build_stats.max_coord
+            /// this build's ".index.list" bytes (IndexPageList.Save, Build.cs:99-118)
+            internal byte[] ListImage()
+            {
+                UIntPtr n;
+                Native.dcd_build_list_image(h, null, UIntPtr.Zero, out n);               // size query (DCD_E_OVERFLOW by design)
+                var img = new byte[Math.Max(1, (int)n)];
+                fixed (byte* p = img) Native.Check(Native.dcd_build_list_image(h, p, (UIntPtr)img.Length, out n));
+                Array.Resize(ref img, (int)n);
+                return img;
+            }
+
+            public GpuBuilder(Index parent, ulong coordBase = 0, bool shardOnly = false, int device = -1)
             {
                 Parent = parent;
                 Path = parent.WorkPath;
                 Native.BuildOpts o;
                 Native.dcd_build_default_opts(out o);
-                o.device = parent.GpuDevice;
+                o.device = device >= 0 ? device : parent.GpuDevice;
                 o.encoding = DCD_ENC_UTF16LE;                          // a C# string pins to UTF-16 code units
                 o.min_word_length = parent.MIN_WORD_LENGTH;            // Index.cs:113
                 o.max_word_length = Index.MAX_WORD_LENGTH;             // Index.cs:97
@@ -350,7 +347,7 @@ namespace Docodo
             {
                 if (!bKeepForms) return null;
                 exact = true;
-                words = GetLikeWords(word);
+                words = GetLikeWordsGpu(word);                              // dictionary scan on the device (IndexGpuMulti.cs)
             }
             var prog = new List<int>();
             int pushed = 0;

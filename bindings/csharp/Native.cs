@@ -20,10 +20,16 @@ namespace Docodo
                                     public float* page_rank; public ulong* pos_off; public int* pos; public ulong* doc_off;
                                     public uint* doc_index; public float* doc_rank; public uint* doc_n_pages;
                                     public ulong* seq_off; public ushort* seq_units; public int* seq_R; public float ms_device;
-                                    public ulong n_pages_total, n_pos_total, n_docs_total; }
+                                    public ulong n_pages_total, n_pos_total, n_docs_total;
+                                    // ABI 2: common sub-expressions of the batch (operators named / evaluated, units of their index terms)
+                                    public ulong ops_named, ops_evaluated, units_named, units_evaluated, sub_batches; }
+        public const int DCD_COMM_RCCL = 0, DCD_COMM_HOST = 1, DCD_COMM_ID_BYTES = 128, DCD_ABI_VERSION = 2;
 
         [DllImport(Lib)] public static extern int dcd_last_error(byte* buf, UIntPtr cap);
         [DllImport(Lib)] public static extern int dcd_version();
+        // sizeof of the ABI structs as the library was built (0 BuildOpts, 1 build stats, 2 QueryOpts, 3 ResultsView, 4 term meta):
+        // IndexGpu's static constructor compares them with Marshal.SizeOf of the declarations above
+        [DllImport(Lib)] public static extern ulong dcd_struct_size(int which);
         [DllImport(Lib)] public static extern int dcd_device_count(out int n);
         // device-memory cache of the library: Index.Dispose() trims it so that the memory goes back to the driver
         [DllImport(Lib)] public static extern int dcd_pool_trim(int device);
@@ -63,7 +69,7 @@ namespace Docodo
         [DllImport(Lib)] public static extern int dcd_build_get_stats(IntPtr h, void* stats);   // dcd_build_stats, include/docodo_hip.h
         [DllImport(Lib)] public static extern int dcd_build_index_image(IntPtr h, byte* outp, UIntPtr cap, out UIntPtr n);
         [DllImport(Lib)] public static extern int dcd_build_list_image(IntPtr h, byte* outp, UIntPtr cap, out UIntPtr n);
-        // doc-range shards (Index.cs:537-752): export -> exchange (RCCL, outside the library) -> merge; gather -> one .index
+        // doc-range shards (Index.cs:537-752), piece by piece: export -> (the host moves the buffers) -> merge; dcd_build_merge_distributed does all of it
         [DllImport(Lib)] public static extern int dcd_build_export_plan(IntPtr h, uint nOwners, ulong* termCount, ulong* keyCount, ulong* unitCount);
         [DllImport(Lib)] public static extern int dcd_build_export_fill(IntPtr h, void* metaDev, ushort* keysDev, ushort* unitsDev);
         [DllImport(Lib)] public static extern int dcd_build_export_heavy(IntPtr h, ulong minUnits, ulong* fp, ulong* nUnits, UIntPtr cap, out UIntPtr nOut);
@@ -107,6 +113,20 @@ namespace Docodo
         [DllImport(Lib)] public static extern int dcd_index_suggest(IntPtr h, char* prefix, UIntPtr len, uint n, uint* terms, out uint nOut);      // GetSuggessions
         [DllImport(Lib)] public static extern int dcd_index_save(IntPtr h, [MarshalAs(UnmanagedType.LPUTF8Str)] string dir);
         [DllImport(Lib)] public static extern void dcd_index_free(IntPtr h);
+        [DllImport(Lib)] public static extern int dcd_index_trim(IntPtr h);          // gives the query work arena back (several indexes on one device)
+        // the exchange inside the library (round 4): one communicator per GPU; every call below is collective
+        [DllImport(Lib)] public static extern int dcd_comm_unique_id(int transport, byte* id128);
+        [DllImport(Lib)] public static extern int dcd_comm_create(int nRanks, int rank, byte* id128, int device, int transport, out IntPtr comm);
+        [DllImport(Lib)] public static extern int dcd_comm_create_all(int n, int* devices, int transport, IntPtr* comms);
+        [DllImport(Lib)] public static extern void dcd_comm_free(IntPtr comm);
+        [DllImport(Lib)] public static extern int dcd_comm_rank(IntPtr comm, out int rank, out int nRanks);
+        [DllImport(Lib)] public static extern int dcd_comm_allgather(IntPtr comm, void* mine, UIntPtr bytes, void* all);
+        [DllImport(Lib)] public static extern int dcd_build_merge_distributed(IntPtr build, IntPtr comm, int balanced, out IntPtr owned);
+        [DllImport(Lib)] public static extern int dcd_index_merge_distributed(IntPtr shard, IntPtr comm, int balanced, out IntPtr owned);
+        [DllImport(Lib)] public static extern int dcd_index_allgather(IntPtr owned, IntPtr comm, out IntPtr replica);
+        [DllImport(Lib)] public static extern int dcd_index_gather(IntPtr owned, IntPtr comm, int dst, out IntPtr index);
+        [DllImport(Lib)] public static extern int dcd_balance_owners(uint nOwners, uint nLists, ulong* listOff, ulong* fp, ulong* units, ulong* totals,
+                                                                     ulong* outFp, uint* outOwner, UIntPtr cap, out UIntPtr nOut, uint* lightThr);
         [DllImport(Lib)] public static extern int dcd_index_find(IntPtr h, char* key, UIntPtr len, out uint term);
         [DllImport(Lib)] public static extern int dcd_index_get(IntPtr h, uint term, ushort* outp, UIntPtr cap, out UIntPtr nUnits);
         [DllImport(Lib)] public static extern int dcd_index_term_count(IntPtr h, uint term, out ulong nValues);

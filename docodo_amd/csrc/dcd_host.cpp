@@ -123,6 +123,7 @@ struct RunReader {
       if (!(c & 0x80)) break;
       c = fgetc(f);
     }
+    if (len > (1u << 20)) return DCD_E_IO;              // (keys are <= 3 * 63 UTF-8 bytes: a damaged run, not a 4 GiB allocation)
     std::string kb(len, '\0');
     if (len && fread(&kb[0], 1, len, f) != len) return DCD_E_IO;
     key_bytes += kb;
@@ -138,9 +139,29 @@ struct RunReader {
 };
 }  // namespace
 
+static int32_t merge_index_files_impl(const char* const* paths_utf8, size_t n, const char* out_path_utf8);
+// The output is written as "<out>.tmp" and renamed on success: a failed merge leaves no file that looks like a valid, shorter
+// index.  No C++ exception crosses the C ABI (std::bad_alloc from a damaged run would take a C# host down).
 extern "C" int32_t dcd_merge_index_files(const char* const* paths_utf8, size_t n, const char* out_path_utf8) {
   using namespace dcd;
   if ((!paths_utf8 && n) || !out_path_utf8) DCD_FAIL(DCD_E_BADARG, "dcd_merge_index_files: NULL argument");
+  const std::string tmp = std::string(out_path_utf8) + ".tmp";
+  int32_t st;
+  try {
+    st = merge_index_files_impl(paths_utf8, n, tmp.c_str());
+  } catch (const std::bad_alloc&) {
+    set_error("dcd_merge_index_files: out of host memory");
+    st = DCD_E_NOMEM;
+  } catch (...) {
+    set_error("dcd_merge_index_files: unexpected exception");
+    st = DCD_E_IO;
+  }
+  if (st == DCD_OK && rename(tmp.c_str(), out_path_utf8) != 0) { set_error("cannot rename %s to %s", tmp.c_str(), out_path_utf8); st = DCD_E_IO; }
+  if (st != DCD_OK) (void)remove(tmp.c_str());
+  return st;
+}
+static int32_t merge_index_files_impl(const char* const* paths_utf8, size_t n, const char* out_path_utf8) {
+  using namespace dcd;
   std::vector<std::unique_ptr<RunReader>> runs;
   u64 max_coord = 0;
   for (size_t q = 0; q < n; q++) {

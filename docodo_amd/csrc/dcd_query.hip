@@ -1899,6 +1899,7 @@ struct SubBatchDev {
   u64* tmp = nullptr;              // scratch_cap elements
   u64 pool_cap = 0, scratch_cap = 0;
   u32 seq = 0;                     // passes executed so far
+  u64 n_admit_syncs = 0;           // (statistics: passes whose size the device had to tell)
   PageDev pd;
   ResParams P;
 };
@@ -2073,13 +2074,25 @@ static int32_t exec_chunk(dcd_index* h, const dcd_query_opts& o, SubBatchDev& D,
       scan_exclusive<u32, u64>(d_items_g2.p, d_base_g2.p, (u64)n_rem + 1, d_part_scr.p, st);
       if (stream32) scan_exclusive<u32, u64>(d_items_s32.p, d_base_s32.p, (u64)n_rem + 1, d_part_scr.p, st);
       DCD_HIP(hipMemsetAsync(d_work_ctr.p, 0, 4 * sizeof(u64), st));
-      // how many of them run in this pass: all, when even the host's bounds fit; else the device says (one round trip)
-      u32 n = n_rem;
-      if (C.cap_prefix[end] - C.cap_prefix[first] > D.scratch_cap || C.w_prefix[end] - C.w_prefix[first] > W_cap) {
+      // how many of them run in this pass.  The host knows capacity BOUNDS: the longest prefix whose bounds fit is always safe, and
+      // when it is long (ordinary conjunctions: the bound of a term-term operator is its real size) it is taken as it is, with no
+      // round trip.  When it is short -- a few operators over head terms, whose bounds are the length of the long list while a
+      // galloping evaluation needs a fraction of it or nothing -- the device says how many really fit (one round trip).
+      u32 n;
+      {
+        u32 lo = first, hi = end;                            // largest m in (first, end] with cap / item bounds of [first, m) fitting
+        while (lo < hi) {
+          const u32 m = lo + (hi - lo + 1) / 2;
+          if (C.cap_prefix[m] - C.cap_prefix[first] <= D.scratch_cap && C.w_prefix[m] - C.w_prefix[first] <= W_cap) lo = m; else hi = m - 1;
+        }
+        n = std::max<u32>(lo - first, 1);
+      }
+      if (n < n_rem && n < 256) {
         hipLaunchKernelGGL(k_pair_admit, dim3(1), dim3(64), 0, st, n_rem, d_need_off.p, d_part_base.p, D.scratch_cap, W_cap, d_nadm.p);
         DCD_HIP(hipMemcpyAsync(&pwa[9], d_nadm.p, 8, hipMemcpyDeviceToHost, st));
         DCD_HIP(hipStreamSynchronize(st));
-        n = (u32)std::min<u64>(std::max<u64>(pwa[9], 1), n_rem);
+        n = std::max(n, (u32)std::min<u64>(std::max<u64>(pwa[9], 1), n_rem));
+        D.n_admit_syncs++;
       }
       const u64 W = std::min<u64>(W_cap, C.w_prefix[first + n] - C.w_prefix[first]);
       if (stream32) {
@@ -2432,6 +2445,14 @@ static int32_t run_sub_batch(dcd_index* h, const int32_t* prog, const u64* prog_
   R->units_named += sb.units_named;
   R->units_evaluated += sb.units_evaluated;
   R->sub_batches += 1;
+  static const bool trace = getenv("DOCODO_TRACE") && atoi(getenv("DOCODO_TRACE")) != 0;
+  if (trace) {
+    u64 used[2] = {0, 0};
+    (void)hipMemcpy(used, D.used.p, 16, hipMemcpyDeviceToHost);
+    fprintf(stderr, "[docodo] query sub-batch: %zu queries, %zu chunks, %llu operators named, %u evaluated, %u passes (%llu sized by the device), pool %llu of %llu elements, scratch %llu\n",
+            nq, n_chunks, (unsigned long long)sb.ops_total, sb.n_refs, D.seq, (unsigned long long)D.n_admit_syncs,
+            (unsigned long long)std::max(used[0], used[1]), (unsigned long long)D.pool_cap, (unsigned long long)D.scratch_cap);
+  }
   return DCD_OK;
 }
 
@@ -2464,13 +2485,23 @@ static int32_t run_queries(dcd_index* h, const int32_t* prog, const u64* prog_of
       continue;
     }
     if (st != DCD_E_NOMEM) return st;
-    if (q1 - q0 > 1) { span = (q1 - q0 + 1) / 2; first = false; continue; }   // the pool ran full: half as many queries share it
-    // a single query does not fit: a larger pool if the device has the memory
+    static const bool trace = getenv("DOCODO_TRACE") && atoi(getenv("DOCODO_TRACE")) != 0;
+    if (trace) fprintf(stderr, "[docodo] query sub-batch of %zu queries failed (%s): retrying with %zu\n", q1 - q0, last_error().c_str(), (q1 - q0 + 1) / 2);
+    // The pool ran full.  A larger pool first (up to a quarter of the device memory): the results of a sub-batch are shared by all
+    // its queries, so halving the sub-batch evaluates the operators that both halves name twice -- with phrases over a Zipf
+    // vocabulary that is most of the work (the results of ALL adjacent-word pairs together are only twice the corpus' postings).
+    // Then half as many queries per sub-batch.
     (void)hipMemGetInfo(&free_b, &total_b);
     const u64 avail = ((u64)free_b + (u64)dev_pool_cached_bytes(h->ix.device) + 8 * h->work_pool_elems) / 8;
-    if (env_pool || 2 * pool_bound + scratch_bound > avail / 4 * 3) return st;
-    pool_bound *= 2;
-    first = false;
+    const u64 pool_max = std::min<u64>((u64)total_b / 4 / 8, avail / 4 * 3 > 2 * scratch_bound ? avail / 4 * 3 - 2 * scratch_bound : 0);
+    if (!env_pool && 2 * pool_bound <= pool_max) {
+      pool_bound = std::min(4 * pool_bound, pool_max);
+      h->work_pool.reset();                                    // (the next attempt allocates the larger arena)
+      h->work_pool_elems = 0;
+      continue;
+    }
+    if (q1 - q0 > 1) { span = (q1 - q0 + 1) / 2; first = false; continue; }
+    return st;
   }
   out = std::move(R);
   return DCD_OK;

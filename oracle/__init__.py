@@ -109,6 +109,7 @@ def lib():
         sig("orc_result_found_doc_rank", C.c_float, vp, sz)
         sig("orc_result_found_doc_npages", sz, vp, sz)
         sig("orc_query_batch", None, vp, vp, vp, sz, vp, vp, vp, vp)
+        sig("orc_query_batch_mt", None, vp, vp, vp, sz, C.c_int, vp, vp, vp, vp)
         _LIB = L
     return _LIB
 
@@ -597,6 +598,16 @@ class Index:
         nq = off.size - 1
         out = [np.zeros(nq, np.uint64) for _ in range(4)]
         self.L.orc_query_batch(self.h, prog.ctypes.data, off.ctypes.data, nq, *[o.ctypes.data for o in out])
+        return out
+
+    def query_batch_mt(self, prog, prog_off, n_threads):
+        """The same batch sharded by query over n_threads threads that share this index's posting lists and page table (each
+        with a page cursor of its own): the all-cores baseline of SURVEY 8(d)."""
+        prog = np.ascontiguousarray(prog, np.int32)
+        off = np.ascontiguousarray(prog_off, np.uint64)
+        nq = off.size - 1
+        out = [np.zeros(nq, np.uint64) for _ in range(4)]
+        self.L.orc_query_batch_mt(self.h, prog.ctypes.data, off.ctypes.data, nq, int(n_threads), *[o.ctypes.data for o in out])
         return out
 
 

@@ -29,6 +29,7 @@
 #include <memory>
 #include <set>
 #include <string>
+#include <thread>
 #include <vector>
 
 typedef uint8_t u8;
@@ -625,19 +626,26 @@ bool index_load(Index& ix, const u8* ib, size_t in, const u8* lb, size_t ln) {
 }
 
 // IndexPageList.GetPage, Build.cs:74-97.  Returns page index or -1 for "new DocPage()".
-long get_page(Index& ix, u64 coord) {
+// The enumerator position (_enum, prevc) is the only state a search changes in a loaded index.  `cs` = that state: the index's own
+// (the reference: one cursor per IndexPageList object, every Search under one lock, Search.cs:448), or a thread's private one in the
+// query-sharded CPU baseline (orc_query_batch_mt), where all threads read ONE set of posting lists and page entries.  (A page's
+// base coordinate `coord` is written on arrival; every cursor writes the same value -- the end of the page before it.)
+struct PageCursor { u64 prevc = 0xFFFFFFFFull; size_t cur = 0; };
+long get_page(Index& ix, u64 coord, PageCursor* pc = nullptr) {
+  u64& prevc = pc ? pc->prevc : ix.prevc;
+  size_t& cur = pc ? pc->cur : ix.cur;
   auto key = [&](size_t c) -> u64 { return c < ix.pages.size() ? ix.pages[c].end : 0; };  // default(KeyValuePair) past the end
-  if (ix.prevc == 0xFFFFFFFFull) { ix.cur = 0; ix.prevc = 0; }
+  if (prevc == 0xFFFFFFFFull) { cur = 0; prevc = 0; }
   else {
-    if (key(ix.cur) > coord && ix.prevc <= coord) return ix.cur < ix.pages.size() ? (long)ix.cur : -1;
-    if (key(ix.cur) > coord) { ix.cur = 0; ix.prevc = 0; }
+    if (key(cur) > coord && prevc <= coord) return cur < ix.pages.size() ? (long)cur : -1;
+    if (key(cur) > coord) { cur = 0; prevc = 0; }
   }
   if (ix.pages.empty()) return -1;
   do {
-    if (key(ix.cur) > coord) { ix.pages[ix.cur].coord = ix.prevc; return (long)ix.cur; }
-    ix.prevc = key(ix.cur);
-    if (ix.cur < ix.pages.size()) ix.cur++;
-  } while (ix.cur < ix.pages.size());
+    if (key(cur) > coord) { if (ix.pages[cur].coord != prevc) ix.pages[cur].coord = prevc; return (long)cur; }
+    prevc = key(cur);
+    if (cur < ix.pages.size()) cur++;
+  } while (cur < ix.pages.size());
   return -1;
 }
 
@@ -777,13 +785,13 @@ struct Result {
 
 // PrepareSearchResult, Search.cs:365-420.  doc_mask[d] != 0 <=> the -filter: regexes accept doc d
 // (filter.Length == 0 -> all ones); regex evaluation itself is host string work.
-void PrepareSearchResult(Index& ix, const Seq& res, const u8* doc_mask, Result& result) {
+void PrepareSearchResult(Index& ix, const Seq& res, const u8* doc_mask, Result& result, PageCursor* pc = nullptr) {
   long prevp = -2; int prevd = -2;
   long lastPage = -1; long lastDoc = -1;
   SeqEnum en(res);
   while (en.MoveNext()) {
     u64 coord = en.Current();
-    long _p = get_page(ix, coord);
+    long _p = get_page(ix, coord, pc);
     if (_p < 0) { result.error = true; return; }               // null dereference in the reference
     if (_p != prevp) {
       result.foundPages.push_back(RPage{_p, {}});
@@ -1039,12 +1047,9 @@ size_t orc_result_found_doc_npages(void* r, size_t i) { Result* R = (Result*)r; 
 // run through Count() per term (Search.cs:307), the operators, PrepareSearchResult and the ranks.
 // Outputs per query: number of found pages, number of positions, number of found docs, and an
 // FNV-1a checksum over (page index, positions, page rank bits, doc index, doc rank bits).
-void orc_query_batch(void* h, const int32_t* prog, const u64* prog_off, size_t nq,
-                     u64* n_pages, u64* n_pos, u64* n_docs, u64* checksum) {
-  Index* ix = (Index*)h;
-  std::vector<const Seq*> keys; keys.reserve(ix->self.size());
-  for (auto& kv : ix->self) keys.push_back(&kv.second);
-  for (size_t q = 0; q < nq; q++) {
+static void query_batch_range(Index* ix, const std::vector<const Seq*>& keys, const int32_t* prog, const u64* prog_off, size_t q0, size_t q1,
+                              u64* n_pages, u64* n_pos, u64* n_docs, u64* checksum, PageCursor* pc) {
+  for (size_t q = q0; q < q1; q++) {
     std::vector<Seq> st;
     for (u64 i = prog_off[q]; i < prog_off[q + 1];) {
       int op = prog[i];
@@ -1052,7 +1057,7 @@ void orc_query_batch(void* h, const int32_t* prog, const u64* prog_off, size_t n
       else { Seq b = std::move(st.back()); st.pop_back(); Seq a = std::move(st.back()); st.pop_back(); st.push_back(op == 1 ? seq_mul(a, b) : seq_add(a, b)); i += 1; }
     }
     Result r;
-    PrepareSearchResult(*ix, st.back(), nullptr, r);
+    PrepareSearchResult(*ix, st.back(), nullptr, r, pc);
     FinishRanks(*ix, r);
     u64 hsh = 1469598103934665603ull, np = 0;
     auto mix = [&](u64 v) { for (int k = 0; k < 8; k++) { hsh ^= (v >> (8 * k)) & 0xFF; hsh *= 1099511628211ull; } };
@@ -1067,6 +1072,32 @@ void orc_query_batch(void* h, const int32_t* prog, const u64* prog_off, size_t n
     if (n_docs) n_docs[q] = r.foundDocs.size();
     if (checksum) checksum[q] = r.error ? ~0ull : hsh;
   }
+}
+void orc_query_batch(void* h, const int32_t* prog, const u64* prog_off, size_t nq,
+                     u64* n_pages, u64* n_pos, u64* n_docs, u64* checksum) {
+  Index* ix = (Index*)h;
+  std::vector<const Seq*> keys; keys.reserve(ix->self.size());
+  for (auto& kv : ix->self) keys.push_back(&kv.second);
+  query_batch_range(ix, keys, prog, prog_off, 0, nq, n_pages, n_pos, n_docs, checksum, nullptr);
+}
+// The query-sharded baseline on ALL host cores: n_threads threads evaluate contiguous slices of the batch on ONE loaded
+// index -- the posting lists and the page table are only read, each thread has its own page cursor (a private IndexPageList
+// enumerator: what a private copy of the index per thread would give, without the copies).
+void orc_query_batch_mt(void* h, const int32_t* prog, const u64* prog_off, size_t nq, int n_threads,
+                        u64* n_pages, u64* n_pos, u64* n_docs, u64* checksum) {
+  Index* ix = (Index*)h;
+  std::vector<const Seq*> keys; keys.reserve(ix->self.size());
+  for (auto& kv : ix->self) keys.push_back(&kv.second);
+  if (n_threads < 1) n_threads = 1;
+  std::vector<std::thread> ts;
+  for (int t = 0; t < n_threads; t++) {
+    const size_t a = nq * (size_t)t / (size_t)n_threads, b = nq * (size_t)(t + 1) / (size_t)n_threads;
+    ts.emplace_back([=, &keys] {
+      PageCursor pc;
+      query_batch_range(ix, keys, prog, prog_off, a, b, n_pages, n_pos, n_docs, checksum, &pc);
+    });
+  }
+  for (auto& t : ts) t.join();
 }
 
 }  // extern "C"

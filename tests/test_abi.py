@@ -224,3 +224,12 @@ def test_merge_index_files_is_host_side(tmp_path):
     with pytest.raises(docodo_amd.DocodoError) as e:
         docodo_amd.Index.from_images(open(out, "rb").read()[:-1], b"")
     assert e.value.code == _lib.DCD_E_IO
+    # a failed merge leaves NO output (it is written as "<out>.tmp" and renamed on success) and no exception crosses the ABI:
+    # a truncated payload, and a damaged key length that announces 2^31 - 1 key bytes
+    out2 = tmp_path / "out2.index"
+    for bad in (runs[0][:-1], struct.pack("<Q", 1) + b"\xff\xff\xff\xff\x07" + b"abc"):
+        pb = tmp_path / "bad"
+        pb.write_bytes(bad)
+        arr2 = (C.c_char_p * 2)(paths[1], str(pb).encode())
+        assert docodo_amd.lib().dcd_merge_index_files(arr2, 2, str(out2).encode()) == _lib.DCD_E_IO
+        assert not out2.exists() and not (tmp_path / "out2.index.tmp").exists()

@@ -63,6 +63,39 @@ def test_known_answers_on_disk(tmp_path, testtext1, testheaders1, oracle_mod):
         assert e.value.code == docodo_amd._lib.DCD_E_STATE
 
 
+def test_opening_an_on_disk_index_reads_the_file_about_once(tmp_path):
+    """dcd_index_open_lazy scans keys and stubs with ONE sliding window (round 3 read a fresh 64 KiB window per record: V x 64 KiB).
+    A dictionary of 60 k short lists: the bytes read by the process while opening stay within twice the file size."""
+    import struct
+    import docodo_amd
+
+    def rec(k, units):
+        b = k.encode("utf-8")
+        return bytes([len(b)]) + b + struct.pack("<i", len(units)) + np.array(units, np.uint16).tobytes()
+
+    V = 60000
+    keys = sorted("k%07d" % i for i in range(V))
+    img = struct.pack("<Q", 10 * V) + b"".join(rec(k, [i % 30000 + 1, 7]) for i, k in enumerate(keys))
+    d = tmp_path / "ix"
+    d.mkdir()
+    (d / ".index").write_bytes(img)
+    (d / ".index.list").write_bytes(b"")
+
+    def rchar():
+        for line in open("/proc/self/io"):
+            if line.startswith("rchar:"):
+                return int(line.split()[1])
+        return 0
+    r0 = rchar()
+    ix = docodo_amd.Index.LoadOnDisk(str(d))
+    read = rchar() - r0
+    assert ix.Count == V and ix.find("k0000007") is not None
+    assert read < 2 * len(img) + (1 << 20), (read, len(img))
+    got = ix.get(ix.find(keys[12345]))
+    assert got.units.tolist() == [12345 % 30000 + 1, 7]
+    ix.close()
+
+
 def test_synthetic_index_on_disk_batches(tmp_path, oracle_mod):
     """20 000 synthetic docs: batches of 3-term AND / phrase / OR programs on the on-disk handle == the in-memory handle, the
     resident subset grows with the union of the batches while it fits the budget and is replaced when it does not."""
