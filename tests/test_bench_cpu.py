@@ -1,6 +1,7 @@
-"""CPU-side pieces of bench.py that need no GPU: the oracle query baselines (one thread, and query-sharded over threads with a
-private copy of the index each -- SURVEY 8d; the oracle's page cursor, like the reference's IndexPageList.GetPage
-(Build.cs:74-97), is state of the index object, which is why the reference serialises Search under one lock, Search.cs:448)."""
+"""CPU-side pieces of bench.py that need no GPU: the oracle query baselines (one thread, and query-sharded over ALL cores on one
+shared index with a private page cursor per thread -- SURVEY 8d; the oracle's page cursor, like the reference's
+IndexPageList.GetPage (Build.cs:74-97), is the only state a search changes, which is why the reference serialises Search under one
+lock, Search.cs:448)."""
 import os
 import sys
 
@@ -33,12 +34,17 @@ def test_query_baselines_one_thread_and_query_sharded():
     progs = [(np.array(prog, np.int32), np.array(off, np.uint64))]
     one = bench.oracle_query_sample(o, progs, 0.05)
     assert one["cores"] == 1 and one["kind"] == "port" and 0 < one["queries"] <= 120 and one["queries_per_s"] > 0
-    allc = bench.oracle_query_all_cores(img, lst, progs, one["queries"], 4, 0.05)
+    allc = bench.oracle_query_all_cores(o, progs, one["queries"], 0.05)
     if allc is not None:                             # (None on a one-core host)
-        assert 2 <= allc["cores"] <= 4 and allc["queries_per_s"] > 0
-    # the copies answer exactly like the original: same per-query page / position counts and checksums
+        assert allc["cores"] >= 2 and allc["queries_per_s"] > 0
+    # the threads answer exactly like the one-thread evaluation: same per-query page / position counts and checksums, for any
+    # number of threads (private page cursors on one shared index), also when the programs jump back and forth in the corpus
     pa, oa = progs[0]
     ref = o.query_batch(pa, oa)
+    for nt in (1, 2, 3, 7):
+        got = o.query_batch_mt(pa, oa, nt)
+        for a, b in zip(ref, got):
+            assert np.array_equal(a, b), nt
     o2 = oracle.Index(stemmers=[])
     o2.load(img, lst)
     got = o2.query_batch(pa, oa)
