@@ -477,6 +477,11 @@ __global__ void k_perm_src_start(const u32* __restrict__ dense_of_rank, const u6
   u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   if (r < n) out[r] = start_id[dense_of_rank[r]];
 }
+// END coordinate of page p of a bulk batch = coordinate of the batch's first character + the offset behind the page
+__global__ void k_page_end_from_off(u64* __restrict__ out, const u64* __restrict__ off, u64 n, u64 c0) {
+  const u64 p = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < n) out[p] = c0 + off[p + 1];
+}
 __global__ void k_uniform_page_end(u64* out, u64 n, u64 base, u64 chars) {
   u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] = base + (i + 1) * chars;
@@ -747,6 +752,11 @@ struct dcd_build {
   bool text_borrowed = false;
   u64 n_chars = 0, text_cap = 0;
   std::vector<u64> page_off;  // [n_pages + 1] text-buffer offsets of the BODY pages staged on the device
+  // ... or, for ONE bulk batch on device text (one document per page, id "1": dcd_build_add_pages_dev as bench.py and a C# host that
+  // indexes a prepared buffer call it), the caller's offset array as it came, in pinned memory: uploaded from there without
+  // another copy; the pages' END coordinates are derived from it on the device and, lazily, on the host (PageTable::end)
+  std::shared_ptr<u64> bulk_off;
+  u64 bulk_n = 0, bulk_c0 = 0;
   PageTable pages;
   u64 coord_cursor = 0;       // global coordinate of the next character (IndexTask's `coord`, Build.cs:459)
   std::vector<u32> run_off, run_delta;  // coordinate runs: text index -> local coordinate offset (header pages)
@@ -1005,6 +1015,7 @@ static int32_t add_pages_impl(dcd_build* h, const void* text, u64 n_chars, const
     DCD_FAIL(DCD_E_STATE, "dcd_build_add_doc must precede pages (Build.cs:345-347)");
   }
   if (page_off[0] != 0 || page_off[n_pages] != n_chars) DCD_FAIL(DCD_E_BADARG, "page_off must start at 0 and end at n_chars");
+  if (h->bulk_off) DCD_FAIL(DCD_E_STATE, "dcd_build_add_pages_dev must be the only text batch of its build");
   const bool uniform = ids_off == nullptr;
   if (uniform) {
     if (!h->pages.ids.empty()) DCD_FAIL(DCD_E_STATE, "cannot mix uniform and explicit page ids");
@@ -1039,7 +1050,29 @@ static int32_t add_pages_impl(dcd_build* h, const void* text, u64 n_chars, const
   h->pages.end.reserve(h->pages.end.size() + n_pages);
   if (!uniform) h->pages.ids.reserve(h->pages.ids.size() + n_pages);
   if (!docs_per_page) h->pages.page_doc.reserve(h->pages.page_doc.size() + n_pages);
-  if (uniform && docs_per_page && device_text) {
+  if (uniform && docs_per_page && device_text && h->page_off.size() == 1 && h->pages.end.empty() && staged == 0 && !h->bulk_off) {
+    // Round 4 -- the bulk case as the FIRST batch of its build: ONE pass over the caller's offsets (copy into pinned memory + the
+    // ascending check); no per-page vectors at all.  (Round 3 filled two 8 MB vectors per million pages, uploaded both and copied
+    // the page table into the index: 3.4 ms of host time around 3.9 ms of device time.)
+    void* pin = pinned_stage_acquire((n_pages + 1) * sizeof(u64));
+    if (!pin) DCD_FAIL(DCD_E_NOMEM, "hipHostMalloc failed");
+    std::shared_ptr<u64> sp(static_cast<u64*>(pin), [](u64* q) { pinned_stage_release(q); });
+    u64* dst = sp.get();
+    u64 bad = 0, prev = page_off[0];
+    dst[0] = prev;
+    for (size_t p = 1; p <= n_pages; p++) { const u64 v = page_off[p]; bad |= (u64)(v <= prev); dst[p] = v; prev = v; }
+    if (bad) DCD_FAIL(DCD_E_BADARG, "page_off must be strictly ascending (docs_per_page requires non-empty pages)");
+    const u64 c0 = h->coord_cursor;
+    h->bulk_off = sp;
+    h->bulk_n = n_pages;
+    h->bulk_c0 = c0;
+    const size_t np = n_pages;
+    h->pages.end.set_lazy(np, [sp, c0, np](std::vector<u64>& v) { v.resize(np); const u64* o = sp.get(); for (size_t p = 0; p < np; p++) v[p] = c0 + o[p + 1]; });
+    h->coord_cursor = c0 + n_chars;
+    h->last_is_explicit = false;
+    return DCD_OK;
+  }
+  if (uniform && docs_per_page && device_text && !h->bulk_off) {
     // the bulk case (one document per page, id "1", text already on the device): page bookkeeping only -- two appends per page
     // in one tight loop (a million pages took 14 ms through the general loop below; the text itself is not touched)
     const size_t e0 = h->pages.end.size();
@@ -1331,7 +1364,7 @@ static int32_t build_phase1(dcd_build* h, bool codes_mode) {
 
   const u64 n_chars = h->n_chars;
   const bool uniform = h->pages.uniform;
-  const u64 n_pages_dev = uniform ? h->pages.uni_n : h->page_off.size() - 1;
+  const u64 n_pages_dev = uniform ? h->pages.uni_n : (h->bulk_off ? h->bulk_n : h->page_off.size() - 1);
   const u64 n_tiles = div_up(n_chars, TK_TILE);
   const CharT* text = (const CharT*)h->text_dev;
 
@@ -1353,7 +1386,8 @@ static int32_t build_phase1(dcd_build* h, bool codes_mode) {
   };
   if (!uniform) {
     DCD_TRY(d_page_off.alloc(dev, n_pages_dev + 1));
-    DCD_TRY(upload(0, d_page_off.p, h->page_off.data(), (n_pages_dev + 1) * 8));
+    if (h->bulk_off) DCD_HIP(hipMemcpyAsync(d_page_off.p, h->bulk_off.get(), (n_pages_dev + 1) * 8, hipMemcpyHostToDevice, st));   // (pinned already)
+    else DCD_TRY(upload(0, d_page_off.p, h->page_off.data(), (n_pages_dev + 1) * 8));
   }
   // explicit postings that enter the device vocabulary: all of them, or (codes mode) only the WORDS
   std::vector<u32> xo, xl, xc;
@@ -1380,6 +1414,9 @@ static int32_t build_phase1(dcd_build* h, bool codes_mode) {
     tr.mark("page-end-alloc");
     hipLaunchKernelGGL(k_uniform_page_end, dim3((u32)div_up(h->pages.uni_n, 256)), dim3(256), 0, st, M.d_page_end.p, h->pages.uni_n,
                        h->pages.uni_base, h->pages.uni_chars);
+  } else if (h->bulk_off) {
+    DCD_TRY(M.d_page_end.alloc(dev, h->bulk_n));
+    hipLaunchKernelGGL(k_page_end_from_off, dim3((u32)div_up(h->bulk_n, 256)), dim3(256), 0, st, M.d_page_end.p, d_page_off.p, h->bulk_n, h->bulk_c0);
   } else if (!h->pages.end.empty()) {
     DCD_TRY(M.d_page_end.alloc(dev, h->pages.end.size()));
     DCD_TRY(upload(1, M.d_page_end.p, h->pages.end.data(), h->pages.end.size() * 8));

@@ -1,6 +1,9 @@
 // dcd_build_int.h -- internal layout of a finished build: the HBM-resident index that both the
 // ".index" image writer and the query path consume.
 #pragma once
+#include <functional>
+#include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -10,6 +13,49 @@ namespace dcd {
 
 typedef std::u16string ustr;
 
+// A vector that is SHARED by its copies until one of them writes (then that copy gets its own), and that may be LAZY: known size,
+// contents made by a generator on first access.  The page table of a build is handed to the index the build leaves (DeviceIndex::pages)
+// and stays with the builder for its ".index.list": a deep copy of a million-entry table was 1.3 ms of every build with explicit
+// pages; and the END coordinates of a bulk batch (one u64 per page) are a function of the caller's offset array that the DEVICE
+// needs, the host only if somebody asks for the list image or a page's coordinates.
+template <typename T>
+class CowVec {
+  struct Rep {
+    std::vector<T> v;
+    std::function<void(std::vector<T>&)> gen;   // non-null: v is still to be made (n entries)
+    size_t n = 0;
+    std::once_flag once;
+  };
+  std::shared_ptr<Rep> r;
+  const std::vector<T>& get() const {
+    static const std::vector<T> none;
+    if (!r) return none;
+    if (r->gen) std::call_once(r->once, [&] { r->gen(r->v); r->gen = nullptr; });
+    return r->v;
+  }
+  std::vector<T>& mut() {
+    if (!r) r = std::make_shared<Rep>();
+    else if (r.use_count() > 1 || r->gen) { auto n = std::make_shared<Rep>(); n->v = get(); r = n; }
+    return r->v;
+  }
+
+ public:
+  size_t size() const { return !r ? 0 : (r->gen ? r->n : r->v.size()); }
+  bool empty() const { return size() == 0; }
+  const T& operator[](size_t i) const { return get()[i]; }
+  const T& back() const { return get().back(); }
+  const T* data() const { return get().data(); }
+  typename std::vector<T>::const_iterator begin() const { return get().begin(); }
+  typename std::vector<T>::const_iterator end() const { return get().end(); }
+  T* data() { return mut().data(); }
+  void reserve(size_t n) { mut().reserve(n); }
+  void resize(size_t n) { mut().resize(n); }
+  void push_back(const T& x) { mut().push_back(x); }
+  void clear() { r.reset(); }
+  // n entries, made by gen on first access (only for an empty vector)
+  void set_lazy(size_t n, std::function<void(std::vector<T>&)> gen) { r = std::make_shared<Rep>(); r->n = n; r->gen = std::move(gen); }
+};
+
 // Documents / pages as Index.Builder.pages keeps them (Build.cs:343-367): a document entry opens a
 // doc, page entries carry the id and the END coordinate of the page.
 struct DocMeta {
@@ -18,15 +64,15 @@ struct DocMeta {
 };
 struct PageTable {
   // Explicit pages (ids stored) ...
-  std::vector<ustr> ids;          // per page id; empty vector when `uniform_id` is used
+  CowVec<ustr> ids;               // per page id; empty vector when `uniform_id` is used
   ustr uniform_id;                // id shared by all pages (synthetic corpora: "1")
-  std::vector<u64> end;           // END coordinate per page (IndexPageList key, Build.cs:66)
-  std::vector<DocMeta> docs;      // explicit docs
+  CowVec<u64> end;                // END coordinate per page (IndexPageList key, Build.cs:66)
+  CowVec<DocMeta> docs;           // explicit docs
   // ... or one document per page named by its decimal index
   bool doc_per_page = false;
   ustr source;                    // source name for doc_per_page
   u64 first_doc = 0;
-  std::vector<u32> page_doc;      // doc index per page (explicit docs only)
+  CowVec<u32> page_doc;           // doc index per page (explicit docs only)
   // ... or n uniform pages of `uni_chars` characters (implies doc_per_page, uniform id): no vectors at all
   bool uniform = false;
   u64 uni_n = 0, uni_chars = 0, uni_base = 0;

@@ -819,14 +819,15 @@ constexpr u8 MODE_NONE = 0, MODE_STREAM = 1, MODE_GALLOP = 2, MODE_STREAM32 = 3,
 #endif
 // Work plan of the operators [0, n_ops) of a round that are still to be evaluated, computed on the device once the operand counts
 // are known.  Per operator: mode, work items, and the scratch it NEEDS -- |a| + |b| REAL elements (not the host's capacity bound)
-// for a streaming or galloping operator, nothing for a two-pass galloping one (long list >= DCD_GAL2_RATIO x short list).
+// for a streaming or galloping operator, nothing for a two-pass galloping one (long list >= DCD_GAL2_RATIO x short list and the
+// two together at least 1 / 128 of the scratch arena).
 // items_all: work items of the operator; items_old / items_s32 / items_g2: the same number in the array of the kernel launch that
 // evaluates them (k_pair_parts: galloping items and, with stream32 == 0, the streaming ones; k_pair_stream: the streaming items;
 // the write pass of k_pair_parts: the two-pass items again) -- each launch numbers its own items through the scan of its array
 // and records an item at the operator's place in the scan of items_all.
 struct PlanOut { u64* need; u32* items_all; u32* items_old; u32* items_s32; u32* items_g2; u8* mode; };
 __global__ void k_pair_plan(const PairOp* __restrict__ ops, u32 n_ops, IdxVals idx_values, Pool pool,
-                            u64 PART, PlanOut o, u32 gal_ratio, u32 stream32) {
+                            u64 PART, PlanOut o, u32 gal_ratio, u32 stream32, u64 g2_min_need) {
   u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i > n_ops) return;
   if (i == n_ops || *pool.overflow) {                     // (overflow: the pool ran full, the sub-batch is abandoned)
@@ -846,7 +847,9 @@ __global__ void k_pair_plan(const PairOp* __restrict__ ops, u32 n_ops, IdxVals i
     const u64 ns = a_short ? na : nb, nl = a_short ? nb : na;
     const CV Lv = seg_cv(a_short ? op.b : op.a, idx_values, pool);
     if (ns * (u64)gal_ratio <= nl && (Lv[nl - 1] - Lv[0]) / nl > 4ull * absR) {
-      m = ns * (u64)DCD_GAL2_RATIO <= nl ? MODE_GALLOP2 : MODE_GALLOP;
+      // two passes (twice the searches) only where the scratch region would be a noticeable part of the arena: conjunctions of
+      // ordinary terms (configs[3]: lists of at most ~1e6 postings) keep the single pass
+      m = (ns * (u64)DCD_GAL2_RATIO <= nl && na + nb >= g2_min_need) ? MODE_GALLOP2 : MODE_GALLOP;
       n = (ns + GAL_PER - 1) / GAL_PER;
     }
   }
@@ -2067,7 +2070,7 @@ static int32_t exec_chunk(dcd_index* h, const dcd_query_opts& o, SubBatchDev& D,
       const PairOp* ops = d_ops.p + first;
       // device plan of everything that is left of the round: mode, work items and REAL scratch need per operator, prefix sums
       hipLaunchKernelGGL(k_pair_plan, dim3((u32)div_up((u64)n_rem + 1, 256)), dim3(256), 0, st, ops, n_rem, idx_values, pool, PART, plan_out, gal_ratio,
-                         stream32 ? 1u : 0u);
+                         stream32 ? 1u : 0u, std::max<u64>(D.scratch_cap / 128, 1));
       scan_exclusive<u64, u64>(d_need.p, d_need_off.p, (u64)n_rem + 1, d_part_scr.p, st);
       scan_exclusive<u32, u64>(d_items.p, d_part_base.p, (u64)n_rem + 1, d_part_scr.p, st);
       scan_exclusive<u32, u64>(d_items_old.p, d_base_old.p, (u64)n_rem + 1, d_part_scr.p, st);
@@ -2367,13 +2370,23 @@ static int32_t run_sub_batch(dcd_index* h, const int32_t* prog, const u64* prog_
   if (const char* e = getenv("DOCODO_QUERY_CHUNK")) chunk_q = std::max<size_t>(strtoull(e, nullptr, 10), 1);
   // pre-pass: operators per chunk (sizes of the staging blocks and of the result directory), largest operator capacity
   const size_t nq = q1 - q0;
-  const size_t n_chunks = std::max<size_t>(1, div_up(nq, chunk_q));
+  // chunk boundaries: the FIRST chunk is short (its plan is the only one the device waits for), then full chunks
+  std::vector<size_t> cb(1, q0);
+  {
+    size_t at = q0;
+    const size_t first_q = nq > 2 * chunk_q ? std::max<size_t>(1, chunk_q / 8) : chunk_q;
+    at = std::min(q1, at + first_q);
+    cb.push_back(at);
+    while (at < q1) { at = std::min(q1, at + chunk_q); cb.push_back(at); }
+  }
+  const size_t n_chunks = cb.size() - 1;
+  auto chunk_of = [&](size_t q) { return (size_t)(std::upper_bound(cb.begin(), cb.end(), q) - cb.begin()) - 1; };
   std::vector<u64> chunk_ops(n_chunks, 0);
   u64 ops_total = 0, max_cap = 0, cap_sum = 0;
   for (size_t q = q0; q < q1; q++) {
     u64 no = 0, ls = 0;
     query_prepass(ix, ext_leaves, prog, prog_off[q], prog_off[q + 1], &no, &ls);
-    chunk_ops[(q - q0) / chunk_q] += no;
+    chunk_ops[chunk_of(q)] += no;
     ops_total += no;
     if (no) max_cap = std::max(max_cap, ls);
     cap_sum += no * ls;                                     // (bound of the results of the query's operators together)
@@ -2407,8 +2420,8 @@ static int32_t run_sub_batch(dcd_index* h, const int32_t* prog, const u64* prog_
   auto prepare = [&](size_t c) -> int32_t {                // staging of chunk c (the executor owns every HIP object)
     ChunkPlan& P = plans[c & 1];
     P.chunk = (u32)c;
-    P.q0 = q0 + c * chunk_q;
-    P.q1 = std::min(q1, P.q0 + chunk_q);
+    P.q0 = cb[c];
+    P.q1 = cb[c + 1];
     P.status = DCD_OK;
     P.err.clear();
     P.ops_cap = chunk_ops[c];
