@@ -113,6 +113,7 @@ namespace Docodo
         [DllImport(Lib)] public static extern int dcd_index_suggest(IntPtr h, char* prefix, UIntPtr len, uint n, uint* terms, out uint nOut);      // GetSuggessions
         [DllImport(Lib)] public static extern int dcd_index_save(IntPtr h, [MarshalAs(UnmanagedType.LPUTF8Str)] string dir);
         [DllImport(Lib)] public static extern void dcd_index_free(IntPtr h);
+        [DllImport(Lib)] public static extern int dcd_index_prepare(IntPtr h, out float msDevice);   // resident coordinates + cell directories now (else: first batch)
         [DllImport(Lib)] public static extern int dcd_index_trim(IntPtr h);          // gives the query work arena back (several indexes on one device)
         // the exchange inside the library (round 4): one communicator per GPU; every call below is collective
         [DllImport(Lib)] public static extern int dcd_comm_unique_id(int transport, byte* id128);

@@ -103,6 +103,7 @@ SIGNATURES = {
     "dcd_index_from_images": (_i32, [_vp, _sz, _vp, _sz, _i32, C.POINTER(_vp)]),
     "dcd_index_free": (None, [_vp]),
     "dcd_index_trim": (_i32, [_vp]),
+    "dcd_index_prepare": (_i32, [_vp, C.POINTER(C.c_float)]),
     "dcd_debug_sk_network": (_i32, [_vp]),
     "dcd_index_count": (_i32, [_vp, _pu64]),
     "dcd_index_max_coord": (_i32, [_vp, _pu64]),

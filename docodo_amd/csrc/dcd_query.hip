@@ -1595,7 +1595,8 @@ struct dcd_results {
   u64 sub_batches = 0;
 };
 
-static int32_t ensure_values(dcd_index* h) {
+static int32_t ensure_values(dcd_index* h, float* ms_device = nullptr) {
+  if (ms_device) *ms_device = 0.f;
   if (h->values_ready) return DCD_OK;
   DeviceIndex& ix = h->ix;
   const int dev = ix.device;
@@ -1643,6 +1644,9 @@ static int32_t ensure_values(dcd_index* h) {
     u64* pw = pinned_words();
     if (!pw) DCD_FAIL(DCD_E_NOMEM, "no pinned host memory");
     static const bool env_fused = !(getenv("DOCODO_QUERY_ADOPT_FUSED") && atoi(getenv("DOCODO_QUERY_ADOPT_FUSED")) == 0);   // (A/B knob)
+    EvTimer tm;
+    DCD_TRY(tm.init(st, dev));
+    DCD_TRY(tm.start());
     if (env_fused && !h->values_packed) {
       // two passes over the units (see k_adopt_reduce / k_adopt_apply)
       const u64 nt = div_up(U, AD_TILE);
@@ -1682,8 +1686,10 @@ static int32_t ensure_values(dcd_index* h) {
                          (u64*)all.v, (u32*)all.lo, (u8*)all.hi);
       if (tot) hipLaunchKernelGGL(k_build_dir, dim3((u32)div_up(N, 256)), dim3(256), 0, st, all, N, ix.term_item_start.p, V, d_off.p, d_sh.p, h->dir.p);
     }
+    DCD_TRY(tm.stop());
     DCD_HIP(hipStreamSynchronize(st));
     DCD_HIP(hipGetLastError());
+    if (ms_device) *ms_device = tm.ms();
   }
   h->values_ready = true;
   return DCD_OK;
@@ -2634,6 +2640,19 @@ int32_t dcd_debug_sk_network(uint32_t* keys256) {
   DCD_HIP(hipStreamSynchronize(st));
   DCD_HIP(hipGetLastError());
   return DCD_OK;
+}
+
+// Adoption made explicit: the resident coordinates and the cell directories of the query side (otherwise made by the first batch).
+// ms_device (may be NULL): device time of the kernels that made them, 0 when they existed already.
+int32_t dcd_index_prepare(dcd_index* h, float* ms_device) {
+  if (!h) DCD_FAIL(DCD_E_BADARG, "dcd_index_prepare: NULL argument");
+  if (ms_device) *ms_device = 0.f;
+  std::lock_guard<std::mutex> guard(h->mu);
+  if (h->lazy) return DCD_OK;                                // (an on-disk index adopts the lists a batch names)
+  DCD_TRY(ensure_device(h->ix.device));
+  DCD_TRY(index_fetch_host(h->ix));
+  StreamScope ss_(h->st);
+  return ensure_values(h, ms_device);
 }
 
 // gives the handle's work arena (and, for an on-disk index, the resident subset) back to the device

@@ -263,6 +263,12 @@ class Index:
         except Exception:
             pass
 
+    def prepare(self):
+        """dcd_index_prepare: makes the resident coordinates + cell directories of the query side now; -> device ms (0 if present)."""
+        ms = C.c_float(0)
+        check(lib().dcd_index_prepare(self.h, C.byref(ms)))
+        return float(ms.value)
+
     def trim(self):
         """Releases the work arena of the query batches (and the resident lists of an on-disk index)."""
         check(lib().dcd_index_trim(self.h))

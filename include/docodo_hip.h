@@ -236,6 +236,10 @@ void dcd_index_free(dcd_index* h);
  * memory) and, for an on-disk index, the resident posting lists -- and returns the library's cached device blocks to the device.
  * The index stays usable; the next batch allocates again.  For processes that keep several indexes open on one device. */
 int32_t dcd_index_trim(dcd_index* h);
+/* The query side keeps every posting list decoded (8-byte absolute coordinates) plus a cell directory per long list: auxiliary
+ * structures made from the units in two passes, by the first dcd_query_batch of a handle or -- explicitly -- here (a serving host
+ * calls it right after Load / Build).  *ms_device (may be NULL): device time of that work, 0 if it was done before. */
+int32_t dcd_index_prepare(dcd_index* h, float* ms_device);
 /* tests: the 256-key merge network of the streaming operator kernel (k_pair_stream) on a bitonic sequence in host memory, in place */
 int32_t dcd_debug_sk_network(uint32_t* keys256);
 int32_t dcd_index_count(dcd_index* h, uint64_t* n_terms);              /* Index.Count */

@@ -433,3 +433,16 @@ def test_utf16_and_latin1_builds_of_one_corpus_agree():
     assert sa.id_keys == sb.id_keys and sb.id_keys in (1, 2)
     assert (sa.n_postings, sa.n_terms, sa.n_units) == (sb.n_postings, sb.n_terms, sb.n_units)
     assert a.index_image() == b.index_image() and a.list_image() == b.list_image()
+
+
+def test_randomised_build_differential_small():
+    """tests/stress_build.py (random vocabularies, Zipf exponents, word classes incl. Latin-1 letters, separators or none at a class
+    change, ragged documents, word-length limits, both encodings; ".index" and ".index.list" byte for byte against the oracle) at a
+    small size: 10 cases of one seed.  The long form (320 cases over six seeds and two build variants) stays a manual run."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "stress_build.py"), "10", "4"], capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert ", 0 mismatches" in r.stdout.strip().splitlines()[-1], r.stdout[-2000:]
