@@ -757,6 +757,7 @@ struct dcd_build {
   // another copy; the pages' END coordinates are derived from it on the device and, lazily, on the host (PageTable::end)
   std::shared_ptr<u64> bulk_off;
   u64 bulk_n = 0, bulk_c0 = 0;
+  DevBuf<u64> d_bulk_off;     // ... and its device copy, uploaded piece by piece while the host still copies the next piece
   PageTable pages;
   u64 coord_cursor = 0;       // global coordinate of the next character (IndexTask's `coord`, Build.cs:459)
   std::vector<u32> run_off, run_delta;  // coordinate runs: text index -> local coordinate offset (header pages)
@@ -1058,10 +1059,19 @@ static int32_t add_pages_impl(dcd_build* h, const void* text, u64 n_chars, const
     if (!pin) DCD_FAIL(DCD_E_NOMEM, "hipHostMalloc failed");
     std::shared_ptr<u64> sp(static_cast<u64*>(pin), [](u64* q) { pinned_stage_release(q); });
     u64* dst = sp.get();
+    DCD_TRY(ensure_device(h->device));
+    DCD_TRY(h->d_bulk_off.alloc(h->device, n_pages + 1));
     u64 bad = 0, prev = page_off[0];
     dst[0] = prev;
-    for (size_t p = 1; p <= n_pages; p++) { const u64 v = page_off[p]; bad |= (u64)(v <= prev); dst[p] = v; prev = v; }
-    if (bad) DCD_FAIL(DCD_E_BADARG, "page_off must be strictly ascending (docs_per_page requires non-empty pages)");
+    // (copy + check in pieces of 128 K offsets; every piece goes to the device as soon as it is in pinned memory, so that the
+    // upload of a piece runs while the host copies the next one)
+    constexpr size_t PIECE = 128 * 1024;
+    for (size_t a = 0; a <= n_pages; a += PIECE) {
+      const size_t b = std::min(n_pages + 1, a + PIECE);
+      for (size_t p = std::max<size_t>(a, 1); p < b; p++) { const u64 v = page_off[p]; bad |= (u64)(v <= prev); dst[p] = v; prev = v; }
+      DCD_HIP(hipMemcpyAsync(h->d_bulk_off.p + a, dst + a, (b - a) * sizeof(u64), hipMemcpyHostToDevice, h->st));
+    }
+    if (bad) { (void)hipStreamSynchronize(h->st); h->d_bulk_off.reset(); DCD_FAIL(DCD_E_BADARG, "page_off must be strictly ascending (docs_per_page requires non-empty pages)"); }
     const u64 c0 = h->coord_cursor;
     h->bulk_off = sp;
     h->bulk_n = n_pages;
@@ -1374,6 +1384,7 @@ static int32_t build_phase1(dcd_build* h, bool codes_mode) {
   tr.mark("timers");
   // ---- uploads (not part of the timed device pipeline: the text is already resident) ----------
   DevBuf<u64> d_page_off;
+  if (h->bulk_off && h->d_bulk_off.p) d_page_off = std::move(h->d_bulk_off);      // (uploaded by dcd_build_add_pages_dev already)
   // (host -> device through pinned staging, see pinned_stage_acquire: a pageable upload of these megabytes made the runtime lock
   //  the vectors' pages, and freeing the vectors with the handle then stalled the next build by 20 ms)
   struct Staged { void* p[2] = {nullptr, nullptr}; ~Staged() { pinned_stage_release(p[0]); pinned_stage_release(p[1]); } } staged;
@@ -1385,9 +1396,11 @@ static int32_t build_phase1(dcd_build* h, bool codes_mode) {
     return DCD_OK;
   };
   if (!uniform) {
-    DCD_TRY(d_page_off.alloc(dev, n_pages_dev + 1));
-    if (h->bulk_off) DCD_HIP(hipMemcpyAsync(d_page_off.p, h->bulk_off.get(), (n_pages_dev + 1) * 8, hipMemcpyHostToDevice, st));   // (pinned already)
-    else DCD_TRY(upload(0, d_page_off.p, h->page_off.data(), (n_pages_dev + 1) * 8));
+    if (!d_page_off.p) {
+      DCD_TRY(d_page_off.alloc(dev, n_pages_dev + 1));
+      if (h->bulk_off) DCD_HIP(hipMemcpyAsync(d_page_off.p, h->bulk_off.get(), (n_pages_dev + 1) * 8, hipMemcpyHostToDevice, st));   // (pinned already)
+      else DCD_TRY(upload(0, d_page_off.p, h->page_off.data(), (n_pages_dev + 1) * 8));
+    }
   }
   // explicit postings that enter the device vocabulary: all of them, or (codes mode) only the WORDS
   std::vector<u32> xo, xl, xc;
