@@ -891,12 +891,12 @@ def big_index_legs(args, rank, world, device, dist, cdev, comm=None):
                                     "frac": round(a_q / 1e9 / (ms / 1e3) / (HBM_PEAK_GBS * world), 4), "peak": HBM_PEAK_GBS * world})
         if name == "c4_and3":
             # HBM-side bytes of the leg's dominant kernel from the committed PMC pass (valid for the configuration it was measured on)
-            tp = os.path.join(ROOT, "profiles", "r03_c4_traffic.json")
+            tp = os.path.join(ROOT, "profiles", "r04_c4_traffic.json")
             if os.path.exists(tp):
                 tr = json.load(open(tp))
                 if tr.get("total_docs") == args.total_docs and tr.get("queries"):
                     res["roofline"]["traffic"] = int(tr["fetch_bytes"] / tr["queries"] * res["queries"])
-                    res["roofline"]["traffic_note"] = ("k_pair_parts, FETCH_SIZE per query of a 20 k-query batch (profiles/r03_c4_traffic.json) "
+                    res["roofline"]["traffic_note"] = ("k_pair_parts + k_pair_stream, FETCH_SIZE per query of a 20 k-query call (profiles/r04_c4_traffic.json) "
                                                        "x the leg's queries: the operands at 8 B per coordinate + 4 B per directory cell")
         if rank == 0 and world == 1 and args.cpu_docs > 0 and progs:
             if oix is None:

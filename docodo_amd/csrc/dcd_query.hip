@@ -815,19 +815,20 @@ constexpr u32 GAL_PER = DCD_GAL_PER;
 static_assert(DCD_GAL_PER <= 65536, "part_gallop's walk-list entries are 16-bit element indices");      // short-list elements per galloping work item (256 / 512 / 1024 / 2048 -> 26.5 / 24.3 / 23.8 / 23.8 ms per 20 k C4 queries)
 constexpr u8 MODE_NONE = 0, MODE_STREAM = 1, MODE_GALLOP = 2, MODE_STREAM32 = 3, MODE_GALLOP2 = 4;
 #ifndef DCD_GAL2_RATIO
-#define DCD_GAL2_RATIO 16
+#define DCD_GAL2_RATIO 256
 #endif
 // Work plan of the operators [0, n_ops) of a round that are still to be evaluated, computed on the device once the operand counts
 // are known.  Per operator: mode, work items, and the scratch it NEEDS -- |a| + |b| REAL elements (not the host's capacity bound)
 // for a streaming or galloping operator, nothing for a two-pass galloping one (long list >= DCD_GAL2_RATIO x short list and the
-// two together at least 1 / 128 of the scratch arena).
+// two together at least 1 / 128 of the scratch arena; configs[4], 100 k phrases: ratio 16 / 64 / 256 / never -> 2.67 / 2.56 / 2.51 /
+// 2.76 s in 309 / 352 / 442 / 1713 passes).
 // items_all: work items of the operator; items_old / items_s32 / items_g2: the same number in the array of the kernel launch that
 // evaluates them (k_pair_parts: galloping items and, with stream32 == 0, the streaming ones; k_pair_stream: the streaming items;
 // the write pass of k_pair_parts: the two-pass items again) -- each launch numbers its own items through the scan of its array
 // and records an item at the operator's place in the scan of items_all.
 struct PlanOut { u64* need; u32* items_all; u32* items_old; u32* items_s32; u32* items_g2; u8* mode; };
 __global__ void k_pair_plan(const PairOp* __restrict__ ops, u32 n_ops, IdxVals idx_values, Pool pool,
-                            u64 PART, PlanOut o, u32 gal_ratio, u32 stream32, u64 g2_min_need) {
+                            u64 PART, PlanOut o, u32 gal_ratio, u32 stream32, u64 g2_min_need, u32 g2_ratio) {
   u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i > n_ops) return;
   if (i == n_ops || *pool.overflow) {                     // (overflow: the pool ran full, the sub-batch is abandoned)
@@ -849,7 +850,7 @@ __global__ void k_pair_plan(const PairOp* __restrict__ ops, u32 n_ops, IdxVals i
     if (ns * (u64)gal_ratio <= nl && (Lv[nl - 1] - Lv[0]) / nl > 4ull * absR) {
       // two passes (twice the searches) only where the scratch region would be a noticeable part of the arena: conjunctions of
       // ordinary terms (configs[3]: lists of at most ~1e6 postings) keep the single pass
-      m = (ns * (u64)DCD_GAL2_RATIO <= nl && na + nb >= g2_min_need) ? MODE_GALLOP2 : MODE_GALLOP;
+      m = (ns * (u64)g2_ratio <= nl && na + nb >= g2_min_need) ? MODE_GALLOP2 : MODE_GALLOP;
       n = (ns + GAL_PER - 1) / GAL_PER;
     }
   }
@@ -2065,6 +2066,8 @@ static int32_t exec_chunk(dcd_index* h, const dcd_query_opts& o, SubBatchDev& D,
   const u64 pw_grid = pw_grid_of(dev);
   const u64 sk_grid = std::max<u64>(1, pw_grid * DCD_SK_WAVES / DCD_PW_WAVES);       // (the same multiple of ITS wavefront slots)
   static const u32 gal_ratio = getenv("DOCODO_QUERY_GAL_RATIO") ? (u32)atoi(getenv("DOCODO_QUERY_GAL_RATIO")) : GAL_RATIO;   // (A/B knob)
+  static const u32 g2_ratio = getenv("DOCODO_QUERY_G2_RATIO") ? (u32)atoi(getenv("DOCODO_QUERY_G2_RATIO")) : (u32)DCD_GAL2_RATIO;   // (A/B knobs of the two-pass rule)
+  static const u64 g2_div = getenv("DOCODO_QUERY_G2_NEED_DIV") ? std::max<u64>(1, strtoull(getenv("DOCODO_QUERY_G2_NEED_DIV"), nullptr, 10)) : 128;
   u64* pwa = pinned_words();
   if (!pwa) DCD_FAIL(DCD_E_NOMEM, "no pinned host memory");
   const PlanOut plan_out{d_need.p, d_items.p, d_items_old.p, d_items_s32.p, d_items_g2.p, d_mode.p};
@@ -2076,7 +2079,7 @@ static int32_t exec_chunk(dcd_index* h, const dcd_query_opts& o, SubBatchDev& D,
       const PairOp* ops = d_ops.p + first;
       // device plan of everything that is left of the round: mode, work items and REAL scratch need per operator, prefix sums
       hipLaunchKernelGGL(k_pair_plan, dim3((u32)div_up((u64)n_rem + 1, 256)), dim3(256), 0, st, ops, n_rem, idx_values, pool, PART, plan_out, gal_ratio,
-                         stream32 ? 1u : 0u, std::max<u64>(D.scratch_cap / 128, 1));
+                         stream32 ? 1u : 0u, std::max<u64>(D.scratch_cap / g2_div, 1), g2_ratio);
       scan_exclusive<u64, u64>(d_need.p, d_need_off.p, (u64)n_rem + 1, d_part_scr.p, st);
       scan_exclusive<u32, u64>(d_items.p, d_part_base.p, (u64)n_rem + 1, d_part_scr.p, st);
       scan_exclusive<u32, u64>(d_items_old.p, d_base_old.p, (u64)n_rem + 1, d_part_scr.p, st);
