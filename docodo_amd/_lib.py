@@ -45,6 +45,12 @@ KERNEL_NAMES = ["k_tok_count", "k_tok_emit", "k_rs_hist", "k_rs_scatter", "k_enc
                 "vocab_sort"]
 
 
+class TermMeta(C.Structure):
+    """dcd_term_meta: one record of a shard export (include/docodo_hip.h); dist.py views the device buffer as 4 x u64."""
+    _fields_ = [("first", C.c_uint64), ("last", C.c_uint64), ("n_values", C.c_uint64), ("n_units", C.c_uint32),
+                ("key_len", C.c_uint32)]
+
+
 class QueryOpts(C.Structure):
     _fields_ = [("max_found_pages", C.c_int32), ("max_found_docs", C.c_int32), ("doc_rank_multiply", C.c_float),
                 ("want_sequences", C.c_int32), ("doc_match", C.c_void_p), ("n_doc_match", C.c_uint64),

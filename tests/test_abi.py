@@ -233,3 +233,60 @@ def test_merge_index_files_is_host_side(tmp_path):
         arr2 = (C.c_char_p * 2)(paths[1], str(pb).encode())
         assert docodo_amd.lib().dcd_merge_index_files(arr2, 2, str(out2).encode()) == _lib.DCD_E_IO
         assert not out2.exists() and not (tmp_path / "out2.index.tmp").exists()
+
+
+def test_struct_layouts_agree_with_the_library():
+    """Hosts that declare the ABI's structs by hand (ctypes here, P/Invoke in bindings/csharp) must have the library's sizes:
+    dcd_struct_size reports sizeof as the library was built, dcd_version the ABI revision the header names."""
+    import docodo_amd
+    from docodo_amd import _lib
+    L = docodo_amd.lib()
+    hdr = open(os.path.join(ROOT, "include", "docodo_hip.h")).read()
+    assert L.dcd_version() == int(re.search(r"#define\s+DCD_ABI_VERSION\s+(\d+)", hdr).group(1))
+    for which, cls in enumerate([_lib.BuildOpts, _lib.BuildStats, _lib.QueryOpts, _lib.ResultsView, _lib.TermMeta]):
+        assert L.dcd_struct_size(which) == C.sizeof(cls), cls.__name__
+    assert L.dcd_struct_size(5) == 0 and L.dcd_struct_size(-1) == 0
+
+
+def _c_struct_fields(hdr, name):
+    body = re.search(r"typedef\s+struct\s+%s\s*\{(.*?)\}\s*%s\s*;" % (name, name), hdr, flags=re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    out = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        first, *rest = decl.split(",")
+        out.append(re.findall(r"[A-Za-z_][A-Za-z0-9_]*", first)[-1])
+        out += [re.findall(r"[A-Za-z_][A-Za-z0-9_]*", r)[-1] for r in rest]
+    return out
+
+
+def _cs_struct_fields(src, name):
+    body = re.search(r"public\s+struct\s+%s\s*\{(.*?)\}" % name, src, flags=re.S).group(1)
+    body = re.sub(r"//[^\n]*", "", body)
+    out = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if not decl.startswith("public"):
+            continue
+        first, *rest = decl.split(",")
+        out.append(re.findall(r"[A-Za-z_][A-Za-z0-9_]*", first)[-1])
+        out += [r.strip() for r in rest]
+    return out
+
+
+def test_csharp_and_ctypes_structs_name_the_headers_fields_in_order():
+    """No C# compiler in this image: the P/Invoke structs are checked textually -- same field names in the same order as
+    include/docodo_hip.h (LayoutKind.Sequential then gives the C layout), and the same for the ctypes mirror."""
+    from docodo_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "docodo_hip.h")).read()
+    cs = open(os.path.join(ROOT, "bindings", "csharp", "Native.cs")).read()
+    pairs = [("dcd_build_opts", "BuildOpts", _lib.BuildOpts), ("dcd_build_stats", "BuildStats", _lib.BuildStats),
+             ("dcd_query_opts", "QueryOpts", _lib.QueryOpts), ("dcd_results_view", "ResultsView", _lib.ResultsView),
+             ("dcd_term_meta", "TermMeta", _lib.TermMeta)]
+    for cname, csname, cls in pairs:
+        want = _c_struct_fields(hdr, cname)
+        assert [f[0] for f in cls._fields_] == want, cname
+        if re.search(r"public\s+struct\s+%s\b" % csname, cs):
+            assert _cs_struct_fields(cs, csname) == want, csname
