@@ -138,7 +138,7 @@ __device__ __forceinline__ u64 sk_split(const u64* __restrict__ A, u64 na, const
 
 // kind_base: exclusive scan of the STREAMING work items per operator (this kernel's items); part_base: of all items (where an
 // item's count and scratch slot are recorded).  idx_v64: the index's resident coordinates (never the packed planes).
-__global__ __launch_bounds__(64, DCD_SK_WAVES) void k_pair_stream(const PairOp* __restrict__ ops, u32 n_ops, const u64* __restrict__ kind_base,
+__global__ __launch_bounds__(64, DCD_SK_WAVES) void k_pair_stream_lanes(const PairOp* __restrict__ ops, u32 n_ops, const u64* __restrict__ kind_base,
                                                                   const u64* __restrict__ part_base, const u64* __restrict__ idx_v64, Pool pool,
                                                                   u64* __restrict__ tmp, u64* __restrict__ part_count, u64* __restrict__ part_src,
                                                                   u64 PART, unsigned long long* __restrict__ work_ctr, const u64* __restrict__ tmp_off) {
@@ -418,6 +418,347 @@ __global__ __launch_bounds__(64, DCD_SK_WAVES) void k_pair_stream(const PairOp* 
       advance();
       wsync();
     }
+    if (lane == 0) { part_count[wi] = cursor; part_src[wi] = slot; }
+    wsync();                                                     // (the next item reuses the rings)
+    w = rfl64(w_next);
+  }
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Mask form (round 4, second half).  k_pair_stream_lanes above spends two thirds of its ~700 vector instructions per tile on
+// per-lane 0 / 1 flags (selects, compares, 64-bit key arithmetic) and on scalar registers spilled to vector lanes; configs[3]
+// and configs[4] are bound by exactly that: vector-instruction issue (profiles/r04_pmc_c4.txt).  This form keeps
+//   * every per-element flag as a 64-bit LANE MASK per element slot k (element t = 4 * lane + k: four masks cover the tile).  A
+//     v_cmp writes such a mask straight into a scalar register pair; the chain logic -- running ORs inside the lane, heads and
+//     tails, the two carry-chain fills across the lanes, ownership windows, the emit decision -- is then scalar bit arithmetic,
+//     ONE instruction for all 64 lanes (the scalar unit issues beside the vector unit and was idle); a mask gets back into the
+//     lanes as an exec mask or a carry-in, not through a select;
+//   * the rings as 32-bit keys (coordinate - E) << 1 | operand relative to an EPOCH coordinate E of the work item, saturated
+//     at 2^31 - 1 and mirrored (slot j also at j + 256: a lane's four consecutive elements are at one address + constant
+//     offsets, no wrap-around arithmetic).  A tile's key is the ring value minus twice the head's distance from E -- one
+//     subtraction; keys at or above 2^31 (an element 2^30 coordinates or more beyond the tile's head, a saturated one, the
+//     padding behind a list's end) count as not staged yet, exactly as in the lane form.  When the head itself comes within
+//     2^30 of the window's end, E moves to the head and both rings are staged again.
+// Work items, ownership and roll-back rules and results are those of the lane form (tests/helpers/pair_stream_model.py holds both
+// models; tests/test_pair_stream_model.py checks them against the oracle without a GPU).
+// ------------------------------------------------------------------------------------------------------------------------
+constexpr u32 SKM_SLOTS = 256;
+constexpr u32 SKM_RING = 2 * SKM_SLOTS;          // mirrored
+constexpr u64 SKM_SAT = 0x7FFFFFFFull;           // ring keys: coordinate - E below this is representable
+constexpr u32 SKM_INF = 0xFFFFFFFEu;             // saturated / padding key of operand 0 (operand 1: | 1)
+
+// ring key of a coordinate >= E; Elim = E + SKM_SAT
+__device__ __forceinline__ u32 skm_enc(u64 coord, u64 E, u64 Elim, u32 src) {
+  return coord < Elim ? ((((u32)coord - (u32)E) << 1) | src) : (SKM_INF | src);
+}
+// lanes l with 4 * l + k < v
+__device__ __forceinline__ u64 skm_lt(u32 v, u32 k) {
+  const u32 n = (min(v, 256u) + 3u - k) >> 2;
+  return n >= 64u ? ~0ull : ((1ull << n) - 1ull);
+}
+// v + (bit `lane` of the wave-uniform mask m): the mask is the carry-in of one add
+__device__ __forceinline__ u32 skm_add_bit(u32 v, u64 m) {
+  u32 r;
+  u64 co;
+  asm("v_addc_co_u32 %0, %1, %2, 0, %3" : "=v"(r), "=s"(co) : "v"(v), "s"(m));
+  return r;
+}
+__device__ __forceinline__ bool skm_bit(u64 m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
+template <int V> struct SkmMode { static constexpr int value = V; };      // 0: '*', 1: '*' ordered (R < 0), 2: '+'
+
+__global__ __launch_bounds__(64, DCD_SK_WAVES) void k_pair_stream(const PairOp* __restrict__ ops, u32 n_ops, const u64* __restrict__ kind_base,
+                                                                  const u64* __restrict__ part_base, const u64* __restrict__ idx_v64, Pool pool,
+                                                                  u64* __restrict__ tmp, u64* __restrict__ part_count, u64* __restrict__ part_src,
+                                                                  u64 PART, unsigned long long* __restrict__ work_ctr, const u64* __restrict__ tmp_off) {
+  __shared__ __attribute__((aligned(16))) u32 s_ring[2 * SKM_RING];
+  u32* sA = s_ring;
+  u32* sB = s_ring + SKM_RING;
+  const u32 lane = threadIdx.x;
+  const u64 n_items = kind_base[n_ops];
+  u64 w = blockIdx.x;
+  while (w < n_items) {
+    unsigned long long w_next = 0;
+    if (lane == 0) w_next = atomicAdd(work_ctr, 1ull) + gridDim.x;
+    u32 oi;
+    {   // operator of this work item: last op with kind_base[op] <= w
+      u32 lo = 0, hi = n_ops;
+      while (lo + 1 < hi) { u32 m = (lo + hi) >> 1; if (kind_base[m] <= w) lo = m; else hi = m; }
+      oi = lo;
+    }
+    const u64 p = w - kind_base[oi];
+    const u64 wi = part_base[oi] + p;
+    const PairOp op = ops[oi];
+    const u64* __restrict__ A = op.a.kind ? pool.base + pool.res_off[op.a.cnt_ref] : idx_v64 + op.a.off;
+    const u64* __restrict__ B = op.b.kind ? pool.base + pool.res_off[op.b.cnt_ref] : idx_v64 + op.b.off;
+    const u64 na = seg_cnt(op.a, pool), nb = seg_cnt(op.b, pool);
+    u64* tmp_op = tmp + tmp_off[oi];
+    const u32 absR = (u32)max(abs(op.Ra), abs(op.Rb));
+    const bool ordered = op.Ra < 0 && op.Rb < 0 && absR != 0;   // R = -absR < 0  (IndexSequence.cs:221-222)
+    const bool is_or = op.op == DCD_OP_OR;
+    const u32 thr = absR != 0 ? absR : 0xFFFFFFFFu;             // absR == 0: nothing ever breaks a chain
+    const u64 d_begin = p * PART, d_end = d_begin + PART;
+    u64 ia = rfl64(sk_split(A, na, B, nb, d_begin)), ib = d_begin - ia;
+    u64 prev_val = 0;
+    u32 prev_src = 0, have_prev = 0;
+    if (d_begin > 0) {
+      have_prev = 1;
+      const bool ua = ia > 0, ub = ib > 0;
+      const u64 pa = ua ? A[ia - 1] : 0, pb = ub ? B[ib - 1] : 0;
+      if (ua && ub) { if (pb >= pa) { prev_val = pb; prev_src = 1; } else { prev_val = pa; prev_src = 0; } }
+      else if (ua) { prev_val = pa; prev_src = 0; }
+      else { prev_val = pb; prev_src = 1; }
+      prev_val = rfl64(prev_val); prev_src = rfl(prev_src);
+    }
+    u64 cursor = 0, slot = d_begin;
+    // The tile loop, compiled once per operator kind: the masks an ordered '*' needs on top of a plain one (left elements seen) and
+    // everything a '+' does not need (chains) would otherwise cost scalar registers in all three.
+    auto run = [&](auto mode_tag) {
+    constexpr int MODE = decltype(mode_tag)::value;
+    u64 g = d_begin;                 // union index of the next unconsumed element
+    u64 out_start = 0;
+    u32 open = 0, committed = 0, seenA = 0;
+    u32 hA = 0, hB = 0;              // ring slot of the operands' next unconsumed element
+    bool skipping = MODE != 2;       // '*': nothing is owned before the first chain break of the partition
+    u64* out = tmp_op + slot;
+    u64 E = 0, Elim = 0;
+    // stages A[ia ..], B[ib ..] (256 slots each, padding behind the lists' ends) relative to a new epoch at the smaller head
+    auto stage = [&]() {
+      const u64 ha = ia < na ? A[ia] : ~0ull, hb = ib < nb ? B[ib] : ~0ull;
+      E = rfl64(ha < hb ? ha : hb);
+      Elim = E + SKM_SAT;
+      hA = 0; hB = 0;
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const u32 t = lane + (u32)q * 64u;
+        const u32 va = ia + t < na ? skm_enc(A[ia + t], E, Elim, 0u) : SKM_INF;
+        const u32 vb = ib + t < nb ? skm_enc(B[ib + t], E, Elim, 1u) : (SKM_INF | 1u);
+        sA[t] = va; sA[t + SKM_SLOTS] = va;
+        sB[t] = vb; sB[t + SKM_SLOTS] = vb;
+      }
+      wsync();
+    };
+    if (ia < na || ib < nb) stage();
+    while ((na - ia) + (nb - ib) != 0) {
+      if (g >= d_end && (skipping || MODE == 2)) break;
+      // ---- the tile's head and keys ------------------------------------------------------------------------------------
+      u32 hk = rfl(min(sA[hA], sB[hB]));                         // (one address each: every lane gets the value)
+      if (hk >= 0x80000000u) {                                   // the head left the epoch's window (or is saturated)
+        stage();
+        hk = rfl(min(sA[0], sB[0]));
+      }
+      const u32 twob = hk & ~1u;
+      const u64 base = E + (u64)(hk >> 1);
+      u32 x[4];
+      {
+        const u32* pa = sA + hA + 4u * lane;                     // elements t = 4 * lane + k of A's staged run
+        const u32* pb = sB + hB + 252u - 4u * lane;              // elements 255 - t of B's
+#pragma unroll
+        for (int k = 0; k < 4; k++) x[k] = min(pa[k] - twob, pb[3 - k] - twob);
+      }
+      // ---- bitonic merge: distances 128 .. 4 across lanes, 2 and 1 inside the lane (element t = 4 * lane + k) -------------
+      sk_merge_network(x, lane);
+      // ---- lane masks of the sorted tile: per element slot k, breaks / valid non-duplicates / contacts (/ left elements) ---
+      u32 c[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) c[k] = x[k] >> 1;
+      u64 BRK[4], ALND[4], XQ[4], AQ[4];
+      u32 cnt = 0, ca = 0;
+      {
+        u32 pgap = 0xFFFFFFFFu;      // (the element before the tile is the carried one: its distance saturates far above any absR)
+        if (have_prev) { const u64 dd = base - prev_val; pgap = dd < 0xFFFFFFFFull ? (u32)dd : 0xFFFFFFFFu; }
+        u32 cp = (u32)__builtin_amdgcn_update_dpp(0, (int)c[3], 0x138, 0xF, 0xF, false);           // wave_shr:1: c[3] of the lane below
+        asm volatile("" : "+v"(cp));     // (keeps the move a v_mov_b32_dpp: folded into the subtraction -- v_subrev_u32_dpp ... wave_shr:1 --
+                                         //  the lanes got wrong neighbours on gfx950: every cross-lane gap was garbage)
+        u32 gap[4];
+        gap[0] = lane == 0u ? pgap : c[0] - cp;
+#pragma unroll
+        for (int k = 1; k < 4; k++) gap[k] = c[k] - c[k - 1];
+        const u64 S3 = ballot64((x[3] & 1u) != 0u);
+        u64 ps = (S3 << 1) | (u64)prev_src;                      // operand of the predecessor
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const u64 V = ballot64((int)x[k] >= 0);                // (the valid keys are the first cnt elements)
+          const u64 S = k == 3 ? S3 : ballot64((x[k] & 1u) != 0u);
+          const u64 G = ballot64(gap[k] > thr);
+          const u64 Zk = ballot64(gap[k] == 0u);
+          const u64 HP = (k == 0 && !have_prev) ? ~1ull : ~0ull;
+          cnt += popc64(V);                                      // >= 1: the head itself
+          ca += popc64(V & ~S);
+          BRK[k] = V & (G | ~HP);
+          ALND[k] = V & ~(S & ~ps & Zk & HP);                    // valid and not the right operand's copy of the element before
+          const u64 CT = V & HP & (ps ^ S) & ~G;                 // neighbours from different operands within absR (never a break)
+          XQ[k] = MODE == 1 ? (CT & S) : CT;                     // (ordered mode: a right element directly after a left one)
+          AQ[k] = V & ~S;
+          ps = S;
+        }
+      }
+      const u32 cb = cnt - ca;
+      // ---- request the refill: the ca / cb freed slots take the elements behind the 256 staged ones -------------------------
+      u64 pfA[4], pfB[4];
+      const u64 leftA = na - ia > SKM_SLOTS ? na - ia - SKM_SLOTS : 0, leftB = nb - ib > SKM_SLOTS ? nb - ib - SKM_SLOTS : 0;
+      {
+        const u64* __restrict__ nA = A + ia + SKM_SLOTS;
+        const u64* __restrict__ nB = B + ib + SKM_SLOTS;
+        const u32 loadA = (u32)min((u64)ca, leftA), loadB = (u32)min((u64)cb, leftB);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const u32 xx = lane + (u32)q * 64u;
+          pfA[q] = ~0ull; pfB[q] = ~0ull;                        // (behind a list's end: beyond every epoch window = padding)
+          if ((u32)q * 64u < loadA) { if (xx < loadA) pfA[q] = nA[xx]; }
+          if ((u32)q * 64u < loadB) { if (xx < loadB) pfB[q] = nB[xx]; }
+        }
+      }
+      // the tile's last element
+      u32 lkey;
+      {
+        const u32 last = cnt - 1u, last_lane = last >> 2, last_k = last & 3u;
+        const u32 l0 = rdl(x[0], last_lane), l1 = rdl(x[1], last_lane), l2 = rdl(x[2], last_lane), l3 = rdl(x[3], last_lane);
+        lkey = last_k == 0u ? l0 : last_k == 1u ? l1 : last_k == 2u ? l2 : l3;
+      }
+      const bool inputs_end = (ia + ca == na) && (ib + cb == nb);
+      // ---- ownership: [t_lo, t_hi) of this tile belongs to the work item ------------------------------------------------------
+      u32 t_lo = 0, t_hi = cnt;
+      const bool may_end = g + cnt > d_end;
+      if (skipping || may_end) {
+        const u32 lim = may_end ? (d_end > g ? (u32)(d_end - g) : 0u) : 0xFFFFFFFFu;
+        if (MODE == 2) {                                         // '+': every element starts a chain of its own
+          t_hi = min(lim, cnt);
+        } else {
+          u32 fb = NONE32, fe = NONE32;
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            const u64 C = BRK[k];
+            if (C) fb = min(fb, 4u * (u32)__builtin_ctzll(C) + (u32)k);
+            const u64 Ce = C & ~skm_lt(lim, (u32)k);
+            if (Ce) fe = min(fe, 4u * (u32)__builtin_ctzll(Ce) + (u32)k);
+          }
+          if (skipping) t_lo = min(fb, cnt);
+          if (may_end) t_hi = min(fe, cnt);
+          if (t_hi < t_lo) t_hi = t_lo;
+        }
+      }
+      const bool ends_here = t_hi < cnt;       // a chain break at or beyond the partition end: stop before it
+      auto advance = [&]() {
+        wsync();                               // (the rings were read at the top of the tile)
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const u32 xx = lane + (u32)q * 64u;
+          if ((u32)q * 64u < ca) {
+            if (xx < ca) {
+              const u32 v = skm_enc(pfA[q], E, Elim, 0u);
+              const u32 j = (hA + xx) & (SKM_SLOTS - 1u);
+              sA[j] = v; sA[j + SKM_SLOTS] = v;
+            }
+          }
+          if ((u32)q * 64u < cb) {
+            if (xx < cb) {
+              const u32 v = skm_enc(pfB[q], E, Elim, 1u);
+              const u32 j = (hB + xx) & (SKM_SLOTS - 1u);
+              sB[j] = v; sB[j + SKM_SLOTS] = v;
+            }
+          }
+        }
+        ia += ca; ib += cb;
+        hA = (hA + ca) & (SKM_SLOTS - 1u); hB = (hB + cb) & (SKM_SLOTS - 1u);
+        prev_val = base + (u64)(lkey >> 1); prev_src = lkey & 1u; have_prev = 1;
+        g += cnt;
+        wsync();
+      };
+      if (t_lo >= t_hi) {                      // nothing owned in this tile
+        if (ends_here) {
+          if (open && !committed) cursor = out_start;   // the carried chain closes without the other operand
+          open = 0;
+          break;
+        }
+        advance();
+        continue;
+      }
+      if (skipping) { skipping = false; slot = g + t_lo; out = tmp_op + slot; }
+      if (t_lo > 0 || ends_here) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const u64 W = skm_lt(t_hi, (u32)k) & ~skm_lt(t_lo, (u32)k);
+          ALND[k] &= W; BRK[k] &= W; XQ[k] &= W; AQ[k] &= W;
+        }
+      }
+      const bool final_tile = ends_here || inputs_end;
+      u64 EM[4];
+      u32 total_emit = 0;
+      if (MODE == 2) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) { EM[k] = ALND[k]; total_emit += popc64(EM[k]); }
+      } else {
+        // ---- chains ---------------------------------------------------------------------------------------------------------
+        // A chain is emitted iff it holds both operands, i.e. iff two NEIGHBOURS of it come from different operands (ordered
+        // mode: an element of the right operand directly after one of the left operand), and ordered mode emits only from the
+        // first left element of the chain on.  Inside the lane: running ORs since the lane's last break (forward) and up to its
+        // next break (backward), as masks over the lanes; across the lanes: the carry chains of sk_fill_fwd / sk_fill_bwd.
+        u64 nobrk = ~0ull, headx = 0, fx = 0, fa = 0;
+        u32 LB = 0;                                              // position of the tile's last break
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const u64 NBk = ~BRK[k];
+          nobrk &= NBk;                                          // no break at or before k in the lane
+          headx |= nobrk & XQ[k];                                // contacts before the lane's first break
+          fx = XQ[k] | (fx & NBk);                               // running OR since the lane's last break
+          if (MODE == 1) fa = AQ[k] | (fa & NBk);
+          if (BRK[k]) LB = max(LB, 4u * (63u - (u32)__builtin_clzll(BRK[k])) + (u32)k);
+        }
+        const bool has_brk = nobrk != ~0ull;                     // a chain starts in this tile
+        const u64 Fx = sk_fill_fwd(fx, nobrk, committed);        // chain leaving lane l holds a contact (so far)
+        const u64 Gx = sk_fill_bwd(headx, nobrk);                // chain entering lane l holds one further on
+        const u64 INX = (Fx << 1) | (u64)committed, OUTX = Gx >> 1;
+        u64 Fa = 0, INA = ~0ull;
+        if (MODE == 1) {
+          Fa = sk_fill_fwd(fa, nobrk, seenA);
+          INA = (Fa << 1) | (u64)seenA;
+        }
+        const bool chain0_commit = committed || ((Gx & 1ull) != 0ull);         // (Gx bit 0: a contact before the tile's first break)
+        if (open && !committed && (has_brk || final_tile) && !chain0_commit) cursor = out_start;   // roll back
+        // backward: contacts behind k in k's run (or beyond the lane, if no break follows)
+        u64 R[4];
+        R[3] = OUTX;
+#pragma unroll
+        for (int k = 2; k >= 0; k--) R[k] = ~BRK[k + 1] & (XQ[k + 1] | R[k + 1]);
+        u64 F = INX, FAr = INA;
+        u32 before_lb = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const u64 NBk = ~BRK[k];
+          F = XQ[k] | (F & NBk);                                 // contacts at or before k in k's run (or in front of the lane)
+          const u64 LTLB = has_brk ? skm_lt(LB, (u32)k) : 0ull;  // elements in front of the last break
+          const u64 CLOSED = final_tile ? ~0ull : LTLB;
+          u64 e = ALND[k] & (F | R[k] | ~CLOSED);
+          if (MODE == 1) { FAr = AQ[k] | (FAr & NBk); e &= FAr; }   // a left element at or before k in the chain
+          EM[k] = e;
+          total_emit += popc64(e);
+          before_lb += popc64(e & LTLB);
+        }
+        // the chain that is open at the end of the tile: where its output starts, whether it holds a contact / a left element
+        if (has_brk || !open) out_start = cursor + before_lb;
+        open = 1; seenA = (u32)(Fa >> 63); committed = (u32)(Fx >> 63);
+      }
+      // compaction: position = emitted elements before (lanes below: v_mbcnt over the four masks; in the lane: the masks' own bits)
+      {
+        u32 pos = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) pos = __builtin_amdgcn_mbcnt_hi((u32)(EM[k] >> 32), __builtin_amdgcn_mbcnt_lo((u32)EM[k], pos));
+        u64* __restrict__ oc = out + cursor;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          if (skm_bit(EM[k])) oc[pos] = base + (u64)c[k];
+          if (k < 3) pos = skm_add_bit(pos, EM[k]);
+        }
+      }
+      cursor += total_emit;
+      if (ends_here) { open = 0; break; }
+      advance();
+    }
+    };
+    if (is_or) run(SkmMode<2>());
+    else if (ordered) run(SkmMode<1>());
+    else run(SkmMode<0>());
     if (lane == 0) { part_count[wi] = cursor; part_src[wi] = slot; }
     wsync();                                                     // (the next item reuses the rings)
     w = rfl64(w_next);

@@ -2112,8 +2112,11 @@ static int32_t exec_chunk(dcd_index* h, const dcd_query_opts& o, SubBatchDev& D,
         // merging ones share the CUs (round 3 measured the two kinds in consecutive launches: 35 % slower than in one)
         DCD_HIP(hipEventRecord(ev_plan, st));
         DCD_HIP(hipStreamWaitEvent(st2, ev_plan, 0));
-        hipLaunchKernelGGL(k_pair_stream, dim3((u32)std::min<u64>(W, sk_grid)), dim3(64), 0, st2, ops, n, d_base_s32.p, d_part_base.p, idx_values.v64,
-                           pool, D.tmp, d_part_count.p, d_part_src.p, PART, reinterpret_cast<unsigned long long*>(d_work_ctr.p + 1), d_need_off.p);
+        // (DOCODO_QUERY_STREAM_FORM=lanes: the first form of the kernel, per-lane flags -- kept for the A/B of round 4)
+        static const bool lanes_form = getenv("DOCODO_QUERY_STREAM_FORM") && !strcmp(getenv("DOCODO_QUERY_STREAM_FORM"), "lanes");
+        hipLaunchKernelGGL(lanes_form ? k_pair_stream_lanes : k_pair_stream, dim3((u32)std::min<u64>(W, sk_grid)), dim3(64), 0, st2, ops, n,
+                           d_base_s32.p, d_part_base.p, idx_values.v64, pool, D.tmp, d_part_count.p, d_part_src.p, PART,
+                           reinterpret_cast<unsigned long long*>(d_work_ctr.p + 1), d_need_off.p);
         DCD_HIP(hipEventRecord(ev_s32, st2));
       }
       hipLaunchKernelGGL(k_pair_parts, dim3((u32)std::min<u64>(W, pw_grid)), dim3(PW_T), 0, st, ops, n, d_base_old.p, d_part_base.p, idx_values, pool,

@@ -293,3 +293,236 @@ def evaluate(A, B, Ra, Rb, is_or, PART=8192):
     for p in range(n):
         res += work_item(A, B, Ra, Rb, is_or, PART, p)
     return res
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# Mask form (round 4, second half): the same work items, but every per-element flag is a 64-bit LANE MASK per element slot k
+# (element t = 4 * lane + k: four masks cover the tile), so the kernel evaluates the chain logic with scalar bit operations on
+# SGPR pairs -- one instruction for 64 lanes -- instead of per-lane selects, and the rings hold 32-bit keys relative to an
+# EPOCH coordinate E of the work item ((coordinate - E) << 1 | operand, saturated), so a tile's keys are one subtraction away.
+# ------------------------------------------------------------------------------------------------------------------------
+SAT = 0x7FFFFFFF            # ring keys: coordinate - E below this is representable
+KINF = 0xFFFFFFFE           # saturated / padding key of operand 0 (operand 1: | 1)
+REBASE = 0x80000000         # head key at or above this: new epoch
+
+
+def enc(coord, E, src):
+    d = coord - E
+    return ((d << 1) | src) if d < SAT else (KINF | src)
+
+
+def ff1(m):
+    return (m & -m).bit_length() - 1
+
+
+def lt_mask(v, k):
+    """lanes l with 4 * l + k < v"""
+    n = (min(v, 256) + 3 - k) >> 2
+    return M64 if n >= 64 else (1 << n) - 1
+
+
+def work_item_masks(A, B, Ra, Rb, is_or, PART, p, stats=None):
+    na, nb = len(A), len(B)
+    absR = max(abs(Ra), abs(Rb))
+    ordered = Ra < 0 and Rb < 0 and absR != 0
+    thr = absR if absR != 0 else 0xFFFFFFFF
+    d_begin, d_end = p * PART, p * PART + PART
+    ia = split(A, B, d_begin)
+    ib = d_begin - ia
+    have_prev, prev_val, prev_src = 0, 0, 0
+    if d_begin > 0:
+        have_prev = 1
+        ua, ub = ia > 0, ib > 0
+        pa, pb = (A[ia - 1] if ua else 0), (B[ib - 1] if ub else 0)
+        if ua and ub:
+            prev_val, prev_src = (pb, 1) if pb >= pa else (pa, 0)
+        elif ua:
+            prev_val, prev_src = pa, 0
+        else:
+            prev_val, prev_src = pb, 1
+    g = d_begin
+    out = []
+    cursor, out_start = 0, 0
+    opn, committed, seenA = 0, 0, 0
+    skipping = not is_or
+    if ia >= na and ib >= nb:
+        return out
+    E = min(A[ia] if ia < na else M64, B[ib] if ib < nb else M64)
+
+    def stage():
+        rA = [enc(A[ia + t], E, 0) if ia + t < na else KINF for t in range(TILE)]
+        rB = [enc(B[ib + t], E, 1) if ib + t < nb else (KINF | 1) for t in range(TILE)]
+        return rA, rB
+    ringA, ringB = stage()
+    while (na - ia) + (nb - ib) != 0:
+        if g >= d_end and (skipping or is_or):
+            break
+        hk = min(ringA[0], ringB[0])
+        if hk >= REBASE:                               # the head left the epoch's window (or is saturated): new epoch at the head
+            E = min(A[ia] if ia < na else M64, B[ib] if ib < nb else M64)
+            ringA, ringB = stage()
+            hk = min(ringA[0], ringB[0])
+            if stats is not None:
+                stats["rebase"] = stats.get("rebase", 0) + 1
+            assert hk < 2
+        twob = hk & ~1
+        base = E + (hk >> 1)
+        x = [[min(ringA[4 * l + k] - twob, ringB[TILE - 1 - 4 * l - k] - twob) for k in range(4)] for l in range(64)]
+        x = network(x)
+        VALID = [ballot([x[l][k] < 0x80000000 for l in range(64)]) for k in range(4)]
+        SRC = [ballot([x[l][k] & 1 for l in range(64)]) for k in range(4)]
+        cnt = sum(popc(v) for v in VALID)
+        ca = sum(popc(VALID[k] & ~SRC[k] & M64) for k in range(4))
+        cb = cnt - ca
+        assert cnt >= 1
+        pgap = 0xFFFFFFFF
+        if have_prev:
+            dd = base - prev_val
+            pgap = dd if dd < 0xFFFFFFFF else 0xFFFFFFFF
+        GT, Z = [0] * 4, [0] * 4
+        for k in range(4):
+            for l in range(64):
+                cp = (x[l][k - 1] >> 1) if k else ((x[l - 1][3] >> 1) if l else 0)
+                gap = ((x[l][k] >> 1) - cp) & 0xFFFFFFFF
+                if k == 0 and l == 0:
+                    gap = pgap
+                GT[k] |= (1 << l) if gap > thr else 0
+                Z[k] |= (1 << l) if gap == 0 else 0
+        # (exactly the kernel's arrangement: per slot k the breaks, the valid non-duplicates, the contacts and the left elements)
+        BRK, ALND, XQ, AQ = [0] * 4, [0] * 4, [0] * 4, [0] * 4
+        ps = ((SRC[3] << 1) | prev_src) & M64
+        for k in range(4):
+            HP = (M64 ^ 1) if (k == 0 and not have_prev) else M64
+            V, S, G, Zk = VALID[k], SRC[k], GT[k], Z[k]
+            BRK[k] = V & (G | (~HP & M64))
+            ALND[k] = V & ~(S & ~ps & Zk & HP) & M64
+            CT = V & HP & (ps ^ S) & ~G & M64
+            XQ[k] = (CT & S) if ordered else CT
+            AQ[k] = V & ~S & M64
+            ps = S
+        last_lane, last_k = (cnt - 1) >> 2, (cnt - 1) & 3
+        lkey = x[last_lane][last_k]
+        t_last_val, t_last_src = base + (lkey >> 1), lkey & 1
+        inputs_end = (ia + ca == na) and (ib + cb == nb)
+        t_lo, t_hi = 0, cnt
+        may_end = g + cnt > d_end
+        if skipping or may_end:
+            lim = (d_end - g if d_end > g else 0) if may_end else 0xFFFFFFFF
+            if is_or:
+                t_hi = min(lim, cnt)
+            else:
+                fb = fe = 0xFFFFFFFF
+                for k in range(4):
+                    C = BRK[k]
+                    if C:
+                        fb = min(fb, 4 * ff1(C) + k)
+                    Ce = C & ~lt_mask(lim, k) & M64
+                    if Ce:
+                        fe = min(fe, 4 * ff1(Ce) + k)
+                if skipping:
+                    t_lo = min(fb, cnt)
+                if may_end:
+                    t_hi = min(fe, cnt)
+                if t_hi < t_lo:
+                    t_hi = t_lo
+        ends_here = t_hi < cnt
+
+        def advance():
+            nonlocal ia, ib, prev_val, prev_src, have_prev, g, ringA, ringB
+            # the ca / cb consumed slots are refilled behind the 256 - ca / 256 - cb elements that stay
+            ringA = ringA[ca:] + [enc(A[ia + TILE + i], E, 0) if ia + TILE + i < na else KINF for i in range(ca)]
+            ringB = ringB[cb:] + [enc(B[ib + TILE + i], E, 1) if ib + TILE + i < nb else (KINF | 1) for i in range(cb)]
+            ia += ca
+            ib += cb
+            prev_val, prev_src, have_prev = t_last_val, t_last_src, 1
+            g += cnt
+        if t_lo >= t_hi:
+            if ends_here:
+                if opn and not committed:
+                    cursor = out_start
+                opn = 0
+                break
+            advance()
+            continue
+        if skipping:
+            skipping = False
+        if t_lo > 0 or ends_here:
+            for k in range(4):
+                W = lt_mask(t_hi, k) & ~lt_mask(t_lo, k) & M64
+                ALND[k] &= W
+                BRK[k] &= W
+                XQ[k] &= W
+                AQ[k] &= W
+        final_tile = ends_here or inputs_end
+        EM = [0] * 4
+        has_brk, LB = False, 0
+        if is_or:
+            EM = list(ALND)
+        else:
+            nobrk, headx, fx, fa = M64, 0, 0, 0
+            for k in range(4):
+                NBk = ~BRK[k] & M64
+                nobrk &= NBk
+                headx |= nobrk & XQ[k]
+                fx = XQ[k] | (fx & NBk)
+                fa = AQ[k] | (fa & NBk)
+                if BRK[k]:
+                    LB = max(LB, 4 * (BRK[k].bit_length() - 1) + k)
+            has_brk = nobrk != M64
+            Fx = fill_fwd(fx, nobrk, committed)
+            Gx = fill_bwd(headx, nobrk)
+            INX, OUTX = ((Fx << 1) | committed) & M64, Gx >> 1
+            Fa, INA = 0, M64
+            if ordered:
+                Fa = fill_fwd(fa, nobrk, seenA)
+                INA = ((Fa << 1) | seenA) & M64
+            chain0_commit = committed or (Gx & 1)
+            if opn and (not committed) and (has_brk or final_tile) and not chain0_commit:
+                cursor = out_start
+            R = [0, 0, 0, OUTX]
+            for k in (2, 1, 0):
+                R[k] = ~BRK[k + 1] & (XQ[k + 1] | R[k + 1]) & M64
+            F, FAr = INX, INA
+            for k in range(4):
+                NBk = ~BRK[k] & M64
+                F = XQ[k] | (F & NBk)
+                LTLB = lt_mask(LB, k) if has_brk else 0
+                CLOSED = M64 if final_tile else LTLB
+                e = ALND[k] & (F | R[k] | (~CLOSED & M64))
+                if ordered:
+                    FAr = AQ[k] | (FAr & NBk)
+                    e &= FAr
+                EM[k] = e
+        del out[cursor:]
+        emitted = [None] * sum(popc(m) for m in EM)
+        for l in range(64):
+            below = (1 << l) - 1
+            pos = sum(popc(EM[k] & below) for k in range(4))
+            for k in range(4):
+                if (EM[k] >> l) & 1:
+                    emitted[pos] = base + (x[l][k] >> 1)
+                    pos += 1
+        before_lb = sum(popc(EM[k] & lt_mask(LB, k)) for k in range(4)) if has_brk else 0
+        out.extend(emitted)
+        if not is_or:
+            if has_brk or not opn:
+                out_start = cursor + before_lb
+            opn, seenA, committed = 1, (Fa >> 63) & 1, (Fx >> 63) & 1
+        cursor += len(emitted)
+        if ends_here:
+            opn = 0
+            break
+        advance()
+    del out[cursor:]
+    return out
+
+
+def evaluate_masks(A, B, Ra, Rb, is_or, PART=8192, stats=None):
+    A, B = [int(v) for v in A], [int(v) for v in B]
+    if (not is_or) and (len(A) == 0 or len(B) == 0):
+        return []
+    n = (len(A) + len(B) + PART - 1) // PART
+    res = []
+    for p in range(n):
+        res += work_item_masks(A, B, Ra, Rb, is_or, PART, p, stats)
+    return res

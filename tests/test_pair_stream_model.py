@@ -59,3 +59,19 @@ def test_model_equals_oracle(oracle_mod, seed):
         want, _ = o.seq_or(ua, Ra, ub, Rb)
         got = psm.evaluate(a, b, Ra, Rb, True, part)
         assert np.array_equal(o.seq_encode(np.array(got, np.uint64)), want), ("or", a.size, b.size, Ra, Rb, part)
+
+
+@pytest.mark.parametrize("seed", [11, 12, 13])
+def test_mask_form_equals_oracle(oracle_mod, seed):
+    """The mask form of the kernel (lane masks per element slot, epoch-relative 32-bit ring keys) against the oracle."""
+    o = oracle_mod
+    stats = {}
+    for a, b, Ra, Rb, part in _cases(seed, 60):
+        ua, ub = o.seq_encode(a), o.seq_encode(b)
+        want, _ = o.seq_and(ua, Ra, ub, Rb)
+        got = psm.evaluate_masks(a, b, Ra, Rb, False, part, stats)
+        assert np.array_equal(o.seq_encode(np.array(got, np.uint64)), want), ("and", a.size, b.size, Ra, Rb, part)
+        want, _ = o.seq_or(ua, Ra, ub, Rb)
+        got = psm.evaluate_masks(a, b, Ra, Rb, True, part, stats)
+        assert np.array_equal(o.seq_encode(np.array(got, np.uint64)), want), ("or", a.size, b.size, Ra, Rb, part)
+    assert stats.get("rebase", 0) > 0, "no case left its epoch: the re-staging path was not exercised"
