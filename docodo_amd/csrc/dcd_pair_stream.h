@@ -467,10 +467,20 @@ __device__ __forceinline__ u32 skm_add_bit(u32 v, u64 m) {
 __device__ __forceinline__ bool skm_bit(u64 m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
 template <int V> struct SkmMode { static constexpr int value = V; };      // 0: '*', 1: '*' ordered (R < 0), 2: '+'
 
-__global__ __launch_bounds__(64, DCD_SK_WAVES) void k_pair_stream(const PairOp* __restrict__ ops, u32 n_ops, const u64* __restrict__ kind_base,
-                                                                  const u64* __restrict__ part_base, const u64* __restrict__ idx_v64, Pool pool,
-                                                                  u64* __restrict__ tmp, u64* __restrict__ part_count, u64* __restrict__ part_src,
-                                                                  u64 PART, unsigned long long* __restrict__ work_ctr, const u64* __restrict__ tmp_off) {
+// hides where a scalar comes from: the halves of a 64-bit scalar compared on their own stay 32-bit SCALAR compares (put back
+// together the compiler issues a 64-bit vector compare: the scalar unit has none)
+__device__ __forceinline__ u32 skm_opaque(u32 v) { asm volatile("" : "+s"(v)); return v; }
+__device__ __forceinline__ bool skm_gt(u64 v, u32 k) { return skm_opaque((u32)(v >> 32)) != 0u || (u32)v > k; }
+
+// PART < 2^32 (the host checks).  Scalar state of the tile loop, kept small on purpose -- the lane masks need the registers:
+// pA / pB point at the operands' next unconsumed element, remA / remB count what is left of them; `left` = union elements up to
+// the partition's end (0 once it is passed); `slot` follows the union index until the first owned element is found.
+// WPE: wavefronts per SIMD the kernel is compiled for = its scalar-register budget (8: 80 registers, 7: 96, 6 and fewer: 102)
+template <int WPE>
+__global__ __launch_bounds__(64, WPE) void k_pair_stream(const PairOp* __restrict__ ops, u32 n_ops, const u64* __restrict__ kind_base,
+                                                         const u64* __restrict__ part_base, const u64* __restrict__ idx_v64, Pool pool,
+                                                         u64* __restrict__ tmp, u64* __restrict__ part_count, u64* __restrict__ part_src,
+                                                         u64 PART, unsigned long long* __restrict__ work_ctr, const u64* __restrict__ tmp_off) {
   __shared__ __attribute__((aligned(16))) u32 s_ring[2 * SKM_RING];
   u32* sA = s_ring;
   u32* sB = s_ring + SKM_RING;
@@ -497,50 +507,56 @@ __global__ __launch_bounds__(64, DCD_SK_WAVES) void k_pair_stream(const PairOp* 
     const bool ordered = op.Ra < 0 && op.Rb < 0 && absR != 0;   // R = -absR < 0  (IndexSequence.cs:221-222)
     const bool is_or = op.op == DCD_OP_OR;
     const u32 thr = absR != 0 ? absR : 0xFFFFFFFFu;             // absR == 0: nothing ever breaks a chain
-    const u64 d_begin = p * PART, d_end = d_begin + PART;
-    u64 ia = rfl64(sk_split(A, na, B, nb, d_begin)), ib = d_begin - ia;
+    const u64 d_begin = p * PART;
     u64 prev_val = 0;
     u32 prev_src = 0, have_prev = 0;
-    if (d_begin > 0) {
-      have_prev = 1;
-      const bool ua = ia > 0, ub = ib > 0;
-      const u64 pa = ua ? A[ia - 1] : 0, pb = ub ? B[ib - 1] : 0;
-      if (ua && ub) { if (pb >= pa) { prev_val = pb; prev_src = 1; } else { prev_val = pa; prev_src = 0; } }
-      else if (ua) { prev_val = pa; prev_src = 0; }
-      else { prev_val = pb; prev_src = 1; }
-      prev_val = rfl64(prev_val); prev_src = rfl(prev_src);
+    const u64* __restrict__ pA;
+    const u64* __restrict__ pB;
+    u64 remA, remB;
+    {
+      const u64 ia = rfl64(sk_split(A, na, B, nb, d_begin)), ib = d_begin - ia;
+      if (d_begin > 0) {
+        have_prev = 1;
+        const bool ua = ia > 0, ub = ib > 0;
+        const u64 pa = ua ? A[ia - 1] : 0, pb = ub ? B[ib - 1] : 0;
+        if (ua && ub) { if (pb >= pa) { prev_val = pb; prev_src = 1; } else { prev_val = pa; prev_src = 0; } }
+        else if (ua) { prev_val = pa; prev_src = 0; }
+        else { prev_val = pb; prev_src = 1; }
+        prev_val = rfl64(prev_val); prev_src = rfl(prev_src);
+      }
+      pA = (const u64*)rfl64((u64)(A + ia)); pB = (const u64*)rfl64((u64)(B + ib));
+      remA = rfl64(na - ia); remB = rfl64(nb - ib);
     }
     u64 cursor = 0, slot = d_begin;
     // The tile loop, compiled once per operator kind: the masks an ordered '*' needs on top of a plain one (left elements seen) and
     // everything a '+' does not need (chains) would otherwise cost scalar registers in all three.
     auto run = [&](auto mode_tag) {
     constexpr int MODE = decltype(mode_tag)::value;
-    u64 g = d_begin;                 // union index of the next unconsumed element
+    u32 left = (u32)PART;            // union elements up to the partition's end
     u64 out_start = 0;
     u32 open = 0, committed = 0, seenA = 0;
     u32 hA = 0, hB = 0;              // ring slot of the operands' next unconsumed element
     bool skipping = MODE != 2;       // '*': nothing is owned before the first chain break of the partition
-    u64* out = tmp_op + slot;
-    u64 E = 0, Elim = 0;
-    // stages A[ia ..], B[ib ..] (256 slots each, padding behind the lists' ends) relative to a new epoch at the smaller head
+    u64 E = 0;
+    // stages pA[0 ..], pB[0 ..] (256 slots each, padding behind the lists' ends) relative to a new epoch at the smaller head
     auto stage = [&]() {
-      const u64 ha = ia < na ? A[ia] : ~0ull, hb = ib < nb ? B[ib] : ~0ull;
+      const u64 ha = remA ? pA[0] : ~0ull, hb = remB ? pB[0] : ~0ull;
       E = rfl64(ha < hb ? ha : hb);
-      Elim = E + SKM_SAT;
+      const u64 Elim = E + SKM_SAT;
       hA = 0; hB = 0;
 #pragma unroll
       for (int q = 0; q < 4; q++) {
         const u32 t = lane + (u32)q * 64u;
-        const u32 va = ia + t < na ? skm_enc(A[ia + t], E, Elim, 0u) : SKM_INF;
-        const u32 vb = ib + t < nb ? skm_enc(B[ib + t], E, Elim, 1u) : (SKM_INF | 1u);
+        const u32 va = (u64)t < remA ? skm_enc(pA[t], E, Elim, 0u) : SKM_INF;
+        const u32 vb = (u64)t < remB ? skm_enc(pB[t], E, Elim, 1u) : (SKM_INF | 1u);
         sA[t] = va; sA[t + SKM_SLOTS] = va;
         sB[t] = vb; sB[t + SKM_SLOTS] = vb;
       }
       wsync();
     };
-    if (ia < na || ib < nb) stage();
-    while ((na - ia) + (nb - ib) != 0) {
-      if (g >= d_end && (skipping || MODE == 2)) break;
+    if ((remA | remB) != 0) stage();
+    while ((remA | remB) != 0) {
+      if (left == 0u && (skipping || MODE == 2)) break;
       // ---- the tile's head and keys ------------------------------------------------------------------------------------
       u32 hk = rfl(min(sA[hA], sB[hB]));                         // (one address each: every lane gets the value)
       if (hk >= 0x80000000u) {                                   // the head left the epoch's window (or is saturated)
@@ -566,7 +582,7 @@ __global__ __launch_bounds__(64, DCD_SK_WAVES) void k_pair_stream(const PairOp* 
       u32 cnt = 0, ca = 0;
       {
         u32 pgap = 0xFFFFFFFFu;      // (the element before the tile is the carried one: its distance saturates far above any absR)
-        if (have_prev) { const u64 dd = base - prev_val; pgap = dd < 0xFFFFFFFFull ? (u32)dd : 0xFFFFFFFFu; }
+        if (have_prev) { const u64 dd = base - prev_val; pgap = skm_opaque((u32)(dd >> 32)) != 0u ? 0xFFFFFFFFu : (u32)dd; }
         u32 cp = (u32)__builtin_amdgcn_update_dpp(0, (int)c[3], 0x138, 0xF, 0xF, false);           // wave_shr:1: c[3] of the lane below
         asm volatile("" : "+v"(cp));     // (keeps the move a v_mov_b32_dpp: folded into the subtraction -- v_subrev_u32_dpp ... wave_shr:1 --
                                          //  the lanes got wrong neighbours on gfx950: every cross-lane gap was garbage)
@@ -591,22 +607,21 @@ __global__ __launch_bounds__(64, DCD_SK_WAVES) void k_pair_stream(const PairOp* 
           XQ[k] = MODE == 1 ? (CT & S) : CT;                     // (ordered mode: a right element directly after a left one)
           AQ[k] = V & ~S;
           ps = S;
+          __builtin_amdgcn_sched_barrier(0);                     // (slot by slot: all sixteen compare results at once do not fit the scalar registers)
         }
       }
       const u32 cb = cnt - ca;
       // ---- request the refill: the ca / cb freed slots take the elements behind the 256 staged ones -------------------------
       u64 pfA[4], pfB[4];
-      const u64 leftA = na - ia > SKM_SLOTS ? na - ia - SKM_SLOTS : 0, leftB = nb - ib > SKM_SLOTS ? nb - ib - SKM_SLOTS : 0;
       {
-        const u64* __restrict__ nA = A + ia + SKM_SLOTS;
-        const u64* __restrict__ nB = B + ib + SKM_SLOTS;
-        const u32 loadA = (u32)min((u64)ca, leftA), loadB = (u32)min((u64)cb, leftB);
+        const u32 loadA = skm_gt(remA, SKM_SLOTS + ca) ? ca : skm_gt(remA, SKM_SLOTS) ? (u32)remA - SKM_SLOTS : 0u;   // min(ca, remA - 256)
+        const u32 loadB = skm_gt(remB, SKM_SLOTS + cb) ? cb : skm_gt(remB, SKM_SLOTS) ? (u32)remB - SKM_SLOTS : 0u;
 #pragma unroll
         for (int q = 0; q < 4; q++) {
           const u32 xx = lane + (u32)q * 64u;
           pfA[q] = ~0ull; pfB[q] = ~0ull;                        // (behind a list's end: beyond every epoch window = padding)
-          if ((u32)q * 64u < loadA) { if (xx < loadA) pfA[q] = nA[xx]; }
-          if ((u32)q * 64u < loadB) { if (xx < loadB) pfB[q] = nB[xx]; }
+          if ((u32)q * 64u < loadA) { if (xx < loadA) pfA[q] = pA[SKM_SLOTS + xx]; }
+          if ((u32)q * 64u < loadB) { if (xx < loadB) pfB[q] = pB[SKM_SLOTS + xx]; }
         }
       }
       // the tile's last element
@@ -616,12 +631,12 @@ __global__ __launch_bounds__(64, DCD_SK_WAVES) void k_pair_stream(const PairOp* 
         const u32 l0 = rdl(x[0], last_lane), l1 = rdl(x[1], last_lane), l2 = rdl(x[2], last_lane), l3 = rdl(x[3], last_lane);
         lkey = last_k == 0u ? l0 : last_k == 1u ? l1 : last_k == 2u ? l2 : l3;
       }
-      const bool inputs_end = (ia + ca == na) && (ib + cb == nb);
+      const bool inputs_end = remA == (u64)ca && remB == (u64)cb;
       // ---- ownership: [t_lo, t_hi) of this tile belongs to the work item ------------------------------------------------------
       u32 t_lo = 0, t_hi = cnt;
-      const bool may_end = g + cnt > d_end;
+      const bool may_end = cnt > left;
       if (skipping || may_end) {
-        const u32 lim = may_end ? (d_end > g ? (u32)(d_end - g) : 0u) : 0xFFFFFFFFu;
+        const u32 lim = may_end ? left : 0xFFFFFFFFu;
         if (MODE == 2) {                                         // '+': every element starts a chain of its own
           t_hi = min(lim, cnt);
         } else {
@@ -640,6 +655,7 @@ __global__ __launch_bounds__(64, DCD_SK_WAVES) void k_pair_stream(const PairOp* 
       }
       const bool ends_here = t_hi < cnt;       // a chain break at or beyond the partition end: stop before it
       auto advance = [&]() {
+        const u64 Elim = E + SKM_SAT;
         wsync();                               // (the rings were read at the top of the tile)
 #pragma unroll
         for (int q = 0; q < 4; q++) {
@@ -659,10 +675,11 @@ __global__ __launch_bounds__(64, DCD_SK_WAVES) void k_pair_stream(const PairOp* 
             }
           }
         }
-        ia += ca; ib += cb;
+        pA += ca; pB += cb; remA -= ca; remB -= cb;
         hA = (hA + ca) & (SKM_SLOTS - 1u); hB = (hB + cb) & (SKM_SLOTS - 1u);
         prev_val = base + (u64)(lkey >> 1); prev_src = lkey & 1u; have_prev = 1;
-        g += cnt;
+        left = left > cnt ? left - cnt : 0u;
+        if (skipping) slot += cnt;             // (slot = union index of the tile's first element while nothing is owned yet)
         wsync();
       };
       if (t_lo >= t_hi) {                      // nothing owned in this tile
@@ -674,7 +691,7 @@ __global__ __launch_bounds__(64, DCD_SK_WAVES) void k_pair_stream(const PairOp* 
         advance();
         continue;
       }
-      if (skipping) { skipping = false; slot = g + t_lo; out = tmp_op + slot; }
+      if (skipping) { skipping = false; slot += t_lo; }
       if (t_lo > 0 || ends_here) {
 #pragma unroll
         for (int k = 0; k < 4; k++) {
@@ -744,7 +761,7 @@ __global__ __launch_bounds__(64, DCD_SK_WAVES) void k_pair_stream(const PairOp* 
         u32 pos = 0;
 #pragma unroll
         for (int k = 0; k < 4; k++) pos = __builtin_amdgcn_mbcnt_hi((u32)(EM[k] >> 32), __builtin_amdgcn_mbcnt_lo((u32)EM[k], pos));
-        u64* __restrict__ oc = out + cursor;
+        u64* __restrict__ oc = tmp_op + slot + cursor;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
           if (skm_bit(EM[k])) oc[pos] = base + (u64)c[k];

@@ -2064,7 +2064,8 @@ static int32_t exec_chunk(dcd_index* h, const dcd_query_opts& o, SubBatchDev& D,
   DCD_TRY(tm.init(st, dev));
   DCD_TRY(tm.start());
   const u64 pw_grid = pw_grid_of(dev);
-  const u64 sk_grid = std::max<u64>(1, pw_grid * DCD_SK_WAVES / DCD_PW_WAVES);       // (the same multiple of ITS wavefront slots)
+  static const u64 sk_env = [] { const char* e = getenv("DOCODO_QUERY_SK_GRID"); return (e && atoll(e) > 0) ? (u64)atoll(e) : 0ull; }();
+  const u64 sk_grid = sk_env ? sk_env : std::max<u64>(1, pw_grid * DCD_SK_WAVES / DCD_PW_WAVES);       // (the same multiple of ITS wavefront slots)
   static const u32 gal_ratio = getenv("DOCODO_QUERY_GAL_RATIO") ? (u32)atoi(getenv("DOCODO_QUERY_GAL_RATIO")) : GAL_RATIO;   // (A/B knob)
   static const u32 g2_ratio = getenv("DOCODO_QUERY_G2_RATIO") ? (u32)atoi(getenv("DOCODO_QUERY_G2_RATIO")) : (u32)DCD_GAL2_RATIO;   // (A/B knobs of the two-pass rule)
   static const u64 g2_div = getenv("DOCODO_QUERY_G2_NEED_DIV") ? std::max<u64>(1, strtoull(getenv("DOCODO_QUERY_G2_NEED_DIV"), nullptr, 10)) : 128;
@@ -2114,10 +2115,14 @@ static int32_t exec_chunk(dcd_index* h, const dcd_query_opts& o, SubBatchDev& D,
         DCD_HIP(hipStreamWaitEvent(st2, ev_plan, 0));
         // (DOCODO_QUERY_STREAM_FORM=lanes: the first form of the kernel, per-lane flags -- kept for the A/B of round 4)
         static const bool lanes_form = getenv("DOCODO_QUERY_STREAM_FORM") && !strcmp(getenv("DOCODO_QUERY_STREAM_FORM"), "lanes");
-        hipLaunchKernelGGL(lanes_form ? k_pair_stream_lanes : k_pair_stream, dim3((u32)std::min<u64>(W, sk_grid)), dim3(64), 0, st2, ops, n,
+        static const int sk_wpe = getenv("DOCODO_QUERY_STREAM_WPE") ? atoi(getenv("DOCODO_QUERY_STREAM_WPE")) : DCD_SK_WAVES;
+        hipLaunchKernelGGL(lanes_form ? k_pair_stream_lanes : sk_wpe >= 8 ? k_pair_stream<8> : sk_wpe == 7 ? k_pair_stream<7> : k_pair_stream<6>,
+                           dim3((u32)std::min<u64>(W, sk_grid)), dim3(64), 0, st2, ops, n,
                            d_base_s32.p, d_part_base.p, idx_values.v64, pool, D.tmp, d_part_count.p, d_part_src.p, PART,
                            reinterpret_cast<unsigned long long*>(d_work_ctr.p + 1), d_need_off.p);
         DCD_HIP(hipEventRecord(ev_s32, st2));
+        static const bool serial = getenv("DOCODO_QUERY_STREAM_SERIAL") && atoi(getenv("DOCODO_QUERY_STREAM_SERIAL")) != 0;   // (diagnosis: one kernel after the other)
+        if (serial) DCD_HIP(hipStreamWaitEvent(st, ev_s32, 0));
       }
       hipLaunchKernelGGL(k_pair_parts, dim3((u32)std::min<u64>(W, pw_grid)), dim3(PW_T), 0, st, ops, n, d_base_old.p, d_part_base.p, idx_values, pool,
                          D.tmp, d_part_count.p, d_part_src.p, PART, ext_values ? nullptr : h->dir.p, ix.max_coord, d_mode.p, W,
@@ -2377,19 +2382,26 @@ static int32_t run_sub_batch(dcd_index* h, const int32_t* prog, const u64* prog_
   if (o.max_found_docs > 512 || o.max_found_docs < 0 || o.max_found_pages < 0) DCD_FAIL(DCD_E_BADARG, "max_found_docs must be in [0, 512]");
   if (!ext_values) DCD_TRY(ensure_values(h));
   u64 PART = PART_DEFAULT;
-  if (const char* e = getenv("DOCODO_QUERY_PART")) PART = std::max<u64>(strtoull(e, nullptr, 10), 1);   // tests: tiny partitions
+  if (const char* e = getenv("DOCODO_QUERY_PART")) PART = std::min<u64>(std::max<u64>(strtoull(e, nullptr, 10), 1), 1ull << 31);   // tests: tiny partitions (k_pair_stream counts a partition in 32 bits)
   size_t chunk_q = 16384;                                   // queries per chunk (plan of chunk k + 1 is made while chunk k runs)
   if (const char* e = getenv("DOCODO_QUERY_CHUNK")) chunk_q = std::max<size_t>(strtoull(e, nullptr, 10), 1);
   // pre-pass: operators per chunk (sizes of the staging blocks and of the result directory), largest operator capacity
   const size_t nq = q1 - q0;
-  // chunk boundaries: the FIRST chunk is short (its plan is the only one the device waits for), then full chunks
+  // chunk boundaries: the FIRST chunk is short (its plan is the only one the device waits for) and the following ones grow by
+  // half: planning a query takes about 0.6 of the time its evaluation takes on a 10 M-document index, so the plan of a chunk
+  // 1.5 x as long as the one that is running is still ready in time (with full chunks right behind a first one of 2048 queries the
+  // device idled for 8 of the 100 ms of 100 k conjunctions)
   std::vector<size_t> cb(1, q0);
   {
     size_t at = q0;
-    const size_t first_q = nq > 2 * chunk_q ? std::max<size_t>(1, chunk_q / 8) : chunk_q;
-    at = std::min(q1, at + first_q);
-    cb.push_back(at);
-    while (at < q1) { at = std::min(q1, at + chunk_q); cb.push_back(at); }
+    size_t len = nq > chunk_q / 4 ? std::max<size_t>(1, chunk_q / 8) : chunk_q;
+    do {                                                    // (an empty batch is one empty chunk)
+      at = std::min(q1, at + len);
+      cb.push_back(at);
+      len = std::min(chunk_q, len + std::max<size_t>(1, len / 2));
+    } while (at < q1);
+    // (a short tail joins the chunk before it)
+    if (cb.size() > 2 && cb.back() - cb[cb.size() - 2] < chunk_q / 16) cb.erase(cb.end() - 2);
   }
   const size_t n_chunks = cb.size() - 1;
   auto chunk_of = [&](size_t q) { return (size_t)(std::upper_bound(cb.begin(), cb.end(), q) - cb.begin()) - 1; };
