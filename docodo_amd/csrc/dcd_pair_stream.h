@@ -2,23 +2,26 @@
 //
 // Round 4.  k_pair_parts merges on 64-bit keys (coordinate << 1 | operand): every compare-exchange of its bitonic network is two
 // LDS-crossbar shuffles, a 64-bit compare and two selects, its chain scans are log-step shuffles, and it shares one register
-// budget with the galloping path (106 SGPRs + 135 spilled).  This kernel evaluates the SAME work items -- partitions of the
-// operand union cut at fixed diagonals, a wavefront per item, chains owned by the partition they start in, exactly the rules of
-// k_pair_parts -- with:
-//   * keys (coordinate - tile base) << 1 | operand in 32 bits.  The base is the smallest staged coordinate, so every key is exact
-//     by construction; a staged element 2^31 - 1 or more beyond the base gets the key +inf, i.e. counts as not staged yet: the
-//     tile then consumes fewer than 256 elements (at least the base element itself) and the next tile starts from a new base.
-//     No 64-bit fallback path exists or is needed;
+// budget with the galloping path (106 SGPRs + 135 spilled).  The kernels of this file evaluate the SAME work items -- partitions
+// of the operand union cut at fixed diagonals, a wavefront per item, chains owned by the partition they start in, exactly the
+// rules of k_pair_parts -- with:
+//   * keys (coordinate - base) << 1 | operand in 32 bits, exact by construction: an element too far beyond the tile's head gets
+//     the key +inf, i.e. counts as not staged yet -- the tile then consumes fewer than 256 elements (at least the head itself) and
+//     the next tile starts from a new head.  No 64-bit fallback path exists or is needed;
 //   * the bitonic merge as ONE v_med3_u32 per compare-exchange (med3(x, y, 0) = min, med3(x, y, ~0) = max: the third operand is
 //     the lane's side of the stage), partners fetched by DPP (row_ror:8, quad_perm, row_shl/shr:4) and by the gfx950 lane swaps
 //     v_permlane32_swap / v_permlane16_swap -- no LDS crossbar, no address registers; 61 instructions per 256-key tile;
-//   * the chain logic on BALLOT MASKS: a lane summarises its four consecutive elements (break inside? flags of the part that
-//     belongs to the chain entering / leaving the lane), the cross-lane part -- "does the chain hold a contact", "a left element
-//     at or before me" -- is a segmented OR over 64 lanes, which is the carry chain of ONE 64-bit scalar addition
-//     (generate = the lanes' flags, propagate = lanes without a break); positions come from s_ff1 / s_flbit, counts from s_bcnt1;
-//   * operand rings in LDS as four planes (element j at plane j & 3): the lane's four consecutive elements are read without bank
-//     conflicts.
-// Results are bit-identical to k_pair_parts (tests/test_gpu_query.py, stress_ops.py, stress_queries.py run both).
+//   * the cross-lane part of the chain logic -- "does the chain hold a contact", "a left element at or before me" -- as a
+//     segmented OR over 64 lanes, which is the carry chain of ONE 64-bit scalar addition (generate = the lanes' flags, propagate =
+//     lanes without a break); positions come from s_ff1 / s_flbit, counts from s_bcnt1.
+// Two forms of the tile logic:
+//   k_pair_stream_lanes  (first half of round 4; DOCODO_QUERY_STREAM_FORM=lanes)  per-lane 0 / 1 flags for the lane's four elements,
+//                        ballots only for the cross-lane part; 64-bit coordinates in the LDS rings (four padded planes).
+//   k_pair_stream<WPE>   (the default)  every per-element flag as a 64-bit LANE MASK per element slot, the whole chain logic on the
+//                        scalar unit; rings of 32-bit keys relative to an epoch of the work item (see below).  40 % fewer vector
+//                        instructions per tile (profiles/r04_pmc_c4.txt), the same scalar count.
+// Results are bit-identical to k_pair_parts (tests/test_gpu_query.py, stress_ops.py, stress_queries.py run all paths;
+// tests/helpers/pair_stream_model.py holds a Python model of either form, checked against the oracle on the CPU).
 #pragma once
 
 namespace dcd {
@@ -524,7 +527,7 @@ __global__ __launch_bounds__(64, WPE) void k_pair_stream(const PairOp* __restric
         else { prev_val = pb; prev_src = 1; }
         prev_val = rfl64(prev_val); prev_src = rfl(prev_src);
       }
-      pA = (const u64*)rfl64((u64)(A + ia)); pB = (const u64*)rfl64((u64)(B + ib));
+      pA = A + ia; pB = B + ib;             // (no detour through integers: the pointers must stay GLOBAL ones -- flat loads otherwise)
       remA = rfl64(na - ia); remB = rfl64(nb - ib);
     }
     u64 cursor = 0, slot = d_begin;

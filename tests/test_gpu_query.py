@@ -30,6 +30,32 @@ def _ops_cases():
     return cases
 
 
+def test_neighbours_across_lane_borders(oracle_mod):
+    """k_pair_stream keeps four consecutive union elements per lane; the gap to the element before a lane's first one comes from
+    the lane below (a DPP move).  Round 4: folded into the subtraction by the compiler (v_subrev_u32_dpp ... wave_shr:1) that
+    move delivered garbage on gfx950 -- every chain broke at a lane border and a coordinate held by both operands was emitted
+    twice when its two copies sat in different lanes.  Tiny operands that put a pair exactly on every border position."""
+    import docodo_amd
+    o = oracle_mod
+    cases = []
+    for n in range(1, 10):                                   # [1 .. n - 1, 5 n] x [5 n]: the shared coordinate at union index n - 1, n
+        a = list(range(1, n)) + [5 * n]
+        cases.append((a, [5 * n]))
+        cases.append((a, [5 * n, 5 * n + 4]))
+        cases.append(([5 * n], a))
+    cases.append((list(range(10, 100, 10)), list(range(10, 100, 10))))
+    cases.append(([5, 9], [5, 9, 13]))
+    for Ra, Rb in [(258, 259), (-7, -9), (0, 0), (3, 2)]:
+        for a, b in cases:
+            a, b = np.array(a, np.uint64), np.array(b, np.uint64)
+            ua, ub = o.seq_encode(a), o.seq_encode(b)
+            sa, sb = docodo_amd.IndexSequence(ua, Ra), docodo_amd.IndexSequence(ub, Rb)
+            want, _ = o.seq_and(ua, Ra, ub, Rb)
+            assert np.array_equal((sa * sb).units, want), ("and", list(a), list(b), Ra, Rb)
+            want, _ = o.seq_or(ua, Ra, ub, Rb)
+            assert np.array_equal((sa + sb).units, want), ("or", list(a), list(b), Ra, Rb)
+
+
 def test_stream_kernel_merge_network_sorts_bitonic_tiles():
     """k_pair_stream's merge network (v_med3 compare-exchanges fed by DPP moves and the gfx950 lane swaps) on its own: the half-
     cleaner output of two ascending key sequences -- min(A[t], B[255 - t]), a bitonic sequence incl. +inf padding -- must come
