@@ -308,9 +308,11 @@ __global__ void k_unpack(const u32* __restrict__ lo, const u8* __restrict__ hi, 
 // with consecutive gaps <= absR); the first short-list element of a chain ("leader") emits the chain if it
 // satisfies the both-operands / ordered-prefix rule.  Exactly the same output as the streaming merge.
 #ifndef DCD_GAL_RATIO
-#define DCD_GAL_RATIO 2
+#define DCD_GAL_RATIO 3
 #endif
-constexpr u32 GAL_RATIO = DCD_GAL_RATIO;   // gallop when RATIO * |short| <= |long|
+// gallop when RATIO * |short| <= |long|.  Measured with the mask form of k_pair_stream (round 4, 100 k queries on the 10 M-document index,
+// configs[3] / configs[4] device ms): ratio 2: 85.2 / 2410, 3: 85.4 / 2370, 4: 86.9 / 2356, 6: 89.8 / 2353, 8: 91.6 / 2356, 16: 97.7 / 2414
+constexpr u32 GAL_RATIO = DCD_GAL_RATIO;
 
 __device__ __forceinline__ u64 lower_bound_u64(const CV& a, u64 n, u64 v) {
   u64 lo = 0, hi = n;
