@@ -1619,6 +1619,7 @@ static int32_t ensure_values(dcd_index* h, float* ms_device = nullptr) {
   if (N) {
     // cell directories for the longer lists: about one cell per posting (cell width 2^shift)
     constexpr u64 DIR_MIN = 1024;
+    constexpr int DIR_FINER = 0;
     const u32 coord_bits = log2_ceil(ix.max_coord + 2);
     h->h_dir_off.assign(V + 1, 0);
     h->h_dir_shift.assign(V, 255);
@@ -1629,7 +1630,9 @@ static int32_t ensure_values(dcd_index* h, float* ms_device = nullptr) {
       if (cnt >= DIR_MIN) {
         u32 lg = 0;
         while ((2ull << lg) <= cnt) lg++;                     // floor(log2 cnt)
-        const u32 sh = coord_bits > lg ? coord_bits - lg : 0u;
+        static const int finer = getenv("DOCODO_QUERY_DIR_FINER") ? atoi(getenv("DOCODO_QUERY_DIR_FINER")) : DIR_FINER;   // (A/B knob)
+        const int sh0 = coord_bits > lg ? (int)(coord_bits - lg) : 0;
+        const u32 sh = (u32)std::min(std::max(sh0 - finer, 0), 62);
         h->h_dir_shift[t] = (u8)sh;
         tot += (ix.max_coord >> sh) + 2;                       // cells 0 .. max_coord >> sh, plus the end entry
       }
