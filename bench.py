@@ -51,7 +51,7 @@ HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 
 HBM_COPY_GBS = 6290.0
 
 
-def algorithmic_bytes(kernel, T, N, U, n_launch=1, n_hot=0, id_keys=False, passes=0):
+def algorithmic_bytes(kernel, T, N, U, n_launch=1, n_hot=0, id_keys=False, passes=0, hot32=False):
     """Algorithmic HBM bytes of ONE launch, averaged over the kernel's launches of a step.
     With the hot / cold split the radix kernels run once over all N tuples and (n_launch - 1) times over the N - n_hot
     cold ones; an id-keyed build's k_img_units also writes the units in term order (one read, two writes).  Round 3: the
@@ -61,6 +61,15 @@ def algorithmic_bytes(kernel, T, N, U, n_launch=1, n_hot=0, id_keys=False, passe
     tuples = (N + (n_launch - 1) * (N - n_hot)) / n_launch if n_hot else N
     if kernel == "k_rs_hist" and n_hot and passes and n_launch < passes:
         tuples = N - n_hot
+    # round 4 (hot32): the hot buckets leave the first pass as 4-byte coordinates -- that pass writes, and the pack kernels read,
+    # 4 instead of 8 bytes for every hot posting
+    h4 = 4 * n_hot if (hot32 and n_hot) else 0
+    if kernel == "k_rs_scatter":
+        return 16 * tuples - h4 / n_launch
+    if kernel == "k_enc_reduce":
+        return 8 * N - h4
+    if kernel == "k_enc_write":
+        return 8 * N - h4 + 2 * U
     return {
         "k_tok_count": T,                 # reads the text once
         "k_tok_emit": T + 8 * N,          # reads the text, writes one (term, coord) tuple per posting
@@ -591,7 +600,8 @@ def main():
         lps = kcnt / args.steps            # launches per step of every kernel
 
         def abytes_of(k):
-            return algorithmic_bytes(KERNEL_NAMES[k], T, N, U, lps[k], hot_post, bool(id_keys), passes)
+            hot32 = id_keys == 2 and hot_terms > 0 and os.environ.get("DOCODO_BUILD_HOT32", "1") != "0"    # (the library's own rule)
+            return algorithmic_bytes(KERNEL_NAMES[k], T, N, U, lps[k], hot_post, bool(id_keys), passes, hot32)
         ms_step = dt / args.steps * 1e3
         value = world * T / 1e9 / (dt / args.steps)
         # dominant kernel = largest total device time per step (HIP events on the build stream)

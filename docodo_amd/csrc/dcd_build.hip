@@ -581,7 +581,9 @@ __global__ __launch_bounds__(1024) void k_dir_partials(u64* __restrict__ partial
 __global__ __launch_bounds__(SCAN_THREADS) void k_dir_apply(PermDirF f, u64 n, const u64* __restrict__ partial, u64 pstride, const u64* __restrict__ totals,
                                                            u64* __restrict__ unit_start, u64* __restrict__ item_start, u64* __restrict__ rec_off,
                                                            u64* __restrict__ src_start, const uint2* __restrict__ sorted, u64 base_coord,
-                                                           u64* __restrict__ first, u64* __restrict__ last) {
+                                                           u64* __restrict__ first, u64* __restrict__ last, u64 n_hot32) {
+  // (round 4: the first n_hot32 postings are 4-byte coordinates, EncSrcPairs::n_hot32)
+  auto coord_at = [sorted, n_hot32](u64 idx) -> u32 { return idx < n_hot32 ? reinterpret_cast<const u32*>(sorted)[idx] : sorted[idx].y; };
   __shared__ u64 lds[5];
   const u64 base = (u64)blockIdx.x * SCAN_TILE + (u64)threadIdx.x * SCAN_ITEMS;
   u64 va[SCAN_ITEMS], vb[SCAN_ITEMS], vc[SCAN_ITEMS];
@@ -595,8 +597,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_dir_apply(PermDirF f, u64 n, c
       f(i, va[j], vb[j], vc[j], &d);
       const u64 is = f.is_id[d];
       src_start[i] = f.us_id[d];
-      first[i] = base_coord + sorted[is].y;
-      last[i] = base_coord + sorted[is + vb[j] - 1].y;
+      first[i] = base_coord + coord_at(is);
+      last[i] = base_coord + coord_at(is + vb[j] - 1);
     }
     sa += va[j]; sb += vb[j]; sc += vc[j];
   }
@@ -2020,6 +2022,9 @@ static int32_t build_phase2(dcd_build* h) {
   uint2* sorted = a;
   int passes = 0;
   u32 hot_n = 0, hot_s = 0;
+  bool hot32 = false;                  // the hot region of `sorted` holds 4-byte coordinates
+  const u32* hot_starts = nullptr;     // scanned histogram of pass A: hot term d starts at hot_starts[d * hot_stride]
+  u32 hot_stride = 0;
   u64 n_hot_postings = 0;
   std::vector<hipEvent_t> hist_events, scatter_events;
   if (N) {
@@ -2076,6 +2081,12 @@ static int32_t build_phase2(dcd_build* h) {
         DCD_TRY(M.d_hist1.alloc(dev, (u64)tp.nblk << w0));      // (every block of pass A writes its row: no memset)
         sd.next_hist = M.d_hist1.p; sd.next_bits = (u32)w0;
       }
+      // round 4: the hot buckets leave pass A as 4-byte coordinates (RsStrided::hot32).  Only with the emit kernel's own histogram:
+      // its scanned copy -- the buckets' borders, which the pack kernels need -- then lives in a buffer no later pass reuses.
+      static const bool env_hot32 = !(getenv("DOCODO_BUILD_HOT32") && atoi(getenv("DOCODO_BUILD_HOT32")) == 0);   // (A/B knob)
+      hot32 = env_hot32 && have_hist;
+      sd.hot32 = hot32;
+      hot_starts = histA; hot_stride = tp.nblk;
       nh.src = histA + (u64)hot_n * tp.nblk; nh.dst = (u32*)pin; nh.ev = event_acquire(dev); nh.status = DCD_OK;
       if (!nh.ev) DCD_FAIL(DCD_E_HIP, "hipEventCreate failed");
       // ... and the vocabulary chain is queued right there, behind the histogram kernel it is to run beside, and the main
@@ -2173,6 +2184,14 @@ static int32_t build_phase2(dcd_build* h) {
   src.term_item_start = idk ? is_id.p : ix.term_item_start.p;
   src.hot_n = hot_n; src.hot_s = hot_s;
   src.id_dense = early ? id_dense.p : nullptr;
+  DevBuf<u32> hot_tile;
+  if (hot32 && hot_n && n_hot_postings) {
+    src.n_hot32 = n_hot_postings; src.hstart = hot_starts; src.hstride = hot_stride;
+    const u64 nth = pack_hot_tiles(n_hot_postings);
+    DCD_TRY(hot_tile.alloc(dev, nth));
+    src.hot_tile = hot_tile.p;
+    hipLaunchKernelGGL(k_pack_hot_tiles, dim3((u32)div_up(nth, 256)), dim3(256), 0, st, src, nth, hot_tile.p);
+  }
   u64* d_U = enc_scr.p + scan_nblocks(enb);        // the scan leaves the number of units here
   if (N) {
     probes.begin(DCD_K_ENC_REDUCE);
@@ -2244,7 +2263,7 @@ static int32_t build_phase2(dcd_build* h) {
       e3 = hipEventRecord(ev, st);
       hipLaunchKernelGGL(k_dir_apply, dim3((u32)nbd), dim3(SCAN_THREADS), 0, st, f, V, (const u64*)dir_scr.p, pstride, (const u64*)totals,
                          ix.term_unit_start.p, ix.term_item_start.p, rec_off.p, src_start.p, (const uint2*)sorted, h->opts.coord_base,
-                         ix.term_first.p, ix.term_last.p);
+                         ix.term_first.p, ix.term_last.p, src.n_hot32);
     }
     hipError_t e4 = (a1 == DCD_OK && a2 == DCD_OK && e1 == hipSuccess && e3 == hipSuccess) ? hipEventSynchronize(ev) : hipErrorUnknown;
     event_release(dev, ev);

@@ -44,19 +44,37 @@ struct EncSrcPairs {
     const u32 hi = x >> hot_s;
     return hi < hot_n ? hi : hot_n + (x - (hot_n << hot_s));
   }
+  // round 4: the first n_hot32 postings (the hot terms' buckets of pass A, RsStrided::hot32) are stored as 4-byte coordinates at
+  // ((const u32*)p)[i]; their key is the bucket: hot term d owns [hstart[d * hstride], hstart[(d + 1) * hstride]) -- the scanned
+  // histogram of pass A, entry (digit d, block 0)
+  u64 n_hot32 = 0;
+  const u32* hstart = nullptr;
+  u32 hstride = 0;
+  // per tile of the pack kernels that starts at or before n_hot32 (k_pack_hot_tiles): bucket + 1 if the tile is full, lies inside
+  // ONE hot bucket together with the posting before it (no term head in it, every key the bucket's), else 0 (posting by posting)
+  const u32* hot_tile = nullptr;
   __device__ __forceinline__ u32 id_of(u32 x) const {
     const u32 id = hot_s ? hot_key_id(x, hot_n, hot_s) : x;
     return id_dense ? id_dense[id] : id;
   }
-  __device__ __forceinline__ bool head(u64 i) const { return i == 0 || p[i].x != p[i - 1].x; }
+  __device__ __forceinline__ u32 hot_bucket(u64 i) const {       // the last hot term whose bucket starts at or before posting i
+    u32 lo = 0, hi = hot_n;
+    while (lo + 1 < hi) { const u32 m = (lo + hi) >> 1; if ((u64)hstart[(u64)m * hstride] <= i) lo = m; else hi = m; }
+    return lo;
+  }
+  __device__ __forceinline__ uint2 at(u64 i) const {             // (key, coordinate) of posting i, wherever it is stored
+    if (i < n_hot32) return make_uint2(hot_bucket(i) << hot_s, reinterpret_cast<const u32*>(p)[i]);
+    return p[i];
+  }
+  __device__ __forceinline__ bool head(u64 i) const { return i == 0 || at(i).x != at(i - 1).x; }
   __device__ __forceinline__ u64 delta(u64 i) const {
-    uint2 c = p[i];
+    uint2 c = at(i);
     if (i == 0) return base + c.y;
-    uint2 q = p[i - 1];
+    uint2 q = at(i - 1);
     return q.x != c.x ? base + c.y : (u64)c.y - (u64)q.y;
   }
   __device__ __forceinline__ void on_item(u64 i, u64 off, u64) const {
-    if (head(i)) { const u32 t = id_of(p[i].x); term_unit_start[t] = off; term_item_start[t] = i; }
+    if (head(i)) { const u32 t = id_of(at(i).x); term_unit_start[t] = off; term_item_start[t] = i; }
   }
 };
 
@@ -129,6 +147,8 @@ __global__ __launch_bounds__(CODEC_THREADS) void k_enc_write(Src src, u64 n, con
 #endif
 __global__ __launch_bounds__(CODEC_THREADS, DCD_PACK_WPE) void k_pack_write(EncSrcPairs src, u64 n, const u64* __restrict__ partial, u16* __restrict__ out);
 __global__ __launch_bounds__(CODEC_THREADS) void k_pack_count(EncSrcPairs src, u64 n, u64* __restrict__ partial);   // == k_enc_reduce<EncSrcPairs>
+__global__ void k_pack_hot_tiles(EncSrcPairs src, u64 n_tiles_hot, u32* __restrict__ hot_tile);
+inline u64 pack_hot_tiles(u64 n_hot32) { return n_hot32 ? n_hot32 / CODEC_TILE + 1 : 0; }      // tiles with t0 <= n_hot32
 
 // Encodes n items.  partial: >= div_up(n, CODEC_TILE) + 1 u64 (grand total of units left in
 // partial[nblocks]).  out must hold the total (<= 5 n).

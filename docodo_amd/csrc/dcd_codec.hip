@@ -63,6 +63,40 @@ __global__ __launch_bounds__(CODEC_THREADS) void k_pack_count(EncSrcPairs src, u
   __shared__ u32 lds[4];
   const u64 t0 = (u64)blockIdx.x * CODEC_TILE;
   const u32 lane = lane_id();
+  if (src.n_hot32 && t0 <= src.n_hot32) {
+    // round 4: a tile of the hot region -- 4-byte coordinates, the term is the bucket.  A full tile inside ONE bucket (the element
+    // before it included: by weight all of them -- 249 hot terms hold 65 % of the postings) has no term head: every posting is a
+    // 32-bit delta to the coordinate before it; four coordinates per 16-byte load.  The few tiles that hold a bucket border, and the
+    // one that holds the border to the cold region, go posting by posting through the general accessor.
+    u32 s = 0;
+    if (src.hot_tile[blockIdx.x]) {
+      const u32* c32 = reinterpret_cast<const u32*>(src.p);
+      const uint4* c4 = reinterpret_cast<const uint4*>(c32 + t0);          // (t0 is a multiple of the tile: 16-byte aligned)
+      uint4 v[CODEC_ITEMS / 4];
+      u32 before[CODEC_ITEMS / 4];
+#pragma unroll
+      for (int j = 0; j < CODEC_ITEMS / 4; j++) {
+        v[j] = c4[j * CODEC_THREADS + threadIdx.x];
+        before[j] = lane == 0 ? c32[t0 + 4u * (u32)(j * CODEC_THREADS + threadIdx.x) - 1u] : 0u;
+      }
+#pragma unroll
+      for (int j = 0; j < CODEC_ITEMS / 4; j++) {
+        u32 q = __shfl_up(v[j].w, 1, DCD_WAVE);
+        if (lane == 0) q = before[j];
+        s += seq_nunits32(v[j].x - q) + seq_nunits32(v[j].y - v[j].x) + seq_nunits32(v[j].z - v[j].y) + seq_nunits32(v[j].w - v[j].z);
+      }
+    } else {
+      for (int j = 0; j < CODEC_ITEMS; j++) {
+        const u64 i = t0 + (u64)j * CODEC_THREADS + threadIdx.x;
+        if (i < n) s += seq_nunits(src.delta(i));
+      }
+    }
+    s = wave_sum(s);
+    if (lane == 0) lds[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (u64)lds[0] + lds[1] + lds[2] + lds[3];
+    return;
+  }
   const uint4* p2 = reinterpret_cast<const uint4*>(src.p);      // t0 is even and src.p 16-byte aligned (checked by the host)
   constexpr int NL = CODEC_ITEMS / 2;
   uint4 kv[NL];
@@ -90,6 +124,20 @@ __global__ __launch_bounds__(CODEC_THREADS) void k_pack_count(EncSrcPairs src, u
   if (threadIdx.x == 0) partial[blockIdx.x] = (u64)lds[0] + lds[1] + lds[2] + lds[3];
 }
 
+// which tiles of the hot region lie inside one bucket (EncSrcPairs::hot_tile): one thread per tile, two searches over the <= 256
+// bucket starts (in the pack kernels themselves every workgroup would repeat them: sixteen dependent loads in front of 8 KB of work)
+__global__ void k_pack_hot_tiles(EncSrcPairs src, u64 n_tiles_hot, u32* __restrict__ hot_tile) {
+  const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_tiles_hot) return;
+  const u64 t0 = t * CODEC_TILE;
+  u32 v = 0;
+  if (t0 != 0 && t0 + CODEC_TILE <= src.n_hot32) {
+    const u32 b = src.hot_bucket(t0 - 1);
+    if (b == src.hot_bucket(t0 + CODEC_TILE - 1)) v = b + 1u;
+  }
+  hot_tile[t] = v;
+}
+
 // A workgroup writes PACK_TPB consecutive tiles.  The barriers order LDS only and the pairs of the next tile are fetched
 // into registers while the current one is encoded, so that loads and stores stay in flight across tiles.
 __global__ __launch_bounds__(CODEC_THREADS, DCD_PACK_WPE) void k_pack_write(EncSrcPairs src, u64 n, const u64* __restrict__ partial, u16* __restrict__ out) {
@@ -106,6 +154,26 @@ __global__ __launch_bounds__(CODEC_THREADS, DCD_PACK_WPE) void k_pack_write(EncS
   auto fetch = [&](u64 tile) {
     const u64 t0 = tile * CODEC_TILE;
     const u32 cnt = (u32)min((u64)CODEC_TILE, n - t0);
+    if (src.n_hot32 && t0 <= src.n_hot32) {                              // a tile of the hot region (see k_pack_count)
+      const u32 ti = src.hot_tile[tile];
+      if (ti) {
+        const u32 hk = (ti - 1u) << src.hot_s;
+        const u32* c32 = reinterpret_cast<const u32*>(src.p);
+#pragma unroll
+        for (int i = 0; i < NLD; i++) {
+          const u32 k = threadIdx.x + i * CODEC_THREADS;
+          pf[i] = k < cnt + 1 ? make_uint2(hk, c32[t0 + k - 1]) : make_uint2(0xFFFFFFFFu, 0u);
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < NLD; i++) {
+          const u32 k = threadIdx.x + i * CODEC_THREADS;
+          const u64 g = t0 + k;
+          pf[i] = (k < cnt + 1 && g) ? src.at(g - 1) : make_uint2(0xFFFFFFFFu, 0u);
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < NLD; i++) {
       const u32 k = threadIdx.x + i * CODEC_THREADS;                   // pairs[k] = p[t0 + k - 1]

@@ -165,6 +165,11 @@ struct RsStrided {
   // of a following pass whose block b sorts the cold tuples block b of this pass wrote (contiguous, in order).
   u32* next_hist = nullptr;
   u32 next_bits = 0;
+  // first pass with a hot set (round 4): the tuples of the hot digits leave as their 4-byte COORDINATES only -- the bucket implies
+  // the term -- at out32[position] (out32 = the output array seen as u32: the hot region [0, N_hot) then takes the first half of
+  // the bytes its tuples would; the cold tuples keep their places behind it).  The pack kernels read 4 instead of 8 bytes for
+  // two thirds of the postings (EncSrcPairs::n_hot32).
+  bool hot32 = false;
   // following pass (cnt == nullptr, range != nullptr): dense input, but block b owns the tuples [range[b], range[b + 1]) of `in`
   // (the last block ends at range_end) instead of a fixed number: range = the first pass's scanned offsets of the cold digit.
   const u32* range = nullptr;
@@ -492,6 +497,7 @@ __global__ __launch_bounds__(RSS_THREADS) __attribute__((amdgpu_waves_per_eu(DCD
       uint2 it = s_tile[j];
       u32 d = (it.x >> shift) & (NB - 1);
       if (count_next && d == sd.hot_n) atomicAdd(&s_nx[it.x & ((1u << sd.next_bits) - 1u)], 1u);
+      if (STRIDED && sd.hot32 && d < sd.hot_n) { reinterpret_cast<u32*>(out)[(u64)(u32)(s_off[d] + j)] = it.y; continue; }
 #if DCD_RS_NT >= 2
       if (STRIDED) {
         typedef u32 u32x2_t __attribute__((ext_vector_type(2)));
