@@ -181,6 +181,40 @@ __global__ __launch_bounds__(CODEC_THREADS, DCD_PACK_WPE) void k_pack_write(EncS
       pf[i] = (k < cnt + 1 && g) ? src.p[g - 1] : make_uint2(0xFFFFFFFFu, 0u);
     }
   };
+  // round 4: a full tile inside one hot bucket (hot_tile) whose postings take ONE unit each -- the scanned counts say so: as many
+  // units as postings; the head of a Zipf index: gaps of tens to hundreds of characters -- is a plain difference of neighbouring
+  // 4-byte coordinates: no staging of pairs, no scan, no term heads (PACK_TPB == 1: the tile is the workgroup's only one)
+  auto one_unit_tile = [&](u64 tile) -> bool {
+    if (PACK_TPB != 1 || !src.n_hot32 || tile * CODEC_TILE > src.n_hot32 || !src.hot_tile[tile] || tile + 1 >= n_tiles) return false;   // (partial[] has n_tiles entries)
+    return partial[tile + 1] - partial[tile] == (u64)CODEC_TILE;
+  };
+  if (tile_a < tile_b && one_unit_tile(tile_a)) {
+    const u64 t0 = tile_a * CODEC_TILE;
+    const u64 gbase = partial[tile_a];
+    const u32* c32 = reinterpret_cast<const u32*>(src.p) + t0;
+    const u32 l0 = threadIdx.x * CODEC_ITEMS;
+    u32 c[CODEC_ITEMS];
+#pragma unroll
+    for (int j = 0; j < CODEC_ITEMS; j += 4) {
+      const uint4 v = *reinterpret_cast<const uint4*>(c32 + l0 + j);
+      c[j] = v.x; c[j + 1] = v.y; c[j + 2] = v.z; c[j + 3] = v.w;
+    }
+    u32 q = __shfl_up(c[CODEC_ITEMS - 1], 1, DCD_WAVE);
+    if (lane == 0) q = c32[(int64_t)l0 - 1];                          // (t0 >= one tile: the posting before the tile exists)
+#pragma unroll
+    for (int j = 0; j < CODEC_ITEMS; j++) { sh.units[l0 + j] = (u16)(c[j] - q); q = c[j]; }
+    lds_barrier();
+    u16* dst = out + gbase;
+    const u32 tot = CODEC_TILE;
+    u32 head = (u32)(((uintptr_t)dst >> 1) & 1u);
+    if (threadIdx.x == 0 && head) dst[0] = sh.units[0];
+    u32 npair = (tot - head) >> 1;
+    u32* dst32 = reinterpret_cast<u32*>(dst + head);
+    for (u32 k = threadIdx.x; k < npair; k += CODEC_THREADS)
+      dst32[k] = (u32)sh.units[head + 2 * k] | ((u32)sh.units[head + 2 * k + 1] << 16);
+    if (threadIdx.x == 0 && ((tot - head) & 1u)) dst[tot - 1] = sh.units[tot - 1];
+    return;
+  }
   if (tile_a < tile_b) fetch(tile_a);
   for (u64 tile = tile_a; tile < tile_b; tile++) {
     const u64 t0 = tile * CODEC_TILE;
