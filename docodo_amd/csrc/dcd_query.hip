@@ -2410,16 +2410,27 @@ static int32_t run_sub_batch(dcd_index* h, const int32_t* prog, const u64* prog_
   if (const char* e = getenv("DOCODO_QUERY_PART")) PART = std::min<u64>(std::max<u64>(strtoull(e, nullptr, 10), 1), 1ull << 31);   // tests: tiny partitions (k_pair_stream counts a partition in 32 bits)
   size_t chunk_q = 16384;                                   // queries per chunk (plan of chunk k + 1 is made while chunk k runs)
   if (const char* e = getenv("DOCODO_QUERY_CHUNK")) chunk_q = std::max<size_t>(strtoull(e, nullptr, 10), 1);
-  // pre-pass: operators per chunk (sizes of the staging blocks and of the result directory), largest operator capacity
   const size_t nq = q1 - q0;
+  // pre-pass: operators per query (sizes of the staging blocks and of the result directory), largest operator capacity
+  std::vector<u32> q_ops(nq);
+  u64 ops_total = 0, max_cap = 0, cap_sum = 0;
+  for (size_t q = q0; q < q1; q++) {
+    u64 no = 0, ls = 0;
+    query_prepass(ix, ext_leaves, prog, prog_off[q], prog_off[q + 1], &no, &ls);
+    q_ops[q - q0] = (u32)std::min<u64>(no, 0xFFFFFFFFull);
+    ops_total += no;
+    if (no) max_cap = std::max(max_cap, ls);
+    cap_sum += no * ls;                                     // (bound of the results of the query's operators together)
+  }
   // chunk boundaries: the FIRST chunk is short (its plan is the only one the device waits for) and the following ones grow by
   // half: planning a query takes about 0.6 of the time its evaluation takes on a 10 M-document index, so the plan of a chunk
   // 1.5 x as long as the one that is running is still ready in time (with full chunks right behind a first one of 2048 queries the
-  // device idled for 8 of the 100 ms of 100 k conjunctions)
+  // device idled for 8 of the 100 ms of 100 k conjunctions).  A batch without operators (single-term queries) has nothing to plan:
+  // full chunks from the start.
   std::vector<size_t> cb(1, q0);
   {
     size_t at = q0;
-    size_t len = nq > chunk_q / 4 ? std::max<size_t>(1, chunk_q / 8) : chunk_q;
+    size_t len = (ops_total != 0 && nq > chunk_q / 4) ? std::max<size_t>(1, chunk_q / 8) : chunk_q;
     do {                                                    // (an empty batch is one empty chunk)
       at = std::min(q1, at + len);
       cb.push_back(at);
@@ -2429,17 +2440,9 @@ static int32_t run_sub_batch(dcd_index* h, const int32_t* prog, const u64* prog_
     if (cb.size() > 2 && cb.back() - cb[cb.size() - 2] < chunk_q / 16) cb.erase(cb.end() - 2);
   }
   const size_t n_chunks = cb.size() - 1;
-  auto chunk_of = [&](size_t q) { return (size_t)(std::upper_bound(cb.begin(), cb.end(), q) - cb.begin()) - 1; };
   std::vector<u64> chunk_ops(n_chunks, 0);
-  u64 ops_total = 0, max_cap = 0, cap_sum = 0;
-  for (size_t q = q0; q < q1; q++) {
-    u64 no = 0, ls = 0;
-    query_prepass(ix, ext_leaves, prog, prog_off[q], prog_off[q + 1], &no, &ls);
-    chunk_ops[chunk_of(q)] += no;
-    ops_total += no;
-    if (no) max_cap = std::max(max_cap, ls);
-    cap_sum += no * ls;                                     // (bound of the results of the query's operators together)
-  }
+  for (size_t c = 0; c < n_chunks; c++)
+    for (size_t q = cb[c]; q < cb[c + 1]; q++) chunk_ops[c] += q_ops[q - q0];
   if (ops_total >= 0xFFFFFFF0ull) DCD_FAIL(DCD_E_OVERFLOW, "query batch too large: %llu operators", (unsigned long long)ops_total);
   // the arena is as large as this sub-batch can need, up to the bounds: a small index never reserves gigabytes
   const u64 scratch_elems = std::max<u64>(std::max(std::min(scratch_bound, cap_sum), max_cap), 1);
