@@ -94,7 +94,7 @@ LIMITER["k_tok_emit"] = ("VALU issue + the latency of one table gather per token
                          "lookup +0.35 ms; round 3 adds the first radix pass's digit counts, +0.04 ms, which removes a 0.19 ms histogram kernel)")
 
 
-TRAFFIC_FILES = ("r03_final_traffic.json", "r02_final_traffic.json")
+TRAFFIC_FILES = ("r04_final_traffic.json", "r03_final_traffic.json", "r02_final_traffic.json")
 
 
 def measured_traffic(kernel, T, N, U):
