@@ -655,10 +655,13 @@ __device__ __forceinline__ u64 img_term_of(const u64* __restrict__ unit_start, u
   while (lo + 1 < hi) { u64 m = (lo + hi) >> 1; if (unit_start[m] <= u) lo = m; else hi = m; }
   return lo;
 }
+typedef u32 u32x4_t __attribute__((ext_vector_type(4)));
+// (round 4: ONE 16-byte access at the run's byte / 2-byte alignment -- the unaligned access mode of the memory pipeline takes it --
+//  instead of four dword accesses 16 bytes apart: a quarter of the memory instructions)
 __device__ __forceinline__ void img_copy8(const u16* __restrict__ units, u64 u0, u8* __restrict__ img, u64 dst) {
   const uint4 v = *reinterpret_cast<const uint4*>(units + u0);     // units is 16-byte aligned at u0 (a multiple of 8)
-  u32_a1* d = reinterpret_cast<u32_a1*>(img + dst);
-  d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+  u32x4_t w; w.x = v.x; w.y = v.y; w.z = v.z; w.w = v.w;
+  __builtin_memcpy(img + dst, &w, 16);
 }
 // PERM: the source holds the terms in another order (src_start[t] = first unit of term t in `units`); the units also go,
 // in term order, to units_out (the index's posting array): one read, two writes.  The source run of a term starts at an
@@ -666,14 +669,10 @@ __device__ __forceinline__ void img_copy8(const u16* __restrict__ units, u64 u0,
 template <bool W_IMG, bool W_OUT>
 __device__ __forceinline__ void img_copy8_perm(const u16* __restrict__ units, u64 s0, u8* __restrict__ img, u64 dst, u16* __restrict__ units_out,
                                                u64 u0) {
-  const u32_a1* s = reinterpret_cast<const u32_a1*>(units + s0);
-  uint4 v;
-  v.x = s[0]; v.y = s[1]; v.z = s[2]; v.w = s[3];
-  if (W_IMG) {
-    u32_a1* d = reinterpret_cast<u32_a1*>(img + dst);
-    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-  }
-  if (W_OUT) *reinterpret_cast<uint4*>(units_out + u0) = v;
+  u32x4_t w;
+  __builtin_memcpy(&w, units + s0, 16);
+  if (W_IMG) __builtin_memcpy(img + dst, &w, 16);
+  if (W_OUT) { uint4 v; v.x = w.x; v.y = w.y; v.z = w.z; v.w = w.w; *reinterpret_cast<uint4*>(units_out + u0) = v; }
 }
 // W_IMG / W_OUT (PERM only): which of the two destinations is written.  Round 3: the BUILD writes the image only (the units stay
 // where the pack kernel left them, in sort-key order); the term-ordered posting array is an auxiliary structure of a QUERYABLE
@@ -706,13 +705,40 @@ __global__ __launch_bounds__(IMG_THREADS) void k_img_units(const u16* __restrict
     for (int c = 0; c < IMG_CPL; c++) img_copy8(units, span + (u64)(c * 64 + lane) * IMG_UPT, img, dst0 + (u64)(c * 64 + lane) * IMG_UPT * 2);
     return;
   }
+  // (round 4: the four chunks of a lane find their terms TOGETHER -- the searches, then the directory loads, advance in lock step,
+  //  their dependent loads overlap -- instead of chunk after chunk)
+  u64 tc[IMG_CPL], lo[IMG_CPL], hi[IMG_CPL];
+#pragma unroll
+  for (int c = 0; c < IMG_CPL; c++) { lo[c] = t0; hi[c] = s_t[1] + 1; }
+  for (bool more = true; more;) {
+    more = false;
+    u64 mv[IMG_CPL], sv[IMG_CPL];
+#pragma unroll
+    for (int c = 0; c < IMG_CPL; c++) { mv[c] = (lo[c] + hi[c]) >> 1; sv[c] = unit_start[mv[c]]; }
+#pragma unroll
+    for (int c = 0; c < IMG_CPL; c++) {
+      const u64 u0 = min(span + (u64)(c * 64 + lane) * IMG_UPT, n_units - 1);
+      if (lo[c] + 1 < hi[c]) { if (sv[c] <= u0) lo[c] = mv[c]; else hi[c] = mv[c]; }
+      more |= lo[c] + 1 < hi[c];
+    }
+  }
+  u64 nx[IMG_CPL], us[IMG_CPL], po[IMG_CPL], ss[IMG_CPL];
+#pragma unroll
+  for (int c = 0; c < IMG_CPL; c++) {
+    tc[c] = lo[c];
+    nx[c] = unit_start[tc[c] + 1];
+    us[c] = unit_start[tc[c]];
+    po[c] = W_IMG ? pay_off[tc[c]] : 0;
+    ss[c] = PERM ? src_start[tc[c]] : 0;
+  }
+#pragma unroll
   for (int c = 0; c < IMG_CPL; c++) {
     const u64 u0 = span + (u64)(c * 64 + lane) * IMG_UPT;
     if (u0 >= n_units) break;
-    u64 t = img_term_of(unit_start, t0, s_t[1] + 1, u0);
-    u64 next = unit_start[t + 1];
-    u64 dst = W_IMG ? pay_off[t] + 2 * (u0 - unit_start[t]) : 0;
-    u64 sp = PERM ? src_start[t] + (u0 - unit_start[t]) : u0;       // source position of unit u0
+    u64 t = tc[c];
+    u64 next = nx[c];
+    u64 dst = W_IMG ? po[c] + 2 * (u0 - us[c]) : 0;
+    u64 sp = PERM ? ss[c] + (u0 - us[c]) : u0;                       // source position of unit u0
     if (u0 + IMG_UPT <= next) {
       if (PERM) img_copy8_perm<W_IMG, W_OUT>(units, sp, img, dst, units_out, u0); else img_copy8(units, u0, img, dst);
       continue;
