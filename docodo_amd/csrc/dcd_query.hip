@@ -1310,6 +1310,64 @@ __global__ __launch_bounds__(256) void k_pair_gather(const PairOp* __restrict__ 
   }
 }
 
+// The plan's five exclusive scans (scratch need, work items of every kind) in ONE single-workgroup launch: a pass's operators
+// are a few thousand, five scan launches cost more in launch latency than in work (round 4: 0.26 ms of small kernels sit
+// between the heavy kernels of consecutive passes).  out[k][i] = sum of in[k][0 .. i), i <= n (the arrays hold n + 1 entries).
+struct Scan5 { const u64* in64; const u32* in32[4]; u64* out[5]; };
+__global__ __launch_bounds__(1024) void k_pair_scan5(Scan5 a, u64 n1) {
+  __shared__ u64 lds[17];
+  constexpr u64 PER = 8;
+  for (int k = 0; k < 5; k++) {
+    if (k && !a.in32[k - 1]) continue;
+    u64 carry = 0;
+    for (u64 b0 = 0; b0 < n1; b0 += 1024 * PER) {
+      const u64 i0 = b0 + (u64)threadIdx.x * PER;
+      u64 v[PER], sum = 0;
+#pragma unroll
+      for (u64 j = 0; j < PER; j++) { v[j] = i0 + j < n1 ? (k == 0 ? a.in64[i0 + j] : (u64)a.in32[k - 1][i0 + j]) : 0ull; sum += v[j]; }
+      u64 tot;
+      u64 ex = carry + block_scan_excl<u64, 16>(sum, lds, &tot);
+#pragma unroll
+      for (u64 j = 0; j < PER; j++) { if (i0 + j < n1) a.out[k][i0 + j] = ex; ex += v[j]; }
+      carry += tot;
+    }
+  }
+}
+// result counts of a pass's operators, their exclusive scan and their places in the pool (k_pair_totals + scan + k_pair_assign
+// in one single-workgroup launch; see those kernels)
+__global__ __launch_bounds__(1024) void k_pair_place(const PairOp* __restrict__ ops, u32 n_ops, const u64* __restrict__ part_base,
+                                                    const u64* __restrict__ excl, u64* __restrict__ counts, u64* __restrict__ used, u32 seq,
+                                                    u64 pool_cap, u64* __restrict__ res_off, u32* __restrict__ overflow) {
+  __shared__ u64 lds[17];
+  constexpr u32 PER = 4;
+  const u64 u0 = used[seq & 1u];
+  u64 carry = 0;
+  for (u32 b0 = 0; b0 < n_ops; b0 += 1024 * PER) {
+    const u32 i0 = b0 + threadIdx.x * PER;
+    u64 v[PER], sum = 0;
+#pragma unroll
+    for (u32 j = 0; j < PER; j++) {
+      const u32 i = i0 + j;
+      v[j] = i < n_ops ? excl[part_base[i + 1]] - excl[part_base[i]] : 0ull;
+      sum += v[j];
+    }
+    u64 tot;
+    u64 ex = carry + block_scan_excl<u64, 16>(sum, lds, &tot);
+#pragma unroll
+    for (u32 j = 0; j < PER; j++) {
+      const u32 i = i0 + j;
+      if (i < n_ops) { const u32 ref = ops[i].out_cnt_ref; counts[ref] = v[j]; res_off[ref] = u0 + ex; }
+      ex += v[j];
+    }
+    carry += tot;
+  }
+  if (threadIdx.x == 0) {
+    const u64 u1 = u0 + carry;
+    used[(seq + 1u) & 1u] = u1;
+    if (u1 > pool_cap) *overflow = 1u;
+  }
+}
+
 __global__ void k_pair_totals(const PairOp* __restrict__ ops, u32 n_ops, const u64* __restrict__ part_base, const u64* __restrict__ excl,
                               u64* __restrict__ counts, u64* __restrict__ slice_cnt) {
   u32 i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2106,11 +2164,21 @@ static int32_t exec_chunk(dcd_index* h, const dcd_query_opts& o, SubBatchDev& D,
       // device plan of everything that is left of the round: mode, work items and REAL scratch need per operator, prefix sums
       hipLaunchKernelGGL(k_pair_plan, dim3((u32)div_up((u64)n_rem + 1, 256)), dim3(256), 0, st, ops, n_rem, idx_values, pool, PART, plan_out, gal_ratio,
                          stream32 ? 1u : 0u, std::max<u64>(D.scratch_cap / g2_div, 1), g2_ratio);
-      scan_exclusive<u64, u64>(d_need.p, d_need_off.p, (u64)n_rem + 1, d_part_scr.p, st);
-      scan_exclusive<u32, u64>(d_items.p, d_part_base.p, (u64)n_rem + 1, d_part_scr.p, st);
-      scan_exclusive<u32, u64>(d_items_old.p, d_base_old.p, (u64)n_rem + 1, d_part_scr.p, st);
-      scan_exclusive<u32, u64>(d_items_g2.p, d_base_g2.p, (u64)n_rem + 1, d_part_scr.p, st);
-      if (stream32) scan_exclusive<u32, u64>(d_items_s32.p, d_base_s32.p, (u64)n_rem + 1, d_part_scr.p, st);
+      if ((u64)n_rem + 1 <= 64 * 1024) {
+        Scan5 s5;
+        s5.in64 = d_need.p; s5.out[0] = d_need_off.p;
+        s5.in32[0] = d_items.p; s5.out[1] = d_part_base.p;
+        s5.in32[1] = d_items_old.p; s5.out[2] = d_base_old.p;
+        s5.in32[2] = d_items_g2.p; s5.out[3] = d_base_g2.p;
+        s5.in32[3] = stream32 ? d_items_s32.p : nullptr; s5.out[4] = stream32 ? d_base_s32.p : nullptr;
+        hipLaunchKernelGGL(k_pair_scan5, dim3(1), dim3(1024), 0, st, s5, (u64)n_rem + 1);
+      } else {
+        scan_exclusive<u64, u64>(d_need.p, d_need_off.p, (u64)n_rem + 1, d_part_scr.p, st);
+        scan_exclusive<u32, u64>(d_items.p, d_part_base.p, (u64)n_rem + 1, d_part_scr.p, st);
+        scan_exclusive<u32, u64>(d_items_old.p, d_base_old.p, (u64)n_rem + 1, d_part_scr.p, st);
+        scan_exclusive<u32, u64>(d_items_g2.p, d_base_g2.p, (u64)n_rem + 1, d_part_scr.p, st);
+        if (stream32) scan_exclusive<u32, u64>(d_items_s32.p, d_base_s32.p, (u64)n_rem + 1, d_part_scr.p, st);
+      }
       DCD_HIP(hipMemsetAsync(d_work_ctr.p, 0, 4 * sizeof(u64), st));
       // how many of them run in this pass.  The host knows capacity BOUNDS: the longest prefix whose bounds fit is always safe, and
       // when it is long (ordinary conjunctions: the bound of a term-term operator is its real size) it is taken as it is, with no
@@ -2156,10 +2224,15 @@ static int32_t exec_chunk(dcd_index* h, const dcd_query_opts& o, SubBatchDev& D,
       DCD_HIP(hipMemsetAsync(d_part_count.p + W, 0, 8, st));
       scan_exclusive<u64, u64>(d_part_count.p, d_part_excl.p, W + 1, d_part_scr.p, st);
       // result lengths -> their places in the pool (device-side bump allocation) -> copy out of the scratch / second pass
-      hipLaunchKernelGGL(k_pair_totals, dim3((u32)div_up((u64)n, 256)), dim3(256), 0, st, ops, n, d_part_base.p, d_part_excl.p, D.counts.p, d_slice_cnt.p);
-      scan_exclusive<u64, u64>(d_slice_cnt.p, d_slice_off.p, (u64)n, d_slice_scr.p, st);
-      hipLaunchKernelGGL(k_pair_assign, dim3((u32)div_up((u64)n, 256)), dim3(256), 0, st, ops, n, d_slice_off.p, d_slice_scr.p + scan_nblocks(n), D.used.p,
-                         D.seq, D.pool_cap, D.res_off.p, D.overflow.p);
+      if (n <= 64 * 1024) {
+        hipLaunchKernelGGL(k_pair_place, dim3(1), dim3(1024), 0, st, ops, n, d_part_base.p, d_part_excl.p, D.counts.p, D.used.p, D.seq, D.pool_cap,
+                           D.res_off.p, D.overflow.p);
+      } else {
+        hipLaunchKernelGGL(k_pair_totals, dim3((u32)div_up((u64)n, 256)), dim3(256), 0, st, ops, n, d_part_base.p, d_part_excl.p, D.counts.p, d_slice_cnt.p);
+        scan_exclusive<u64, u64>(d_slice_cnt.p, d_slice_off.p, (u64)n, d_slice_scr.p, st);
+        hipLaunchKernelGGL(k_pair_assign, dim3((u32)div_up((u64)n, 256)), dim3(256), 0, st, ops, n, d_slice_off.p, d_slice_scr.p + scan_nblocks(n), D.used.p,
+                           D.seq, D.pool_cap, D.res_off.p, D.overflow.p);
+      }
       D.seq++;
       const u32 gg = (u32)std::min<u64>(div_up(div_up(W, 8), 4), 16384);
       hipLaunchKernelGGL(k_pair_gather, dim3(gg), dim3(256), 0, st, ops, n, d_part_base.p, W, d_part_count.p, d_part_src.p, d_part_excl.p, D.tmp,
@@ -2528,7 +2601,10 @@ static int32_t run_queries(dcd_index* h, const int32_t* prog, const u64* prog_of
   DCD_HIP(hipMemGetInfo(&free_b, &total_b));
   static const u64 env_arena = getenv("DOCODO_QUERY_ARENA_BYTES") ? strtoull(getenv("DOCODO_QUERY_ARENA_BYTES"), nullptr, 10) : 0;
   const u64 arena_b = env_arena ? env_arena : (u64)total_b / 8;
-  u64 pool_bound = std::max<u64>(arena_b / 16, 1ull << 16), scratch_bound = pool_bound;   // elements: half of the arena each
+  // elements: a quarter of the arena for the pool (operator results: doubled when it runs full), three quarters for the scratch --
+  // the scratch decides into how many passes a round of operators falls (configs[3]: 16 k conjunctions of a chunk need 52 GB of
+  // regions; arena of 36 / 77 / 154 GB split in halves: 84.5 / 80.6 / 78.7 ms per 100 k queries, 2.36 / 2.28 / 2.24 s per 100 k phrases)
+  u64 pool_bound = std::max<u64>(arena_b / 32, 1ull << 16), scratch_bound = std::max<u64>(arena_b / 32 * 3, 1ull << 16);
   bool env_pool = false;
   if (const char* e = getenv("DOCODO_QUERY_POOL_ELEMS")) {   // tests / hosts short of memory: pool and scratch of this many elements
     pool_bound = scratch_bound = std::max<u64>(strtoull(e, nullptr, 10), 1);
