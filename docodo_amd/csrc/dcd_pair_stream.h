@@ -421,7 +421,7 @@ __global__ __launch_bounds__(64, DCD_SK_WAVES) void k_pair_stream_lanes(const Pa
       advance();
       wsync();
     }
-    if (lane == 0) { part_count[wi] = cursor; part_src[wi] = slot; }
+    if (lane == 0) { part_count[wi] = cursor; part_src[wi] = slot | ((u64)oi << PSRC_OP_SHIFT); }
     wsync();                                                     // (the next item reuses the rings)
     w = rfl64(w_next);
   }
@@ -779,7 +779,7 @@ __global__ __launch_bounds__(64, WPE) void k_pair_stream(const PairOp* __restric
     if (is_or) run(SkmMode<2>());
     else if (ordered) run(SkmMode<1>());
     else run(SkmMode<0>());
-    if (lane == 0) { part_count[wi] = cursor; part_src[wi] = slot; }
+    if (lane == 0) { part_count[wi] = cursor; part_src[wi] = slot | ((u64)oi << PSRC_OP_SHIFT); }
     wsync();                                                     // (the next item reuses the rings)
     w = rfl64(w_next);
   }

@@ -41,6 +41,11 @@
 namespace dcd {
 
 constexpr u32 NONE32 = 0xFFFFFFFFu;
+// part_src[item] = (operator of the item within the pass) << 36 | first scratch slot of its output: k_pair_gather gets the operator
+// without a search over the items' prefix (round 4: the 14 dependent loads of that search were most of its 0.12 ms per pass)
+constexpr int PSRC_OP_SHIFT = 36;
+constexpr u64 PSRC_SLOT_MASK = (1ull << PSRC_OP_SHIFT) - 1ull;
+constexpr u32 PSRC_MAX_OPS = 1u << 28;
 
 struct Seg {       // a sequence of absolute coordinates somewhere on the device
   u64 off;         // kind 0: element offset into the index values (kind 1: unused -- the pool offset of a result is assigned on the device)
@@ -1267,7 +1272,7 @@ __global__ __launch_bounds__(PW_T, DCD_PW_WAVES) void k_pair_parts(const PairOp*
       count = cursor;
     }
   }
-  if (lane == 0 && pass == 0) { part_count[wi] = count; part_src[wi] = slot; }
+  if (lane == 0 && pass == 0) { part_count[wi] = count; part_src[wi] = slot | ((u64)oi << PSRC_OP_SHIFT); }
   PROF(10);
   wsync();                                                     // (the next item reuses the rings / records)
   w = rfl64(w_next);
@@ -1296,10 +1301,10 @@ __global__ __launch_bounds__(256) void k_pair_gather(const PairOp* __restrict__ 
     const u64 w = base + grp;
     const u64 c = w < W_act ? part_count[w] : 0;
     if (!c) continue;
-    u32 lo = 0, hi = n_ops;                                  // operator of the item (the eight lanes read the same words)
-    while (lo + 1 < hi) { u32 mid = (lo + hi) >> 1; if (part_base[mid] <= w) lo = mid; else hi = mid; }
+    const u64 ps = part_src[w];                              // operator of the item and its first scratch slot
+    const u32 lo = (u32)(ps >> PSRC_OP_SHIFT);
     if (op_mode[lo] == MODE_GALLOP2) continue;               // (written in place by the second pass of k_pair_parts)
-    const u64* sp = tmp + tmp_off[lo] + part_src[w];
+    const u64* sp = tmp + tmp_off[lo] + (ps & PSRC_SLOT_MASK);
     u64* dp = pool + res_off[ops[lo].out_cnt_ref] + (excl[w] - excl[part_base[lo]]);
     u64 k = sub;
     for (; k + 24 < c; k += 32) {                            // four steps in flight
@@ -2200,6 +2205,7 @@ static int32_t exec_chunk(dcd_index* h, const dcd_query_opts& o, SubBatchDev& D,
         n = std::max(n, (u32)std::min<u64>(std::max<u64>(pwa[9], 1), n_rem));
         D.n_admit_syncs++;
       }
+      n = std::min<u32>(n, PSRC_MAX_OPS - 1u);               // (the operator's number travels in 28 bits of part_src)
       const u64 W = std::min<u64>(W_cap, C.w_prefix[first + n] - C.w_prefix[first]);
       if (stream32) {
         // the streaming items run BESIDE the galloping ones, on a second stream: memory-bound galloping wavefronts and the
