@@ -2198,7 +2198,11 @@ static int32_t exec_chunk(dcd_index* h, const dcd_query_opts& o, SubBatchDev& D,
         }
         n = std::max<u32>(lo - first, 1);
       }
-      if (n < n_rem && n < 256) {
+      // (round 4, second half: ALWAYS when the bounds do not admit everything that is left -- the second operator of a conjunction has a
+      //  result as an operand, whose bound is the length of its operands: 16 k of them fell into four passes where one does;
+      //  DOCODO_QUERY_ADMIT_BELOW = 256 is the rule of the first half: configs[3] 81.6 against 79.4 ms)
+      static const u32 admit_below = getenv("DOCODO_QUERY_ADMIT_BELOW") ? (u32)atoll(getenv("DOCODO_QUERY_ADMIT_BELOW")) : 0xFFFFFFFFu;
+      if (n < n_rem && n < admit_below) {
         hipLaunchKernelGGL(k_pair_admit, dim3(1), dim3(64), 0, st, n_rem, d_need_off.p, d_part_base.p, D.scratch_cap, W_cap, d_nadm.p);
         DCD_HIP(hipMemcpyAsync(&pwa[9], d_nadm.p, 8, hipMemcpyDeviceToHost, st));
         DCD_HIP(hipStreamSynchronize(st));
