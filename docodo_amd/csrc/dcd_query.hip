@@ -1320,59 +1320,50 @@ __global__ __launch_bounds__(256) void k_pair_gather(const PairOp* __restrict__ 
 // between the heavy kernels of consecutive passes).  out[k][i] = sum of in[k][0 .. i), i <= n (the arrays hold n + 1 entries).
 struct Scan5 { const u64* in64; const u32* in32[4]; u64* out[5]; };
 __global__ __launch_bounds__(1024) void k_pair_scan5(Scan5 a, u64 n1) {
-  __shared__ u64 lds[17];
+  // the five arrays go through the workgroup TOGETHER: their loads are in flight at the same time and one pair of barriers serves
+  // all five scans of a round (one array after the other, the single workgroup waited for memory ten times: 48 us)
+  __shared__ u64 lds[5][17];
   constexpr u64 PER = 8;
-  for (int k = 0; k < 5; k++) {
-    if (k && !a.in32[k - 1]) continue;
-    u64 carry = 0;
-    for (u64 b0 = 0; b0 < n1; b0 += 1024 * PER) {
-      const u64 i0 = b0 + (u64)threadIdx.x * PER;
-      u64 v[PER], sum = 0;
+  const u32 lane = lane_id(), w = threadIdx.x >> 6;
+  u64 carry[5] = {0, 0, 0, 0, 0};
+  for (u64 b0 = 0; b0 < n1; b0 += 1024 * PER) {
+    const u64 i0 = b0 + (u64)threadIdx.x * PER;
+    u64 v[5][PER], incl[5], sum[5];
 #pragma unroll
-      for (u64 j = 0; j < PER; j++) { v[j] = i0 + j < n1 ? (k == 0 ? a.in64[i0 + j] : (u64)a.in32[k - 1][i0 + j]) : 0ull; sum += v[j]; }
-      u64 tot;
-      u64 ex = carry + block_scan_excl<u64, 16>(sum, lds, &tot);
+    for (int k = 0; k < 5; k++) {
+      sum[k] = 0;
 #pragma unroll
-      for (u64 j = 0; j < PER; j++) { if (i0 + j < n1) a.out[k][i0 + j] = ex; ex += v[j]; }
-      carry += tot;
+      for (u64 j = 0; j < PER; j++) {
+        u64 x = 0;
+        if (i0 + j < n1) { if (k == 0) x = a.in64[i0 + j]; else if (a.in32[k - 1]) x = (u64)a.in32[k - 1][i0 + j]; }
+        v[k][j] = x; sum[k] += x;
+      }
     }
+#pragma unroll
+    for (int k = 0; k < 5; k++) { incl[k] = wave_scan_incl(sum[k]); if (lane == DCD_WAVE - 1) lds[k][w] = incl[k]; }
+    __syncthreads();
+    if (w == 0) {
+#pragma unroll
+      for (int k = 0; k < 5; k++) {
+        const u64 t = lane < 16u ? lds[k][lane] : 0ull;
+        const u64 ti = wave_scan_incl(t);
+        if (lane < 16u) lds[k][lane] = ti - t;
+        if (lane == 15u) lds[k][16] = ti;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+      u64 ex = carry[k] + lds[k][w] + incl[k] - sum[k];
+      if (k == 0 || a.in32[k - 1]) {
+#pragma unroll
+        for (u64 j = 0; j < PER; j++) { if (i0 + j < n1) a.out[k][i0 + j] = ex; ex += v[k][j]; }
+      }
+      carry[k] += lds[k][16];
+    }
+    __syncthreads();
   }
 }
-// result counts of a pass's operators, their exclusive scan and their places in the pool (k_pair_totals + scan + k_pair_assign
-// in one single-workgroup launch; see those kernels)
-__global__ __launch_bounds__(1024) void k_pair_place(const PairOp* __restrict__ ops, u32 n_ops, const u64* __restrict__ part_base,
-                                                    const u64* __restrict__ excl, u64* __restrict__ counts, u64* __restrict__ used, u32 seq,
-                                                    u64 pool_cap, u64* __restrict__ res_off, u32* __restrict__ overflow) {
-  __shared__ u64 lds[17];
-  constexpr u32 PER = 4;
-  const u64 u0 = used[seq & 1u];
-  u64 carry = 0;
-  for (u32 b0 = 0; b0 < n_ops; b0 += 1024 * PER) {
-    const u32 i0 = b0 + threadIdx.x * PER;
-    u64 v[PER], sum = 0;
-#pragma unroll
-    for (u32 j = 0; j < PER; j++) {
-      const u32 i = i0 + j;
-      v[j] = i < n_ops ? excl[part_base[i + 1]] - excl[part_base[i]] : 0ull;
-      sum += v[j];
-    }
-    u64 tot;
-    u64 ex = carry + block_scan_excl<u64, 16>(sum, lds, &tot);
-#pragma unroll
-    for (u32 j = 0; j < PER; j++) {
-      const u32 i = i0 + j;
-      if (i < n_ops) { const u32 ref = ops[i].out_cnt_ref; counts[ref] = v[j]; res_off[ref] = u0 + ex; }
-      ex += v[j];
-    }
-    carry += tot;
-  }
-  if (threadIdx.x == 0) {
-    const u64 u1 = u0 + carry;
-    used[(seq + 1u) & 1u] = u1;
-    if (u1 > pool_cap) *overflow = 1u;
-  }
-}
-
 __global__ void k_pair_totals(const PairOp* __restrict__ ops, u32 n_ops, const u64* __restrict__ part_base, const u64* __restrict__ excl,
                               u64* __restrict__ counts, u64* __restrict__ slice_cnt) {
   u32 i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2234,15 +2225,12 @@ static int32_t exec_chunk(dcd_index* h, const dcd_query_opts& o, SubBatchDev& D,
       DCD_HIP(hipMemsetAsync(d_part_count.p + W, 0, 8, st));
       scan_exclusive<u64, u64>(d_part_count.p, d_part_excl.p, W + 1, d_part_scr.p, st);
       // result lengths -> their places in the pool (device-side bump allocation) -> copy out of the scratch / second pass
-      if (n <= 64 * 1024) {
-        hipLaunchKernelGGL(k_pair_place, dim3(1), dim3(1024), 0, st, ops, n, d_part_base.p, d_part_excl.p, D.counts.p, D.used.p, D.seq, D.pool_cap,
-                           D.res_off.p, D.overflow.p);
-      } else {
-        hipLaunchKernelGGL(k_pair_totals, dim3((u32)div_up((u64)n, 256)), dim3(256), 0, st, ops, n, d_part_base.p, d_part_excl.p, D.counts.p, d_slice_cnt.p);
-        scan_exclusive<u64, u64>(d_slice_cnt.p, d_slice_off.p, (u64)n, d_slice_scr.p, st);
-        hipLaunchKernelGGL(k_pair_assign, dim3((u32)div_up((u64)n, 256)), dim3(256), 0, st, ops, n, d_slice_off.p, d_slice_scr.p + scan_nblocks(n), D.used.p,
-                           D.seq, D.pool_cap, D.res_off.p, D.overflow.p);
-      }
+      // (one single-workgroup kernel for totals + scan + placement was tried: its 4 x 16 k dependent loads from ONE CU took 62 us
+      //  where these three launches take 20)
+      hipLaunchKernelGGL(k_pair_totals, dim3((u32)div_up((u64)n, 256)), dim3(256), 0, st, ops, n, d_part_base.p, d_part_excl.p, D.counts.p, d_slice_cnt.p);
+      scan_exclusive<u64, u64>(d_slice_cnt.p, d_slice_off.p, (u64)n, d_slice_scr.p, st);
+      hipLaunchKernelGGL(k_pair_assign, dim3((u32)div_up((u64)n, 256)), dim3(256), 0, st, ops, n, d_slice_off.p, d_slice_scr.p + scan_nblocks(n), D.used.p,
+                         D.seq, D.pool_cap, D.res_off.p, D.overflow.p);
       D.seq++;
       const u32 gg = (u32)std::min<u64>(div_up(div_up(W, 8), 4), 16384);
       hipLaunchKernelGGL(k_pair_gather, dim3(gg), dim3(256), 0, st, ops, n, d_part_base.p, W, d_part_count.p, d_part_src.p, d_part_excl.p, D.tmp,
