@@ -20,7 +20,9 @@ def _ops_cases():
                            (100000, 2500, 60, 2400),
                            # sparse + skewed: the galloping path (16 |short| <= |long|, mean gap of the long list > 4 absR)
                            (300, 30000, 300000, 3000), (20000, 700, 2000, 60000), (5, 4000, 9000000, 12000), (1, 2000, 10, 5000),
-                           (1500, 60000, 40, 1500)]:
+                           (1500, 60000, 40, 1500),
+                           # gaps beyond 2^31: k_pair_stream's ring keys leave their epoch (the rings are staged again at the head)
+                           (300, 500, 1 << 33, 1 << 33), (700, 600, 40, 1 << 34), (2000, 1500, 1 << 30, 1 << 31)]:
         a, b = _rand_seq(rng, na, ga), _rand_seq(rng, nb, gb)
         # force shared values (double-tagged elements)
         if na and nb:
