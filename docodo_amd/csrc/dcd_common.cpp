@@ -3,6 +3,7 @@
 #include <atomic>
 
 #include <cstdlib>
+#include <chrono>
 #include <map>
 #include <mutex>
 
@@ -166,7 +167,14 @@ int32_t dev_alloc(int device, size_t bytes, void** out) {
   }
   DCD_HIP(hipSetDevice(device));
   void* p = nullptr;
+  const auto t_alloc = std::chrono::steady_clock::now();
   hipError_t e = hipMalloc(&p, r);
+  {
+    // (a hipMalloc of gigabytes takes milliseconds on most boxes of the pool and SECONDS on some -- first_query_ready_ms of the
+    //  bench line went from 23 ms to 2 s and back between runs; said on stderr so that such a figure explains itself)
+    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_alloc).count();
+    if (ms > 250.0) fprintf(stderr, "[docodo] hipMalloc(%.2f GB) took %.0f ms\n", (double)r / 1e9, ms);
+  }
   if (e != hipSuccess) {
     (void)hipGetLastError();
     dev_pool_trim(device);
