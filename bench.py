@@ -444,6 +444,12 @@ def main():
     if args.gpus > 1 and "RANK" not in os.environ:
         spawn_ranks(args, sys.argv[1:])
 
+    # The contract is ONE JSON line on stdout.  Libraries write there too (RCCL prints a version banner to fd 1 when a communicator
+    # is created): from here on fd 1 is stderr, and the result line goes to the saved descriptor.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -696,7 +702,8 @@ def main():
         if rank == 0:
             out["configs234"] = big
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if comm is not None:
         comm.close()
     if dist is not None:
