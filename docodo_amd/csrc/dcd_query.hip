@@ -368,7 +368,8 @@ constexpr u32 PW_T = 64;
 constexpr u32 PW_ITEMS = DCD_PW_ITEMS;
 static_assert(PW_ITEMS == 4, "the in-lane stages of the bitonic tile merge are written for 4 elements per lane");
 constexpr u32 PW_TILE = PW_T * PW_ITEMS;
-constexpr u64 PART_DEFAULT = 8192;   // union elements per work item (measured on MI355X: 2048 / 4096 / 8192 / 16384 -> 51.5 / 43.6 / 41.7 / 41.9 ms for 20 k AND3 queries on the 10 M-doc index)
+constexpr u64 PART_DEFAULT = 16384;  // union elements per streaming work item (round 2: 2048 / 4096 / 8192 / 16384 -> 51.5 / 43.6 / 41.7 / 41.9 ms for 20 k AND3 queries
+                                     // on the 10 M-doc index; end of round 4, 100 k queries / 100 k phrases: 4096 / 8192 / 16384 / 32768 -> 83.2 / 78.2 / 76.9 / 79.8 ms and 2.49 / 2.33 / 2.30 / 2.27 s)
 
 // orders a wave's LDS writes before its later LDS reads of other lanes' data: the work items are single
 // wavefronts, LDS executes a wave's accesses in order, so no s_barrier / s_waitcnt is needed (and the
