@@ -2,6 +2,7 @@
 #pragma once
 #include <memory>
 #include <mutex>
+#include <vector>
 
 #include "dcd_build_int.h"
 #include "dcd_prims.h"
@@ -22,8 +23,36 @@ struct LazyPostings {
   ~LazyPostings();
 };
 
+// Table of the common sub-expressions of a sub-batch (dcd_query.hip, plan_chunk): operator (operand keys, R values, opcode) -> number of
+// its result.  It lives in the handle and is emptied by advancing a generation number: clearing 2 x the operators of a 100 k-query
+// batch (20 MB) took 2 ms of every call.
+struct CseTable {
+  struct Ent { uint64_t ka, kb; int32_t Ra, Rb; uint32_t op, ref, gen, pad; };
+  std::vector<Ent> t;
+  uint64_t mask = 0;
+  uint32_t gen = 0;
+  void init(uint64_t n_ops) {
+    uint64_t c = 64;
+    while (c < 2 * n_ops + 16) c <<= 1;
+    if (c > t.size() || gen == 0xFFFFFFFFu) { t.assign(c, Ent{0, 0, 0, 0, 0, 0xFFFFFFFFu, 0, 0}); gen = 0; }
+    mask = t.size() - 1;
+    gen++;                                                     // (entries of earlier generations are empty)
+  }
+  static uint64_t mix(uint64_t x) { x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33; return x; }
+  // the entry of the key; ref == 0xFFFFFFFF: new (the caller sets ref)
+  Ent& slot(uint64_t ka, uint64_t kb, int32_t Ra, int32_t Rb, uint32_t op) {
+    const uint64_t h = mix(mix(ka) + 0x9E3779B97F4A7C15ULL * mix(kb ^ 0x632BE59BD9B4E019ULL) + ((((uint64_t)(uint32_t)Ra) << 32) | (uint32_t)Rb) * 0xD1B54A32D192ED03ULL + op);
+    for (uint64_t i = h & mask;; i = (i + 1) & mask) {
+      Ent& e = t[i];
+      if (e.gen != gen) { e.ka = ka; e.kb = kb; e.Ra = Ra; e.Rb = Rb; e.op = op; e.ref = 0xFFFFFFFFu; e.gen = gen; return e; }
+      if (e.ka == ka && e.kb == kb && e.Ra == Ra && e.Rb == Rb && e.op == op) return e;
+    }
+  }
+};
+
 struct dcd_index {
   dcd::DeviceIndex ix;
+  CseTable cse;                         // (used under `mu`, by one sub-batch at a time)
   hipStream_t st = nullptr;
   std::unique_ptr<LazyPostings> lazy;   // non-null: on-disk postings (dcd_index_open_lazy)
   // Search is issued from many pool threads (server.cs:16-30) and serialised by lock(DoSearchLock) in the reference

@@ -32,6 +32,7 @@
 #include <functional>
 #include <memory>
 #include <mutex>
+#include <chrono>
 #include <thread>
 
 #include "dcd_codec.h"
@@ -1767,33 +1768,11 @@ struct SymVal { Seg s; int32_t R; u64 cap; u32 round; u64 key; };
 // operator ONCE and every query that contains it refers to the one result.  Under a Zipf query load this is most of the work: 100 k
 // phrases sampled from corpus positions name the pair of the two most frequent terms 1 800 times (p1 * p1 * 100 k), each
 // evaluation a streaming merge of 3.7e8 postings.  Key of an operand: the term ordinal, or the number of the operator result.
-struct CseTable {
-  struct Ent { u64 ka, kb; int32_t Ra, Rb; u32 op, ref; };
-  std::vector<Ent> t;
-  u64 mask = 0;
-  void init(u64 n_ops) {
-    u64 c = 64;
-    while (c < 2 * n_ops + 16) c <<= 1;
-    t.assign(c, Ent{0, 0, 0, 0, 0, NONE32});
-    mask = c - 1;
-  }
-  static u64 mix(u64 x) { x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33; return x; }
-  // the entry of the key; ref == NONE32: new (the caller sets ref)
-  Ent& slot(u64 ka, u64 kb, int32_t Ra, int32_t Rb, u32 op) {
-    const u64 h = mix(mix(ka) + 0x9E3779B97F4A7C15ULL * mix(kb ^ 0x632BE59BD9B4E019ULL) + ((((u64)(u32)Ra) << 32) | (u32)Rb) * 0xD1B54A32D192ED03ULL + op);
-    for (u64 i = h & mask;; i = (i + 1) & mask) {
-      Ent& e = t[i];
-      if (e.ref == NONE32) { e.ka = ka; e.kb = kb; e.Ra = Ra; e.Rb = Rb; e.op = op; return e; }
-      if (e.ka == ka && e.kb == kb && e.Ra == Ra && e.Rb == Rb && e.op == op) return e;
-    }
-  }
-};
-
 // State of a SUB-BATCH: the scope of the work pool and of the common sub-expressions.  Its queries are planned and run in CHUNKS
 // (a chunk's plan is made while the previous chunk runs); operator results stay in the pool until the sub-batch ends, so a later
 // chunk refers to the results of an earlier one.
 struct SubBatch {
-  CseTable cse;
+  CseTable* cse = nullptr;          // the handle's table (dcd_index_int.h), emptied for this sub-batch
   bool use_cse = true;
   std::vector<u64> ref_cap;      // [n_refs] bound of the result length
   std::vector<u32> ref_chunk;    // [n_refs] chunk that evaluates it
@@ -1880,7 +1859,7 @@ static void plan_chunk(const dcd_index* h, const std::vector<SymVal>* ext_leaves
         if (a.s.kind == 0) op_units += ext_leaves ? a.cap : ix.h_term_unit_start[a.key + 1] - ix.h_term_unit_start[a.key];
         if (b.s.kind == 0) op_units += ext_leaves ? b.cap : ix.h_term_unit_start[b.key + 1] - ix.h_term_unit_start[b.key];
         sb.units_named += op_units;
-        CseTable::Ent* e = sb.use_cse ? &sb.cse.slot(a.key, b.key, a.R, b.R, (u32)opc) : nullptr;
+        CseTable::Ent* e = sb.use_cse ? &sb.cse->slot(a.key, b.key, a.R, b.R, (u32)opc) : nullptr;
         SymVal r;
         u32 ref;
         if (e && e->ref != NONE32) {                       // evaluated already (this chunk or an earlier one of the sub-batch)
@@ -2477,6 +2456,9 @@ static int32_t run_sub_batch(dcd_index* h, const int32_t* prog, const u64* prog_
   hipStream_t st = h->st;
   StreamScope ss_(st);
   if (o.max_found_docs > 512 || o.max_found_docs < 0 || o.max_found_pages < 0) DCD_FAIL(DCD_E_BADARG, "max_found_docs must be in [0, 512]");
+  const auto t_sb0 = std::chrono::steady_clock::now();          // (DOCODO_TRACE: host phases of the sub-batch)
+  auto ms_since = [](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); };
+  double ms_pre = 0, ms_setup = 0, ms_plan0 = 0, ms_exec = 0, ms_append = 0, ms_join = 0;
   if (!ext_values) DCD_TRY(ensure_values(h));
   u64 PART = PART_DEFAULT;
   if (const char* e = getenv("DOCODO_QUERY_PART")) PART = std::min<u64>(std::max<u64>(strtoull(e, nullptr, 10), 1), 1ull << 31);   // tests: tiny partitions (k_pair_stream counts a partition in 32 bits)
@@ -2515,6 +2497,7 @@ static int32_t run_sub_batch(dcd_index* h, const int32_t* prog, const u64* prog_
   std::vector<u64> chunk_ops(n_chunks, 0);
   for (size_t c = 0; c < n_chunks; c++)
     for (size_t q = cb[c]; q < cb[c + 1]; q++) chunk_ops[c] += q_ops[q - q0];
+  ms_pre = ms_since(t_sb0);
   if (ops_total >= 0xFFFFFFF0ull) DCD_FAIL(DCD_E_OVERFLOW, "query batch too large: %llu operators", (unsigned long long)ops_total);
   // the arena is as large as this sub-batch can need, up to the bounds: a small index never reserves gigabytes
   const u64 scratch_elems = std::max<u64>(std::max(std::min(scratch_bound, cap_sum), max_cap), 1);
@@ -2523,7 +2506,8 @@ static int32_t run_sub_batch(dcd_index* h, const int32_t* prog, const u64* prog_
   SubBatch sb;
   static const bool env_cse = !(getenv("DOCODO_QUERY_CSE") && atoi(getenv("DOCODO_QUERY_CSE")) == 0);   // (A/B knob)
   sb.use_cse = env_cse;
-  if (sb.use_cse) sb.cse.init(ops_total);
+  sb.cse = &h->cse;
+  if (sb.use_cse) sb.cse->init(ops_total);
   sb.ref_cap.reserve(ops_total); sb.ref_chunk.reserve(ops_total); sb.ref_round.reserve(ops_total);
   SubBatchDev D;
   DCD_TRY(D.counts.alloc(dev, ops_total ? ops_total : 1));
@@ -2555,8 +2539,10 @@ static int32_t run_sub_batch(dcd_index* h, const int32_t* prog, const u64* prog_
     P.finals = static_cast<FinalSeq*>(pin_fin[c & 1].p);
     return DCD_OK;
   };
+  ms_setup = ms_since(t_sb0) - ms_pre;
   DCD_TRY(prepare(0));
   plan_chunk(h, ext_leaves, sb, prog, prog_off, PART, plans[0]);
+  ms_plan0 = ms_since(t_sb0) - ms_pre - ms_setup;
   int32_t status = DCD_OK;
   for (size_t c = 0; c < n_chunks && status == DCD_OK; c++) {
     ChunkPlan& P = plans[c & 1];
@@ -2568,13 +2554,19 @@ static int32_t run_sub_batch(dcd_index* h, const int32_t* prog, const u64* prog_
       if (status != DCD_OK) break;
       planner = std::thread(plan_chunk, h, ext_leaves, std::ref(sb), prog, prog_off, PART, std::ref(plans[(c + 1) & 1]));
     }
+    const auto t_c = std::chrono::steady_clock::now();
     if (n_chunks == 1) status = exec_chunk(h, o, D, P, PART, R, ext_values, refs_after);
     else {
       dcd_results part;
       status = exec_chunk(h, o, D, P, PART, &part, ext_values, refs_after);
+      const double e = ms_since(t_c);
       if (status == DCD_OK) append_results(*R, part);
+      ms_append += ms_since(t_c) - e;
     }
+    ms_exec += ms_since(t_c);
+    const auto t_j = std::chrono::steady_clock::now();
     if (planner.joinable()) planner.join();
+    ms_join += ms_since(t_j);
   }
   if (status != DCD_OK) { (void)hipStreamSynchronize(st); return status; }
   R->ops_named += sb.ops_total;
@@ -2589,6 +2581,8 @@ static int32_t run_sub_batch(dcd_index* h, const int32_t* prog, const u64* prog_
     fprintf(stderr, "[docodo] query sub-batch: %zu queries, %zu chunks, %llu operators named, %u evaluated, %u passes (%llu sized by the device), pool %llu of %llu elements, scratch %llu\n",
             nq, n_chunks, (unsigned long long)sb.ops_total, sb.n_refs, D.seq, (unsigned long long)D.n_admit_syncs,
             (unsigned long long)std::max(used[0], used[1]), (unsigned long long)D.pool_cap, (unsigned long long)D.scratch_cap);
+    fprintf(stderr, "[docodo]   host ms: prepass %.2f, setup %.2f, first plan %.2f, chunks %.2f (appending results %.2f), waiting for plans %.2f, total %.2f\n",
+            ms_pre, ms_setup, ms_plan0, ms_exec, ms_append, ms_join, ms_since(t_sb0));
   }
   return DCD_OK;
 }
@@ -2785,6 +2779,7 @@ int32_t dcd_index_trim(dcd_index* h) {
   h->work_pool.reset();
   h->work_pool_elems = 0;
   h->res_arena.reset();
+  { std::vector<CseTable::Ent>().swap(h->cse.t); h->cse.mask = 0; h->cse.gen = 0; }     // (host memory: the table of common sub-expressions)
   if (h->lazy && h->lazy->sub) { dcd_index* old = h->lazy->sub.release(); dcd_index_free(old); h->lazy->terms.clear(); }
   dev_pool_trim(h->ix.device);
   return DCD_OK;
